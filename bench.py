@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X streaming-filter path.
+
+    python bench.py --gpus N --steps K --warmup W           (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W    (N>1, one rank per GPU)
+
+A "step" = one pass of multirate_FIR.filter (1024-tap lowpass, complex64) over each
+rank's contiguous sample block of 2^26 samples, inputs already resident in HBM:
+halo exchange of the Ntaps-1 = 1023 preceding samples over RCCL (N>1), then the
+overlap-save kernel.  value = total samples all ranks filtered / max-over-ranks time.
+
+The product path uses no PyTorch; with N>1 the ranks rendezvous through a file
+(sk_dsp_comm_amd.sharding.FileRendezvous) and barrier / max-reduce through RCCL.
+
+Prints ONE JSON line on rank 0 (fields per the driver contract + "roofline" and
+"cpu_baseline").  Other workloads (--workload updn43|iir8|fir127) are measurement aids
+for the remaining BASELINE.json configs and print the same shape.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "scikit-dsp-comm_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+
+
+def firwin_lowpass(ntaps, cutoff):
+    """scipy.signal.firwin(ntaps, cutoff) (Hamming window, unit DC gain) restated so the
+    bench does not need SciPy: fir_design_helper.firwin_lpf(n, fc) == firwin(n, 2*fc)."""
+    m = np.arange(ntaps) - (ntaps - 1) / 2.0
+    h = cutoff * np.sinc(cutoff * m) * np.hamming(ntaps)
+    return h / np.sum(h)
+
+
+def elliptic_bpf_sos():
+    """IIR_bpf(0.19,0.2,0.3,0.31,0.5,60,1.0,'ellip') from the golden fixture (8 biquads)."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "g7_iir_sos.npz"))["sos8"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="fir1024", choices=["fir1024", "updn43", "iir8", "fir127"])
+    ap.add_argument("--log2n", type=int, default=26, help="samples per GPU = 2^log2n")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    args = ap.parse_args()
+
+    from sk_dsp_comm_amd import _ffi, sharding
+
+    rank, world, local = sharding.env_rank_world()
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with one process per GPU "
+                     "(python -m torch.distributed.run --nproc-per-node %d ...)" % (args.gpus, args.gpus))
+        args.gpus = world
+    tr = sharding.RcclTransport(rank, world, local)  # binds this process to GPU LOCAL_RANK
+    info = _ffi.device_info()
+
+    n = 1 << args.log2n
+    K, W = args.steps, args.warmup
+
+    # ------------------------------------------------------------- workload
+    if args.workload == "fir1024":
+        b = firwin_lowpass(1024, 0.2)
+        dtype, arith = np.complex64, "c64"
+        fir = sharding.ShardedFIR(b, tr, dtype=dtype)
+        xd = fir.new_shard_buffer(n).fill_noise(2026, first_index=rank * n)
+        yd = _ffi.DeviceArray(n, dtype)
+        step = lambda: fir.filter_local_dev(xd, yd, n)           # noqa: E731
+        units, alg_bytes = n, 16.0 * n                           # 8 B in + 8 B out per sample
+        kern = "ols_tile_kernel"
+        wl = "multirate_FIR.filter: 1024-tap lowpass, complex64, 2^%d samples per GPU, FFT overlap-save" % args.log2n
+        metric = "complex64 MSamples/s (FIR-1024 tap, 2^26 samples)"
+    elif args.workload == "fir127":
+        b = firwin_lowpass(127, 0.2)
+        dtype, arith = np.float32, "f32"
+        k = _ffi.FirKernel(b, _ffi.F32)
+        xd = _ffi.DeviceArray(n, dtype).fill_noise(2026)
+        yd = _ffi.DeviceArray(n, dtype)
+        step = lambda: k.filter_dev(xd, yd)                      # noqa: E731
+        units, alg_bytes = n, 8.0 * n
+        kern = "fir_poly_kernel"
+        wl = "multirate_FIR.filter: 127-tap lowpass, float32, 2^%d samples, direct form" % args.log2n
+        metric = "float32 MSamples/s (FIR-127 tap)"
+    elif args.workload == "updn43":
+        b = firwin_lowpass(512, 0.225)
+        dtype, arith = np.complex64, "c64"
+        k = _ffi.FirKernel(b, _ffi.C64)
+        xd = _ffi.DeviceArray(n, dtype).fill_noise(2026)
+        n_out = (n * 4) // 3
+        yd = _ffi.DeviceArray(n_out, dtype)
+        step = lambda: k.updn_dev(xd, yd, 4, 3)                  # noqa: E731
+        units, alg_bytes = n, 8.0 * n + 8.0 * n_out              # 18.67 B per input sample
+        kern = "fir_poly_kernel"
+        wl = "downsample(multirate_FIR.up(x,4),3): 512-tap prototype, complex64, 2^%d input samples, fused polyphase" % args.log2n
+        metric = "complex64 input MSamples/s (polyphase L=4/M=3, 512 taps)"
+    else:
+        sos = elliptic_bpf_sos()
+        dtype, arith = np.float32, "f32 I/O, f64 state"
+        k = _ffi.IirKernel(_ffi.F32, sos=sos)
+        xd = _ffi.DeviceArray(n, dtype).fill_noise(2026)
+        yd = _ffi.DeviceArray(n, dtype)
+        step = lambda: k.filter_dev(xd, yd)                      # noqa: E731
+        units, alg_bytes = n, 8.0 * n
+        kern = "iir_chunk_kernel x2 + iir_wg_scan_kernel"
+        wl = "multirate_IIR.filter: 8-biquad elliptic bandpass, float32, 2^%d samples, affine scan" % args.log2n
+        metric = "float32 MSamples/s (8-biquad SOS IIR)"
+
+    # --------------------------------------------------------------- timing
+    for _ in range(W):
+        step()
+    _ffi.sync()
+    tr.barrier()
+    _ffi.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    ev_ms = _ffi.timer_stop()  # HIP events on the stream the kernels run on (synchronises)
+    _ffi.sync()
+    tr.barrier()
+    t1 = time.perf_counter()
+    elapsed = tr.allreduce_max(t1 - t0)
+    ev_ms = tr.allreduce_max(ev_ms)
+
+    # quick parity spot check of what was just computed (oracle = checker only)
+    check = None
+    if rank == 0 and args.workload == "fir1024":
+        from oracle import oracle as orc
+        s0, w = 3 * 7168 - 100, 2048
+        xs = xd.to_host(s0 - 1023, w + 1023)
+        ref = orc.fir_filter(b, xs)[1023:]
+        got = yd.to_host(s0, w)
+        check = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+
+    # --------------------------------------------------------- cpu baseline
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, b if args.workload != "iir8" else None, xd)
+
+    if rank == 0:
+        total_units = float(units) * world * K
+        ms_per_step = elapsed * 1e3 / K
+        t_kernel = ev_ms * 1e-3 / K  # average launch (+ halo) duration from HIP events
+        achieved = alg_bytes / t_kernel / 1e9
+        out = {
+            "metric": metric,
+            "value": total_units / elapsed / 1e6,
+            "unit": "MSamples/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": arith,
+            "data": "synthetic",
+            "config": {"workload": wl, "samples_per_gpu": n, "total_samples": n * world,
+                       "sharding": "contiguous sample blocks, %d-sample RCCL halo" % 1023 if world > 1 else "single GPU",
+                       "device": info["name"], "compute_units": info["compute_units"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kern,
+                         "kernel_ms": t_kernel * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
+            "cpu_baseline": cpu,
+        }
+        if check is not None:
+            out["parity_spot_check_max_err"] = check
+        print(json.dumps(out))
+    tr.close()
+
+
+def cpu_baseline(args, b, xd):
+    """The oracle (C port of the reference's arithmetic: float64 accumulation of a
+    complex64/float32 input, i.e. what scipy.signal.lfilter/sosfilt do for the reference)
+    timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    cores_avail = os.cpu_count()
+    if args.workload == "iir8":
+        sos = elliptic_bpf_sos()
+        m = 1 << 22
+        x = xd.to_host(0, m)
+        t0 = time.perf_counter(); orc.sos_filter_f32in_timed(sos, x[:1 << 18]); dt = time.perf_counter() - t0
+        m = int(min(1 << 26, max(1 << 18, (1 << 18) * args.cpu_seconds / max(dt, 1e-6))))
+        m = min(m, xd.n)
+        x = xd.to_host(0, m)
+        best = min(_timed(lambda: orc.sos_filter_f32in_timed(sos, x)) for _ in range(2))
+        return {"value": m / best / 1e6, "unit": "MSamples/s", "cores": 1, "kind": "port",
+                "sample": "first %d of the 2^%d float32 samples, sequential DF2T in float64 (sosfilt restated in C)" % (m, args.log2n),
+                "cores_available": cores_avail}
+    if args.workload == "updn43":
+        m = 1 << 16
+        x = xd.to_host(0, m)
+        best = min(_timed(lambda: orc.downsample(orc.fir_up(b, x, 4), 3)) for _ in range(2))
+        return {"value": m / best / 1e6, "unit": "MSamples/s", "cores": 1, "kind": "port",
+                "sample": "first %d input samples through upsample -> 512-tap FIR at the 4x rate -> downsample" % m,
+                "cores_available": cores_avail}
+    x = xd.to_host(0, 1 << 16)
+    t0 = time.perf_counter(); orc.fir_filter_f32in_timed(b, x); dt = time.perf_counter() - t0
+    m = int(min(xd.n, max(1 << 16, (1 << 16) * args.cpu_seconds / max(dt, 1e-6))))
+    x = xd.to_host(0, m)
+    best = min(_timed(lambda: orc.fir_filter_f32in_timed(b, x)) for _ in range(2))
+    return {"value": m / best / 1e6, "unit": "MSamples/s", "cores": 1, "kind": "port",
+            "sample": "first %d of the 2^%d samples, direct-form float64 accumulation (lfilter FIR branch restated in C, 1 thread like the reference)" % (m, args.log2n),
+            "cores_available": cores_avail}
+
+
+def _timed(fn):
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/*
+ * skdsp.h -- C ABI of libskdsp_hip.so: the MI355X (gfx950) replacement for the
+ * native kernels that scikit-dsp-comm's streaming-filter hot path executes.
+ *
+ * The reference has NO FFI of its own for this path: it is pure Python whose
+ * arithmetic is one-line calls into scipy.signal / numpy.  The entry points
+ * below are therefore "what a binding for this path would bind": one entry per
+ * reference call site, cited as /root/reference/src/sk_dsp_comm/<file>:<line>.
+ * INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success or a negative skdsp_status; the
+ *     message for the calling thread is in skdsp_last_error().
+ *   - dtype = arithmetic/storage type of the signal: F32/C64 (hot path),
+ *     F64/C128 (direct-form kernels in double, for float64 callers).
+ *     Complex is interleaved (re,im), C-contiguous, as NumPy stores it.
+ *   - coefficient arrays are always host float64 / complex128 (what the
+ *     reference objects hold); the library rounds once to the signal dtype.
+ *   - "*_dev" variants take DEVICE pointers (from skdsp_malloc) and run
+ *     asynchronously on the library stream; host variants copy in/out and
+ *     return after the stream is idle.  The caller owns every buffer; the
+ *     library copies coefficients at create() and never retains x/y.
+ *   - n_hist: number of valid samples stored immediately BEFORE x_dev[0] in the
+ *     same allocation (x_dev[-n_hist..-1]).  0 = zero initial state, which is
+ *     what every reference call uses (lfilter/sosfilt without zi).  The sharded
+ *     path uses it for the Ntaps-1 halo received from the left neighbour.
+ *   - a handle serialises its own calls; different handles may be used from
+ *     different threads.  ctypes releases the GIL around each call.
+ */
+#ifndef SKDSP_H
+#define SKDSP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { SKDSP_F32 = 0, SKDSP_C64 = 1, SKDSP_F64 = 2, SKDSP_C128 = 3 } skdsp_dtype;
+
+typedef enum {
+    SKDSP_OK = 0,
+    SKDSP_ERR_BADARG = -1,   /* -> ValueError / TypeError in the Python mirror */
+    SKDSP_ERR_NODEVICE = -2, /* no HIP device: the product path fails loudly   */
+    SKDSP_ERR_NOMEM = -3,
+    SKDSP_ERR_HIP = -4,
+    SKDSP_ERR_RCCL = -5,
+    SKDSP_ERR_UNSUPPORTED = -6
+} skdsp_status;
+
+/* FIR algorithm selector (skdsp_fir_set_algo). AUTO picks by dtype / tap count. */
+typedef enum { SKDSP_FIR_AUTO = 0, SKDSP_FIR_DIRECT = 1, SKDSP_FIR_OLS = 2 } skdsp_fir_algo;
+
+typedef void *skdsp_handle;
+
+/* ---- runtime ------------------------------------------------------------ */
+int skdsp_init(int device);               /* bind this process to one GPU, create the stream */
+int skdsp_shutdown(void);
+int skdsp_device_count(void);
+int skdsp_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes, int *clock_khz);
+const char *skdsp_last_error(void);
+const char *skdsp_version(void);
+
+int skdsp_malloc(void **dptr, int64_t bytes);
+int skdsp_free(void *dptr);
+int skdsp_memcpy_h2d(void *dst_dev, const void *src_host, int64_t bytes);
+int skdsp_memcpy_d2h(void *dst_host, const void *src_dev, int64_t bytes);
+int skdsp_memcpy_d2d(void *dst_dev, const void *src_dev, int64_t bytes);
+int skdsp_memset(void *dst_dev, int value, int64_t bytes);
+int skdsp_sync(void);                      /* wait for the library stream */
+/* HIP-event stopwatch on the library stream (bench.py times kernels with it) */
+int skdsp_timer_start(void);
+int skdsp_timer_stop(float *elapsed_ms);   /* synchronises on the stop event */
+/* fill a device buffer with counter-based N(0,1)/sqrt(2) complex (or N(0,1) real)
+ * noise keyed by (seed, global sample index): any window can be regenerated. */
+int skdsp_fill_noise_dev(void *x_dev, int64_t n, int dtype, uint64_t seed, int64_t first_index);
+
+/* ---- FIR: multirate_FIR (multirate_helper.py:95-127) ---------------------- */
+/* ctor, multirate_helper.py:95-101.  taps: ntaps float64 (taps_complex=0) or
+ * ntaps complex128 (taps_complex=1). */
+int skdsp_fir_create(const void *taps, int ntaps, int taps_complex, int dtype, skdsp_handle *out);
+int skdsp_fir_set_algo(skdsp_handle h, int algo);
+int skdsp_fir_get_algo(skdsp_handle h, int64_t n, int *algo_used);
+/* .filter(x): signal.lfilter(b,[1],x), multirate_helper.py:104-109.  y has n samples. */
+int skdsp_fir_filter(skdsp_handle h, const void *x, int64_t n, void *y);
+int skdsp_fir_filter_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev);
+/* .up(x,L): lfilter(b,[1], L*upsample(x,L)), multirate_helper.py:112-118.  y has n*L samples. */
+int skdsp_fir_up(skdsp_handle h, const void *x, int64_t n, int L, void *y);
+int skdsp_fir_up_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev);
+/* .dn(x,M): downsample(lfilter(b,[1],x), M), multirate_helper.py:121-127.  y has n/M samples. */
+int skdsp_fir_dn(skdsp_handle h, const void *x, int64_t n, int M, void *y);
+int skdsp_fir_dn_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev);
+/* fused rational resampler = downsample(.up(x,L), M) (BASELINE.json config 3;
+ * sigsys.py:3078-3083 applied to multirate_helper.py:112-118).  y has (n*L)/M samples. */
+int skdsp_fir_updn(skdsp_handle h, const void *x, int64_t n, int L, int M, void *y);
+int skdsp_fir_updn_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev);
+
+/* ---- IIR: multirate_IIR (multirate_helper.py:159-192), rate_change (:54-83) - */
+/* sos: nsec x 6 float64, sos[:,3]==1 (scipy.signal.sosfilt contract). */
+int skdsp_sos_create(const double *sos, int nsec, int dtype, skdsp_handle *out);
+/* transfer function (b,a) for signal.lfilter(b,a,.), multirate_helper.py:74,81;
+ * a[0]-normalised, direct-form II transposed like scipy. */
+int skdsp_tf_create(const double *b, int nb, const double *a, int na, int dtype, skdsp_handle *out);
+/* .filter: sosfilt(sos,x) (:169-174) / lfilter(b,a,x) */
+int skdsp_iir_filter(skdsp_handle h, const void *x, int64_t n, void *y);
+int skdsp_iir_filter_dev(skdsp_handle h, const void *x_dev, int64_t n, void *y_dev);
+/* .up: filter(L*upsample(x,L)) (:69-75, :177-183); y has n*L samples */
+int skdsp_iir_up(skdsp_handle h, const void *x, int64_t n, int L, void *y);
+int skdsp_iir_up_dev(skdsp_handle h, const void *x_dev, int64_t n, int L, void *y_dev);
+/* .dn: downsample(filter(x), M) (:77-83, :186-192); y has n/M samples */
+int skdsp_iir_dn(skdsp_handle h, const void *x, int64_t n, int M, void *y);
+int skdsp_iir_dn_dev(skdsp_handle h, const void *x_dev, int64_t n, int M, void *y_dev);
+
+/* ---- rate-change primitives (sigsys.py:3031-3083) -------------------------- */
+/* upsample: y[k*L] = x[k], zeros elsewhere (sigsys.py:3050-3053). y has n*L samples. */
+int skdsp_upsample(const void *x, int64_t n, int L, int dtype, void *y);
+int skdsp_upsample_dev(const void *x_dev, int64_t n, int L, int dtype, double scale, void *y_dev);
+/* downsample: y[k] = x[k*M+p], k < n/M, 0 <= p < M (sigsys.py:3078-3083). */
+int skdsp_downsample(const void *x, int64_t n, int M, int p, int dtype, void *y);
+int skdsp_downsample_dev(const void *x_dev, int64_t n, int M, int p, int dtype, void *y_dev);
+
+int skdsp_destroy(skdsp_handle h);
+
+/* ---- sample-block sharding across GPUs (one process per GPU, RCCL) ------- */
+/* rank 0 creates the 128-byte RCCL unique id; the launcher hands it to every rank. */
+int skdsp_dist_unique_id(void *id128);
+int skdsp_dist_init(int rank, int world, const void *id128);
+int skdsp_dist_shutdown(void);
+int skdsp_dist_barrier(void);                     /* 1-element RCCL all-reduce + stream sync */
+int skdsp_dist_allreduce_max(double *value);      /* in-place max over ranks */
+int skdsp_dist_allreduce_sum(double *value);
+/* Halo exchange for a contiguous sample-block shard: send my LAST n_halo samples of
+ * x_dev (n local samples) to rank+1, receive rank-1's into x_dev[-n_halo..-1]
+ * (rank 0 zero-fills).  x_dev must have n_halo samples of headroom before it. */
+int skdsp_dist_halo_exchange(void *x_dev, int64_t n, int64_t n_halo, int dtype);
+/* sharded .filter: halo exchange of ntaps-1 samples, then the local filter. */
+int skdsp_fir_filter_shard_dev(skdsp_handle h, void *x_dev, int64_t n_local, void *y_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKDSP_H */

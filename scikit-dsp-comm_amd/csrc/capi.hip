@@ -1,0 +1,578 @@
+// capi.hip -- the extern "C" boundary of libskdsp_hip.so (see include/skdsp.h).
+// Runtime context (one GPU per process, one stream), grow-only staging workspaces
+// for the host-pointer entry points, handle lifetime, algorithm selection.
+#include "skdsp_internal.hpp"
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+namespace skdsp {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    (void)hipGetLastError();
+    if (e == hipErrorOutOfMemory) return SKDSP_ERR_NOMEM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return SKDSP_ERR_NODEVICE;
+    return SKDSP_ERR_HIP;
+}
+
+Context &ctx()
+{
+    static Context c;
+    return c;
+}
+
+static int init_locked(int device)
+{
+    Context &c = ctx();
+    if (c.ready) {
+        SK_CHECK(device < 0 || device == c.device, SKDSP_ERR_BADARG,
+                 "skdsp_init: already bound to device %d (one GPU per process)", c.device);
+        return SKDSP_OK;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (hipGetDeviceCount -> %d, %s): the MI355X path has no CPU fallback",
+                  ndev, e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        (void)hipGetLastError();
+        return SKDSP_ERR_NODEVICE;
+    }
+    if (device < 0) device = 0;
+    SK_CHECK(device < ndev, SKDSP_ERR_NODEVICE, "skdsp_init: device %d out of range (%d visible)", device, ndev);
+    SK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SK_HIP(hipGetDeviceProperties(&prop, device));
+    c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    SK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    SK_HIP(hipEventCreate(&c.ev_start));
+    SK_HIP(hipEventCreate(&c.ev_stop));
+    c.device = device;
+    c.ready = true;
+    return SKDSP_OK;
+}
+
+int ensure_init()
+{
+    Context &c = ctx();
+    if (c.ready) return SKDSP_OK;
+    std::lock_guard<std::mutex> lk(c.mu);
+    int dev = -1;
+    if (const char *env = getenv("SKDSP_DEVICE")) dev = atoi(env);
+    return init_locked(dev);
+}
+
+int ws_reserve(int slot, size_t bytes, void **out)
+{
+    Context &c = ctx();
+    if (bytes > c.ws_bytes[slot]) {
+        if (c.ws[slot]) {
+            SK_HIP(hipStreamSynchronize(c.stream));
+            SK_HIP(hipFree(c.ws[slot]));
+            c.ws[slot] = nullptr;
+            c.ws_bytes[slot] = 0;
+        }
+        size_t cap = bytes + bytes / 8 + 4096;
+        SK_HIP(hipMalloc(&c.ws[slot], cap));
+        c.ws_bytes[slot] = cap;
+    }
+    *out = c.ws[slot];
+    return SKDSP_OK;
+}
+
+static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// FIR .filter algorithm choice.  OLS needs complex64; it wins once direct form stops
+// being HBM-bound (2*P FMA per c64 sample on the VALU vs ~120 flop in the FFT domain).
+static int pick_fir_algo(const FirHandle *h, int64_t n)
+{
+    int algo = h->algo;
+    if (const char *env = getenv("SKDSP_FIR_ALGO")) {
+        if (!strcmp(env, "direct")) algo = SKDSP_FIR_DIRECT;
+        else if (!strcmp(env, "ols")) algo = SKDSP_FIR_OLS;
+    }
+    if (algo == SKDSP_FIR_OLS && !fir_ols_supported(h)) algo = SKDSP_FIR_DIRECT;
+    if (algo != SKDSP_FIR_AUTO) return algo;
+    if (fir_ols_supported(h) && h->ntaps >= 48 && n >= 4096) return SKDSP_FIR_OLS;
+    return SKDSP_FIR_DIRECT;
+}
+
+static int fir_filter_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev)
+{
+    if (pick_fir_algo(h, n) == SKDSP_FIR_OLS) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream);
+    return fir_direct_launch(h, x_dev, n, n_hist, 1, 1, n, y_dev, ctx().stream);
+}
+
+template <typename H> static H *as_handle(skdsp_handle h, int kind)
+{
+    HandleBase *b = reinterpret_cast<HandleBase *>(h);
+    if (!b || b->kind != kind) return nullptr;
+    return static_cast<H *>(b);
+}
+
+// Stage a host vector into workspace slot 0 behind kHeadroomBytes of headroom.
+static int stage_in(const void *x_host, size_t bytes, void **x_dev)
+{
+    void *base = nullptr;
+    int rc = ws_reserve(0, kHeadroomBytes + round_up(bytes, 256) + 256, &base);
+    if (rc) return rc;
+    *x_dev = (char *)base + kHeadroomBytes;
+    if (bytes) SK_HIP(hipMemcpyAsync(*x_dev, x_host, bytes, hipMemcpyHostToDevice, ctx().stream));
+    return SKDSP_OK;
+}
+
+static int stage_out(void *y_host, const void *y_dev, size_t bytes)
+{
+    if (bytes) SK_HIP(hipMemcpyAsync(y_host, y_dev, bytes, hipMemcpyDeviceToHost, ctx().stream));
+    SK_HIP(hipStreamSynchronize(ctx().stream));
+    return SKDSP_OK;
+}
+
+// IIR on an interleaved-or-real device vector (handles the complex -> 2 planes detour).
+// tmp slot 3 holds the planes.  y may alias x.
+static int iir_any_dev(IirHandle *h, const void *x_dev, int64_t n, void *y_dev)
+{
+    hipStream_t s = ctx().stream;
+    if (n <= 0) return SKDSP_OK;
+    if (!dtype_complex(h->dtype)) return iir_launch_planar(h, x_dev, n, 1, 0, y_dev, s);
+    const size_t rsz = dtype_double(h->dtype) ? 8 : 4;
+    const int64_t stride = (int64_t)round_up((size_t)n, 64);
+    void *planes = nullptr;
+    int rc = ws_reserve(3, (size_t)2 * stride * rsz, &planes);
+    if (rc) return rc;
+    void *re = planes, *im = (char *)planes + (size_t)stride * rsz;
+    if ((rc = deinterleave_launch(x_dev, n, h->dtype, re, im, s))) return rc;
+    if ((rc = iir_launch_planar(h, planes, n, 2, stride, planes, s))) return rc;
+    return interleave_launch(re, im, n, h->dtype, y_dev, s);
+}
+
+}  // namespace skdsp
+
+using namespace skdsp;
+
+#define API_BEGIN                        \
+    {                                    \
+        int _rc = ensure_init();         \
+        if (_rc) return _rc;             \
+    }                                    \
+    std::lock_guard<std::mutex> _ctxlk(ctx().mu)
+
+extern "C" {
+
+const char *skdsp_last_error(void) { return g_err; }
+const char *skdsp_version(void) { return "skdsp-hip 0.1.0 (gfx950)"; }
+
+int skdsp_init(int device)
+{
+    std::lock_guard<std::mutex> lk(ctx().mu);
+    return init_locked(device);
+}
+
+int skdsp_shutdown(void)
+{
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.ready) return SKDSP_OK;
+    (void)hipStreamSynchronize(c.stream);
+    for (int i = 0; i < 4; ++i) {
+        if (c.ws[i]) (void)hipFree(c.ws[i]);
+        c.ws[i] = nullptr;
+        c.ws_bytes[i] = 0;
+    }
+    (void)hipEventDestroy(c.ev_start);
+    (void)hipEventDestroy(c.ev_stop);
+    (void)hipStreamDestroy(c.stream);
+    c.ready = false;
+    c.device = -1;
+    return SKDSP_OK;
+}
+
+int skdsp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int skdsp_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes, int *clock_khz)
+{
+    API_BEGIN;
+    hipDeviceProp_t prop;
+    SK_HIP(hipGetDeviceProperties(&prop, ctx().device));
+    if (name && name_cap > 0) {
+        snprintf(name, (size_t)name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    return SKDSP_OK;
+}
+
+int skdsp_malloc(void **dptr, int64_t bytes)
+{
+    API_BEGIN;
+    SK_CHECK(dptr && bytes >= 0, SKDSP_ERR_BADARG, "skdsp_malloc: bad arguments");
+    SK_HIP(hipMalloc(dptr, (size_t)(bytes > 0 ? bytes : 1)));
+    return SKDSP_OK;
+}
+int skdsp_free(void *dptr)
+{
+    API_BEGIN;
+    if (dptr) {
+        SK_HIP(hipStreamSynchronize(ctx().stream));
+        SK_HIP(hipFree(dptr));
+    }
+    return SKDSP_OK;
+}
+int skdsp_memcpy_h2d(void *dst, const void *src, int64_t bytes)
+{
+    API_BEGIN;
+    if (bytes > 0) SK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx().stream));
+    SK_HIP(hipStreamSynchronize(ctx().stream));
+    return SKDSP_OK;
+}
+int skdsp_memcpy_d2h(void *dst, const void *src, int64_t bytes)
+{
+    API_BEGIN;
+    if (bytes > 0) SK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx().stream));
+    SK_HIP(hipStreamSynchronize(ctx().stream));
+    return SKDSP_OK;
+}
+int skdsp_memcpy_d2d(void *dst, const void *src, int64_t bytes)
+{
+    API_BEGIN;
+    if (bytes > 0) SK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx().stream));
+    return SKDSP_OK;
+}
+int skdsp_memset(void *dst, int value, int64_t bytes)
+{
+    API_BEGIN;
+    if (bytes > 0) SK_HIP(hipMemsetAsync(dst, value, (size_t)bytes, ctx().stream));
+    return SKDSP_OK;
+}
+int skdsp_sync(void)
+{
+    API_BEGIN;
+    SK_HIP(hipStreamSynchronize(ctx().stream));
+    return SKDSP_OK;
+}
+int skdsp_timer_start(void)
+{
+    API_BEGIN;
+    SK_HIP(hipEventRecord(ctx().ev_start, ctx().stream));
+    return SKDSP_OK;
+}
+int skdsp_timer_stop(float *ms)
+{
+    API_BEGIN;
+    SK_HIP(hipEventRecord(ctx().ev_stop, ctx().stream));
+    SK_HIP(hipEventSynchronize(ctx().ev_stop));
+    float t = 0.f;
+    SK_HIP(hipEventElapsedTime(&t, ctx().ev_start, ctx().ev_stop));
+    if (ms) *ms = t;
+    return SKDSP_OK;
+}
+int skdsp_fill_noise_dev(void *x_dev, int64_t n, int dtype, uint64_t seed, int64_t first_index)
+{
+    API_BEGIN;
+    SK_CHECK(dtype_valid(dtype), SKDSP_ERR_BADARG, "fill_noise: bad dtype %d", dtype);
+    return fill_noise_launch(x_dev, n, dtype, seed, first_index, ctx().stream);
+}
+
+// ------------------------------------------------------------------------ FIR
+int skdsp_fir_create(const void *taps, int ntaps, int taps_complex, int dtype, skdsp_handle *out)
+{
+    API_BEGIN;
+    SK_CHECK(out, SKDSP_ERR_BADARG, "fir_create: null out");
+    SK_CHECK(taps && ntaps >= 1, SKDSP_ERR_BADARG, "fir_create: need at least one tap");
+    SK_CHECK(dtype_valid(dtype), SKDSP_ERR_BADARG, "fir_create: bad dtype %d", dtype);
+    SK_CHECK(!(taps_complex && !dtype_complex(dtype)), SKDSP_ERR_BADARG,
+             "fir_create: complex taps need a complex signal dtype");
+    std::unique_ptr<FirHandle> h(new FirHandle());
+    h->kind = H_FIR;
+    h->dtype = dtype;
+    h->ntaps = ntaps;
+    h->taps_complex = taps_complex != 0;
+    const int comp = taps_complex ? 2 : 1;
+    h->taps_host.assign((const double *)taps, (const double *)taps + (size_t)ntaps * comp);
+    *out = h.release();
+    return SKDSP_OK;
+}
+
+int skdsp_fir_set_algo(skdsp_handle hh, int algo)
+{
+    FirHandle *h = as_handle<FirHandle>(hh, H_FIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "fir_set_algo: not a FIR handle");
+    SK_CHECK(algo >= SKDSP_FIR_AUTO && algo <= SKDSP_FIR_OLS, SKDSP_ERR_BADARG, "fir_set_algo: bad algo %d", algo);
+    h->algo = algo;
+    return SKDSP_OK;
+}
+
+int skdsp_fir_get_algo(skdsp_handle hh, int64_t n, int *algo_used)
+{
+    FirHandle *h = as_handle<FirHandle>(hh, H_FIR);
+    SK_CHECK(h && algo_used, SKDSP_ERR_BADARG, "fir_get_algo: bad arguments");
+    *algo_used = pick_fir_algo(h, n);
+    return SKDSP_OK;
+}
+
+int skdsp_fir_filter_dev(skdsp_handle hh, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev)
+{
+    API_BEGIN;
+    FirHandle *h = as_handle<FirHandle>(hh, H_FIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "fir_filter: not a FIR handle");
+    SK_CHECK(n >= 0 && n_hist >= 0, SKDSP_ERR_BADARG, "fir_filter: negative length");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return fir_filter_any(h, x_dev, n, n_hist, y_dev);
+}
+
+int skdsp_fir_up_dev(skdsp_handle hh, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev)
+{
+    API_BEGIN;
+    FirHandle *h = as_handle<FirHandle>(hh, H_FIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "fir_up: not a FIR handle");
+    SK_CHECK(L >= 1, SKDSP_ERR_BADARG, "fir_up: L must be >= 1");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return fir_direct_launch(h, x_dev, n, n_hist, L, 1, n * L, y_dev, ctx().stream);
+}
+
+int skdsp_fir_dn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev)
+{
+    API_BEGIN;
+    FirHandle *h = as_handle<FirHandle>(hh, H_FIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "fir_dn: not a FIR handle");
+    SK_CHECK(M >= 1, SKDSP_ERR_BADARG, "fir_dn: M must be >= 1");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return fir_direct_launch(h, x_dev, n, n_hist, 1, M, n / M, y_dev, ctx().stream);
+}
+
+int skdsp_fir_updn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev)
+{
+    API_BEGIN;
+    FirHandle *h = as_handle<FirHandle>(hh, H_FIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "fir_updn: not a FIR handle");
+    SK_CHECK(L >= 1 && M >= 1, SKDSP_ERR_BADARG, "fir_updn: L, M must be >= 1");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return fir_direct_launch(h, x_dev, n, n_hist, L, M, (n * L) / M, y_dev, ctx().stream);
+}
+
+static int fir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M, int mode, void *y)
+{
+    API_BEGIN;
+    FirHandle *h = as_handle<FirHandle>(hh, H_FIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "fir: not a FIR handle");
+    SK_CHECK(n >= 0 && L >= 1 && M >= 1, SKDSP_ERR_BADARG, "fir: bad arguments (n=%lld L=%d M=%d)", (long long)n, L, M);
+    SK_CHECK(n == 0 || (x && y), SKDSP_ERR_BADARG, "fir: null buffer");
+    const size_t esz = dtype_size(h->dtype);
+    const int64_t n_out = mode == 0 ? n : (n * L) / M;
+    if (n_out == 0) return SKDSP_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    void *x_dev = nullptr, *y_dev = nullptr;
+    int rc = stage_in(x, (size_t)n * esz, &x_dev);
+    if (rc) return rc;
+    if ((rc = ws_reserve(1, (size_t)n_out * esz + 256, &y_dev))) return rc;
+    if (mode == 0) rc = fir_filter_any(h, x_dev, n, 0, y_dev);
+    else rc = fir_direct_launch(h, x_dev, n, 0, L, M, n_out, y_dev, ctx().stream);
+    if (rc) return rc;
+    return stage_out(y, y_dev, (size_t)n_out * esz);
+}
+
+int skdsp_fir_filter(skdsp_handle h, const void *x, int64_t n, void *y) { return fir_host_call(h, x, n, 1, 1, 0, y); }
+int skdsp_fir_up(skdsp_handle h, const void *x, int64_t n, int L, void *y) { return fir_host_call(h, x, n, L, 1, 1, y); }
+int skdsp_fir_dn(skdsp_handle h, const void *x, int64_t n, int M, void *y) { return fir_host_call(h, x, n, 1, M, 1, y); }
+int skdsp_fir_updn(skdsp_handle h, const void *x, int64_t n, int L, int M, void *y) { return fir_host_call(h, x, n, L, M, 1, y); }
+
+// ------------------------------------------------------------------------ IIR
+static int iir_create_common(int nsec, int order, const std::vector<double> &coef, int dtype, skdsp_handle *out)
+{
+    SK_CHECK(out, SKDSP_ERR_BADARG, "iir_create: null out");
+    SK_CHECK(dtype_valid(dtype), SKDSP_ERR_BADARG, "iir_create: bad dtype %d", dtype);
+    SK_CHECK(iir_shape_supported(nsec, order), SKDSP_ERR_UNSUPPORTED,
+             "iir_create: %d sections of order %d not supported (SOS: 1..12 sections; (b,a): order 1..12)", nsec, order);
+    std::unique_ptr<IirHandle> h(new IirHandle());
+    h->kind = H_IIR;
+    h->dtype = dtype;
+    h->nsec = nsec;
+    h->order = order;
+    h->coef = coef;
+    *out = h.release();
+    return SKDSP_OK;
+}
+
+int skdsp_sos_create(const double *sos, int nsec, int dtype, skdsp_handle *out)
+{
+    API_BEGIN;
+    SK_CHECK(sos && nsec >= 1, SKDSP_ERR_BADARG, "sos_create: sos array must be shape (n_sections, 6)");
+    std::vector<double> coef((size_t)nsec * 5);
+    for (int s = 0; s < nsec; ++s) {
+        const double *q = sos + 6 * s;
+        SK_CHECK(q[3] == 1.0, SKDSP_ERR_BADARG, "sos[:, 3] should be all ones");
+        double *c = coef.data() + 5 * s;
+        c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; c[3] = q[4]; c[4] = q[5];
+    }
+    return iir_create_common(nsec, 2, coef, dtype, out);
+}
+
+int skdsp_tf_create(const double *b, int nb, const double *a, int na, int dtype, skdsp_handle *out)
+{
+    API_BEGIN;
+    SK_CHECK(b && a && nb >= 1 && na >= 1, SKDSP_ERR_BADARG, "tf_create: need b and a");
+    SK_CHECK(a[0] != 0.0, SKDSP_ERR_BADARG, "tf_create: a[0] must be nonzero");
+    const int K = nb > na ? nb : na;
+    SK_CHECK(K >= 2, SKDSP_ERR_BADARG, "tf_create: order-0 system: use a FIR handle");
+    const int order = K - 1;
+    std::vector<double> coef((size_t)2 * order + 1, 0.0);
+    for (int k = 0; k <= order; ++k) coef[k] = (k < nb ? b[k] : 0.0) / a[0];
+    for (int k = 1; k <= order; ++k) coef[order + k] = (k < na ? a[k] : 0.0) / a[0];
+    return iir_create_common(1, order, coef, dtype, out);
+}
+
+int skdsp_iir_filter_dev(skdsp_handle hh, const void *x_dev, int64_t n, void *y_dev)
+{
+    API_BEGIN;
+    IirHandle *h = as_handle<IirHandle>(hh, H_IIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "iir_filter: not an IIR handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return iir_any_dev(h, x_dev, n, y_dev);
+}
+
+int skdsp_iir_up_dev(skdsp_handle hh, const void *x_dev, int64_t n, int L, void *y_dev)
+{
+    API_BEGIN;
+    IirHandle *h = as_handle<IirHandle>(hh, H_IIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "iir_up: not an IIR handle");
+    SK_CHECK(L >= 1, SKDSP_ERR_BADARG, "iir_up: L must be >= 1");
+    std::lock_guard<std::mutex> lk(h->mu);
+    // y = filter(L * upsample(x, L)): zero-stuff straight into y, then filter in place
+    int rc = upsample_launch(x_dev, n, L, h->dtype, (double)L, y_dev, ctx().stream);
+    if (rc) return rc;
+    return iir_any_dev(h, y_dev, n * L, y_dev);
+}
+
+int skdsp_iir_dn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int M, void *y_dev)
+{
+    API_BEGIN;
+    IirHandle *h = as_handle<IirHandle>(hh, H_IIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "iir_dn: not an IIR handle");
+    SK_CHECK(M >= 1, SKDSP_ERR_BADARG, "iir_dn: M must be >= 1");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (n <= 0) return SKDSP_OK;
+    void *full = nullptr;
+    int rc = ws_reserve(2, (size_t)n * dtype_size(h->dtype) + 256, &full);
+    if (rc) return rc;
+    if ((rc = iir_any_dev(h, x_dev, n, full))) return rc;
+    return downsample_launch(full, n, M, 0, h->dtype, y_dev, ctx().stream);
+}
+
+static int iir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M, void *y)
+{
+    API_BEGIN;
+    IirHandle *h = as_handle<IirHandle>(hh, H_IIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "iir: not an IIR handle");
+    SK_CHECK(n >= 0 && L >= 1 && M >= 1, SKDSP_ERR_BADARG, "iir: bad arguments");
+    SK_CHECK(n == 0 || (x && y), SKDSP_ERR_BADARG, "iir: null buffer");
+    const size_t esz = dtype_size(h->dtype);
+    const int64_t n_out = (n * L) / M;
+    if (n_out == 0) return SKDSP_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    void *x_dev = nullptr, *y_dev = nullptr;
+    int rc = stage_in(x, (size_t)n * esz, &x_dev);
+    if (rc) return rc;
+    hipStream_t s = ctx().stream;
+    if (L > 1) {
+        if ((rc = ws_reserve(1, (size_t)n * L * esz + 256, &y_dev))) return rc;
+        if ((rc = upsample_launch(x_dev, n, L, h->dtype, (double)L, y_dev, s))) return rc;
+        if ((rc = iir_any_dev(h, y_dev, n * L, y_dev))) return rc;
+    } else if (M > 1) {
+        void *full = nullptr;
+        if ((rc = ws_reserve(2, (size_t)n * esz + 256, &full))) return rc;
+        if ((rc = ws_reserve(1, (size_t)n_out * esz + 256, &y_dev))) return rc;
+        if ((rc = iir_any_dev(h, x_dev, n, full))) return rc;
+        if ((rc = downsample_launch(full, n, M, 0, h->dtype, y_dev, s))) return rc;
+    } else {
+        if ((rc = ws_reserve(1, (size_t)n * esz + 256, &y_dev))) return rc;
+        if ((rc = iir_any_dev(h, x_dev, n, y_dev))) return rc;
+    }
+    return stage_out(y, y_dev, (size_t)n_out * esz);
+}
+
+int skdsp_iir_filter(skdsp_handle h, const void *x, int64_t n, void *y) { return iir_host_call(h, x, n, 1, 1, y); }
+int skdsp_iir_up(skdsp_handle h, const void *x, int64_t n, int L, void *y) { return iir_host_call(h, x, n, L, 1, y); }
+int skdsp_iir_dn(skdsp_handle h, const void *x, int64_t n, int M, void *y) { return iir_host_call(h, x, n, 1, M, y); }
+
+// ---------------------------------------------------------------- resamplers
+int skdsp_upsample_dev(const void *x_dev, int64_t n, int L, int dtype, double scale, void *y_dev)
+{
+    API_BEGIN;
+    SK_CHECK(dtype_valid(dtype), SKDSP_ERR_BADARG, "upsample: bad dtype %d", dtype);
+    return upsample_launch(x_dev, n, L, dtype, scale, y_dev, ctx().stream);
+}
+
+int skdsp_downsample_dev(const void *x_dev, int64_t n, int M, int p, int dtype, void *y_dev)
+{
+    API_BEGIN;
+    SK_CHECK(dtype_valid(dtype), SKDSP_ERR_BADARG, "downsample: bad dtype %d", dtype);
+    return downsample_launch(x_dev, n, M, p, dtype, y_dev, ctx().stream);
+}
+
+int skdsp_upsample(const void *x, int64_t n, int L, int dtype, void *y)
+{
+    API_BEGIN;
+    SK_CHECK(dtype_valid(dtype) && n >= 0 && L >= 1, SKDSP_ERR_BADARG, "upsample: bad arguments");
+    if (n == 0) return SKDSP_OK;
+    const size_t esz = dtype_size(dtype);
+    void *x_dev = nullptr, *y_dev = nullptr;
+    int rc = stage_in(x, (size_t)n * esz, &x_dev);
+    if (rc) return rc;
+    if ((rc = ws_reserve(1, (size_t)n * L * esz + 256, &y_dev))) return rc;
+    if ((rc = upsample_launch(x_dev, n, L, dtype, 1.0, y_dev, ctx().stream))) return rc;
+    return stage_out(y, y_dev, (size_t)n * L * esz);
+}
+
+int skdsp_downsample(const void *x, int64_t n, int M, int p, int dtype, void *y)
+{
+    API_BEGIN;
+    SK_CHECK(dtype_valid(dtype) && n >= 0 && M >= 1, SKDSP_ERR_BADARG, "downsample: bad arguments");
+    SK_CHECK(p >= 0 && p < M, SKDSP_ERR_BADARG, "downsample: phase p=%d out of range for M=%d", p, M);
+    const int64_t n_out = n / M;
+    if (n_out == 0) return SKDSP_OK;
+    const size_t esz = dtype_size(dtype);
+    void *x_dev = nullptr, *y_dev = nullptr;
+    int rc = stage_in(x, (size_t)n * esz, &x_dev);
+    if (rc) return rc;
+    if ((rc = ws_reserve(1, (size_t)n_out * esz + 256, &y_dev))) return rc;
+    if ((rc = downsample_launch(x_dev, n, M, p, dtype, y_dev, ctx().stream))) return rc;
+    return stage_out(y, y_dev, (size_t)n_out * esz);
+}
+
+int skdsp_destroy(skdsp_handle hh)
+{
+    if (!hh) return SKDSP_OK;
+    HandleBase *b = reinterpret_cast<HandleBase *>(hh);
+    if (ctx().ready) {
+        std::lock_guard<std::mutex> lk(ctx().mu);
+        (void)hipStreamSynchronize(ctx().stream);
+        delete b;
+    } else {
+        delete b;
+    }
+    return SKDSP_OK;
+}
+
+}  // extern "C"

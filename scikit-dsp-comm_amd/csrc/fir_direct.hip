@@ -1,0 +1,235 @@
+// fir_direct.hip -- direct-form / polyphase FIR for gfx950 (MI355X).
+//
+// One kernel family serves every time-domain FIR entry of the path:
+//   .filter  y[n] = sum_k b[k] x[n-k]                      multirate_helper.py:104-109
+//   .up      y    = lfilter(b,[1], L*upsample(x,L))         multirate_helper.py:112-118
+//   .dn      y    = downsample(lfilter(b,[1],x), M)         multirate_helper.py:121-127
+//   updn     y    = downsample(.up(x,L), M)                 (BASELINE.json config 3)
+// through the polyphase identity: with j = m*M,
+//   y[m] = L * sum_t b[(j mod L) + L t] * x[(j div L) - t]
+// so zero-stuffed samples are never materialised and discarded outputs are never
+// computed.  Outputs are grouped in classes c = m mod L' (L' = L/gcd(L,M)): within a
+// class the tap phase is fixed and the input index advances by q = M/gcd(L,M) per
+// output, so a whole wave uses ONE tap per step (scalar load, SGPR operand) and reads
+// a stride-q run of the LDS-staged input window.
+//
+// Layout: a 256-thread workgroup stages the input window
+//   [q*s0 - (T-1), q*(s0 + s_tile) + q)   (T = ceil(P/L) taps per phase)
+// once into LDS with coalesced loads (zero-filled outside [-n_hist, n)), then loops
+// over the L' classes; each thread keeps R accumulators (outputs s = s0 + tid + 256 r).
+// Accumulation is in the signal precision (f32 / f64), taps applied in k order.
+//
+// Roofline note: this kernel is FP32-VALU/LDS bound for long filters (4*P flop per
+// c64 sample); long .filter calls go to fir_ols.hip instead.  It is the HBM-bound
+// choice only for short filters.
+#include "skdsp_internal.hpp"
+#include <cstring>
+#include <numeric>
+
+namespace skdsp {
+
+// ------------------------------------------------------------------ arithmetic
+__device__ inline void mac(float &a, float b, float x) { a = fmaf(b, x, a); }
+__device__ inline void mac(double &a, double b, double x) { a = fma(b, x, a); }
+__device__ inline void mac(float2 &a, float b, float2 x) { a.x = fmaf(b, x.x, a.x); a.y = fmaf(b, x.y, a.y); }
+__device__ inline void mac(double2 &a, double b, double2 x) { a.x = fma(b, x.x, a.x); a.y = fma(b, x.y, a.y); }
+__device__ inline void mac(float2 &a, float2 b, float2 x)
+{
+    a.x = fmaf(b.x, x.x, a.x); a.x = fmaf(-b.y, x.y, a.x);
+    a.y = fmaf(b.x, x.y, a.y); a.y = fmaf(b.y, x.x, a.y);
+}
+__device__ inline void mac(double2 &a, double2 b, double2 x)
+{
+    a.x = fma(b.x, x.x, a.x); a.x = fma(-b.y, x.y, a.x);
+    a.y = fma(b.x, x.y, a.y); a.y = fma(b.y, x.x, a.y);
+}
+template <typename X> __device__ inline X zero_of();
+template <> __device__ inline float zero_of<float>() { return 0.f; }
+template <> __device__ inline double zero_of<double>() { return 0.; }
+template <> __device__ inline float2 zero_of<float2>() { return make_float2(0.f, 0.f); }
+template <> __device__ inline double2 zero_of<double2>() { return make_double2(0., 0.); }
+__device__ inline float scl(float a, float s) { return a * s; }
+__device__ inline double scl(double a, double s) { return a * s; }
+__device__ inline float2 scl(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+__device__ inline double2 scl(double2 a, double s) { return make_double2(a.x * s, a.y * s); }
+
+template <typename X> struct ScalarOf { using type = float; };
+template <> struct ScalarOf<double> { using type = double; };
+template <> struct ScalarOf<double2> { using type = double; };
+
+struct PolyArgs {
+    int64_t n;        // input samples
+    int64_t n_hist;   // valid samples before x[0]
+    int64_t n_out;    // total outputs
+    int64_t n_s;      // outputs per class (max over classes)
+    int T;            // taps per phase
+    int L, M;
+    int Lp;           // classes  L' = L / gcd(L,M)
+    int q;            // input stride per output within a class
+    int s_tile;       // outputs per class per workgroup (<= 256*R)
+    int win;          // staged window length in samples
+};
+
+template <typename X, typename B, int R>
+__global__ __launch_bounds__(256) void fir_poly_kernel(const X *__restrict__ x, const B *__restrict__ bank, PolyArgs a,
+                                                       X *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    X *win = reinterpret_cast<X *>(smem_raw);
+    using S = typename ScalarOf<X>::type;
+
+    const int tid = threadIdx.x;
+    const int64_t s0 = (int64_t)blockIdx.x * a.s_tile;
+    const int64_t w0 = (int64_t)a.q * s0 - (a.T - 1);  // global input index of win[0]
+
+    // ---- stage the window (coalesced; zero outside [-n_hist, n)) ----
+    for (int i = tid; i < a.win; i += 256) {
+        const int64_t g = w0 + i;
+        X v = zero_of<X>();
+        if (g >= -a.n_hist && g < a.n) v = x[g];
+        win[i] = v;
+    }
+    __syncthreads();
+
+    const S gain = (S)a.L;
+    for (int c = 0; c < a.Lp; ++c) {
+        const int64_t cm = (int64_t)c * a.M;
+        const int phi = (int)(cm % a.L);
+        const int ic = (int)(cm / a.L);
+        const B *__restrict__ bp = bank + (size_t)phi * a.T;
+        X acc[R];
+        int off[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[r] = zero_of<X>();
+            // window offset of x[i_c + q*s] for this thread's r-th output, tap 0
+            off[r] = ic + a.q * (tid + 256 * r) + (a.T - 1);
+            if (tid + 256 * r >= a.s_tile) off[r] = a.T - 1;  // idle slot: stay in range
+        }
+        int t = 0;
+        for (; t + 4 <= a.T; t += 4) {
+            const B b0 = bp[t], b1 = bp[t + 1], b2 = bp[t + 2], b3 = bp[t + 3];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const X *p = win + off[r] - t;
+                mac(acc[r], b0, p[0]);
+                mac(acc[r], b1, p[-1]);
+                mac(acc[r], b2, p[-2]);
+                mac(acc[r], b3, p[-3]);
+            }
+        }
+        for (; t < a.T; ++t) {
+            const B b0 = bp[t];
+#pragma unroll
+            for (int r = 0; r < R; ++r) mac(acc[r], b0, win[off[r] - t]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int sl = tid + 256 * r;
+            const int64_t m = (int64_t)c + (int64_t)a.Lp * (s0 + sl);
+            if (sl < a.s_tile && m < a.n_out) y[m] = (a.L == 1) ? acc[r] : scl(acc[r], gain);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+FirHandle::~FirHandle()
+{
+    if (taps_dev) (void)hipFree(taps_dev);
+    for (auto &p : poly) if (p.dev) (void)hipFree(p.dev);
+    if (ols) fir_ols_free(ols);
+}
+
+// polyphase bank for interpolation factor L in the compute precision
+static int get_bank(FirHandle *h, int L, void **dev, int *T_out)
+{
+    for (auto &p : h->poly)
+        if (p.L == L) { *dev = p.dev; *T_out = p.T; return SKDSP_OK; }
+    const int P = h->ntaps;
+    const int T = (P + L - 1) / L;
+    const bool dbl = dtype_double(h->dtype);
+    const int comp = h->taps_complex ? 2 : 1;
+    const size_t esz = (dbl ? 8 : 4) * comp;
+    std::vector<char> host((size_t)L * T * esz, 0);
+    for (int phi = 0; phi < L; ++phi)
+        for (int t = 0; t < T; ++t) {
+            const int k = phi + L * t;
+            if (k >= P) continue;
+            for (int cc = 0; cc < comp; ++cc) {
+                const double v = h->taps_host[(size_t)k * comp + cc];
+                const size_t idx = ((size_t)phi * T + t) * comp + cc;
+                if (dbl) reinterpret_cast<double *>(host.data())[idx] = v;
+                else reinterpret_cast<float *>(host.data())[idx] = (float)v;
+            }
+        }
+    void *d = nullptr;
+    SK_HIP(hipMalloc(&d, host.size()));
+    SK_HIP(hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
+    h->poly.push_back({L, T, d});
+    *dev = d;
+    *T_out = T;
+    return SKDSP_OK;
+}
+
+template <typename X, typename B>
+static int launch_typed(const X *x, const B *bank, const PolyArgs &a, int R, int nblocks, size_t lds, X *y, hipStream_t s)
+{
+    switch (R) {
+    case 1: hipLaunchKernelGGL((fir_poly_kernel<X, B, 1>), dim3(nblocks), dim3(256), lds, s, x, bank, a, y); break;
+    case 2: hipLaunchKernelGGL((fir_poly_kernel<X, B, 2>), dim3(nblocks), dim3(256), lds, s, x, bank, a, y); break;
+    default: hipLaunchKernelGGL((fir_poly_kernel<X, B, 4>), dim3(nblocks), dim3(256), lds, s, x, bank, a, y); break;
+    }
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, int M, int64_t n_out, void *y,
+                      hipStream_t s)
+{
+    SK_CHECK(L >= 1 && M >= 1, SKDSP_ERR_BADARG, "fir: L and M must be >= 1 (L=%d M=%d)", L, M);
+    if (n_out <= 0) return SKDSP_OK;
+    SK_CHECK(!(h->taps_complex && !dtype_complex(h->dtype)), SKDSP_ERR_BADARG,
+             "fir: complex taps need a complex signal dtype (promote x first)");
+    void *bank = nullptr;
+    int T = 0;
+    int rc = get_bank(h, L, &bank, &T);
+    if (rc) return rc;
+
+    const int g = std::gcd(L, M);
+    PolyArgs a;
+    a.n = n; a.n_hist = n_hist; a.n_out = n_out;
+    a.T = T; a.L = L; a.M = M; a.Lp = L / g; a.q = M / g;
+    a.n_s = (n_out + a.Lp - 1) / a.Lp;
+
+    const size_t esz = dtype_size(h->dtype);
+    const size_t lds_cap = 64 * 1024;  // <= 2 workgroups per CU of the 160 KiB LDS
+    const int64_t cap_elems = (int64_t)(lds_cap / esz);
+    // window = q*s_tile + T + q  <=  cap_elems
+    int64_t s_tile = (cap_elems - T - a.q) / a.q;
+    SK_CHECK(s_tile >= 1, SKDSP_ERR_UNSUPPORTED,
+             "fir_direct: %d taps/phase with stride %d do not fit the 64 KiB LDS window", T, a.q);
+    int R = 4;
+    if (s_tile > 1024) s_tile = 1024;
+    if (a.n_s < s_tile) s_tile = a.n_s;
+    if (s_tile <= 256) R = 1; else if (s_tile <= 512) R = 2;
+    // spread small problems over more workgroups
+    while (R > 1 && (a.n_s + s_tile - 1) / s_tile < 2 * ctx().num_cus) { R >>= 1; s_tile = (s_tile > 256 * R) ? 256 * R : s_tile; }
+    a.s_tile = (int)s_tile;
+    a.win = (int)(a.q * s_tile + T + a.q);
+    const size_t lds = (size_t)a.win * esz;
+    const int nblocks = (int)((a.n_s + s_tile - 1) / s_tile);
+
+    switch (h->dtype) {
+    case SKDSP_F32: return launch_typed((const float *)x, (const float *)bank, a, R, nblocks, lds, (float *)y, s);
+    case SKDSP_F64: return launch_typed((const double *)x, (const double *)bank, a, R, nblocks, lds, (double *)y, s);
+    case SKDSP_C64:
+        if (h->taps_complex) return launch_typed((const float2 *)x, (const float2 *)bank, a, R, nblocks, lds, (float2 *)y, s);
+        return launch_typed((const float2 *)x, (const float *)bank, a, R, nblocks, lds, (float2 *)y, s);
+    case SKDSP_C128:
+        if (h->taps_complex) return launch_typed((const double2 *)x, (const double2 *)bank, a, R, nblocks, lds, (double2 *)y, s);
+        return launch_typed((const double2 *)x, (const double *)bank, a, R, nblocks, lds, (double2 *)y, s);
+    }
+    SK_CHECK(false, SKDSP_ERR_BADARG, "fir: bad dtype %d", h->dtype);
+}
+
+}  // namespace skdsp

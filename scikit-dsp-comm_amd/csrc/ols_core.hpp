@@ -1,0 +1,297 @@
+// ols_core.hpp -- register-resident FFT building blocks and the per-thread phases of
+// the 8192-point overlap-save tile (fir_ols.hip).  Written so that the SAME code
+// compiles for the device (hipcc, gfx950) and for the host (g++, used by
+// tests/host/ols_emul.cpp to check the index algebra without a GPU).
+//
+// Tile: N = 8192 complex64 points held by 256 threads x 32 points, factored
+//   N = 16 (stride 512)  x  16 (stride 32 inside 512)  x  32
+// forward = decimation in frequency, inverse = the exact mirror (decimation in time),
+// so no bit-reversal pass exists anywhere: the spectrum lives in a scrambled,
+// thread-major order and H is stored pre-permuted to match.
+//
+//   n = 512 a + rho,   rho = 32 b + c,   c = 2 q + e        (a,b,q in [0,16), e in {0,1})
+//   k = k1 + 16 k2 + 256 k3                                 (k1,k2 in [0,16), k3 in [0,32))
+//
+//   pass 1  thread (b,q)  : DFT16 over a  -> k1, times W_8192^(rho k1)
+//   xchg 1  (k1,b,q,e) : thread (b,q) -> thread (k1,q)      [workgroup-wide, one barrier]
+//   pass 2  thread (k1,q) : DFT16 over b  -> k2, times W_512^(c k2)
+//   xchg 2  (k1,k2,q,e): thread (k1,q) -> thread (k1,k2)    [inside 16-lane groups: wave-local]
+//   pass 3  thread (k1,k2): DFT32 over c  -> k3
+//   multiply by H (pre-permuted, 1/N folded in), then the mirror image back to (b,q).
+//
+// LDS image: 16 rows (k1) x 16 x 17 float4 (one float4 = the e=0/e=1 pair); the +1
+// pad makes every ds_read_b128 / ds_write_b128 pattern used below bank-conflict free
+// (MI355X: 64 banks x 4 B, b128 serviced in 16-lane groups).
+#pragma once
+
+#include <type_traits>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SK_HD __host__ __device__ __forceinline__
+#define SK_UNROLL _Pragma("unroll")
+#else
+#include <cmath>
+#define SK_UNROLL
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+#define SK_HD inline
+#endif
+
+namespace skdsp {
+namespace ols {
+
+typedef float2 cf;
+
+constexpr int kN = 8192;
+constexpr int kThreads = 256;
+constexpr int kRowPitch = 272;             // float4 units per k1 row (16 x 17)
+constexpr int kLdsUnits = 16 * kRowPitch;  // 4352 float4 = 69632 B
+
+// cos/sin(2 pi k / 32), k = 0..31, rounded from float64
+#define SK_C32                                                                                             \
+    {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f,        \
+     0.55557023301960229f, 0.38268343236508984f, 0.19509032201612833f, 0.0f, -0.19509032201612819f,       \
+     -0.38268343236508973f, -0.55557023301960196f, -0.70710678118654746f, -0.83146961230254535f,           \
+     -0.92387953251128674f, -0.98078528040323043f, -1.0f, -0.98078528040323043f, -0.92387953251128685f,    \
+     -0.83146961230254546f, -0.70710678118654768f, -0.55557023301960218f, -0.38268343236509034f,           \
+     -0.19509032201612866f, 0.0f, 0.19509032201612828f, 0.38268343236509f, 0.55557023301960184f,           \
+     0.70710678118654735f, 0.83146961230254524f, 0.92387953251128652f, 0.98078528040323032f}
+#define SK_S32                                                                                             \
+    {0.0f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f,         \
+     0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f, 1.0f, 0.98078528040323043f,         \
+     0.92387953251128674f, 0.83146961230254546f, 0.70710678118654757f, 0.55557023301960218f,               \
+     0.38268343236508989f, 0.19509032201612861f, 0.0f, -0.19509032201612836f, -0.38268343236508967f,       \
+     -0.55557023301960196f, -0.70710678118654746f, -0.83146961230254524f, -0.92387953251128652f,           \
+     -0.98078528040323032f, -1.0f, -0.98078528040323043f, -0.92387953251128663f, -0.83146961230254546f,    \
+     -0.70710678118654768f, -0.55557023301960218f, -0.38268343236509039f, -0.19509032201612872f}
+
+SK_HD cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+SK_HD cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+// a * b
+SK_HD cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// a * conj(b)
+SK_HD cf cmulc(cf a, cf b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+template <bool INV> SK_HD cf cmul_dir(cf a, cf w) { return INV ? cmulc(a, w) : cmul(a, w); }
+// a * (-i) forward, a * (+i) inverse
+template <bool INV> SK_HD cf mul_mi(cf a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+
+// a * W_N^K  (forward, W = exp(-2 pi i / N)) or a * conj(W_N^K) (INV); K compile-time
+template <int N, int K, bool INV> SK_HD cf twmul(cf a)
+{
+    constexpr int k32 = ((K % N) * (32 / N)) & 31;
+    constexpr float C[32] = SK_C32;
+    constexpr float S[32] = SK_S32;
+    if constexpr (k32 == 0) return a;
+    else if constexpr (k32 == 8) return mul_mi<INV>(a);
+    else if constexpr (k32 == 16) return make_float2(-a.x, -a.y);
+    else if constexpr (k32 == 24) return mul_mi<!INV>(a);
+    else if constexpr (k32 == 4) {   // (1 - i)/sqrt2 forward, (1 + i)/sqrt2 inverse
+        constexpr float r = 0.70710678118654757f;
+        return INV ? make_float2((a.x - a.y) * r, (a.x + a.y) * r) : make_float2((a.x + a.y) * r, (a.y - a.x) * r);
+    } else if constexpr (k32 == 12) {  // (-1 - i)/sqrt2 forward, (-1 + i)/sqrt2 inverse
+        constexpr float r = 0.70710678118654757f;
+        return INV ? make_float2(-(a.x + a.y) * r, (a.x - a.y) * r) : make_float2((a.y - a.x) * r, -(a.x + a.y) * r);
+    } else if constexpr (k32 == 20) {  // (-1 + i)/sqrt2 forward
+        constexpr float r = 0.70710678118654757f;
+        return INV ? make_float2((a.y - a.x) * r, -(a.x + a.y) * r) : make_float2(-(a.x + a.y) * r, (a.x - a.y) * r);
+    } else if constexpr (k32 == 28) {  // (1 + i)/sqrt2 forward
+        constexpr float r = 0.70710678118654757f;
+        return INV ? make_float2((a.x + a.y) * r, (a.y - a.x) * r) : make_float2((a.x - a.y) * r, (a.x + a.y) * r);
+    } else {
+        constexpr float c = C[k32], s = S[k32];  // W = c - i s (forward)
+        return INV ? make_float2(a.x * c - a.y * s, a.y * c + a.x * s) : make_float2(a.x * c + a.y * s, a.y * c - a.x * s);
+    }
+}
+
+// compile-time loop
+template <int I, int E, class F> SK_HD void static_for(F &&f)
+{
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(static_cast<F &&>(f));
+    }
+}
+
+// Out-of-place N-point DFT of x[0], x[S], x[2S], ... into X[0..N) (natural order).
+// INV = unnormalised inverse.  N in {1,2,4,8,16,32}.  Everything is unrolled at
+// compile time, so x/X live in registers.
+template <int N, int S, bool INV> struct Dft {
+    static SK_HD void run(const cf *x, cf *X)
+    {
+        if constexpr (N == 1) {
+            X[0] = x[0];
+        } else if constexpr (N == 2) {
+            X[0] = cadd(x[0], x[S]);
+            X[1] = csub(x[0], x[S]);
+        } else if constexpr (N == 4) {
+            const cf s02 = cadd(x[0], x[2 * S]), d02 = csub(x[0], x[2 * S]);
+            const cf s13 = cadd(x[S], x[3 * S]), d13 = mul_mi<INV>(csub(x[S], x[3 * S]));
+            X[0] = cadd(s02, s13);
+            X[2] = csub(s02, s13);
+            X[1] = cadd(d02, d13);
+            X[3] = csub(d02, d13);
+        } else if constexpr (N == 8) {
+            cf E[4], O[4];
+            Dft<4, 2 * S, INV>::run(x, E);
+            Dft<4, 2 * S, INV>::run(x + S, O);
+            static_for<0, 4>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const cf t = twmul<8, k, INV>(O[k]);
+                X[k] = cadd(E[k], t);
+                X[k + 4] = csub(E[k], t);
+            });
+        } else {
+            constexpr int M = N / 4;
+            cf S0[M], S1[M], S2[M], S3[M];
+            Dft<M, 4 * S, INV>::run(x, S0);
+            Dft<M, 4 * S, INV>::run(x + S, S1);
+            Dft<M, 4 * S, INV>::run(x + 2 * S, S2);
+            Dft<M, 4 * S, INV>::run(x + 3 * S, S3);
+            static_for<0, M>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const cf t0 = S0[k];
+                const cf t1 = twmul<N, k, INV>(S1[k]);
+                const cf t2 = twmul<N, 2 * k, INV>(S2[k]);
+                const cf t3 = twmul<N, 3 * k, INV>(S3[k]);
+                const cf s02 = cadd(t0, t2), d02 = csub(t0, t2);
+                const cf s13 = cadd(t1, t3), d13 = mul_mi<INV>(csub(t1, t3));
+                X[k] = cadd(s02, s13);
+                X[k + 2 * M] = csub(s02, s13);
+                X[k + M] = cadd(d02, d13);
+                X[k + 3 * M] = csub(d02, d13);
+            });
+        }
+    }
+};
+
+// ----------------------------------------------------------------------------
+// LDS addressing (float4 units)
+// ----------------------------------------------------------------------------
+SK_HD int lds_unit(int row_k1, int mid, int q) { return row_k1 * kRowPitch + mid * 17 + q; }
+
+SK_HD cf lo(float4 f) { return make_float2(f.x, f.y); }
+SK_HD cf hi(float4 f) { return make_float2(f.z, f.w); }
+SK_HD float4 pack(cf a, cf b) { return make_float4(a.x, a.y, b.x, b.y); }
+
+// ----------------------------------------------------------------------------
+// Per-thread phases.  v[a*2+e] on entry to fwd_pass1 holds x[512 a + 2 t + e].
+// T1[k1*256 + t] = (W_8192^((2t)k1), W_8192^((2t+1)k1));  T2[k2*16 + q] = (W_512^((2q)k2), W_512^((2q+1)k2)).
+// ----------------------------------------------------------------------------
+// pass 1 + twiddle + exchange-1 write.  thread t = 16 b + q.
+SK_HD void fwd_pass1(int t, const cf *v, const float4 *T1, float4 *lds)
+{
+    cf in[16], o0[16], o1[16];
+    SK_UNROLL
+    for (int a = 0; a < 16; ++a) in[a] = v[2 * a];
+    Dft<16, 1, false>::run(in, o0);
+    SK_UNROLL
+    for (int a = 0; a < 16; ++a) in[a] = v[2 * a + 1];
+    Dft<16, 1, false>::run(in, o1);
+    const int b = t >> 4, q = t & 15;
+    lds[lds_unit(0, b, q)] = pack(o0[0], o1[0]);
+    SK_UNROLL
+    for (int k1 = 1; k1 < 16; ++k1) {
+        const float4 w = T1[k1 * 256 + t];
+        lds[lds_unit(k1, b, q)] = pack(cmul(o0[k1], lo(w)), cmul(o1[k1], hi(w)));
+    }
+}
+
+// exchange-1 read + pass 2 + twiddle + exchange-2 write/read + pass 3.
+// thread t = 16 k1 + q for pass 2 and t = 16 k1 + k2 for pass 3.  Z[k3] out (32).
+SK_HD void fwd_pass23(int t, const float4 *T2, float4 *lds, cf *Z)
+{
+    const int k1 = t >> 4, q = t & 15;
+    cf in0[16], in1[16], o0[16], o1[16];
+    SK_UNROLL
+    for (int b = 0; b < 16; ++b) {
+        const float4 f = lds[lds_unit(k1, b, q)];
+        in0[b] = lo(f);
+        in1[b] = hi(f);
+    }
+    Dft<16, 1, false>::run(in0, o0);
+    Dft<16, 1, false>::run(in1, o1);
+    lds[lds_unit(k1, 0, q)] = pack(o0[0], o1[0]);
+    SK_UNROLL
+    for (int k2 = 1; k2 < 16; ++k2) {
+        const float4 w = T2[k2 * 16 + q];
+        lds[lds_unit(k1, k2, q)] = pack(cmul(o0[k2], lo(w)), cmul(o1[k2], hi(w)));
+    }
+    // (wave-local: the 16 lanes of this k1 row only read what they wrote)
+    const int k2 = q;
+    cf z[32];
+    SK_UNROLL
+    for (int qq = 0; qq < 16; ++qq) {
+        const float4 f = lds[lds_unit(k1, k2, qq)];
+        z[2 * qq] = lo(f);
+        z[2 * qq + 1] = hi(f);
+    }
+    Dft<32, 1, false>::run(z, Z);
+}
+
+// pointwise multiply by the pre-permuted, pre-scaled transfer function.
+// Hp[j*256 + t] = (H[k(k3=2j)], H[k(k3=2j+1)]),  k = k1 + 16 k2 + 256 k3, t = 16 k1 + k2.
+SK_HD void mul_H(int t, const float4 *Hp, cf *Z)
+{
+    SK_UNROLL
+    for (int j = 0; j < 16; ++j) {
+        const float4 h = Hp[j * 256 + t];
+        Z[2 * j] = cmul(Z[2 * j], lo(h));
+        Z[2 * j + 1] = cmul(Z[2 * j + 1], hi(h));
+    }
+}
+
+// inverse pass 3 + conj twiddle + exchange-2' + inverse pass 2 + exchange-1' write.
+SK_HD void inv_pass32(int t, const float4 *T2, float4 *lds, const cf *Z)
+{
+    const int k1 = t >> 4, k2 = t & 15;
+    cf z[32];
+    Dft<32, 1, true>::run(Z, z);
+    SK_UNROLL
+    for (int qq = 0; qq < 16; ++qq) {
+        const float4 w = T2[k2 * 16 + qq];
+        lds[lds_unit(k1, k2, qq)] = pack(cmulc(z[2 * qq], lo(w)), cmulc(z[2 * qq + 1], hi(w)));
+    }
+    const int q = k2;  // now thread (k1,q)
+    cf in0[16], in1[16], o0[16], o1[16];
+    SK_UNROLL
+    for (int kk = 0; kk < 16; ++kk) {
+        const float4 f = lds[lds_unit(k1, kk, q)];
+        in0[kk] = lo(f);
+        in1[kk] = hi(f);
+    }
+    Dft<16, 1, true>::run(in0, o0);
+    Dft<16, 1, true>::run(in1, o1);
+    SK_UNROLL
+    for (int b = 0; b < 16; ++b) lds[lds_unit(k1, b, q)] = pack(o0[b], o1[b]);
+}
+
+// exchange-1' read + conj twiddle + inverse pass 1.  v[a*2+e] = y[512 a + 2 t + e] out.
+SK_HD void inv_pass1(int t, const float4 *T1, const float4 *lds, cf *v)
+{
+    const int b = t >> 4, q = t & 15;
+    cf in0[16], in1[16], o0[16], o1[16];
+    {
+        const float4 f = lds[lds_unit(0, b, q)];
+        in0[0] = lo(f);
+        in1[0] = hi(f);
+    }
+    SK_UNROLL
+    for (int k1 = 1; k1 < 16; ++k1) {
+        const float4 f = lds[lds_unit(k1, b, q)];
+        const float4 w = T1[k1 * 256 + t];
+        in0[k1] = cmulc(lo(f), lo(w));
+        in1[k1] = cmulc(hi(f), hi(w));
+    }
+    Dft<16, 1, true>::run(in0, o0);
+    Dft<16, 1, true>::run(in1, o1);
+    SK_UNROLL
+    for (int a = 0; a < 16; ++a) {
+        v[2 * a] = o0[a];
+        v[2 * a + 1] = o1[a];
+    }
+}
+
+}  // namespace ols
+}  // namespace skdsp

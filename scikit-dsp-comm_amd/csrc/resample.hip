@@ -1,0 +1,237 @@
+// resample.hip -- zero-stuff upsampler, phase-selectable downsampler, planar
+// <-> interleaved helpers and the synthetic-noise generator.  gfx950.
+//
+//   upsample    sigsys.py:3050-3053  y = hstack((x.reshape(N,1), zeros((N,L-1)))).flatten()
+//   downsample  sigsys.py:3078-3083  y = x[0:floor(N/M)*M].reshape(-1,M)[:,p]
+//
+// Both are pure index moves (bit-exact by construction).  HBM-bound: the
+// upsampler writes 16 B per lane (1 KiB per wave instruction); the downsampler
+// is a strided gather (only 1/M of every fetched line is useful -- inherent).
+#include "skdsp_internal.hpp"
+
+namespace skdsp {
+
+template <typename T> struct Zero { __device__ static T v() { return T(0); } };
+template <> struct Zero<float2> { __device__ static float2 v() { return make_float2(0.f, 0.f); } };
+template <> struct Zero<double2> { __device__ static double2 v() { return make_double2(0., 0.); } };
+
+__device__ inline float scale_v(float a, double s) { return (float)(a * (float)s); }
+__device__ inline double scale_v(double a, double s) { return a * s; }
+__device__ inline float2 scale_v(float2 a, double s) { return make_float2(a.x * (float)s, a.y * (float)s); }
+__device__ inline double2 scale_v(double2 a, double s) { return make_double2(a.x * s, a.y * s); }
+
+// VEC consecutive outputs per thread = 16 bytes.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void upsample_kernel(const T *__restrict__ x, int64_t n_out, int L, double scale,
+                                                       bool do_scale, T *__restrict__ y)
+{
+    const int64_t nvec = (n_out + VEC - 1) / VEC;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o0 = v * VEC;
+        T out[VEC];
+        // first multiple of L at or after o0
+        int64_t q = o0 / L;
+        int64_t r = o0 - q * L;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            T val = Zero<T>::v();
+            if (r == 0 && o0 + e < n_out) {
+                val = x[q];
+                if (do_scale) val = scale_v(val, scale);
+            }
+            out[e] = val;
+            if (++r == L) { r = 0; ++q; }
+        }
+        if (o0 + VEC <= n_out) {
+            // 16-byte store
+            *reinterpret_cast<float4 *>(y + o0) = *reinterpret_cast<const float4 *>(out);
+        } else {
+            for (int e = 0; e < VEC && o0 + e < n_out; ++e) y[o0 + e] = out[e];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void downsample_kernel(const T *__restrict__ x, int64_t n_out, int M, int p,
+                                                         T *__restrict__ y)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_out; k += (int64_t)gridDim.x * blockDim.x)
+        y[k] = x[k * M + p];
+}
+
+template <typename T2, typename T>
+__global__ __launch_bounds__(256) void deinterleave_kernel(const T2 *__restrict__ x, int64_t n, T *__restrict__ re,
+                                                           T *__restrict__ im)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        T2 v = x[k];
+        re[k] = v.x;
+        im[k] = v.y;
+    }
+}
+
+template <typename T2, typename T>
+__global__ __launch_bounds__(256) void interleave_kernel(const T *__restrict__ re, const T *__restrict__ im, int64_t n,
+                                                         T2 *__restrict__ y)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        T2 v;
+        v.x = re[k];
+        v.y = im[k];
+        y[k] = v;
+    }
+}
+
+static inline int grid_for(int64_t work_items)
+{
+    int64_t g = (work_items + 255) / 256;
+    const int64_t cap = (int64_t)ctx().num_cus * 8;  // grid-stride the rest
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int upsample_launch(const void *x, int64_t n, int L, int dtype, double scale, void *y, hipStream_t s)
+{
+    SK_CHECK(L >= 1, SKDSP_ERR_BADARG, "upsample: L must be >= 1 (got %d)", L);
+    if (n <= 0) return SKDSP_OK;
+    const int64_t n_out = n * L;
+    const bool ds = scale != 1.0;
+    switch (dtype) {
+    case SKDSP_F32:
+        hipLaunchKernelGGL((upsample_kernel<float, 4>), dim3(grid_for((n_out + 3) / 4)), dim3(256), 0, s,
+                           (const float *)x, n_out, L, scale, ds, (float *)y);
+        break;
+    case SKDSP_C64:
+        hipLaunchKernelGGL((upsample_kernel<float2, 2>), dim3(grid_for((n_out + 1) / 2)), dim3(256), 0, s,
+                           (const float2 *)x, n_out, L, scale, ds, (float2 *)y);
+        break;
+    case SKDSP_F64:
+        hipLaunchKernelGGL((upsample_kernel<double, 2>), dim3(grid_for((n_out + 1) / 2)), dim3(256), 0, s,
+                           (const double *)x, n_out, L, scale, ds, (double *)y);
+        break;
+    case SKDSP_C128:
+        hipLaunchKernelGGL((upsample_kernel<double2, 1>), dim3(grid_for(n_out)), dim3(256), 0, s, (const double2 *)x,
+                           n_out, L, scale, ds, (double2 *)y);
+        break;
+    default:
+        SK_CHECK(false, SKDSP_ERR_BADARG, "upsample: bad dtype %d", dtype);
+    }
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+int downsample_launch(const void *x, int64_t n, int M, int p, int dtype, void *y, hipStream_t s)
+{
+    SK_CHECK(M >= 1, SKDSP_ERR_BADARG, "downsample: M must be >= 1 (got %d)", M);
+    SK_CHECK(p >= 0 && p < M, SKDSP_ERR_BADARG, "downsample: phase p=%d out of range for M=%d", p, M);
+    const int64_t n_out = n / M;
+    if (n_out <= 0) return SKDSP_OK;
+    const int g = grid_for(n_out);
+    switch (dtype) {
+    case SKDSP_F32:
+        hipLaunchKernelGGL((downsample_kernel<float>), dim3(g), dim3(256), 0, s, (const float *)x, n_out, M, p, (float *)y);
+        break;
+    case SKDSP_C64:
+        hipLaunchKernelGGL((downsample_kernel<float2>), dim3(g), dim3(256), 0, s, (const float2 *)x, n_out, M, p, (float2 *)y);
+        break;
+    case SKDSP_F64:
+        hipLaunchKernelGGL((downsample_kernel<double>), dim3(g), dim3(256), 0, s, (const double *)x, n_out, M, p, (double *)y);
+        break;
+    case SKDSP_C128:
+        hipLaunchKernelGGL((downsample_kernel<double2>), dim3(g), dim3(256), 0, s, (const double2 *)x, n_out, M, p, (double2 *)y);
+        break;
+    default:
+        SK_CHECK(false, SKDSP_ERR_BADARG, "downsample: bad dtype %d", dtype);
+    }
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+int deinterleave_launch(const void *x, int64_t n, int dt, void *re, void *im, hipStream_t s)
+{
+    if (n <= 0) return SKDSP_OK;
+    if (dt == SKDSP_C64)
+        hipLaunchKernelGGL((deinterleave_kernel<float2, float>), dim3(grid_for(n)), dim3(256), 0, s, (const float2 *)x, n,
+                           (float *)re, (float *)im);
+    else
+        hipLaunchKernelGGL((deinterleave_kernel<double2, double>), dim3(grid_for(n)), dim3(256), 0, s, (const double2 *)x,
+                           n, (double *)re, (double *)im);
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+int interleave_launch(const void *re, const void *im, int64_t n, int dt, void *y, hipStream_t s)
+{
+    if (n <= 0) return SKDSP_OK;
+    if (dt == SKDSP_C64)
+        hipLaunchKernelGGL((interleave_kernel<float2, float>), dim3(grid_for(n)), dim3(256), 0, s, (const float *)re,
+                           (const float *)im, n, (float2 *)y);
+    else
+        hipLaunchKernelGGL((interleave_kernel<double2, double>), dim3(grid_for(n)), dim3(256), 0, s, (const double *)re,
+                           (const double *)im, n, (double2 *)y);
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+// ---------------------------------------------------------------- noise
+// Counter-based: value depends only on (seed, global scalar index).  splitmix64
+// -> two 24-bit uniforms -> Box-Muller.  Complex samples are scaled by 1/sqrt(2)
+// so E|x|^2 = 1 (SURVEY.md 8d synthetic inputs).
+__device__ inline uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ inline float2 gauss_pair(uint64_t seed, uint64_t idx)
+{
+    const uint64_t h = splitmix64(seed ^ (idx * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull));
+    const float u1 = ((float)((h >> 40) & 0xFFFFFF) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
+    const float u2 = (float)((h >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);           // [0,1)
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    return make_float2(r * cs, r * sn);
+}
+
+template <typename T2, typename T>
+__global__ __launch_bounds__(256) void noise_complex_kernel(T2 *x, int64_t n, uint64_t seed, int64_t first)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        float2 g = gauss_pair(seed, (uint64_t)(first + k));
+        T2 v;
+        v.x = (T)(g.x * 0.70710678118654752440f);
+        v.y = (T)(g.y * 0.70710678118654752440f);
+        x[k] = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void noise_real_kernel(T *x, int64_t n, uint64_t seed, int64_t first)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t gi = first + k;
+        float2 g = gauss_pair(seed, (uint64_t)(gi >> 1));
+        x[k] = (T)((gi & 1) ? g.y : g.x);
+    }
+}
+
+int fill_noise_launch(void *x, int64_t n, int dtype, uint64_t seed, int64_t first, hipStream_t s)
+{
+    if (n <= 0) return SKDSP_OK;
+    const int g = grid_for(n);
+    switch (dtype) {
+    case SKDSP_F32: hipLaunchKernelGGL((noise_real_kernel<float>), dim3(g), dim3(256), 0, s, (float *)x, n, seed, first); break;
+    case SKDSP_F64: hipLaunchKernelGGL((noise_real_kernel<double>), dim3(g), dim3(256), 0, s, (double *)x, n, seed, first); break;
+    case SKDSP_C64: hipLaunchKernelGGL((noise_complex_kernel<float2, float>), dim3(g), dim3(256), 0, s, (float2 *)x, n, seed, first); break;
+    case SKDSP_C128: hipLaunchKernelGGL((noise_complex_kernel<double2, double>), dim3(g), dim3(256), 0, s, (double2 *)x, n, seed, first); break;
+    default: SK_CHECK(false, SKDSP_ERR_BADARG, "fill_noise: bad dtype %d", dtype);
+    }
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+}  // namespace skdsp

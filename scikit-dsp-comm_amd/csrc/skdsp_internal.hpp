@@ -1,0 +1,113 @@
+// Internal declarations shared by the HIP translation units of libskdsp_hip.so.
+// gfx950 (MI355X / CDNA4) only -- no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <mutex>
+#include "../../include/skdsp.h"
+
+namespace skdsp {
+
+// ------------------------------------------------------------------ errors
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define SK_HIP(call)                                                        \
+    do {                                                                    \
+        hipError_t _e = (call);                                             \
+        if (_e != hipSuccess) return skdsp::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define SK_CHECK(cond, code, ...)            \
+    do {                                     \
+        if (!(cond)) {                       \
+            skdsp::set_error(__VA_ARGS__);   \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+// ------------------------------------------------------------------ context
+struct Context {
+    bool ready = false;
+    int device = -1;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // grow-only device workspaces used by the host-pointer entry points
+    void *ws[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[4] = {0, 0, 0, 0};
+    std::mutex mu;
+};
+Context &ctx();
+int ensure_init();
+int ws_reserve(int slot, size_t bytes, void **out);  // grow-only workspace slot 0..3
+
+inline size_t dtype_size(int dt) { return dt == SKDSP_F32 ? 4 : dt == SKDSP_C64 ? 8 : dt == SKDSP_F64 ? 8 : 16; }
+inline bool dtype_complex(int dt) { return dt == SKDSP_C64 || dt == SKDSP_C128; }
+inline bool dtype_double(int dt) { return dt == SKDSP_F64 || dt == SKDSP_C128; }
+inline bool dtype_valid(int dt) { return dt >= 0 && dt <= 3; }
+
+// headroom (in samples) the host-pointer paths keep in front of the staged input
+// so that kernels may be handed n_hist > 0; also keeps x 256-byte aligned.
+constexpr int64_t kHeadroomBytes = 65536;
+
+// ------------------------------------------------------------------ handles
+enum HandleKind { H_FIR = 1, H_IIR = 2 };
+
+struct HandleBase {
+    int kind;
+    int dtype;
+    std::mutex mu;
+    virtual ~HandleBase() {}
+};
+
+// ---- FIR -----------------------------------------------------------------
+struct OlsPlan;  // fir_ols.hip
+struct FirHandle : HandleBase {
+    int ntaps = 0;
+    bool taps_complex = false;
+    int algo = SKDSP_FIR_AUTO;
+    std::vector<double> taps_host;  // ntaps (real) or 2*ntaps (complex, interleaved)
+    // device taps in the compute precision, natural order: real -> T[ntaps], complex -> T[2*ntaps]
+    void *taps_dev = nullptr;
+    // polyphase tap banks, keyed by L (lazy): bank[phase][t] = b[phase + L*t], T = ceil(P/L)
+    struct Poly { int L; int T; void *dev; };
+    std::vector<Poly> poly;
+    OlsPlan *ols = nullptr;
+    ~FirHandle();
+};
+
+// direct-form / polyphase launcher (fir_direct.hip).
+//   y[m] = L * sum_t b[phi + L t] * x[i - t],  j = m*M, phi = j mod L, i = j div L,  m in [0, n_out)
+int fir_direct_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, int64_t n_out,
+                      void *y_dev, hipStream_t s);
+// FFT overlap-save (fir_ols.hip): c64 (and packed f32) .filter
+bool fir_ols_supported(const FirHandle *h);
+int fir_ols_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, hipStream_t s);
+void fir_ols_free(OlsPlan *p);
+
+// ---- IIR -----------------------------------------------------------------
+struct IirPlan;  // iir_scan.hip
+struct IirHandle : HandleBase {
+    int nsec = 0;   // number of cascaded sections
+    int order = 0;  // order of each section (2 for SOS, K-1 for a transfer function)
+    std::vector<double> coef;  // per section: b[0..order], a[1..order]  (a0-normalised)
+    IirPlan *plan = nullptr;
+    ~IirHandle();
+};
+// x/y: real planar arrays in the handle's precision; complex callers pass nbatch=2 planes
+// (re, im) batch_stride elements apart.  In-place (y == x) is allowed.
+int iir_launch_planar(IirHandle *h, const void *x_dev, int64_t n, int nbatch, int64_t batch_stride, void *y_dev, hipStream_t s);
+void iir_free(IirPlan *p);
+bool iir_shape_supported(int nsec, int order);
+
+// ---- resamplers (resample.hip) ---------------------------------------------
+int upsample_launch(const void *x_dev, int64_t n, int L, int dtype, double scale, void *y_dev, hipStream_t s);
+int downsample_launch(const void *x_dev, int64_t n, int M, int p, int dtype, void *y_dev, hipStream_t s);
+int deinterleave_launch(const void *x_dev, int64_t n, int dtype_complex_in, void *re_dev, void *im_dev, hipStream_t s);
+int interleave_launch(const void *re_dev, const void *im_dev, int64_t n, int dtype_complex_out, void *y_dev, hipStream_t s);
+int fill_noise_launch(void *x_dev, int64_t n, int dtype, uint64_t seed, int64_t first, hipStream_t s);
+
+}  // namespace skdsp

@@ -1,0 +1,337 @@
+"""ctypes binding of libskdsp_hip.so (the C ABI declared in include/skdsp.h).
+
+No PyTorch, no CPU fallback: if the library or a HIP device is missing the calls
+raise -- the product path must fail loudly rather than silently run elsewhere.
+"""
+import ctypes
+import os
+import threading
+import weakref
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libskdsp_hip.so"
+
+F32, C64, F64, C128 = 0, 1, 2, 3
+FIR_AUTO, FIR_DIRECT, FIR_OLS = 0, 1, 2
+
+_NP_OF = {F32: np.float32, C64: np.complex64, F64: np.float64, C128: np.complex128}
+_CODE_OF = {np.dtype(np.float32): F32, np.dtype(np.complex64): C64, np.dtype(np.float64): F64,
+            np.dtype(np.complex128): C128}
+
+# every symbol include/skdsp.h declares (tests check the built library exports all of them)
+SYMBOLS = [
+    "skdsp_init", "skdsp_shutdown", "skdsp_device_count", "skdsp_device_info", "skdsp_last_error", "skdsp_version",
+    "skdsp_malloc", "skdsp_free", "skdsp_memcpy_h2d", "skdsp_memcpy_d2h", "skdsp_memcpy_d2d", "skdsp_memset",
+    "skdsp_sync", "skdsp_timer_start", "skdsp_timer_stop", "skdsp_fill_noise_dev",
+    "skdsp_fir_create", "skdsp_fir_set_algo", "skdsp_fir_get_algo", "skdsp_fir_filter", "skdsp_fir_filter_dev",
+    "skdsp_fir_up", "skdsp_fir_up_dev", "skdsp_fir_dn", "skdsp_fir_dn_dev", "skdsp_fir_updn", "skdsp_fir_updn_dev",
+    "skdsp_sos_create", "skdsp_tf_create", "skdsp_iir_filter", "skdsp_iir_filter_dev", "skdsp_iir_up",
+    "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev",
+    "skdsp_upsample", "skdsp_upsample_dev", "skdsp_downsample", "skdsp_downsample_dev", "skdsp_destroy",
+    "skdsp_dist_unique_id", "skdsp_dist_init", "skdsp_dist_shutdown", "skdsp_dist_barrier",
+    "skdsp_dist_allreduce_max", "skdsp_dist_allreduce_sum", "skdsp_dist_halo_exchange", "skdsp_fir_filter_shard_dev",
+]
+
+_lib = None
+_lock = threading.Lock()
+
+
+class SkdspError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, LIB_NAME)
+
+
+def load():
+    """dlopen the library and declare prototypes.  Does NOT touch the GPU."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            raise SkdspError(
+                "%s not found next to the package: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C scikit-dsp-comm_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+        L = ctypes.CDLL(path)
+        vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+        pvp = ctypes.POINTER(ctypes.c_void_p)
+        L.skdsp_last_error.restype = ctypes.c_char_p
+        L.skdsp_version.restype = ctypes.c_char_p
+        L.skdsp_init.argtypes = [ci]
+        L.skdsp_device_info.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(ci), ctypes.POINTER(i64), ctypes.POINTER(ci)]
+        L.skdsp_malloc.argtypes = [pvp, i64]
+        L.skdsp_free.argtypes = [vp]
+        for f in (L.skdsp_memcpy_h2d, L.skdsp_memcpy_d2h, L.skdsp_memcpy_d2d):
+            f.argtypes = [vp, vp, i64]
+        L.skdsp_memset.argtypes = [vp, ci, i64]
+        L.skdsp_timer_stop.argtypes = [ctypes.POINTER(ctypes.c_float)]
+        L.skdsp_fill_noise_dev.argtypes = [vp, i64, ci, ctypes.c_uint64, i64]
+        L.skdsp_fir_create.argtypes = [vp, ci, ci, ci, pvp]
+        L.skdsp_fir_set_algo.argtypes = [vp, ci]
+        L.skdsp_fir_get_algo.argtypes = [vp, i64, ctypes.POINTER(ci)]
+        L.skdsp_fir_filter.argtypes = [vp, vp, i64, vp]
+        L.skdsp_fir_filter_dev.argtypes = [vp, vp, i64, i64, vp]
+        L.skdsp_fir_up.argtypes = [vp, vp, i64, ci, vp]
+        L.skdsp_fir_up_dev.argtypes = [vp, vp, i64, i64, ci, vp]
+        L.skdsp_fir_dn.argtypes = [vp, vp, i64, ci, vp]
+        L.skdsp_fir_dn_dev.argtypes = [vp, vp, i64, i64, ci, vp]
+        L.skdsp_fir_updn.argtypes = [vp, vp, i64, ci, ci, vp]
+        L.skdsp_fir_updn_dev.argtypes = [vp, vp, i64, i64, ci, ci, vp]
+        L.skdsp_sos_create.argtypes = [vp, ci, ci, pvp]
+        L.skdsp_tf_create.argtypes = [vp, ci, vp, ci, ci, pvp]
+        L.skdsp_iir_filter.argtypes = [vp, vp, i64, vp]
+        L.skdsp_iir_filter_dev.argtypes = [vp, vp, i64, vp]
+        L.skdsp_iir_up.argtypes = [vp, vp, i64, ci, vp]
+        L.skdsp_iir_up_dev.argtypes = [vp, vp, i64, ci, vp]
+        L.skdsp_iir_dn.argtypes = [vp, vp, i64, ci, vp]
+        L.skdsp_iir_dn_dev.argtypes = [vp, vp, i64, ci, vp]
+        L.skdsp_upsample.argtypes = [vp, i64, ci, ci, vp]
+        L.skdsp_upsample_dev.argtypes = [vp, i64, ci, ci, ctypes.c_double, vp]
+        L.skdsp_downsample.argtypes = [vp, i64, ci, ci, ci, vp]
+        L.skdsp_downsample_dev.argtypes = [vp, i64, ci, ci, ci, vp]
+        L.skdsp_destroy.argtypes = [vp]
+        L.skdsp_dist_unique_id.argtypes = [vp]
+        L.skdsp_dist_init.argtypes = [ci, ci, vp]
+        L.skdsp_dist_allreduce_max.argtypes = [ctypes.POINTER(ctypes.c_double)]
+        L.skdsp_dist_allreduce_sum.argtypes = [ctypes.POINTER(ctypes.c_double)]
+        L.skdsp_dist_halo_exchange.argtypes = [vp, i64, i64, ci]
+        L.skdsp_fir_filter_shard_dev.argtypes = [vp, vp, i64, vp]
+        _lib = L
+        return _lib
+
+
+_EXC = {-1: ValueError, -2: SkdspError, -3: MemoryError, -4: SkdspError, -5: SkdspError, -6: NotImplementedError}
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().skdsp_last_error().decode("utf-8", "replace")
+        raise _EXC.get(rc, SkdspError)("skdsp[%d]: %s" % (rc, msg))
+
+
+def init(device=None):
+    L = load()
+    if device is None:
+        device = int(os.environ.get("SKDSP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    check(L.skdsp_init(int(device)))
+
+
+def device_info():
+    L = load()
+    name = ctypes.create_string_buffer(256)
+    cus, hbm, clk = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int(0)
+    check(L.skdsp_device_info(name, 256, ctypes.byref(cus), ctypes.byref(hbm), ctypes.byref(clk)))
+    return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value, "clock_khz": clk.value}
+
+
+def code_of(dtype):
+    try:
+        return _CODE_OF[np.dtype(dtype)]
+    except KeyError:
+        raise TypeError("unsupported signal dtype %r (float32/complex64/float64/complex128)" % (dtype,))
+
+
+def np_of(code):
+    return _NP_OF[code]
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a.size else ctypes.c_void_p(0)
+
+
+# --------------------------------------------------------------------------
+# device-resident arrays (used by bench.py / sharding; not part of the reference surface)
+# --------------------------------------------------------------------------
+class DeviceArray:
+    """n samples of `dtype` in HBM with `headroom` samples of valid-able space in front
+    (the halo / history region: x[-headroom..-1])."""
+
+    def __init__(self, n, dtype, headroom=0):
+        L = load()
+        self.n = int(n)
+        self.code = code_of(dtype)
+        self.dtype = np.dtype(dtype)
+        esz = self.dtype.itemsize
+        # keep x[0] 256-byte aligned whatever the headroom is
+        self._pad = ((int(headroom) * esz + 255) // 256) * 256
+        self.headroom = int(headroom)
+        base = ctypes.c_void_p(0)
+        check(L.skdsp_malloc(ctypes.byref(base), self._pad + self.n * esz + 256))
+        self._base = base.value
+        self.ptr = self._base + self._pad
+        self._fin = weakref.finalize(self, _free_dev, self._base)
+        if self._pad:
+            check(L.skdsp_memset(ctypes.c_void_p(self._base), 0, self._pad))
+
+    @classmethod
+    def from_host(cls, a, headroom=0):
+        a = np.ascontiguousarray(a)
+        d = cls(a.size, a.dtype, headroom)
+        check(load().skdsp_memcpy_h2d(ctypes.c_void_p(d.ptr), _ptr(a), a.nbytes))
+        return d
+
+    def to_host(self, start=0, count=None):
+        count = self.n - start if count is None else count
+        out = np.empty(count, dtype=self.dtype)
+        esz = self.dtype.itemsize
+        check(load().skdsp_memcpy_d2h(_ptr(out), ctypes.c_void_p(self.ptr + start * esz), out.nbytes))
+        return out
+
+    def fill_noise(self, seed, first_index=0):
+        check(load().skdsp_fill_noise_dev(ctypes.c_void_p(self.ptr), self.n, self.code, int(seed), int(first_index)))
+        return self
+
+    def free(self):
+        self._fin()
+
+
+def _free_dev(base):
+    try:
+        load().skdsp_free(ctypes.c_void_p(base))
+    except Exception:
+        pass
+
+
+def sync():
+    check(load().skdsp_sync())
+
+
+def timer_start():
+    check(load().skdsp_timer_start())
+
+
+def timer_stop():
+    ms = ctypes.c_float(0.0)
+    check(load().skdsp_timer_stop(ctypes.byref(ms)))
+    return float(ms.value)
+
+
+# --------------------------------------------------------------------------
+# handles
+# --------------------------------------------------------------------------
+def _destroy(h):
+    try:
+        load().skdsp_destroy(ctypes.c_void_p(h))
+    except Exception:
+        pass
+
+
+class FirKernel:
+    """A device FIR handle for one (taps, signal dtype) pair."""
+
+    def __init__(self, taps, code):
+        L = load()
+        taps = np.asarray(taps)
+        self.taps_complex = bool(np.iscomplexobj(taps))
+        t = np.ascontiguousarray(taps, dtype=np.complex128 if self.taps_complex else np.float64)
+        self.ntaps = int(t.size)
+        self.code = code
+        h = ctypes.c_void_p(0)
+        check(L.skdsp_fir_create(_ptr(t), self.ntaps, int(self.taps_complex), code, ctypes.byref(h)))
+        self.h = h.value
+        self._fin = weakref.finalize(self, _destroy, self.h)
+
+    def set_algo(self, algo):
+        check(load().skdsp_fir_set_algo(ctypes.c_void_p(self.h), int(algo)))
+
+    def algo_for(self, n):
+        a = ctypes.c_int(0)
+        check(load().skdsp_fir_get_algo(ctypes.c_void_p(self.h), int(n), ctypes.byref(a)))
+        return a.value
+
+    # host vectors ------------------------------------------------------
+    def filter(self, x):
+        y = np.empty(x.size, dtype=x.dtype)
+        check(load().skdsp_fir_filter(ctypes.c_void_p(self.h), _ptr(x), x.size, _ptr(y)))
+        return y
+
+    def up(self, x, L):
+        y = np.empty(x.size * L, dtype=x.dtype)
+        check(load().skdsp_fir_up(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), _ptr(y)))
+        return y
+
+    def dn(self, x, M):
+        y = np.empty(x.size // M, dtype=x.dtype)
+        check(load().skdsp_fir_dn(ctypes.c_void_p(self.h), _ptr(x), x.size, int(M), _ptr(y)))
+        return y
+
+    def updn(self, x, L, M):
+        y = np.empty((x.size * L) // M, dtype=x.dtype)
+        check(load().skdsp_fir_updn(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), int(M), _ptr(y)))
+        return y
+
+    # device vectors ----------------------------------------------------
+    def filter_dev(self, xd, yd, n=None, n_hist=0):
+        n = xd.n if n is None else n
+        check(load().skdsp_fir_filter_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, n_hist, ctypes.c_void_p(yd.ptr)))
+
+    def up_dev(self, xd, yd, L, n=None, n_hist=0):
+        n = xd.n if n is None else n
+        check(load().skdsp_fir_up_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, n_hist, int(L), ctypes.c_void_p(yd.ptr)))
+
+    def dn_dev(self, xd, yd, M, n=None, n_hist=0):
+        n = xd.n if n is None else n
+        check(load().skdsp_fir_dn_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, n_hist, int(M), ctypes.c_void_p(yd.ptr)))
+
+    def updn_dev(self, xd, yd, L, M, n=None, n_hist=0):
+        n = xd.n if n is None else n
+        check(load().skdsp_fir_updn_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, n_hist, int(L), int(M),
+                                         ctypes.c_void_p(yd.ptr)))
+
+    def filter_shard_dev(self, xd, yd, n=None):
+        n = xd.n if n is None else n
+        check(load().skdsp_fir_filter_shard_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, ctypes.c_void_p(yd.ptr)))
+
+
+class IirKernel:
+    """A device IIR handle: cascaded biquads (sos) or a transfer function (b, a)."""
+
+    def __init__(self, code, sos=None, b=None, a=None):
+        L = load()
+        self.code = code
+        h = ctypes.c_void_p(0)
+        if sos is not None:
+            s = np.ascontiguousarray(sos, dtype=np.float64)
+            check(L.skdsp_sos_create(_ptr(s), int(s.shape[0]), code, ctypes.byref(h)))
+        else:
+            bb = np.ascontiguousarray(np.atleast_1d(b), dtype=np.float64)
+            aa = np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64)
+            check(L.skdsp_tf_create(_ptr(bb), bb.size, _ptr(aa), aa.size, code, ctypes.byref(h)))
+        self.h = h.value
+        self._fin = weakref.finalize(self, _destroy, self.h)
+
+    def filter(self, x):
+        y = np.empty(x.size, dtype=x.dtype)
+        check(load().skdsp_iir_filter(ctypes.c_void_p(self.h), _ptr(x), x.size, _ptr(y)))
+        return y
+
+    def up(self, x, L):
+        y = np.empty(x.size * L, dtype=x.dtype)
+        check(load().skdsp_iir_up(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), _ptr(y)))
+        return y
+
+    def dn(self, x, M):
+        y = np.empty(x.size // M, dtype=x.dtype)
+        check(load().skdsp_iir_dn(ctypes.c_void_p(self.h), _ptr(x), x.size, int(M), _ptr(y)))
+        return y
+
+    def filter_dev(self, xd, yd, n=None):
+        n = xd.n if n is None else n
+        check(load().skdsp_iir_filter_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, ctypes.c_void_p(yd.ptr)))
+
+
+def upsample(x, L):
+    y = np.empty(x.size * L, dtype=x.dtype)
+    check(load().skdsp_upsample(_ptr(x), x.size, int(L), code_of(x.dtype), _ptr(y)))
+    return y
+
+
+def downsample(x, M, p):
+    y = np.empty(x.size // M, dtype=x.dtype)
+    check(load().skdsp_downsample(_ptr(x), x.size, int(M), int(p), code_of(x.dtype), _ptr(y)))
+    return y

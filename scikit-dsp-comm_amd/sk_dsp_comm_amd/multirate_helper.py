@@ -1,0 +1,285 @@
+"""Multirate filter objects with the interface of sk_dsp_comm.multirate_helper.
+
+  rate_change    /root/reference/src/sk_dsp_comm/multirate_helper.py:45-83
+  multirate_FIR  /root/reference/src/sk_dsp_comm/multirate_helper.py:85-143
+  multirate_IIR  /root/reference/src/sk_dsp_comm/multirate_helper.py:146-208
+
+Same constructors, attributes, defaults, log lines and output lengths; the arithmetic
+that the reference hands to scipy.signal.lfilter / sosfilt runs in HIP kernels on an
+MI355X (direct/polyphase and FFT overlap-save FIR, exact affine-scan IIR).  Every call
+starts from zero filter state, like the reference (it never passes zi).
+
+dtype policy: float32/complex64 inputs are filtered in float32 on the
+GPU (float64 state inside the IIR), float64/complex128 inputs in float64; results are
+returned as float64/complex128 exactly like the reference unless
+`sk_dsp_comm_amd.config.strict_dtype = False`.
+"""
+import warnings
+from logging import getLogger
+
+import numpy as np
+
+from . import _ffi
+from . import config
+from . import sigsys as ssd
+
+log = getLogger(__name__)
+
+_MAX_SOS = 12  # sections per device cascade; longer designs are split into chained cascades
+
+
+def _signal(x, coef_complex=False):
+    """-> (contiguous array in a device dtype, reference result dtype)."""
+    x = np.asarray(x)
+    cplx = np.iscomplexobj(x) or coef_complex
+    ref_dt = np.complex128 if cplx else np.float64
+    if x.dtype in (np.float64, np.complex128) or not (x.dtype in (np.float32, np.complex64, np.float16)):
+        dev_dt = np.complex128 if cplx else np.float64     # double (and integer) callers: float64 kernels
+    else:
+        dev_dt = np.complex64 if cplx else np.float32
+    return np.ascontiguousarray(x, dtype=dev_dt), ref_dt
+
+
+def _finish(y, ref_dt):
+    return y.astype(ref_dt, copy=False) if config.strict_dtype else y
+
+
+def _rows(fn, xg):
+    """Apply a 1-D kernel call along the last axis (lfilter/sosfilt semantics for N-D)."""
+    if xg.ndim == 1:
+        return fn(xg)
+    flat = xg.reshape(-1, xg.shape[-1])
+    out = [fn(np.ascontiguousarray(r)) for r in flat]
+    return np.stack(out).reshape(xg.shape[:-1] + (out[0].shape[-1],))
+
+
+class _KernelCache:
+    """One device handle per signal dtype, created lazily."""
+
+    def __init__(self, make):
+        self._make = make
+        self._k = {}
+
+    def get(self, np_dtype):
+        code = _ffi.code_of(np_dtype)
+        k = self._k.get(code)
+        if k is None:
+            k = self._k[code] = self._make(code)
+        return k
+
+
+class multirate_FIR(object):
+    """FIR filter / FIR interpolator / FIR decimator (multirate_helper.py:85-143)."""
+
+    def __init__(self, b):
+        self.N_forder = len(b)
+        self.b = b
+        log.info('FIR filter taps = %d' % self.N_forder)
+        self._bc = bool(np.iscomplexobj(np.asarray(b)))
+        self._kern = _KernelCache(lambda code: _ffi.FirKernel(np.asarray(self.b), code))
+
+    # --- reference surface --------------------------------------------------
+    def filter(self, x):
+        """y = lfilter(b, [1], x)  (multirate_helper.py:104-109)"""
+        xg, ref_dt = _signal(x, self._bc)
+        if xg.size == 0:
+            raise ValueError("v cannot be empty")
+        k = self._kern.get(xg.dtype)
+        return _finish(_rows(k.filter, xg), ref_dt)
+
+    def up(self, x, L_change=12):
+        """y = lfilter(b, [1], L*upsample(x, L))  (multirate_helper.py:112-118), polyphase on the GPU."""
+        Li, gain_fix = _stuff_factor(x, L_change)
+        xg, ref_dt = _signal(x, self._bc)
+        if xg.size == 0:
+            raise ValueError("v cannot be empty")
+        k = self._kern.get(xg.dtype)
+        y = k.up(xg, Li)
+        if gain_fix != 1.0:
+            y = y * y.dtype.type(gain_fix) if not np.iscomplexobj(y) else y * gain_fix
+        return _finish(y, ref_dt)
+
+    def dn(self, x, M_change=12):
+        """y = downsample(lfilter(b, [1], x), M)  (multirate_helper.py:121-127); only kept outputs are computed."""
+        if not isinstance(M_change, int):
+            raise TypeError("M must be an int")
+        xg, ref_dt = _signal(x, self._bc)
+        if xg.size == 0:
+            raise ValueError("v cannot be empty")
+        if xg.ndim != 1:
+            raise ValueError("cannot reshape array of size %d into shape (%d,%d)"
+                             % (xg.size, int(np.floor(len(xg) / M_change)), M_change))
+        nk = int(np.floor(len(xg) / M_change))  # ZeroDivisionError for 0, like downsample()
+        if nk == 0:
+            return np.zeros(0, dtype=ref_dt if config.strict_dtype else xg.dtype)
+        k = self._kern.get(xg.dtype)
+        return _finish(k.dn(xg, M_change), ref_dt)
+
+    # --- extension: fused rational resampler (BASELINE.json config 3) --------
+    def updn(self, x, L_change, M_change):
+        """== sigsys.downsample(self.up(x, L_change), M_change), computed in one kernel."""
+        if not isinstance(M_change, int):
+            raise TypeError("M must be an int")
+        Li, gain_fix = _stuff_factor(x, L_change)
+        xg, ref_dt = _signal(x, self._bc)
+        k = self._kern.get(xg.dtype)
+        y = k.updn(xg, Li, M_change)
+        if gain_fix != 1.0:
+            y = y * gain_fix
+        return _finish(y, ref_dt)
+
+    def freq_resp(self, mode='dB', fs=8000, ylim=[-100, 2]):
+        """Plotting helper: out of scope here; delegates to an installed sk_dsp_comm."""
+        return _delegate_plot("multirate_FIR", self.b, "freq_resp", mode, fs, ylim)
+
+    def zplane(self, auto_scale=True, size=2, detect_mult=True, tol=0.001):
+        return _delegate_plot("multirate_FIR", self.b, "zplane", auto_scale, size, detect_mult, tol)
+
+
+class multirate_IIR(object):
+    """SOS IIR filter / interpolator / decimator (multirate_helper.py:146-208)."""
+
+    def __init__(self, sos):
+        self.N_forder = np.sum(np.sign(np.abs(sos[:, 2]))) \
+                      + np.sum(np.sign(np.abs(sos[:, 1])))
+        self.sos = sos
+        log.info('IIR filter order = %d' % self.N_forder)
+        self._kern = _KernelCache(self._make)
+
+    def _validated(self):
+        sos = np.atleast_2d(np.asarray(self.sos))
+        if sos.ndim != 2 or sos.shape[1] != 6:
+            raise ValueError('sos array must be shape (n_sections, 6)')
+        if not (sos[:, 3] == 1).all():
+            raise ValueError('sos[:, 3] should be all ones')
+        return sos
+
+    def _make(self, code):
+        sos = self._validated()
+        return [_ffi.IirKernel(code, sos=sos[i:i + _MAX_SOS]) for i in range(0, sos.shape[0], _MAX_SOS)]
+
+    def _prep(self, x):
+        sos = self._validated()
+        x = np.asarray(x)
+        # scipy: dtype = result_type(sos, x); a float32 sos with float32 x stays float32
+        ref_dt = np.result_type(sos.dtype, x.dtype, np.float32)
+        if ref_dt.kind not in "fc":
+            ref_dt = np.dtype(np.float64)
+        xg, _ = _signal(x)
+        if xg.size == 0:
+            raise ValueError("cannot reshape array of size 0 into shape (0)")
+        return xg, ref_dt
+
+    def _chain(self, xg, first):
+        ks = self._kern.get(xg.dtype)
+        y = first(ks[0], xg)
+        for k in ks[1:]:
+            y = k.filter(y)
+        return y
+
+    def filter(self, x):
+        """y = sosfilt(sos, x)  (multirate_helper.py:169-174)"""
+        xg, ref_dt = self._prep(x)
+        return _finish(_rows(lambda r: self._chain(r, lambda k, v: k.filter(v)), xg), ref_dt)
+
+    def up(self, x, L_change=12):
+        """y = sosfilt(sos, L*upsample(x, L))  (multirate_helper.py:177-183)"""
+        Li, gain_fix = _stuff_factor(x, L_change)
+        xg, ref_dt = self._prep(x)
+        y = self._chain(xg, lambda k, v: k.up(v, Li))
+        if gain_fix != 1.0:
+            y = y * gain_fix
+        return _finish(y, np.result_type(ref_dt, np.float64))
+
+    def dn(self, x, M_change=12):
+        """y = downsample(sosfilt(sos, x), M)  (multirate_helper.py:186-192)"""
+        if not isinstance(M_change, int):
+            raise TypeError("M must be an int")
+        xg, ref_dt = self._prep(x)
+        if xg.ndim != 1:
+            raise ValueError("cannot reshape array of size %d into shape (%d,%d)"
+                             % (xg.size, int(np.floor(len(xg) / M_change)), M_change))
+        ks = self._kern.get(xg.dtype)
+        y = xg
+        for k in ks[:-1]:
+            y = k.filter(y)
+        return _finish(ks[-1].dn(y, M_change), ref_dt)
+
+    def freq_resp(self, mode='dB', fs=8000, ylim=[-100, 2]):
+        return _delegate_plot("multirate_IIR", self.sos, "freq_resp", mode, fs, ylim)
+
+    def zplane(self, auto_scale=True, size=2, detect_mult=True, tol=0.001):
+        return _delegate_plot("multirate_IIR", self.sos, "zplane", auto_scale, size, detect_mult, tol)
+
+
+class rate_change(object):
+    """Upsample/filter and filter/downsample with an IIR lowpass (multirate_helper.py:45-83).
+
+    The (b, a) design stays on the host with scipy.signal (coefficient generation is
+    outside the hot path); lfilter(b, a, .) runs in the GPU scan kernel as a direct-form
+    II transposed section of order N, the structure scipy uses."""
+
+    def __init__(self, M_change=12, fcutoff=0.9, N_filt_order=8, ftype='butter'):
+        import scipy.signal as signal
+        self.M = M_change  # Rate change factor M or L
+        self.fc = fcutoff * .5  # must be fs/(2*M), but scale by fcutoff
+        self.N_forder = N_filt_order
+        if ftype.lower() == 'butter':
+            self.b, self.a = signal.butter(self.N_forder, 2 / self.M * self.fc)
+        elif ftype.lower() == 'cheby1':
+            # Set the ripple to 0.05 dB
+            self.b, self.a = signal.cheby1(self.N_forder, 0.05, 2 / self.M * self.fc)
+        else:
+            warnings.warn('ftype must be "butter" or "cheby1"')
+        self._kern = _KernelCache(lambda code: _ffi.IirKernel(code, b=self.b, a=self.a))
+
+    def up(self, x):
+        """y = lfilter(b, a, M*upsample(x, M))  (multirate_helper.py:69-75)"""
+        Li, gain_fix = _stuff_factor(x, self.M)
+        b = self.b  # AttributeError for an unsupported ftype, like the reference
+        xg, ref_dt = _signal(x)
+        if xg.size == 0:
+            return np.zeros(0, dtype=ref_dt)
+        y = self._kern.get(xg.dtype).up(xg, Li)
+        if gain_fix != 1.0:
+            y = y * gain_fix
+        return _finish(y, ref_dt)
+
+    def dn(self, x):
+        """y = downsample(lfilter(b, a, x), M)  (multirate_helper.py:77-83)"""
+        b = self.b
+        if not isinstance(self.M, int):
+            raise TypeError("M must be an int")
+        xg, ref_dt = _signal(x)
+        if xg.ndim != 1:
+            raise ValueError("cannot reshape array of size %d into shape (%d,%d)"
+                             % (xg.size, int(np.floor(len(xg) / self.M)), self.M))
+        if len(xg) // self.M == 0:
+            return np.zeros(0, dtype=ref_dt)
+        return _finish(self._kern.get(xg.dtype).dn(xg, self.M), ref_dt)
+
+
+# ------------------------------------------------------------------ helpers
+def _stuff_factor(x, L):
+    """upsample()'s argument checks + its integer stuffing factor int(L-1)+1.
+
+    The reference multiplies the zero-stuffed signal by L itself (possibly non-integer)
+    while stuffing int(L-1)+1: return the integer factor and the residual gain."""
+    if not hasattr(x, "reshape"):
+        raise AttributeError("'%s' object has no attribute 'reshape'" % type(x).__name__)
+    if x.ndim != 1:
+        raise ValueError("cannot reshape array of size %d into shape (%d,1)" % (x.size, len(x)))
+    Lz = int(L - 1)
+    if Lz < 0:
+        raise ValueError("negative dimensions are not allowed")
+    Li = Lz + 1
+    return Li, float(L) / float(Li)
+
+
+def _delegate_plot(cls_name, coeffs, method, *args):
+    try:
+        import sk_dsp_comm.multirate_helper as ref
+    except Exception:
+        raise NotImplementedError("%s.%s is a matplotlib helper outside the accelerated path; "
+                                  "install scikit-dsp-comm to use it" % (cls_name, method))
+    return getattr(getattr(ref, cls_name)(coeffs), method)(*args)

@@ -1,0 +1,262 @@
+"""Sample-block sharding of a long FIR across the GPUs of one node.
+
+One process per GPU.  Rank r owns the contiguous samples [start_r, stop_r) of the
+signal; the only exchange the FIR needs is the Ntaps-1 input samples preceding a
+shard, which rank r-1 sends from the END of its own shard (rank 0 uses zeros == the
+zero initial state of lfilter).  Outputs need no exchange: rank r's outputs are the
+samples [start_r, stop_r) of the full-length result.
+
+Transports
+  RcclTransport  device buffers, RCCL send/recv over xGMI inside libskdsp_hip.so
+                 (the production path; rendezvous of the RCCL unique id through a
+                 file because the product does not depend on torch)
+  GlooTransport  host buffers through torch.distributed (gloo): used by the CPU
+                 multi-process tests and usable for TCP-only clusters.
+"""
+import os
+import time
+
+import numpy as np
+
+from . import _ffi
+
+
+def shard_bounds(n, world, multiple=1):
+    """Contiguous shards [(start, stop)] covering [0, n); every boundary is a multiple of
+    `multiple` (use M for a decimator so that output phase 0 stays aligned)."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    units = -(-n // multiple)
+    base, rem = divmod(units, world)
+    bounds, pos = [], 0
+    for r in range(world):
+        cnt = base + (1 if r < rem else 0)
+        start = min(pos * multiple, n)
+        pos += cnt
+        bounds.append((start, min(pos * multiple, n)))
+    return bounds
+
+
+def env_rank_world():
+    """(rank, world, local_rank) from the launcher's environment (torchrun-compatible)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    return rank, world, local
+
+
+class FileRendezvous:
+    """Tiny single-node rendezvous: rank 0 publishes a blob, everyone reads it.
+
+    The directory name is unique per launch: it is keyed by the launcher's pid and
+    start time (all ranks share one parent) plus MASTER_PORT, so stale files from an
+    earlier run cannot be picked up."""
+
+    def __init__(self, rank, world, tag=None, root=None, timeout=300.0):
+        self.rank, self.world, self.timeout = rank, world, timeout
+        if tag is None:
+            ppid = os.getppid()
+            try:
+                with open("/proc/%d/stat" % ppid) as f:
+                    start = f.read().rsplit(")", 1)[1].split()[19]
+            except Exception:
+                start = "0"
+            tag = "%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), ppid, start)
+        root = root or os.environ.get("SKDSP_RDZV_DIR", "/tmp")
+        self.dir = os.path.join(root, "skdsp_rdzv_" + tag)
+        os.makedirs(self.dir, exist_ok=True)
+
+    def _wait(self, path):
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > self.timeout:
+                raise TimeoutError("rendezvous: %s did not appear within %.0f s" % (path, self.timeout))
+            time.sleep(0.01)
+
+    def broadcast(self, name, blob=None):
+        path = os.path.join(self.dir, name)
+        if self.rank == 0:
+            tmp = path + ".tmp%d" % os.getpid()
+            with open(tmp, "wb") as f:
+                f.write(blob)
+            os.rename(tmp, path)  # atomic publish
+            return blob
+        self._wait(path)
+        with open(path, "rb") as f:
+            return f.read()
+
+    def barrier(self, name):
+        open(os.path.join(self.dir, "%s.%d" % (name, self.rank)), "wb").close()
+        for r in range(self.world):
+            self._wait(os.path.join(self.dir, "%s.%d" % (name, r)))
+
+    def cleanup(self):
+        """Every rank signs off; rank 0 waits for all sign-offs, then removes the directory
+        (the other ranks do not wait, so nothing can be deleted under a reader)."""
+        open(os.path.join(self.dir, "bye.%d" % self.rank), "wb").close()
+        if self.rank != 0:
+            return
+        for r in range(self.world):
+            self._wait(os.path.join(self.dir, "bye.%d" % r))
+        for fn in os.listdir(self.dir):
+            try:
+                os.remove(os.path.join(self.dir, fn))
+            except OSError:
+                pass
+        try:
+            os.rmdir(self.dir)
+        except OSError:
+            pass
+
+
+class RcclTransport:
+    """RCCL communicator owned by libskdsp_hip.so; one rank per GPU."""
+
+    def __init__(self, rank=None, world=None, local_rank=None, rdzv=None):
+        er, ew, el = env_rank_world()
+        self.rank = er if rank is None else rank
+        self.world = ew if world is None else world
+        local_rank = el if local_rank is None else local_rank
+        _ffi.init(local_rank)
+        L = _ffi.load()
+        import ctypes
+        if self.world > 1:
+            rdzv = rdzv or FileRendezvous(self.rank, self.world)
+            blob = None
+            if self.rank == 0:
+                buf = ctypes.create_string_buffer(128)
+                _ffi.check(L.skdsp_dist_unique_id(buf))
+                blob = buf.raw
+            blob = rdzv.broadcast("rccl_id", blob)
+            _ffi.check(L.skdsp_dist_init(self.rank, self.world, ctypes.c_char_p(blob)))
+            rdzv.barrier("rccl_up")
+            self._rdzv = rdzv
+        else:
+            _ffi.check(L.skdsp_dist_init(0, 1, None))
+            self._rdzv = None
+
+    def barrier(self):
+        _ffi.check(_ffi.load().skdsp_dist_barrier())
+
+    def allreduce_max(self, v):
+        import ctypes
+        d = ctypes.c_double(float(v))
+        _ffi.check(_ffi.load().skdsp_dist_allreduce_max(ctypes.byref(d)))
+        return d.value
+
+    def allreduce_sum(self, v):
+        import ctypes
+        d = ctypes.c_double(float(v))
+        _ffi.check(_ffi.load().skdsp_dist_allreduce_sum(ctypes.byref(d)))
+        return d.value
+
+    def halo_exchange_dev(self, xd, n, n_halo):
+        import ctypes
+        _ffi.check(_ffi.load().skdsp_dist_halo_exchange(ctypes.c_void_p(xd.ptr), n, n_halo, xd.code))
+
+    def close(self):
+        _ffi.load().skdsp_dist_shutdown()
+        if self._rdzv is not None:
+            self._rdzv.cleanup()
+
+
+class GlooTransport:
+    """Host-buffer transport over torch.distributed (gloo).  The process group must
+    already be initialised by the caller (tests / a TCP launcher)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self._dist = dist
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def allreduce_max(self, v):
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def halo_exchange_host(self, x_local, n_halo):
+        """Send my last n_halo samples right, receive the left neighbour's; rank 0 gets zeros."""
+        import torch
+        dist = self._dist
+        x_local = np.ascontiguousarray(x_local)
+        if n_halo > x_local.size:
+            raise ValueError("halo of %d samples needs a shard of at least that many (got %d)" % (n_halo, x_local.size))
+        hist = np.zeros(n_halo, dtype=x_local.dtype)
+        if n_halo == 0 or self.world == 1:
+            return hist
+        reqs = []
+        if self.rank + 1 < self.world:
+            tail = torch.from_numpy(np.ascontiguousarray(x_local[x_local.size - n_halo:]).view(np.uint8).copy())
+            reqs.append(dist.isend(tail, self.rank + 1))
+        if self.rank > 0:
+            buf = torch.empty(n_halo * x_local.dtype.itemsize, dtype=torch.uint8)
+            dist.recv(buf, self.rank - 1)
+            hist = buf.numpy().view(x_local.dtype).copy()
+        for r in reqs:
+            r.wait()
+        return hist
+
+
+def hip_fir_kernel(fir_kernel):
+    """kernel(x_local, hist) -> y_local on the GPU for host-buffer transports."""
+    def run(x_local, hist):
+        x_local = np.ascontiguousarray(x_local)
+        xd = _ffi.DeviceArray(x_local.size, x_local.dtype, headroom=max(len(hist), 1))
+        esz = x_local.dtype.itemsize
+        import ctypes
+        L = _ffi.load()
+        _ffi.check(L.skdsp_memcpy_h2d(ctypes.c_void_p(xd.ptr), ctypes.c_void_p(x_local.ctypes.data), x_local.nbytes))
+        if len(hist):
+            h = np.ascontiguousarray(hist, dtype=x_local.dtype)
+            _ffi.check(L.skdsp_memcpy_h2d(ctypes.c_void_p(xd.ptr - len(h) * esz), ctypes.c_void_p(h.ctypes.data), h.nbytes))
+        yd = _ffi.DeviceArray(x_local.size, x_local.dtype)
+        fir_kernel.filter_dev(xd, yd, n_hist=len(hist))
+        y = yd.to_host()
+        xd.free()
+        yd.free()
+        return y
+    return run
+
+
+class ShardedFIR:
+    """multirate_FIR.filter on a sample-block shard (multirate_helper.py:104-109 applied
+    to samples [start_r, stop_r) of a longer vector).
+
+    filter_local_dev : device-resident shard + RcclTransport (production / bench.py)
+    filter_local_host: host shard + any host transport and kernel (tests, TCP clusters)
+    """
+
+    def __init__(self, b, transport, dtype=np.complex64, kernel=None):
+        self.b = np.asarray(b)
+        self.ntaps = len(self.b)
+        self.halo = self.ntaps - 1
+        self.transport = transport
+        self.dtype = np.dtype(dtype)
+        self._fir = None
+        self._kernel = kernel
+
+    def _hip(self):
+        if self._fir is None:
+            self._fir = _ffi.FirKernel(self.b, _ffi.code_of(self.dtype))
+        return self._fir
+
+    def new_shard_buffer(self, n_local):
+        """Device buffer for a shard with headroom for the halo in front of x[0]."""
+        return _ffi.DeviceArray(n_local, self.dtype, headroom=max(self.halo, 1))
+
+    def filter_local_dev(self, xd, yd, n_local=None):
+        n_local = xd.n if n_local is None else n_local
+        if self.transport.world > 1 and n_local < self.halo:
+            raise ValueError("shard of %d samples is shorter than the %d-sample halo" % (n_local, self.halo))
+        self._hip().filter_shard_dev(xd, yd, n_local)
+
+    def filter_local_host(self, x_local):
+        x_local = np.ascontiguousarray(x_local, dtype=self.dtype)
+        hist = self.transport.halo_exchange_host(x_local, self.halo)
+        kernel = self._kernel or hip_fir_kernel(self._hip())
+        return kernel(x_local, hist)

@@ -1,0 +1,373 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(libskdsp_hip.so via ctypes); the CPU oracle and the golden vectors captured from the
+real reference are the checkers.
+
+Tolerances (BASELINE.json north_star / SURVEY.md 8c):
+  * integer up/down-sample indexing: bit-exact
+  * float32 / complex64 filtering: <= 1e-6 (max-abs error / max-abs reference) and rel-L2
+  * float64 / complex128 kernels:  <= 1e-11
+"""
+import os
+
+import numpy as np
+import pytest
+
+import sk_dsp_comm_amd as sk
+from sk_dsp_comm_amd import _ffi, multirate_helper as mrh, sigsys as ss
+from oracle import oracle as orc
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-6
+TOL64 = 1e-11
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    _ffi.init()
+    info = _ffi.device_info()
+    assert "gfx950" in info["name"], info
+    yield
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def assert_close(y, ref, tol, what=""):
+    e_max, e_l2 = rel_err(y, ref)
+    assert e_max <= tol and e_l2 <= tol, "%s: max/peak %.3g, rel-L2 %.3g > %.1g" % (what, e_max, e_l2, tol)
+
+
+def cnoise(rng, n, dt=np.complex64):
+    return ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2)).astype(dt)
+
+
+# ----------------------------------------------------------------- resamplers
+def test_g1_upsample_bit_exact():
+    g = load("g1_upsample.npz")
+    for k in [k[2:] for k in g.files if k.startswith("x_")]:
+        L = float(k.split("_L")[1].replace("p", "."))
+        L = int(L) if L == int(L) else L
+        y = ss.upsample(g["x_" + k], L)
+        assert y.dtype == g["y_" + k].dtype and np.array_equal(y, g["y_" + k]), k
+
+
+def test_g2_downsample_bit_exact():
+    g = load("g2_downsample.npz")
+    for k in [k[2:] for k in g.files if k.startswith("y_")]:
+        n, M, p = k.split("_")
+        n, M, p = int(n[1:]), int(M[1:]), int(p[1:].replace("m", "-"))
+        for xk, yk in (("x_n%d" % n, "y_" + k), ("xc_n%d" % n, "yc_" + k)):
+            y = ss.downsample(g[xk], M, p)
+            assert y.dtype == g[yk].dtype and np.array_equal(y, g[yk]), k
+
+
+def test_resample_large_and_other_dtypes():
+    rng = np.random.default_rng(1)
+    x = rng.integers(-2 ** 31, 2 ** 31 - 1, size=1_000_003, dtype=np.int32)
+    assert np.array_equal(ss.downsample(x, 7, 3), orc.downsample(x, 7, 3))
+    x16 = rng.integers(-30000, 30000, size=10_001).astype(np.int16)
+    y = ss.downsample(x16, 4, 1)
+    assert y.dtype == np.int16 and np.array_equal(y, x16[: 2500 * 4].reshape(-1, 4)[:, 1])
+    xc = cnoise(rng, 300_001, np.complex128)
+    assert np.array_equal(ss.upsample(xc, 5), orc.upsample(xc, 5))
+    xf = rng.standard_normal(2 ** 20 + 1).astype(np.float32)
+    y = ss.upsample(xf, 3)
+    assert y.dtype == np.float64 and np.array_equal(y, orc.upsample(xf, 3))
+    # round trip: downsample(upsample(x, L), L) == x
+    assert np.array_equal(ss.downsample(ss.upsample(xf, 6), 6), xf.astype(np.float64))
+
+
+# ------------------------------------------------------------------------ FIR
+def test_g4_fir127():
+    g = load("g4_fir127.npz")
+    f = mrh.multirate_FIR(g["b"])
+    for xk, yk in (("xr", "yr"), ("xc", "yc")):
+        y = f.filter(g[xk])
+        assert y.dtype == g[yk].dtype
+        assert_close(y, g[yk], TOL32, "fir127 " + xk)
+
+
+@pytest.mark.parametrize("algo", [_ffi.FIR_DIRECT, _ffi.FIR_OLS])
+def test_g5_fir1024_both_algorithms(algo):
+    g = load("g5_fir1024.npz")
+    k = _ffi.FirKernel(g["b"], _ffi.C64)
+    k.set_algo(algo)
+    assert k.algo_for(len(g["x"])) == algo
+    assert_close(k.filter(g["x"]), g["y"], TOL32, "fir1024 c64 algo %d" % algo)
+    kc = _ffi.FirKernel(g["bc"], _ffi.C64)
+    kc.set_algo(algo)
+    assert_close(kc.filter(g["x"][:12000].copy()), g["yc"], TOL32, "fir1024 complex taps algo %d" % algo)
+
+
+def test_g5_fir1024_mirror_and_real():
+    g = load("g5_fir1024.npz")
+    f = mrh.multirate_FIR(g["b"])
+    y = f.filter(g["x"])
+    assert y.dtype == np.complex128
+    assert_close(y, g["y"], TOL32, "fir1024 auto")
+    assert_close(f.filter(g["xr"]), g["yr"], TOL32, "fir1024 f32 real")
+    # float64 callers get float64 kernels
+    assert_close(f.filter(g["xr"].astype(np.float64)), g["yr"], TOL64, "fir1024 f64")
+    assert_close(f.filter(g["x"].astype(np.complex128)), g["y"], TOL64, "fir1024 c128")
+
+
+def test_g6_fir512_up_dn_updn():
+    g = load("g6_fir512_updn.npz")
+    f = mrh.multirate_FIR(g["b"])
+    x = g["x"]
+    up4 = f.up(x, 4)
+    assert up4.dtype == g["up4"].dtype and up4.shape == g["up4"].shape
+    assert_close(up4, g["up4"], TOL32, "up4")
+    dn3 = f.dn(x, 3)
+    assert dn3.shape == g["dn3"].shape
+    assert_close(dn3, g["dn3"], TOL32, "dn3")
+    assert_close(f.updn(x, 4, 3), g["up4_dn3"], TOL32, "up4/dn3 fused")
+    assert_close(ss.downsample(up4, 3), g["up4_dn3"], TOL32, "downsample(up4,3)")
+    assert_close(f.up(x[:700]), g["up_default"], TOL32, "up default L=12")
+    assert_close(f.dn(x), g["dn_default"], TOL32, "dn default M=12")
+    assert_close(f.up(g["xr"], 5), g["upr5"], TOL32, "up5 real")
+    assert_close(f.dn(g["xr"], 7), g["dnr7"], TOL32, "dn7 real")
+
+
+@pytest.mark.parametrize("n,P", [(1, 1), (5, 3), (100, 127), (4097, 48), (7168, 1024), (7169, 1024), (8192, 1025),
+                                 (20000, 512), (3 * 7168 + 5, 700), (9000, 2000), (33333, 4097)])
+def test_fir_ols_edges_vs_oracle(n, P):
+    """tile boundaries, ragged tails, tap counts around the overlap quantum (512)"""
+    rng = np.random.default_rng(n * 31 + P)
+    x = cnoise(rng, n)
+    b = rng.standard_normal(P) / np.sqrt(P)
+    ref = orc.fir_filter(b, x)
+    k = _ffi.FirKernel(b, _ffi.C64)
+    if P >= 2:
+        k.set_algo(_ffi.FIR_OLS)
+        assert_close(k.filter(x), ref, TOL32, "ols n=%d P=%d" % (n, P))
+    k.set_algo(_ffi.FIR_DIRECT)
+    assert_close(k.filter(x), ref, TOL32, "direct n=%d P=%d" % (n, P))
+
+
+@pytest.mark.parametrize("L,M", [(1, 1), (2, 1), (1, 2), (4, 3), (3, 4), (12, 1), (1, 12), (6, 4), (5, 5), (7, 24)])
+def test_fir_polyphase_all_ratios_vs_oracle(L, M):
+    rng = np.random.default_rng(L * 100 + M)
+    n = 5003
+    b = rng.standard_normal(193) / 14
+    for x in (cnoise(rng, n), rng.standard_normal(n).astype(np.float32)):
+        k = _ffi.FirKernel(b, _ffi.code_of(x.dtype))
+        ref = orc.downsample(orc.fir_up(b, x, L), M)
+        y = k.updn(x, L, M)
+        assert y.shape == ref.shape
+        assert_close(y, ref, TOL32, "updn L=%d M=%d %s" % (L, M, x.dtype))
+
+
+def test_fir_history_matches_slice_of_whole():
+    """n_hist semantics of the *_dev entry points (what the sharded path relies on)."""
+    rng = np.random.default_rng(5)
+    n, P, cut = 60000, 1024, 23456
+    x = cnoise(rng, n)
+    b = rng.standard_normal(P) / 32
+    ref = orc.fir_filter(b, x)
+    for algo in (_ffi.FIR_OLS, _ffi.FIR_DIRECT):
+        k = _ffi.FirKernel(b, _ffi.C64)
+        k.set_algo(algo)
+        xd = _ffi.DeviceArray.from_host(x[cut:], headroom=P - 1)
+        import ctypes
+        hist = np.ascontiguousarray(x[cut - (P - 1):cut])
+        _ffi.check(_ffi.load().skdsp_memcpy_h2d(ctypes.c_void_p(xd.ptr - hist.nbytes), ctypes.c_void_p(hist.ctypes.data), hist.nbytes))
+        yd = _ffi.DeviceArray(n - cut, np.complex64)
+        k.filter_dev(xd, yd, n_hist=P - 1)
+        assert_close(yd.to_host(), ref[cut:], TOL32, "history algo %d" % algo)
+
+
+def test_fir_2d_and_dtype_matrix():
+    g = load("g10_2d.npz")
+    b = load("g4_fir127.npz")["b"]
+    y = mrh.multirate_FIR(b).filter(g["x"])
+    assert y.shape == g["y_fir"].shape and y.dtype == np.float64
+    assert_close(y, g["y_fir"], TOL32, "2-D")
+    import json
+    dtm = json.load(open(os.path.join(GOLDEN, "g10_conventions.json")))["dtype_matrix"]
+    sos = load("g7_iir_sos.npz")["sos8"]
+    f, i8, rc = mrh.multirate_FIR(b), mrh.multirate_IIR(sos), mrh.rate_change(4)
+    for dt in ("float32", "float64", "complex64", "complex128", "int32"):
+        x = np.ones(24, dtype=dt)
+        got = {"upsample": ss.upsample(x, 2), "downsample": ss.downsample(x, 2), "fir_filter": f.filter(x),
+               "fir_up": f.up(x, 2), "fir_dn": f.dn(x, 2), "iir_filter": i8.filter(x), "iir_up": i8.up(x, 2),
+               "iir_dn": i8.dn(x, 2), "rc_up": rc.up(x), "rc_dn": rc.dn(x)}
+        for kname, arr in got.items():
+            assert str(arr.dtype) == dtm[dt][kname], (dt, kname, arr.dtype)
+    y32 = mrh.multirate_IIR(sos.astype(np.float32)).filter(np.ones(8, np.float32))
+    assert str(y32.dtype) == dtm["float32_sos32"]["iir_filter"]
+
+
+def test_native_dtype_switch():
+    g = load("g4_fir127.npz")
+    sk.config.strict_dtype = False
+    try:
+        y = mrh.multirate_FIR(g["b"]).filter(g["xc"])
+        assert y.dtype == np.complex64
+        assert_close(y, g["yc"], TOL32)
+    finally:
+        sk.config.strict_dtype = True
+
+
+# ------------------------------------------------------------------------ IIR
+def test_g7_iir_sos():
+    g = load("g7_iir_sos.npz")
+    i8, i7 = mrh.multirate_IIR(g["sos8"]), mrh.multirate_IIR(g["sos7"])
+    x = g["x"]
+    y = i8.filter(x)
+    assert y.dtype == np.float64
+    assert_close(y, g["y8"], TOL32, "sos8 filter")
+    assert_close(i7.filter(x), g["y7"], TOL32, "sos7 filter")
+    assert_close(i8.up(x[:6000], 2), g["up2"], TOL32, "sos8 up2")
+    assert_close(i8.dn(x, 3), g["dn3"], TOL32, "sos8 dn3")
+    assert_close(i8.filter(g["xc"]), g["y8c"], TOL32, "sos8 complex")
+    # float64 input -> float64 I/O kernels: essentially exact
+    assert_close(i8.filter(x.astype(np.float64)), g["y8"], 1e-9, "sos8 f64")
+
+
+def test_g8_rate_change():
+    pytest.importorskip("scipy")
+    g = load("g8_rate_change.npz")
+    for tag, args in (("m4", (4,)), ("m12", (12,)), ("m4_cheby", (4, 0.8, 6, 'cheby1'))):
+        rc = mrh.rate_change(*args)
+        assert_close(rc.up(g["x"]), g[tag + "_up"], TOL32, tag + " up")
+        assert_close(rc.dn(g["x"]), g[tag + "_dn"], TOL32, tag + " dn")
+        assert_close(rc.up(g["xc"]), g[tag + "_upc"], TOL32, tag + " up complex")
+        assert_close(rc.dn(g["xc"]), g[tag + "_dnc"], TOL32, tag + " dn complex")
+
+
+def test_g9_kats_interp24_deci24_through_gpu():
+    """tests/test_sigsys.py:617-653 restated on the GPU primitives (TF-form Butterworth order 10)."""
+    sig = pytest.importorskip("scipy.signal")
+    g = load("g9_kat.npz")
+
+    def interp24(x):
+        y = np.asarray(x, dtype=np.float64)
+        for L in (2, 3, 4):
+            b, a = sig.butter(10, 1.0 / L)
+            y = _ffi.IirKernel(_ffi.F64, b=b, a=a).up(np.ascontiguousarray(y), L)
+        return y
+
+    def deci24(x):
+        y = np.asarray(x, dtype=np.float64)
+        for M in (2, 3, 4):
+            b, a = sig.butter(10, 1.0 / M)
+            y = _ffi.IirKernel(_ffi.F64, b=b, a=a).dn(np.ascontiguousarray(y), M)
+        return y
+
+    y = interp24(g["m2"])
+    np.testing.assert_almost_equal(y, g["interp24_m2"])
+    yd = deci24(interp24(g["m3"]))
+    np.testing.assert_almost_equal(yd, g["deci24"])
+    np.testing.assert_almost_equal(yd, [3.33911797e-22, 3.71880014e-10, 4.33029514e-06, 1.16169513e-03,
+                                        4.34891180e-02, 4.08255952e-01, 1.16839852e+00])
+    # os_filter KAT (tests/test_sigsys.py:688-696) == FIR of ones(10)
+    np.testing.assert_almost_equal(mrh.multirate_FIR(g["os_b"]).filter(g["os_x"]), g["os_y"])
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 8191, 8192 * 3 + 17, 300_001, 2 ** 22 + 5])
+def test_iir_scan_lengths_vs_oracle(n):
+    """chunk / workgroup / tail boundaries of the scan"""
+    g = load("g7_iir_sos.npz")
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n).astype(np.float32)
+    ref = orc.sos_filter(g["sos8"], x)
+    y = _ffi.IirKernel(_ffi.F32, sos=g["sos8"]).filter(x)
+    assert_close(y, ref, TOL32, "sos8 n=%d" % n)
+
+
+def test_iir_slow_decay_and_integrator_exact_scan():
+    """The scan is exact, not a warm-up approximation: poles at radius 0.99999 and a pure
+    integrator (pole on the unit circle) must still match the sequential recurrence."""
+    rng = np.random.default_rng(3)
+    n = 500_000
+    x = rng.standard_normal(n)
+    r = 0.99999
+    sos = np.array([[1.0, 0.0, 0.0, 1.0, -2 * r * np.cos(0.01), r * r],
+                    [1.0, -1.0, 0.0, 1.0, -0.5, 0.0]])
+    assert_close(_ffi.IirKernel(_ffi.F64, sos=sos).filter(x), orc.sos_filter(sos, x), 1e-9, "slow decay")
+    integ = np.array([[1.0, 0.0, 0.0, 1.0, -1.0, 0.0]])
+    xi = rng.standard_normal(n) * 1e-3
+    assert_close(_ffi.IirKernel(_ffi.F64, sos=integ).filter(xi), np.cumsum(xi), 1e-9, "integrator")
+
+
+def test_iir_many_sections_split():
+    sig = pytest.importorskip("scipy.signal")
+    sos = sig.butter(30, 0.2, output="sos")  # 15 sections -> 12 + 3
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(40_000).astype(np.float32)
+    assert_close(mrh.multirate_IIR(sos).filter(x), orc.sos_filter(sos, x), TOL32, "15 sections")
+
+
+# ------------------------------------------------- full-size property tests
+def test_fir_full_size_properties():
+    """BASELINE config 2 size (2^26 c64, 1024 taps): spot windows against the oracle
+    (the FIR is local) + linearity, device resident."""
+    n, P = 2 ** 26, 1024
+    g = load("g5_fir1024.npz")
+    b = g["b"]
+    k = _ffi.FirKernel(b, _ffi.C64)
+    xd = _ffi.DeviceArray(n, np.complex64).fill_noise(2026)
+    yd = _ffi.DeviceArray(n, np.complex64)
+    k.filter_dev(xd, yd)
+    _ffi.sync()
+    assert k.algo_for(n) == _ffi.FIR_OLS
+    rng = np.random.default_rng(0)
+    starts = [0, 7168 - 20, n - 5000] + [int(s) for s in rng.integers(P, n - 5000, size=5)]
+    for s0 in starts:
+        w = 4096
+        lo = max(0, s0 - (P - 1))
+        xs = xd.to_host(lo, s0 + w - lo)
+        ref = orc.fir_filter(b, xs)[s0 - lo:]
+        assert_close(yd.to_host(s0, w), ref, TOL32, "window @%d" % s0)
+    # linearity: filter(2x) == 2 filter(x) exactly in float arithmetic (power-of-two scale)
+    x2 = _ffi.DeviceArray.from_host(2 * xd.to_host(0, 2 ** 20))
+    y2 = _ffi.DeviceArray(2 ** 20, np.complex64)
+    k.filter_dev(x2, y2)
+    assert np.array_equal(y2.to_host(0, 2 ** 19), 2 * yd.to_host(0, 2 ** 19))
+
+
+def test_iir_full_size_properties():
+    """BASELINE config 4 size (2^26 f32, 8 biquads): head against the oracle and
+    time-invariance (a delayed input gives the delayed output) deep inside the vector."""
+    g = load("g7_iir_sos.npz")
+    n = 2 ** 26
+    k = _ffi.IirKernel(_ffi.F32, sos=g["sos8"])
+    xd = _ffi.DeviceArray(n, np.float32).fill_noise(7)
+    yd = _ffi.DeviceArray(n, np.float32)
+    k.filter_dev(xd, yd)
+    _ffi.sync()
+    m = 2 ** 21
+    xh = xd.to_host(0, m)
+    assert_close(yd.to_host(0, m), orc.sos_filter(g["sos8"], xh), TOL32, "head")
+    # window far from the start: the filter forgets (|pole|max = 0.9947) after ~8k samples
+    s0 = n - 3 * m
+    xs = xd.to_host(s0 - 20000, m + 20000)
+    ref = orc.sos_filter(g["sos8"], xs)[20000:]
+    assert_close(yd.to_host(s0, m), ref, TOL32, "deep window")
+
+
+def test_updn_full_size_config3():
+    """BASELINE config 3: L=4 / M=3 with the 512-tap prototype on 2^26 c64 (89 478 485 outputs)."""
+    g = load("g6_fir512_updn.npz")
+    b = g["b"]
+    n = 2 ** 26
+    n_out = (n * 4) // 3
+    assert n_out == 89478485
+    k = _ffi.FirKernel(b, _ffi.C64)
+    xd = _ffi.DeviceArray(n, np.complex64).fill_noise(11)
+    yd = _ffi.DeviceArray(n_out, np.complex64)
+    k.updn_dev(xd, yd, 4, 3)
+    _ffi.sync()
+    for s_in in (0, 12345 * 3, n - 9000):
+        s_in -= s_in % 3
+        lo = max(0, s_in - 200)
+        xs = xd.to_host(lo, min(6000, n - lo))
+        ref = orc.downsample(orc.fir_up(b, xs, 4), 3)
+        m0 = (s_in * 4) // 3
+        skip = ((s_in - lo) * 4) // 3
+        w = 4000
+        assert_close(yd.to_host(m0, w), ref[skip:skip + w], TOL32, "updn window @%d" % s_in)

@@ -1,0 +1,147 @@
+"""CPU-only checks of the boundary and the host logic (no compute calls without a GPU):
+the C-ABI library loads and exports every symbol include/skdsp.h declares, the product
+fails loudly without a device, the Python mirror keeps the reference's signatures and
+error conventions, and the OLS index algebra holds (host emulation of the tile)."""
+import ctypes
+import inspect
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import sk_dsp_comm_amd as sk
+from sk_dsp_comm_amd import _ffi, multirate_helper as mrh, sigsys as ss
+from conftest import GOLDEN, ROOT
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "skdsp.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(skdsp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_ffi.lib_path()), "build libskdsp_hip.so first (__graft_entry__.build())"
+    L = ctypes.CDLL(_ffi.lib_path())
+    declared = _header_symbols()
+    assert len(declared) >= 45
+    for name in declared:
+        assert hasattr(L, name), "missing export: " + name
+    assert sorted(_ffi.SYMBOLS) == declared  # the ctypes layer binds exactly the header
+    assert b"gfx950" in ctypes.cast(L.skdsp_version, ctypes.CFUNCTYPE(ctypes.c_char_p))()
+
+
+def test_library_is_gfx950_code_object():
+    out = subprocess.run(["strings", "-n", "6", _ffi.lib_path()], stdout=subprocess.PIPE).stdout
+    assert b"gfx950" in out
+    for kern in (b"ols_tile_kernel", b"fir_poly_kernel", b"iir_chunk_kernel", b"upsample_kernel"):
+        assert kern in out
+
+
+def test_fails_loudly_without_gpu():
+    L = _ffi.load()
+    if L.skdsp_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_ffi.SkdspError, match="no HIP device"):
+        mrh.multirate_FIR(np.ones(4) / 4).filter(np.ones(16, np.float32))
+    with pytest.raises(_ffi.SkdspError):
+        ss.upsample(np.ones(4), 2)
+
+
+def test_signatures_match_reference():
+    assert str(inspect.signature(mrh.rate_change.__init__)) == "(self, M_change=12, fcutoff=0.9, N_filt_order=8, ftype='butter')"
+    assert str(inspect.signature(mrh.multirate_FIR.__init__)) == "(self, b)"
+    assert str(inspect.signature(mrh.multirate_FIR.up)) == "(self, x, L_change=12)"
+    assert str(inspect.signature(mrh.multirate_FIR.dn)) == "(self, x, M_change=12)"
+    assert str(inspect.signature(mrh.multirate_IIR.up)) == "(self, x, L_change=12)"
+    assert str(inspect.signature(mrh.multirate_IIR.dn)) == "(self, x, M_change=12)"
+    assert str(inspect.signature(ss.downsample)) == "(x, M, p=0)"
+    assert str(inspect.signature(ss.upsample)) == "(x, L)"
+    assert str(inspect.signature(ss.cic)) == "(m, k)"
+
+
+def test_constructors_and_logging(caplog):
+    import logging
+    caplog.set_level(logging.INFO)
+    b = np.ones(127) / 127
+    f = mrh.multirate_FIR(b)
+    assert f.N_forder == 127 and f.b is b
+    assert "FIR filter taps = 127" in caplog.text
+    g = np.load(os.path.join(GOLDEN, "g7_iir_sos.npz"))
+    i8 = mrh.multirate_IIR(g["sos8"])
+    assert i8.N_forder == float(g["N_forder8"]) and "IIR filter order = 16" in caplog.text
+    assert mrh.multirate_IIR(g["sos7"]).N_forder == float(g["N_forder7"])
+    pytest.importorskip("scipy")
+    g8 = np.load(os.path.join(GOLDEN, "g8_rate_change.npz"))
+    rc = mrh.rate_change(4)
+    assert rc.M == 4 and rc.fc == 0.45 and rc.N_forder == 8
+    np.testing.assert_allclose(rc.b, g8["m4_b"], rtol=1e-12)
+    np.testing.assert_allclose(rc.a, g8["m4_a"], rtol=1e-12)
+    rc = mrh.rate_change(4, 0.8, 6, 'cheby1')
+    np.testing.assert_allclose(rc.a, g8["m4_cheby_a"], rtol=1e-12)
+    with pytest.warns(UserWarning, match='ftype must be "butter" or "cheby1"'):
+        bad = mrh.rate_change(4, ftype='bessel')
+    with pytest.raises(AttributeError, match="has no attribute 'b'"):
+        bad.up(np.zeros(4))
+
+
+def test_error_conventions_before_any_gpu_call():
+    conv = json.load(open(os.path.join(GOLDEN, "g10_conventions.json")))
+    for e in conv["downsample_errors"]:
+        if e["type"] == "TypeError":
+            with pytest.raises(TypeError, match="M must be an int"):
+                ss.downsample(np.zeros(e["n"]), eval(e["M"], {"np": np}))
+    with pytest.raises(IndexError, match="index 3 is out of bounds for axis 1 with size 3"):
+        ss.downsample(np.zeros(6), 3, 3)
+    with pytest.raises(ZeroDivisionError):
+        ss.downsample(np.zeros(6), 0)
+    errs = conv["errors"]
+    with pytest.raises(AttributeError, match=re.escape(errs["upsample_list"]["msg"])):
+        ss.upsample([1, 2, 3], 2)
+    with pytest.raises(ValueError, match=re.escape(errs["upsample_2d"]["msg"])):
+        ss.upsample(np.zeros((2, 3)), 2)
+    with pytest.raises(ValueError, match=re.escape(errs["upsample_L0"]["msg"])):
+        ss.upsample(np.zeros(4), 0)
+    with pytest.raises(ValueError, match=re.escape(errs["fir_filter_empty"]["msg"])):
+        mrh.multirate_FIR(np.ones(3)).filter(np.zeros(0))
+    with pytest.raises(ValueError, match=re.escape(errs["iir_bad_sos"]["msg"])):
+        mrh.multirate_IIR(np.ones((2, 5))).filter(np.zeros(4))
+    sos = np.array([[1.0, 0, 0, 2.0, 0, 0]])
+    with pytest.raises(ValueError, match=re.escape("sos[:, 3] should be all ones")):
+        mrh.multirate_IIR(sos).filter(np.zeros(4))
+    with pytest.raises(TypeError, match="M must be an int"):
+        mrh.multirate_FIR(np.ones(3)).dn(np.zeros(9), 3.0)
+    # empty / tiny inputs that the reference answers without filtering
+    assert ss.downsample(np.zeros(2), 3).shape == (0,)
+    assert ss.upsample(np.zeros(0), 3).shape == (0,) and ss.upsample(np.zeros(0), 3).dtype == np.float64
+
+
+def test_cic_golden_exact():
+    g = np.load(os.path.join(GOLDEN, "g3_cic.npz"))
+    for k in g.files:
+        _, m, kk = k.split("_")
+        assert np.array_equal(ss.cic(int(m), int(kk)), g[k]), k
+    # reference KATs tests/test_sigsys.py:13-26, tests/test_digitalcom.py:39-62
+    assert np.sum(np.ones(10) / 10 - ss.cic(10, 1)) == 0
+    correct = [0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07, 0.08, 0.09, 0.1,
+               0.09, 0.08, 0.07, 0.06, 0.05, 0.04, 0.03, 0.02, 0.01]
+    assert np.sum(correct - ss.cic(10, 2)) == 0
+    assert len(ss.cic(4, 7)) == 22
+
+
+def test_ols_tile_index_algebra_host_emulation(tmp_path):
+    """Compiles csrc/ols_core.hpp for the HOST and runs one whole overlap-save tile."""
+    exe = str(tmp_path / "ols_emul")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "scikit-dsp-comm_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host", "ols_emul.cpp"), "-o", exe])
+    out = subprocess.run([exe], stdout=subprocess.PIPE).stdout.decode()
+    assert out.strip().endswith("OK"), out
+
+
+def test_package_surface():
+    for name in ("rate_change", "multirate_FIR", "multirate_IIR", "upsample", "downsample", "cic"):
+        assert hasattr(sk, name)
+    assert sk.config.strict_dtype is True
