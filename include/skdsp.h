@@ -100,8 +100,12 @@ int skdsp_fir_updn_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t n_h
 /* sos: nsec x 6 float64, sos[:,3]==1 (scipy.signal.sosfilt contract). */
 int skdsp_sos_create(const double *sos, int nsec, int dtype, skdsp_handle *out);
 /* transfer function (b,a) for signal.lfilter(b,a,.), multirate_helper.py:74,81;
- * a[0]-normalised, direct-form II transposed like scipy. */
+ * a[0]-normalised.  scipy runs (b,a) as one DF2T section of order N; the scan kernel
+ * runs the same transfer function factored into biquads (see capi.hip: the order-N
+ * companion coordinates are too ill-conditioned for an affine scan).  Order <= 24. */
 int skdsp_tf_create(const double *b, int nb, const double *a, int na, int dtype, skdsp_handle *out);
+/* host-only: the (b,a) -> sos factorisation tf_create applies; sos_out holds up to 12x6 doubles */
+int skdsp_tf2sos(const double *b, int nb, const double *a, int na, double *sos_out, int *nsec_out);
 /* .filter: sosfilt(sos,x) (:169-174) / lfilter(b,a,x) */
 int skdsp_iir_filter(skdsp_handle h, const void *x, int64_t n, void *y);
 int skdsp_iir_filter_dev(skdsp_handle h, const void *x_dev, int64_t n, void *y_dev);

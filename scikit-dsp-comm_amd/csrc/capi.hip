@@ -7,6 +7,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <complex>
+#include <array>
+#include <algorithm>
+#include <cmath>
 
 namespace skdsp {
 
@@ -157,6 +161,217 @@ static int iir_any_dev(IirHandle *h, const void *x_dev, int64_t n, void *y_dev)
     if ((rc = deinterleave_launch(x_dev, n, h->dtype, re, im, s))) return rc;
     if ((rc = iir_launch_planar(h, planes, n, 2, stride, planes, s))) return rc;
     return interleave_launch(re, im, n, h->dtype, y_dev, s);
+}
+
+// ---------------------------------------------------------------------------
+// (b, a) -> cascaded biquads.  scipy.signal.lfilter runs a transfer function as ONE
+// direct-form-II-transposed section of order N.  In those state coordinates the
+// one-chunk transition matrix A^T of a narrow-band design (rate_change(12): Butterworth
+// order 8, cutoff 0.075) has entries ~1e6 that cancel, so the affine scan would lose
+// ~1e-4 of the output even in float64 (measured).  The scan therefore runs the SAME
+// transfer function as second-order sections, whose state coordinates are benign; the
+// result differs from the reference's TF-form recursion by its own float64 roundoff
+// level (~1e-9 relative for rate_change(12), tests/golden/g8).  Conjugate pairs are
+// symmetrised so every section has real coefficients.
+typedef std::complex<long double> cld;
+
+// Roots of c[0] z^n + ... + c[n] as the eigenvalues of the (real) companion matrix by
+// the Francis double-shift QR iteration (the classical EISPACK "hqr" scheme) in long
+// double.  Orthogonal similarity transforms are backward stable, and REAL arithmetic
+// returns exactly conjugate pairs -- both matter for the N-fold zero at z = -1 of a
+// Butterworth numerator: the individual roots scatter by eps^(1/N), yet the product of
+// the resulting real quadratic factors reproduces the coefficients to ~1e-18 (an
+// Aberth iteration, or a complex-shift QR followed by symmetrising the pairs, measured
+// 1e-6 .. 1e-4 there).
+static inline long double sign_ld(long double a, long double b) { return b >= 0.0L ? fabsl(a) : -fabsl(a); }
+
+static bool poly_roots(const std::vector<long double> &c, std::vector<cld> &roots)
+{
+    const int n = (int)c.size() - 1;
+    roots.clear();
+    if (n <= 0) return true;
+    std::vector<long double> A((size_t)n * n, 0.0L);
+    auto a = [&](int i, int j) -> long double & { return A[(size_t)i * n + j]; };
+    for (int j = 0; j < n; ++j) a(0, j) = -c[j + 1] / c[0];
+    for (int i = 1; i < n; ++i) a(i, i - 1) = 1.0L;
+    roots.assign(n, cld(0.0L, 0.0L));
+    long double anorm = 0.0L;
+    for (int i = 0; i < n; ++i)
+        for (int j = (i > 0 ? i - 1 : 0); j < n; ++j) anorm += fabsl(a(i, j));
+    int nn = n - 1;
+    long double t = 0.0L, p = 0, q = 0, r = 0, s = 0, w = 0, x = 0, y = 0, z = 0;
+    while (nn >= 0) {
+        int its = 0, l;
+        do {
+            for (l = nn; l >= 1; --l) {
+                s = fabsl(a(l - 1, l - 1)) + fabsl(a(l, l));
+                if (s == 0.0L) s = anorm;
+                if (fabsl(a(l, l - 1)) + s == s) { a(l, l - 1) = 0.0L; break; }
+            }
+            x = a(nn, nn);
+            if (l == nn) {  // one root
+                roots[nn--] = cld(x + t, 0.0L);
+            } else {
+                y = a(nn - 1, nn - 1);
+                w = a(nn, nn - 1) * a(nn - 1, nn);
+                if (l == nn - 1) {  // two roots
+                    p = 0.5L * (y - x);
+                    q = p * p + w;
+                    z = sqrtl(fabsl(q));
+                    x += t;
+                    if (q >= 0.0L) {
+                        z = p + sign_ld(z, p);
+                        roots[nn - 1] = roots[nn] = cld(x + z, 0.0L);
+                        if (z != 0.0L) roots[nn] = cld(x - w / z, 0.0L);
+                    } else {
+                        roots[nn - 1] = cld(x + p, z);
+                        roots[nn] = cld(x + p, -z);
+                    }
+                    nn -= 2;
+                } else {  // no roots yet: one double-shift sweep
+                    if (its == 120) return false;
+                    if (its % 10 == 0 && its > 0) {  // exceptional shift
+                        t += x;
+                        for (int i = 0; i <= nn; ++i) a(i, i) -= x;
+                        s = fabsl(a(nn, nn - 1)) + fabsl(a(nn - 1, nn - 2));
+                        y = x = 0.75L * s;
+                        w = -0.4375L * s * s;
+                    }
+                    ++its;
+                    int m;
+                    for (m = nn - 2; m >= l; --m) {
+                        z = a(m, m);
+                        r = x - z;
+                        s = y - z;
+                        p = (r * s - w) / a(m + 1, m) + a(m, m + 1);
+                        q = a(m + 1, m + 1) - z - r - s;
+                        r = a(m + 2, m + 1);
+                        s = fabsl(p) + fabsl(q) + fabsl(r);
+                        p /= s; q /= s; r /= s;
+                        if (m == l) break;
+                        const long double u = fabsl(a(m, m - 1)) * (fabsl(q) + fabsl(r));
+                        const long double v = fabsl(p) * (fabsl(a(m - 1, m - 1)) + fabsl(z) + fabsl(a(m + 1, m + 1)));
+                        if (u + v == v) break;
+                    }
+                    for (int i = m + 2; i <= nn; ++i) {
+                        a(i, i - 2) = 0.0L;
+                        if (i != m + 2) a(i, i - 3) = 0.0L;
+                    }
+                    for (int k = m; k <= nn - 1; ++k) {
+                        if (k != m) {
+                            p = a(k, k - 1);
+                            q = a(k + 1, k - 1);
+                            r = 0.0L;
+                            if (k != nn - 1) r = a(k + 2, k - 1);
+                            if ((x = fabsl(p) + fabsl(q) + fabsl(r)) != 0.0L) { p /= x; q /= x; r /= x; }
+                        }
+                        if ((s = sign_ld(sqrtl(p * p + q * q + r * r), p)) != 0.0L) {
+                            if (k == m) {
+                                if (l != m) a(k, k - 1) = -a(k, k - 1);
+                            } else {
+                                a(k, k - 1) = -s * x;
+                            }
+                            p += s;
+                            x = p / s; y = q / s; z = r / s;
+                            q /= p; r /= p;
+                            for (int j = k; j <= nn; ++j) {
+                                p = a(k, j) + q * a(k + 1, j);
+                                if (k != nn - 1) { p += r * a(k + 2, j); a(k + 2, j) -= p * z; }
+                                a(k + 1, j) -= p * y;
+                                a(k, j) -= p * x;
+                            }
+                            const int mmin = nn < k + 3 ? nn : k + 3;
+                            for (int i = l; i <= mmin; ++i) {
+                                p = x * a(i, k) + y * a(i, k + 1);
+                                if (k != nn - 1) { p += z * a(i, k + 2); a(i, k + 2) -= p * r; }
+                                a(i, k + 1) -= p * q;
+                                a(i, k) -= p;
+                            }
+                        }
+                    }
+                }
+            }
+        } while (l < nn - 1);
+    }
+    for (auto &rt : roots)
+        if (!std::isfinite((double)rt.real()) || !std::isfinite((double)rt.imag())) return false;
+    return true;
+}
+
+// group roots of a real polynomial into real quadratic factors 1 + c1 z^-1 + c2 z^-2
+static bool quad_factors(std::vector<cld> roots, std::vector<std::pair<long double, long double>> &quads)
+{
+    quads.clear();
+    std::vector<cld> up, dn;
+    std::vector<long double> re;
+    for (auto &r : roots) {
+        const long double tol = 1e-13L * (1.0L + std::abs(r));
+        if (r.imag() > tol) up.push_back(r);
+        else if (r.imag() < -tol) dn.push_back(r);
+        else re.push_back(r.real());
+    }
+    if (up.size() != dn.size()) return false;
+    for (auto &u : up) {
+        // nearest partner to conj(u)
+        size_t best = 0;
+        long double bd = -1.0L;
+        for (size_t j = 0; j < dn.size(); ++j) {
+            const long double d = std::abs(std::conj(u) - dn[j]);
+            if (bd < 0.0L || d < bd) { bd = d; best = j; }
+        }
+        const cld z = u;  // hqr returns exact conjugate pairs
+        dn.erase(dn.begin() + (long)best);
+        quads.push_back({-2.0L * z.real(), std::norm(z)});
+    }
+    std::sort(re.begin(), re.end());
+    for (size_t i = 0; i + 1 < re.size(); i += 2) quads.push_back({-(re[i] + re[i + 1]), re[i] * re[i + 1]});
+    if (re.size() & 1) quads.push_back({-re.back(), 0.0L});
+    return true;
+}
+
+static int tf_to_sos(const double *b, int nb, const double *a, int na, std::vector<double> &sos, int *nsec_out)
+{
+    // normalise by a[0]; strip trailing zeros (roots at the origin contribute a unit factor)
+    std::vector<long double> bb(b, b + nb), aa(a, a + na);
+    for (auto &v : bb) v /= (long double)a[0];
+    for (auto &v : aa) v /= (long double)a[0];
+    while (bb.size() > 1 && bb.back() == 0.0L) bb.pop_back();
+    while (aa.size() > 1 && aa.back() == 0.0L) aa.pop_back();
+    int delay = 0;  // leading zeros of b = pure delays z^-delay
+    while (bb.size() > 1 && bb.front() == 0.0L) { bb.erase(bb.begin()); ++delay; }
+    const long double gain = bb.front();
+    std::vector<std::pair<long double, long double>> zq, pq;
+    if (gain != 0.0L) {
+        std::vector<cld> zr;
+        SK_CHECK(poly_roots(bb, zr) && quad_factors(zr, zq), SKDSP_ERR_UNSUPPORTED,
+                 "tf_create: could not factor the numerator into real second-order sections");
+    }
+    std::vector<cld> pr;
+    SK_CHECK(poly_roots(aa, pr) && quad_factors(pr, pq), SKDSP_ERR_UNSUPPORTED,
+             "tf_create: could not factor the denominator into real second-order sections");
+    // delays become numerator factors z^-1 / z^-2
+    std::vector<std::array<long double, 3>> num;
+    for (auto &q : zq) num.push_back({1.0L, q.first, q.second});
+    for (; delay >= 2; delay -= 2) num.push_back({0.0L, 0.0L, 1.0L});
+    if (delay == 1) num.push_back({0.0L, 1.0L, 0.0L});
+    const size_t ns = std::max<size_t>(std::max(num.size(), pq.size()), 1);
+    SK_CHECK(ns <= 12, SKDSP_ERR_UNSUPPORTED, "tf_create: order %d needs more than 12 second-order sections",
+             (int)std::max(nb, na) - 1);
+    // sections in order of increasing pole radius (quiet sections first), gain on the first
+    std::sort(pq.begin(), pq.end(), [](const auto &x, const auto &y) { return x.second < y.second; });
+    sos.assign(ns * 6, 0.0);
+    for (size_t s = 0; s < ns; ++s) {
+        std::array<long double, 3> nmr = s < num.size() ? num[s] : std::array<long double, 3>{1.0L, 0.0L, 0.0L};
+        if (s == 0) for (auto &v : nmr) v *= gain;
+        sos[6 * s + 0] = (double)nmr[0];
+        sos[6 * s + 1] = (double)nmr[1];
+        sos[6 * s + 2] = (double)nmr[2];
+        sos[6 * s + 3] = 1.0;
+        sos[6 * s + 4] = s < pq.size() ? (double)pq[s].first : 0.0;
+        sos[6 * s + 5] = s < pq.size() ? (double)pq[s].second : 0.0;
+    }
+    *nsec_out = (int)ns;
+    return SKDSP_OK;
 }
 
 }  // namespace skdsp
@@ -429,18 +644,36 @@ int skdsp_sos_create(const double *sos, int nsec, int dtype, skdsp_handle *out)
     return iir_create_common(nsec, 2, coef, dtype, out);
 }
 
+int skdsp_tf2sos(const double *b, int nb, const double *a, int na, double *sos_out, int *nsec_out)
+{
+    // host-only helper (no GPU needed): the factorisation skdsp_tf_create applies
+    SK_CHECK(b && a && nb >= 1 && na >= 1 && sos_out && nsec_out, SKDSP_ERR_BADARG, "tf2sos: bad arguments");
+    SK_CHECK(a[0] != 0.0, SKDSP_ERR_BADARG, "tf2sos: a[0] must be nonzero");
+    std::vector<double> sos;
+    int nsec = 0;
+    int rc = tf_to_sos(b, nb, a, na, sos, &nsec);
+    if (rc) return rc;
+    memcpy(sos_out, sos.data(), sos.size() * sizeof(double));
+    *nsec_out = nsec;
+    return SKDSP_OK;
+}
+
 int skdsp_tf_create(const double *b, int nb, const double *a, int na, int dtype, skdsp_handle *out)
 {
     API_BEGIN;
     SK_CHECK(b && a && nb >= 1 && na >= 1, SKDSP_ERR_BADARG, "tf_create: need b and a");
     SK_CHECK(a[0] != 0.0, SKDSP_ERR_BADARG, "tf_create: a[0] must be nonzero");
-    const int K = nb > na ? nb : na;
-    SK_CHECK(K >= 2, SKDSP_ERR_BADARG, "tf_create: order-0 system: use a FIR handle");
-    const int order = K - 1;
-    std::vector<double> coef((size_t)2 * order + 1, 0.0);
-    for (int k = 0; k <= order; ++k) coef[k] = (k < nb ? b[k] : 0.0) / a[0];
-    for (int k = 1; k <= order; ++k) coef[order + k] = (k < na ? a[k] : 0.0) / a[0];
-    return iir_create_common(1, order, coef, dtype, out);
+    std::vector<double> sos;
+    int nsec = 0;
+    int rc = tf_to_sos(b, nb, a, na, sos, &nsec);
+    if (rc) return rc;
+    std::vector<double> coef((size_t)nsec * 5);
+    for (int s = 0; s < nsec; ++s) {
+        const double *q = sos.data() + 6 * s;
+        double *c = coef.data() + 5 * s;
+        c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; c[3] = q[4]; c[4] = q[5];
+    }
+    return iir_create_common(nsec, 2, coef, dtype, out);
 }
 
 int skdsp_iir_filter_dev(skdsp_handle hh, const void *x_dev, int64_t n, void *y_dev)

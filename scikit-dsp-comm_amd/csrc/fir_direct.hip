@@ -48,6 +48,10 @@ template <> __device__ inline float zero_of<float>() { return 0.f; }
 template <> __device__ inline double zero_of<double>() { return 0.; }
 template <> __device__ inline float2 zero_of<float2>() { return make_float2(0.f, 0.f); }
 template <> __device__ inline double2 zero_of<double2>() { return make_double2(0., 0.); }
+__device__ inline float add_of(float a, float b) { return a + b; }
+__device__ inline double add_of(double a, double b) { return a + b; }
+__device__ inline float2 add_of(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ inline double2 add_of(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ inline float scl(float a, float s) { return a * s; }
 __device__ inline double scl(double a, double s) { return a * s; }
 __device__ inline float2 scl(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
@@ -106,22 +110,41 @@ __global__ __launch_bounds__(256) void fir_poly_kernel(const X *__restrict__ x, 
             off[r] = ic + a.q * (tid + 256 * r) + (a.T - 1);
             if (tid + 256 * r >= a.s_tile) off[r] = a.T - 1;  // idle slot: stay in range
         }
+        // Blocked summation: taps are accumulated 16 at a time into a fresh partial sum that
+        // is then folded into the running total.  Rounding error grows like
+        // sqrt(16) + sqrt(T/16) instead of sqrt(T) ulps, which keeps 1024-tap float32
+        // filters inside the 1e-6 parity bound at the cost of one add per 16 taps.
         int t = 0;
-        for (; t + 4 <= a.T; t += 4) {
-            const B b0 = bp[t], b1 = bp[t + 1], b2 = bp[t + 2], b3 = bp[t + 3];
+        for (; t + 16 <= a.T; t += 16) {
+            X part[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const X *p = win + off[r] - t;
-                mac(acc[r], b0, p[0]);
-                mac(acc[r], b1, p[-1]);
-                mac(acc[r], b2, p[-2]);
-                mac(acc[r], b3, p[-3]);
+            for (int r = 0; r < R; ++r) part[r] = zero_of<X>();
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                const B b0 = bp[t + u], b1 = bp[t + u + 1], b2 = bp[t + u + 2], b3 = bp[t + u + 3];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const X *p = win + off[r] - (t + u);
+                    mac(part[r], b0, p[0]);
+                    mac(part[r], b1, p[-1]);
+                    mac(part[r], b2, p[-2]);
+                    mac(part[r], b3, p[-3]);
+                }
             }
-        }
-        for (; t < a.T; ++t) {
-            const B b0 = bp[t];
 #pragma unroll
-            for (int r = 0; r < R; ++r) mac(acc[r], b0, win[off[r] - t]);
+            for (int r = 0; r < R; ++r) acc[r] = add_of(acc[r], part[r]);
+        }
+        if (t < a.T) {
+            X part[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) part[r] = zero_of<X>();
+            for (; t < a.T; ++t) {
+                const B b0 = bp[t];
+#pragma unroll
+                for (int r = 0; r < R; ++r) mac(part[r], b0, win[off[r] - t]);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = add_of(acc[r], part[r]);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {

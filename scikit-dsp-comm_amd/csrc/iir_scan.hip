@@ -1,7 +1,8 @@
 // iir_scan.hip -- exact parallel IIR (cascaded DF2T sections) for gfx950 (MI355X).
 //
 // Serves  scipy.signal.sosfilt(sos,x)   multirate_helper.py:173,182,190 (multirate_IIR)
-//         scipy.signal.lfilter(b,a,x)   multirate_helper.py:74,81        (rate_change)
+//         scipy.signal.lfilter(b,a,x)   multirate_helper.py:74,81        (rate_change; the
+//                                       transfer function is factored into biquads by capi.hip)
 // with zero initial state, as the reference always calls them.
 //
 // The recurrence is serial in n, so the signal is cut into J contiguous chunks of T
@@ -35,7 +36,6 @@ namespace skdsp {
 constexpr int kIirThreads = 256;
 constexpr int kPiece = 32;          // samples per thread per staged piece
 constexpr int kMaxChunks = 131072;  // J cap: 512 workgroups of 256 chunks
-constexpr int kMaxD = 24;
 
 struct IirPlan {
     int nsec, order, D;
@@ -311,9 +311,7 @@ __global__ __launch_bounds__(512) void iir_wg_scan_kernel(const double *__restri
 // ------------------------------------------------------------------ host side
 bool iir_shape_supported(int nsec, int order)
 {
-    if (order == 2) return nsec >= 1 && nsec <= 12;
-    if (nsec == 1) return order >= 1 && order <= 12;
-    return false;
+    return order == 2 && nsec >= 1 && nsec <= 12;
 }
 
 IirHandle::~IirHandle() { if (plan) iir_free(plan); }
@@ -435,18 +433,12 @@ template <typename IO>
 static int dispatch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t s)
 {
 #define SK_SOS(N) case N: return launch_shape<N, 2, IO>(h, a, nbatch, W, s);
-#define SK_TF(N) case N: return launch_shape<1, N, IO>(h, a, nbatch, W, s);
     if (h->order == 2) {
         switch (h->nsec) {
             SK_SOS(1) SK_SOS(2) SK_SOS(3) SK_SOS(4) SK_SOS(5) SK_SOS(6) SK_SOS(7) SK_SOS(8) SK_SOS(9) SK_SOS(10) SK_SOS(11) SK_SOS(12)
         }
-    } else if (h->nsec == 1) {
-        switch (h->order) {
-            SK_TF(1) SK_TF(3) SK_TF(4) SK_TF(5) SK_TF(6) SK_TF(7) SK_TF(8) SK_TF(9) SK_TF(10) SK_TF(11) SK_TF(12)
-        }
     }
 #undef SK_SOS
-#undef SK_TF
     SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "iir: unsupported cascade shape (%d sections of order %d)", h->nsec, h->order);
 }
 

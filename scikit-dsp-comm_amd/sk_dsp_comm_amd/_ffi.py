@@ -27,7 +27,7 @@ SYMBOLS = [
     "skdsp_sync", "skdsp_timer_start", "skdsp_timer_stop", "skdsp_fill_noise_dev",
     "skdsp_fir_create", "skdsp_fir_set_algo", "skdsp_fir_get_algo", "skdsp_fir_filter", "skdsp_fir_filter_dev",
     "skdsp_fir_up", "skdsp_fir_up_dev", "skdsp_fir_dn", "skdsp_fir_dn_dev", "skdsp_fir_updn", "skdsp_fir_updn_dev",
-    "skdsp_sos_create", "skdsp_tf_create", "skdsp_iir_filter", "skdsp_iir_filter_dev", "skdsp_iir_up",
+    "skdsp_sos_create", "skdsp_tf_create", "skdsp_tf2sos", "skdsp_iir_filter", "skdsp_iir_filter_dev", "skdsp_iir_up",
     "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev",
     "skdsp_upsample", "skdsp_upsample_dev", "skdsp_downsample", "skdsp_downsample_dev", "skdsp_destroy",
     "skdsp_dist_unique_id", "skdsp_dist_init", "skdsp_dist_shutdown", "skdsp_dist_barrier",
@@ -84,6 +84,7 @@ def load():
         L.skdsp_fir_updn_dev.argtypes = [vp, vp, i64, i64, ci, ci, vp]
         L.skdsp_sos_create.argtypes = [vp, ci, ci, pvp]
         L.skdsp_tf_create.argtypes = [vp, ci, vp, ci, ci, pvp]
+        L.skdsp_tf2sos.argtypes = [vp, ci, vp, ci, vp, ctypes.POINTER(ci)]
         L.skdsp_iir_filter.argtypes = [vp, vp, i64, vp]
         L.skdsp_iir_filter_dev.argtypes = [vp, vp, i64, vp]
         L.skdsp_iir_up.argtypes = [vp, vp, i64, ci, vp]
@@ -323,6 +324,16 @@ class IirKernel:
     def filter_dev(self, xd, yd, n=None):
         n = xd.n if n is None else n
         check(load().skdsp_iir_filter_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, ctypes.c_void_p(yd.ptr)))
+
+
+def tf2sos(b, a):
+    """The (b, a) -> second-order-sections factorisation skdsp_tf_create applies (host only)."""
+    bb = np.ascontiguousarray(np.atleast_1d(b), dtype=np.float64)
+    aa = np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64)
+    sos = np.zeros((12, 6))
+    ns = ctypes.c_int(0)
+    check(load().skdsp_tf2sos(_ptr(bb), bb.size, _ptr(aa), aa.size, _ptr(sos), ctypes.byref(ns)))
+    return sos[:ns.value].copy()
 
 
 def upsample(x, L):

@@ -141,6 +141,29 @@ def test_ols_tile_index_algebra_host_emulation(tmp_path):
     assert out.strip().endswith("OK"), out
 
 
+def test_tf2sos_factorisation_matches_reference_tf_outputs():
+    """skdsp_tf_create runs (b,a) as biquads (host-only factorisation, no GPU needed): the
+    factored cascade, evaluated by the oracle's sosfilt, must reproduce the REFERENCE's
+    lfilter(b,a,.) outputs (rate_change golden vectors, interp24 KAT) far inside 1e-6."""
+    from oracle import oracle as orc
+    from conftest import rel_err
+    g = np.load(os.path.join(GOLDEN, "g8_rate_change.npz"))
+    for tag, M in (("m4", 4), ("m12", 12), ("m4_cheby", 4)):
+        sos = _ffi.tf2sos(g[tag + "_b"], g[tag + "_a"])
+        assert sos.shape[1] == 6 and (sos[:, 3] == 1).all()
+        up = orc.sos_filter(sos, M * orc.upsample(g["x"], M))
+        assert rel_err(up, g[tag + "_up"])[0] < 1e-8, tag
+        dn = orc.downsample(orc.sos_filter(sos, g["xc"]), M)
+        assert rel_err(dn, g[tag + "_dnc"])[0] < 1e-8, tag
+    # degenerate shapes: odd order, more zeros than poles, leading-zero numerator (pure delay)
+    for b, a in (([0.2, 0.3], [1, -0.5, 0.2, 0.1]), ([0, 0, 1.0, 0.5], [1, -0.9]), ([1.0], [2.0, -1.0]),
+                 ([0.5, 0.2, 0.1, 0.7, 0.3], [1.0, 0.1])):
+        x = np.random.default_rng(1).standard_normal(500)
+        assert rel_err(orc.sos_filter(_ffi.tf2sos(b, a), x), orc.lfilter(b, a, x))[0] < 1e-12
+    with pytest.raises(ValueError):
+        _ffi.tf2sos([1.0], [0.0, 1.0])
+
+
 def test_package_surface():
     for name in ("rate_change", "multirate_FIR", "multirate_IIR", "upsample", "downsample", "cic"):
         assert hasattr(sk, name)
