@@ -6,8 +6,10 @@
 // at FP32 peak); in the frequency domain the same outputs cost
 // ~120 flop per sample, so the kernel can be HBM-bound.
 //
-// One workgroup (256 threads, 4 waves) = one tile of N = 8192 points:
-//   load  x[tile*V - OV .. +8192)  straight into registers, 16 x 16-byte loads/lane
+// One workgroup (256 threads, 4 waves) works on one tile of N = 8192 points at a time
+// (persistent: 2 workgroups per CU walk all tiles; compiled with -fno-slp-vectorize):
+//   load  x[tile*V - OV .. +8192)  straight into registers, 16 x 16-byte loads/lane,
+//         issued one tile ahead so the HBM latency hides under the previous FFT
 //   forward FFT (DIF, 16 x 16 x 32, see ols_core.hpp) -> multiply by H -> inverse FFT (DIT)
 //   store the last V = 8192 - OV points (OV = overlap, a multiple of 512 >= P-1)
 // The only HBM traffic is the input tile (read once, + OV/V overlap re-read that the
@@ -18,6 +20,7 @@
 // max-abs/peak against a float64 direct FIR (tests/host/ols_emul.cpp, GPU parity tests).
 #include "skdsp_internal.hpp"
 #include "ols_tables.hpp"
+#include <cstdlib>
 
 namespace skdsp {
 
@@ -37,17 +40,13 @@ struct OlsArgs {
     const float4 *T1, *T2, *Hp;
     int ov, V, a0;  // a0 = ov / 512: first stored 512-block
     int aligned;    // x and y 16-byte aligned
+    int64_t ntiles;
 };
 
-__global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
+// x[in0 + 512 a + 2 t + e] -> v[2a+e]; zero outside [-n_hist, n)
+__device__ __forceinline__ void load_tile(const OlsArgs &A, int64_t tile, int t, cf *v)
 {
-    __shared__ float4 lds[kLdsUnits];
-    const int t = threadIdx.x;
-    const int64_t tile = blockIdx.x;
-    const int64_t out0 = tile * A.V;      // first output sample of this tile
-    const int64_t in0 = out0 - A.ov;      // global index of tile point n = 0
-
-    cf v[32];
+    const int64_t in0 = tile * A.V - A.ov;
     const bool interior = A.aligned && in0 >= -A.n_hist && in0 + kN <= A.n;
     if (interior) {
         const float4 *xp = reinterpret_cast<const float4 *>(A.x + in0 + 2 * t);
@@ -69,16 +68,11 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
             }
         }
     }
+}
 
-    fwd_pass1(t, v, A.T1, lds);
-    __syncthreads();
-    cf Z[32];
-    fwd_pass23(t, A.T2, lds, Z);
-    mul_H(t, A.Hp, Z);
-    inv_pass32(t, A.T2, lds, Z);
-    __syncthreads();
-    inv_pass1(t, A.T1, lds, v);
-
+__device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t, const cf *v)
+{
+    const int64_t out0 = tile * A.V;
     const bool full = A.aligned && out0 + A.V <= A.n;
     if (full) {
         float4 *yp = reinterpret_cast<float4 *>(A.y + out0 + 2 * t);
@@ -95,6 +89,51 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
                 if (g < A.n) A.y[g] = v[2 * a + e];
             }
         }
+    }
+}
+
+// Persistent: gridDim.x = 2 workgroups per CU, each walks tiles blockIdx.x, +gridDim.x, ...
+// Per tile the only vector-memory traffic is [H: 16 loads at tile start, consumed after
+// the forward FFT] [next tile's x: 16 loads issued after the H multiply, consumed at the
+// next iteration: in flight during the whole inverse FFT] [14 stores].  The
+// tile-invariant inter-pass twiddles never touch the VM path (T1 as 15 register-resident
+// powers of W_4096^t, T2 as two 4 KiB LDS tables): vmcnt retires in order, so any table
+// load issued after a prefetch would force the prefetch to land first.
+__global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
+{
+    __shared__ float4 lds[kLdsUnits + 2 * kT2Units];
+    float4 *T2f = lds + kLdsUnits;            // [k2][q]
+    float4 *T2t = lds + kLdsUnits + kT2Units; // [qq][k2] (transposed copy for the inverse)
+    const int t = threadIdx.x;
+
+    // one-time: LDS twiddle tables and this thread's 15 register twiddles
+    {
+        const float4 w = A.T2[t];             // t = k2*16 + q
+        T2f[t] = w;
+        T2t[(t & 15) * 16 + (t >> 4)] = w;
+    }
+    cf tw[16];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) tw[k1] = lo(A.T1[k1 * 256 + t]);  // W_8192^(2t k1) = W_4096^(t k1)
+    tw[0] = make_float2(1.f, 0.f);
+
+    __syncthreads();
+    for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+        // x and H for this tile are requested together; H is consumed after the forward FFT
+        cf v[32];
+        load_tile(A, tile, t, v);
+        float4 hh[16];
+        load_H(t, A.Hp, hh);
+        fwd_pass1(t, v, tw, lds);
+        __syncthreads();
+        cf Z[32];
+        fwd_pass23(t, T2f, lds, Z);
+        mul_H(hh, Z);
+        inv_pass32(t, T2t, lds, Z);
+        __syncthreads();
+        inv_pass1(t, tw, lds, v);
+        store_tile(A, tile, t, v);
+        __syncthreads();  // every wave is done reading the image before the next tile overwrites it
     }
 }
 
@@ -159,7 +198,10 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
     const int64_t ntiles = (n + p->V - 1) / p->V;
     SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols: too many tiles");
-    hipLaunchKernelGGL(ols_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, A);
+    A.ntiles = ntiles;
+    int64_t grid = 2 * (int64_t)ctx().num_cus;  // 2 resident workgroups per CU (76 KiB LDS each)
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(ols_tile_kernel, dim3((unsigned)grid), dim3(256), 0, s, A);
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
 }

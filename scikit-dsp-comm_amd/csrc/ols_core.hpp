@@ -47,7 +47,8 @@ typedef float2 cf;
 constexpr int kN = 8192;
 constexpr int kThreads = 256;
 constexpr int kRowPitch = 272;             // float4 units per k1 row (16 x 17)
-constexpr int kLdsUnits = 16 * kRowPitch;  // 4352 float4 = 69632 B
+constexpr int kLdsUnits = 16 * kRowPitch;  // 4352 float4 = 69632 B  (exchange image)
+constexpr int kT2Units = 256;              // one 16 x 16 float4 twiddle table = 4 KiB (two copies follow the image)
 
 // cos/sin(2 pi k / 32), k = 0..31, rounded from float64
 #define SK_C32                                                                                             \
@@ -179,8 +180,21 @@ SK_HD float4 pack(cf a, cf b) { return make_float4(a.x, a.y, b.x, b.y); }
 // Per-thread phases.  v[a*2+e] on entry to fwd_pass1 holds x[512 a + 2 t + e].
 // T1[k1*256 + t] = (W_8192^((2t)k1), W_8192^((2t+1)k1));  T2[k2*16 + q] = (W_512^((2q)k2), W_512^((2q+1)k2)).
 // ----------------------------------------------------------------------------
+// W_8192^K (forward) or its conjugate, K compile-time, from float64-rounded literals
+template <int K, bool INV> SK_HD cf mul_w8192(cf a)
+{
+    // cos/sin(2 pi k / 8192), k = 0..15
+    constexpr float C[16] = {1.0f, 0.99999970586288223f, 0.99999882345170188f, 0.99999735276697821f, 0.99999529380957619f, 0.99999264658070719f, 0.9999894110819284f, 0.9999855873151432f, 0.99998117528260111f, 0.99997617498689761f, 0.99997058643097414f, 0.99996440961811828f, 0.9999576445519639f, 0.99995029123649048f, 0.99994234967602391f, 0.999933819875236f};
+    constexpr float S[16] = {0.0f, 0.00076699031874270449f, 0.0015339801862847655f, 0.002300969151425805f, 0.0030679567629659761f, 0.0038349425697062275f, 0.0046019261204485705f, 0.0053689069639963425f, 0.0061358846491544753f, 0.0069028587247297558f, 0.007669828739531097f, 0.0084367942423697988f, 0.0092037547820598194f, 0.0099707099074180308f, 0.010737659167264491f, 0.011504602110422714f};
+    constexpr float c = C[K], sn = S[K];
+    if constexpr (K == 0) return a;
+    else return INV ? make_float2(a.x * c - a.y * sn, a.y * c + a.x * sn) : make_float2(a.x * c + a.y * sn, a.y * c - a.x * sn);
+}
+
 // pass 1 + twiddle + exchange-1 write.  thread t = 16 b + q.
-SK_HD void fwd_pass1(int t, const cf *v, const float4 *T1, float4 *lds)
+// tw[k1] = W_4096^(t k1) (k1 = 1..15; tw[0] unused) lives in registers for the whole
+// persistent kernel; the odd column's twiddle W_8192^((2t+1)k1) = tw[k1] * W_8192^k1.
+SK_HD void fwd_pass1(int t, const cf *v, const cf *tw, float4 *lds)
 {
     cf in[16], o0[16], o1[16];
     SK_UNROLL
@@ -191,16 +205,15 @@ SK_HD void fwd_pass1(int t, const cf *v, const float4 *T1, float4 *lds)
     Dft<16, 1, false>::run(in, o1);
     const int b = t >> 4, q = t & 15;
     lds[lds_unit(0, b, q)] = pack(o0[0], o1[0]);
-    SK_UNROLL
-    for (int k1 = 1; k1 < 16; ++k1) {
-        const float4 w = T1[k1 * 256 + t];
-        lds[lds_unit(k1, b, q)] = pack(cmul(o0[k1], lo(w)), cmul(o1[k1], hi(w)));
-    }
+    static_for<1, 16>([&](auto kc) {
+        constexpr int k1 = decltype(kc)::value;
+        lds[lds_unit(k1, b, q)] = pack(cmul(o0[k1], tw[k1]), cmul(mul_w8192<k1, false>(o1[k1]), tw[k1]));
+    });
 }
 
 // exchange-1 read + pass 2 + twiddle + exchange-2 write/read + pass 3.
 // thread t = 16 k1 + q for pass 2 and t = 16 k1 + k2 for pass 3.  Z[k3] out (32).
-SK_HD void fwd_pass23(int t, const float4 *T2, float4 *lds, cf *Z)
+SK_HD void fwd_pass23(int t, const float4 *T2 /* LDS copy [k2][q] */, float4 *lds, cf *Z)
 {
     const int k1 = t >> 4, q = t & 15;
     cf in0[16], in1[16], o0[16], o1[16];
@@ -232,25 +245,29 @@ SK_HD void fwd_pass23(int t, const float4 *T2, float4 *lds, cf *Z)
 
 // pointwise multiply by the pre-permuted, pre-scaled transfer function.
 // Hp[j*256 + t] = (H[k(k3=2j)], H[k(k3=2j+1)]),  k = k1 + 16 k2 + 256 k3, t = 16 k1 + k2.
-SK_HD void mul_H(int t, const float4 *Hp, cf *Z)
+SK_HD void load_H(int t, const float4 *Hp, float4 *hh)
+{
+    SK_UNROLL
+    for (int j = 0; j < 16; ++j) hh[j] = Hp[j * 256 + t];
+}
+SK_HD void mul_H(const float4 *hh, cf *Z)
 {
     SK_UNROLL
     for (int j = 0; j < 16; ++j) {
-        const float4 h = Hp[j * 256 + t];
-        Z[2 * j] = cmul(Z[2 * j], lo(h));
-        Z[2 * j + 1] = cmul(Z[2 * j + 1], hi(h));
+        Z[2 * j] = cmul(Z[2 * j], lo(hh[j]));
+        Z[2 * j + 1] = cmul(Z[2 * j + 1], hi(hh[j]));
     }
 }
 
 // inverse pass 3 + conj twiddle + exchange-2' + inverse pass 2 + exchange-1' write.
-SK_HD void inv_pass32(int t, const float4 *T2, float4 *lds, const cf *Z)
+SK_HD void inv_pass32(int t, const float4 *T2t /* LDS copy, transposed [qq][k2] */, float4 *lds, const cf *Z)
 {
     const int k1 = t >> 4, k2 = t & 15;
     cf z[32];
     Dft<32, 1, true>::run(Z, z);
     SK_UNROLL
     for (int qq = 0; qq < 16; ++qq) {
-        const float4 w = T2[k2 * 16 + qq];
+        const float4 w = T2t[qq * 16 + k2];
         lds[lds_unit(k1, k2, qq)] = pack(cmulc(z[2 * qq], lo(w)), cmulc(z[2 * qq + 1], hi(w)));
     }
     const int q = k2;  // now thread (k1,q)
@@ -268,7 +285,7 @@ SK_HD void inv_pass32(int t, const float4 *T2, float4 *lds, const cf *Z)
 }
 
 // exchange-1' read + conj twiddle + inverse pass 1.  v[a*2+e] = y[512 a + 2 t + e] out.
-SK_HD void inv_pass1(int t, const float4 *T1, const float4 *lds, cf *v)
+SK_HD void inv_pass1(int t, const cf *tw, const float4 *lds, cf *v)
 {
     const int b = t >> 4, q = t & 15;
     cf in0[16], in1[16], o0[16], o1[16];
@@ -277,13 +294,12 @@ SK_HD void inv_pass1(int t, const float4 *T1, const float4 *lds, cf *v)
         in0[0] = lo(f);
         in1[0] = hi(f);
     }
-    SK_UNROLL
-    for (int k1 = 1; k1 < 16; ++k1) {
+    static_for<1, 16>([&](auto kc) {
+        constexpr int k1 = decltype(kc)::value;
         const float4 f = lds[lds_unit(k1, b, q)];
-        const float4 w = T1[k1 * 256 + t];
-        in0[k1] = cmulc(lo(f), lo(w));
-        in1[k1] = cmulc(hi(f), hi(w));
-    }
+        in0[k1] = cmulc(lo(f), tw[k1]);
+        in1[k1] = mul_w8192<k1, true>(cmulc(hi(f), tw[k1]));
+    });
     Dft<16, 1, true>::run(in0, o0);
     Dft<16, 1, true>::run(in1, o1);
     SK_UNROLL

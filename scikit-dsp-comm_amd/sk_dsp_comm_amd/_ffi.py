@@ -43,7 +43,8 @@ class SkdspError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, LIB_NAME)
+    # SKDSP_LIB: developer override to A/B an alternative build of the same library
+    return os.environ.get("SKDSP_LIB") or os.path.join(_HERE, LIB_NAME)
 
 
 def load():

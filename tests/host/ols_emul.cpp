@@ -59,7 +59,15 @@ int main()
     for (int t = 0; t < 256; ++t)
         for (int a = 0; a < 16; ++a)
             for (int ee = 0; ee < 2; ++ee) regs[t * 32 + 2 * a + ee] = x[512 * a + 2 * t + ee];
-    for (int t = 0; t < 256; ++t) fwd_pass1(t, &regs[t * 32], T1.data(), lds.data());
+    // register twiddles exactly as the kernel derives them: tw[k1] = lo(T1[k1][t]) = W_4096^(t k1)
+    std::vector<cf> tw(256 * 16);
+    for (int t = 0; t < 256; ++t) {
+        tw[t * 16] = make_float2(1.f, 0.f);
+        for (int k1 = 1; k1 < 16; ++k1) tw[t * 16 + k1] = lo(T1[k1 * 256 + t]);
+    }
+    std::vector<float4> T2t(256);
+    for (int i = 0; i < 256; ++i) T2t[(i & 15) * 16 + (i >> 4)] = T2[i];
+    for (int t = 0; t < 256; ++t) fwd_pass1(t, &regs[t * 32], &tw[t * 16], lds.data());
     // pass 2/3 are wave-local after the barrier: emulate 16-lane groups in lock-step by
     // running the function per thread only works if reads follow ALL writes of the group,
     // so split it here exactly like the hardware does (in-order per wave).
@@ -104,7 +112,7 @@ int main()
         printf("forward 8192 spectrum rel err %.3g\n", worst / peak);
         fails += worst / peak > 5e-6;
     }
-    for (int t = 0; t < 256; ++t) mul_H(t, Hp.data(), &Z[t * 32]);
+    for (int t = 0; t < 256; ++t) { float4 hh[16]; load_H(t, Hp.data(), hh); mul_H(hh, &Z[t * 32]); }
     // inverse: pass 3 + exchange-2' write for all, then the rest
     {
         for (int t = 0; t < 256; ++t) {
@@ -112,7 +120,7 @@ int main()
             cf z[32];
             Dft<32, 1, true>::run(&Z[t * 32], z);
             for (int qq = 0; qq < 16; ++qq) {
-                float4 w = T2[k2 * 16 + qq];
+                float4 w = T2t[qq * 16 + k2];
                 lds[lds_unit(k1, k2, qq)] = pack(cmulc(z[2 * qq], lo(w)), cmulc(z[2 * qq + 1], hi(w)));
             }
         }
@@ -130,7 +138,7 @@ int main()
             for (int b = 0; b < 16; ++b) lds[lds_unit(k1, b, q)] = pack(tmp[t].o0[b], tmp[t].o1[b]);
         }
     }
-    for (int t = 0; t < 256; ++t) inv_pass1(t, T1.data(), lds.data(), &regs[t * 32]);
+    for (int t = 0; t < 256; ++t) inv_pass1(t, &tw[t * 16], lds.data(), &regs[t * 32]);
     // reference: circular convolution == linear FIR for n >= P-1
     double worst = 0, peak = 0;
     for (int n = P - 1; n < kN; n += 7) {
