@@ -25,6 +25,7 @@
 #include "skdsp_internal.hpp"
 #include <cstring>
 #include <numeric>
+#include <cstdlib>
 
 namespace skdsp {
 
@@ -155,11 +156,124 @@ __global__ __launch_bounds__(256) void fir_poly_kernel(const X *__restrict__ x, 
     }
 }
 
+// ------------------------------------------------------------------ sliding window
+// Register sliding-window variant: a thread owns R CONSECUTIVE outputs of a class, so the
+// taps t = q m + j of one residue j form a stride-1 FIR over S_j(n) = x[i_c + q(s+n) - j]:
+// per tap ONE new LDS element feeds R FMAs (the generic kernel above needs R reads).
+//
+// The staged window is cut into groups of P = q R samples stored with pitch P+1 (odd
+// lane stride => conflict-free b32/b64 reads).  Thread tid's R outputs start at group
+// G + tid; the R window elements a block of R taps needs sit in ONE group:
+//     block beta of (class c, residue j):  group G + tid - beta - 1, offsets rho + q i
+// with rho = i_c - j + q delta in [0, q) (delta in {0,1} prepends one zero tap when
+// i_c < j).  So the inner loop is: R ds_reads at constant offsets from a pointer that
+// steps down by one group, R scalar taps from a zero-padded per-(c, j) table, R*R FMAs.
+// The window lives in registers as wr[R] (current) + nw[R] (next), statically indexed.
+// Summation: R taps -> part, 16 parts -> mid, mid -> acc (keeps 4097-tap float32 sums
+// inside the 1e-6 parity bound).
+struct SwArgs {
+    int64_t n, n_hist, n_out;
+    int L, Lp, q;
+    int G;      // groups staged to the left of the first output group
+    int nB;     // tap blocks per (class, residue) = table pitch / R
+    int win;    // logical window length = (G + 256) * q * R
+};
+
+template <typename X, typename B, int R, int Q>
+__global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, const B *__restrict__ taps,
+                                                     const int *__restrict__ rho_tab, SwArgs a, X *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    X *win = reinterpret_cast<X *>(smem_raw);
+    using S = typename ScalarOf<X>::type;
+    const int tid = threadIdx.x;
+    const int q = Q > 0 ? Q : a.q;
+    const int P = q * R;
+    const int64_t s0 = (int64_t)blockIdx.x * (256 * R);
+    const int64_t w0 = (int64_t)q * s0 - (int64_t)P * a.G;
+
+    for (int i = tid; i < a.win; i += 256) {
+        const int64_t g = w0 + i;
+        X v = zero_of<X>();
+        if (g >= -a.n_hist && g < a.n) v = x[g];
+        win[i + i / P] = v;
+    }
+    __syncthreads();
+
+    const S gain = (S)a.L;
+    for (int c = 0; c < a.Lp; ++c) {
+        X acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = zero_of<X>();
+        for (int j = 0; j < q; ++j) {
+            const int cj = c * q + j;
+            const int rho = rho_tab[cj];
+            if (rho < 0) continue;  // residue j has no taps
+            const B *__restrict__ tb = taps + (size_t)cj * a.nB * R;
+            const X *grp = win + (size_t)(a.G + tid) * (P + 1) + rho;
+            X wr[R];
+#pragma unroll
+            for (int e = 0; e < R; ++e) wr[e] = grp[q * e];
+            X mid[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) mid[r] = zero_of<X>();
+            for (int beta = 0; beta < a.nB; ++beta) {
+                grp -= (P + 1);
+                X nw[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) nw[i] = grp[q * i];
+                X part[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) part[r] = zero_of<X>();
+#pragma unroll
+                for (int u_ = 0; u_ < R; ++u_) {
+                    const B b = tb[beta * R + u_];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int e = r - u_;
+                        mac(part[r], b, e >= 0 ? wr[e >= 0 ? e : 0] : nw[e < 0 ? e + R : 0]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    mid[r] = add_of(mid[r], part[r]);
+                    wr[r] = nw[r];
+                }
+                if ((beta & 15) == 15) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        acc[r] = add_of(acc[r], mid[r]);
+                        mid[r] = zero_of<X>();
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = add_of(acc[r], mid[r]);
+        }
+        const int64_t sb = s0 + (int64_t)R * tid;
+        if (a.Lp == 1 && a.L == 1 && sb + R <= a.n_out && (R * sizeof(X)) % 16 == 0 &&
+            (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+            constexpr int NV = (R * (int)sizeof(X)) / 16;
+            float4 *dst = reinterpret_cast<float4 *>(y + sb);
+            const float4 *src = reinterpret_cast<const float4 *>(acc);
+#pragma unroll
+            for (int v4 = 0; v4 < NV; ++v4) dst[v4] = src[v4];
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t m = (int64_t)c + (int64_t)a.Lp * (sb + r);
+                if (m < a.n_out) y[m] = (a.L == 1) ? acc[r] : scl(acc[r], gain);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host side
 FirHandle::~FirHandle()
 {
     if (taps_dev) (void)hipFree(taps_dev);
     for (auto &p : poly) if (p.dev) (void)hipFree(p.dev);
+    for (auto &t : sw) { if (t.taps) (void)hipFree(t.taps); if (t.rho) (void)hipFree(t.rho); }
     if (ols) fir_ols_free(ols);
 }
 
@@ -206,6 +320,52 @@ static int launch_typed(const X *x, const B *bank, const PolyArgs &a, int R, int
     return SKDSP_OK;
 }
 
+// zero-padded per-(class, residue) tap tables for the sliding-window kernel:
+//   taps[(c q + j) nB R + m'] = b[phi_c + L (q (m' - delta) + j)]   (0 outside),  rho[c q + j] in [0,q) or -1
+static int get_sw_table(FirHandle *h, int L, int M, int R, int nB, const FirHandle::SwTab **out)
+{
+    for (auto &t : h->sw)
+        if (t.L == L && t.M == M && t.R == R) { *out = &t; return SKDSP_OK; }
+    const int g = std::gcd(L, M), Lp = L / g, q = M / g;
+    const int P = h->ntaps, T = (P + L - 1) / L;
+    const bool dbl = dtype_double(h->dtype);
+    const int comp = h->taps_complex ? 2 : 1;
+    const size_t esz = (dbl ? 8 : 4) * comp;
+    const size_t pitch = (size_t)nB * R;
+    std::vector<char> host((size_t)Lp * q * pitch * esz, 0);
+    std::vector<int> rho((size_t)Lp * q, -1);
+    for (int c = 0; c < Lp; ++c) {
+        const long long cm = (long long)c * M;
+        const int phi = (int)(cm % L), ic = (int)(cm / L);
+        for (int j = 0; j < q; ++j) {
+            if (j >= T) continue;
+            const int delta = ic < j ? 1 : 0;
+            rho[(size_t)c * q + j] = ic - j + q * delta;
+            const int Tj = (T - j + q - 1) / q;
+            for (int m = 0; m < Tj; ++m) {
+                const int t = q * m + j;          // tap index inside the phase
+                const int k = phi + L * t;        // original tap
+                if (k >= P) continue;
+                const size_t idx0 = ((size_t)c * q + j) * pitch + (size_t)(m + delta);
+                for (int cc = 0; cc < comp; ++cc) {
+                    const double v = h->taps_host[(size_t)k * comp + cc];
+                    if (dbl) reinterpret_cast<double *>(host.data())[idx0 * comp + cc] = v;
+                    else reinterpret_cast<float *>(host.data())[idx0 * comp + cc] = (float)v;
+                }
+            }
+        }
+    }
+    FirHandle::SwTab t;
+    t.L = L; t.M = M; t.R = R; t.taps = nullptr; t.rho = nullptr;
+    SK_HIP(hipMalloc(&t.taps, host.size()));
+    SK_HIP(hipMalloc(&t.rho, rho.size() * sizeof(int)));
+    SK_HIP(hipMemcpy(t.taps, host.data(), host.size(), hipMemcpyHostToDevice));
+    SK_HIP(hipMemcpy(t.rho, rho.data(), rho.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->sw.push_back(t);
+    *out = &h->sw.back();
+    return SKDSP_OK;
+}
+
 int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, int M, int64_t n_out, void *y,
                       hipStream_t s)
 {
@@ -226,6 +386,58 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
 
     const size_t esz = dtype_size(h->dtype);
     const size_t lds_cap = 64 * 1024;  // <= 2 workgroups per CU of the 160 KiB LDS
+
+    // ---- preferred: register sliding window (R consecutive outputs per thread) ----
+    static const bool no_sw = getenv("SKDSP_FIR_NO_SW") != nullptr;  // developer A/B switch
+    if (!no_sw) {
+        const int Rmax = dtype_double(h->dtype) && dtype_complex(h->dtype) ? 4 : 8;
+        for (int R = Rmax; R >= 2; R >>= 1) {
+            const int q = a.q, P = q * R;
+            const int Tq = (T + q - 1) / q;
+            const int nB = (Tq + 1 + R - 1) / R;      // +1: the optional leading zero tap (delta)
+            const int G = nB;
+            const int64_t win = (int64_t)(G + 256) * P;
+            const int64_t phys = (int64_t)(G + 256) * (P + 1);
+            if ((size_t)phys * esz > lds_cap) continue;
+            const int64_t nb = (a.n_s + 256 * R - 1) / (256 * R);
+            if (nb < ctx().num_cus && R > 2) continue;  // small problems: smaller tiles
+            const FirHandle::SwTab *tab = nullptr;
+            int rc2 = get_sw_table(h, L, M, R, nB, &tab);
+            if (rc2) return rc2;
+            SwArgs w;
+            w.n = n; w.n_hist = n_hist; w.n_out = n_out;
+            w.L = L; w.Lp = a.Lp; w.q = q; w.G = G; w.nB = nB; w.win = (int)win;
+            const size_t lds = (size_t)phys * esz;
+#define SK_SWQ(XT, BT, RR, QQ) \
+    hipLaunchKernelGGL((fir_sw_kernel<XT, BT, RR, QQ>), dim3((unsigned)nb), dim3(256), lds, s, (const XT *)x, (const BT *)tab->taps, (const int *)tab->rho, w, (XT *)y)
+#define SK_SWR(XT, BT, RR)                                   \
+    do {                                                     \
+        if (q == 1) SK_SWQ(XT, BT, RR, 1);                   \
+        else if (q == 2) SK_SWQ(XT, BT, RR, 2);              \
+        else if (q == 3) SK_SWQ(XT, BT, RR, 3);              \
+        else SK_SWQ(XT, BT, RR, 0);                          \
+    } while (0)
+#define SK_SW(XT, BT)                                        \
+    do {                                                     \
+        if (R == 8) SK_SWR(XT, BT, 8);                       \
+        else if (R == 4) SK_SWR(XT, BT, 4);                  \
+        else SK_SWR(XT, BT, 2);                              \
+    } while (0)
+            switch (h->dtype) {
+            case SKDSP_F32: SK_SW(float, float); break;
+            case SKDSP_F64: SK_SW(double, double); break;
+            case SKDSP_C64: if (h->taps_complex) SK_SW(float2, float2); else SK_SW(float2, float); break;
+            case SKDSP_C128: if (h->taps_complex) SK_SW(double2, double2); else SK_SW(double2, double); break;
+            }
+#undef SK_SW
+#undef SK_SWR
+#undef SK_SWQ
+            SK_HIP(hipGetLastError());
+            return SKDSP_OK;
+        }
+    }
+
+    // ---- generic fallback: one LDS read per FMA, any stride ----
     const int64_t cap_elems = (int64_t)(lds_cap / esz);
     // window = q*s_tile + T + q  <=  cap_elems
     int64_t s_tile = (cap_elems - T - a.q) / a.q;

@@ -272,39 +272,56 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
     }
 }
 
-// K2: exclusive scan of W <= 512 workgroup aggregates, one workgroup per batch item.
-// carry[w] = sum_{u<w} (M^256)^(w-1-u) agg[u]
+// K2: exclusive scan of W <= 512 workgroup aggregates, one workgroup per batch item:
+//   carry[w] = sum_{u<w} (M^256)^(w-1-u) agg[u]
+// Hillis-Steele over items with the D x D matvec spread over (item,row) pairs: thread p
+// owns row r = p % D of item i = p / D, so one level costs D fma per pair (the matrix
+// power for the level and both vector buffers live in LDS).  ~10 us for W = 512, D = 16
+// (the first version -- one item per thread, matrix through the scalar cache -- took 78 us).
 template <int D>
-__global__ __launch_bounds__(512) void iir_wg_scan_kernel(const double *__restrict__ agg, const double *__restrict__ pw,
-                                                          int W, double *__restrict__ carry)
+__global__ __launch_bounds__(1024) void iir_wg_scan_kernel(const double *__restrict__ agg, const double *__restrict__ pw,
+                                                           int W, double *__restrict__ carry)
 {
-    __shared__ double sc[D * 512];
+    constexpr int kPer = (512 * D + 1023) / 1024;  // (item,row) pairs per thread
+    __shared__ double vb[512 * D];
+    __shared__ double Ml[D * (D + 1)];  // row pitch D+1: rows land on distinct banks
     const int tid = threadIdx.x;
     const double *in = agg + (size_t)blockIdx.x * W * D;
     double *out = carry + (size_t)blockIdx.x * W * D;
-    double v[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) v[d] = (tid < W) ? in[(size_t)tid * D + d] : 0.0;
-#pragma unroll 1
-    for (int l = 0; l < 9; ++l) {
+    const int npairs = W * D;
+    for (int p = tid; p < npairs; p += 1024) vb[p] = in[p];
+    for (int l = 0; l < 9 && (1 << l) < W; ++l) {
         const int s = 1 << l;
-#pragma unroll
-        for (int d = 0; d < D; ++d) sc[d * 512 + tid] = v[d];
+        for (int e = tid; e < D * D; e += 1024) Ml[(e / D) * (D + 1) + (e % D)] = pw[(size_t)(8 + l) * D * D + e];
         __syncthreads();
-        if (tid >= s) {
-            double left[D];
+        double nv[kPer];
 #pragma unroll
-            for (int d = 0; d < D; ++d) left[d] = sc[d * 512 + tid - s];
-            matvec_acc<D>(pw + (size_t)(8 + l) * D * D, left, v);
+        for (int k = 0; k < kPer; ++k) {
+            const int p = tid + k * 1024;
+            double acc = 0.0;
+            if (p < npairs) {
+                const int i = p / D, r = p - i * D;
+                acc = vb[p];
+                if (i >= s) {
+                    const double *left = &vb[(i - s) * D];
+#pragma unroll
+                    for (int c = 0; c < D; ++c) acc = fma(Ml[r * (D + 1) + c], left[c], acc);
+                }
+            }
+            nv[k] = acc;
+        }
+        __syncthreads();  // everyone has read the old values
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int p = tid + k * 1024;
+            if (p < npairs) vb[p] = nv[k];
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int d = 0; d < D; ++d) sc[d * 512 + tid] = v[d];
     __syncthreads();
-    if (tid < W) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) out[(size_t)tid * D + d] = (tid == 0) ? 0.0 : sc[d * 512 + tid - 1];
+    for (int p = tid; p < npairs; p += 1024) {
+        const int i = p / D;
+        out[p] = (i == 0) ? 0.0 : vb[p - D];
     }
 }
 
@@ -422,7 +439,7 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
     a.carry = carry;
     hipLaunchKernelGGL((iir_chunk_kernel<NSEC, ORD, IO, false>), dim3(W, nbatch), dim3(kIirThreads), 0, s, a, cf);
     SK_HIP(hipGetLastError());
-    hipLaunchKernelGGL((iir_wg_scan_kernel<D>), dim3(nbatch), dim3(512), 0, s, (const double *)agg, (const double *)p->pw_dev, W, carry);
+    hipLaunchKernelGGL((iir_wg_scan_kernel<D>), dim3(nbatch), dim3(1024), 0, s, (const double *)agg, (const double *)p->pw_dev, W, carry);
     SK_HIP(hipGetLastError());
     hipLaunchKernelGGL((iir_chunk_kernel<NSEC, ORD, IO, true>), dim3(W, nbatch), dim3(kIirThreads), 0, s, a, cf);
     SK_HIP(hipGetLastError());

@@ -75,6 +75,9 @@ struct FirHandle : HandleBase {
     // polyphase tap banks, keyed by L (lazy): bank[phase][t] = b[phase + L*t], T = ceil(P/L)
     struct Poly { int L; int T; void *dev; };
     std::vector<Poly> poly;
+    // sliding-window tap tables, keyed by (L, M, R)
+    struct SwTab { int L, M, R; void *taps; void *rho; };
+    std::vector<SwTab> sw;
     OlsPlan *ols = nullptr;
     ~FirHandle();
 };
