@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <cstring>
+#include <cstdlib>
 
 namespace skdsp {
 
@@ -70,6 +71,20 @@ static int rccl_load()
         }                                                                                       \
     } while (0)
 
+// one grouped point-to-point step on the compute stream: send `bytes` to rank dst (if >= 0),
+// receive `bytes` from rank src (if >= 0)
+static int sendrecv_locked(const void *sendbuf, int dst, void *recvbuf, int src, size_t bytes)
+{
+    Rccl &r = rc();
+    SK_CHECK(r.comm, SKDSP_ERR_RCCL, "dist: no communicator (call skdsp_dist_init first)");
+    hipStream_t s = ctx().stream;
+    SK_NCCL(r.GroupStart());
+    if (dst >= 0) SK_NCCL(r.Send(sendbuf, bytes, ncclUint8, dst, r.comm, s));
+    if (src >= 0) SK_NCCL(r.Recv(recvbuf, bytes, ncclUint8, src, r.comm, s));
+    SK_NCCL(r.GroupEnd());
+    return SKDSP_OK;
+}
+
 static int halo_exchange_locked(void *x_dev, int64_t n, int64_t n_halo, int dtype)
 {
     Rccl &r = rc();
@@ -87,18 +102,15 @@ static int halo_exchange_locked(void *x_dev, int64_t n, int64_t n_halo, int dtyp
     }
     const size_t bytes = (size_t)n_halo * esz;
     if (r.rank == 0) SK_HIP(hipMemsetAsync(halo, 0, bytes, s));  // zero initial state
-    SK_NCCL(r.GroupStart());
-    if (r.rank + 1 < r.world) SK_NCCL(r.Send(x0 + (size_t)(n - n_halo) * esz, bytes, ncclUint8, r.rank + 1, r.comm, s));
-    if (r.rank > 0) SK_NCCL(r.Recv(halo, bytes, ncclUint8, r.rank - 1, r.comm, s));
-    SK_NCCL(r.GroupEnd());
-    return SKDSP_OK;
+    return sendrecv_locked(x0 + (size_t)(n - n_halo) * esz, r.rank + 1 < r.world ? r.rank + 1 : -1, halo,
+                           r.rank > 0 ? r.rank - 1 : -1, bytes);
 }
 
 static int allreduce_locked(double *value, ncclRedOp_t op)
 {
     Rccl &r = rc();
     hipStream_t s = ctx().stream;
-    if (r.world <= 1 || !r.comm) return SKDSP_OK;
+    if (!r.comm) return SKDSP_OK;
     SK_HIP(hipMemcpyAsync(r.scratch, value, 8, hipMemcpyHostToDevice, s));
     SK_NCCL(r.AllReduce(r.scratch, r.scratch, 1, ncclFloat64, op, r.comm, s));
     SK_HIP(hipMemcpyAsync(value, r.scratch, 8, hipMemcpyDeviceToHost, s));
@@ -140,7 +152,9 @@ int skdsp_dist_init(int rank, int world, const void *id128)
     SK_CHECK(!r.comm, SKDSP_ERR_BADARG, "dist_init: already initialised");
     r.rank = rank;
     r.world = world;
-    if (world == 1) return SKDSP_OK;
+    // a 1-rank job needs no communicator; SKDSP_DIST_FORCE_COMM=1 builds one anyway so the
+    // RCCL plumbing (dlopen, id, init, p2p to self, all-reduce) can be exercised on one GPU
+    if (world == 1 && !(getenv("SKDSP_DIST_FORCE_COMM") && id128)) return SKDSP_OK;
     SK_CHECK(id128, SKDSP_ERR_BADARG, "dist_init: null unique id");
     int rr = rccl_load();
     if (rr) return rr;
@@ -192,6 +206,16 @@ int skdsp_dist_allreduce_sum(double *value)
     API_BEGIN;
     SK_CHECK(value, SKDSP_ERR_BADARG, "allreduce: null value");
     return allreduce_locked(value, ncclSum);
+}
+
+int skdsp_dist_sendrecv(const void *send_dev, int dst, void *recv_dev, int src, int64_t bytes)
+{
+    API_BEGIN;
+    SK_CHECK(bytes >= 0, SKDSP_ERR_BADARG, "sendrecv: negative size");
+    Rccl &r = rc();
+    SK_CHECK(dst < r.world && src < r.world, SKDSP_ERR_BADARG, "sendrecv: peer out of range");
+    if (bytes == 0) return SKDSP_OK;
+    return sendrecv_locked(send_dev, dst, recv_dev, src, (size_t)bytes);
 }
 
 int skdsp_dist_halo_exchange(void *x_dev, int64_t n, int64_t n_halo, int dtype)

@@ -21,10 +21,16 @@
 #include "skdsp_internal.hpp"
 #include "ols_tables.hpp"
 #include <cstdlib>
+#include <cstdio>
+
+#ifndef SKDSP_OLS_NT
+#define SKDSP_OLS_NT 1  // nontemporal x loads / y stores (streamed once): 0.300 -> 0.295 ms
+#endif
 
 namespace skdsp {
 
 using namespace ols;
+typedef float v4f_t __attribute__((ext_vector_type(4)));
 
 struct OlsPlan {
     int ntaps = 0;
@@ -38,10 +44,20 @@ struct OlsArgs {
     cf *y;
     int64_t n, n_hist;
     const float4 *T1, *T2, *Hp;
+    unsigned long long *trace;  // developer phase timing (SKDSP_OLS_TRACE), else null
     int ov, V, a0;  // a0 = ov / 512: first stored 512-block
     int aligned;    // x and y 16-byte aligned
     int64_t ntiles;
 };
+
+// volatile 16-byte load: keeps the request at its program position (the scheduler would
+// otherwise sink a prefetch down to its first use to save registers)
+__device__ __forceinline__ float4 vld(const volatile float4 *p)
+{
+    float4 r;
+    r.x = p->x; r.y = p->y; r.z = p->z; r.w = p->w;
+    return r;
+}
 
 // x[in0 + 512 a + 2 t + e] -> v[2a+e]; zero outside [-n_hist, n)
 __device__ __forceinline__ void load_tile(const OlsArgs &A, int64_t tile, int t, cf *v)
@@ -49,10 +65,19 @@ __device__ __forceinline__ void load_tile(const OlsArgs &A, int64_t tile, int t,
     const int64_t in0 = tile * A.V - A.ov;
     const bool interior = A.aligned && in0 >= -A.n_hist && in0 + kN <= A.n;
     if (interior) {
-        const float4 *xp = reinterpret_cast<const float4 *>(A.x + in0 + 2 * t);
+        // opaque copy of t: stops LICM from hoisting 16 loop-invariant 64-bit addresses (which
+        // were then spilled and reloaded in front of every load)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const volatile float4 *xp = reinterpret_cast<const volatile float4 *>(A.x + in0);
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            const float4 f = xp[a * 256];  // 512 complex = 256 float4
+#if SKDSP_OLS_NT
+            const v4f_t nv = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(A.x + in0) + (unsigned)(a * 256 + tt));
+            const float4 f = make_float4(nv.x, nv.y, nv.z, nv.w);
+#else
+            const float4 f = vld(xp + (unsigned)(a * 256 + tt));  // 512 complex = 256 float4
+#endif
             v[2 * a] = lo(f);
             v[2 * a + 1] = hi(f);
         }
@@ -78,7 +103,15 @@ __device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t
         float4 *yp = reinterpret_cast<float4 *>(A.y + out0 + 2 * t);
 #pragma unroll
         for (int a = 0; a < 16; ++a)
+#if SKDSP_OLS_NT
+            if (a >= A.a0) {
+                v4f_t nv;
+                nv.x = v[2 * a].x; nv.y = v[2 * a].y; nv.z = v[2 * a + 1].x; nv.w = v[2 * a + 1].y;
+                __builtin_nontemporal_store(nv, reinterpret_cast<v4f_t *>(yp) + (a - A.a0) * 256);
+            }
+#else
             if (a >= A.a0) yp[(a - A.a0) * 256] = pack(v[2 * a], v[2 * a + 1]);
+#endif
     } else {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
@@ -99,6 +132,7 @@ __device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t
 // tile-invariant inter-pass twiddles never touch the VM path (T1 as 15 register-resident
 // powers of W_4096^t, T2 as two 4 KiB LDS tables): vmcnt retires in order, so any table
 // load issued after a prefetch would force the prefetch to land first.
+template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 {
     __shared__ float4 lds[kLdsUnits + 2 * kT2Units];
@@ -118,23 +152,72 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
     tw[0] = make_float2(1.f, 0.f);
 
     __syncthreads();
-    for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
-        // x and H for this tile are requested together; H is consumed after the forward FFT
-        cf v[32];
+    int it = 0;
+#ifndef SKDSP_OLS_PREFETCH
+#define SKDSP_OLS_PREFETCH 1  // request x(tile+1) after the H multiply: 0.311 -> 0.300 ms
+#endif
+    // TRACE build: s_memtime stamps at phase boundaries (each preceded by a full wait so
+    // the phases do not overlap) for wave 0 of the first 16 workgroups, first 8 tiles.
+#define SK_STAMP(k)                                                                          \
+    do {                                                                                     \
+        if (TRACE) {                                                                         \
+            asm volatile(SK_WAIT ::: "memory");                                             \
+            if (t == 0 && blockIdx.x < 16 && it < 8)                                         \
+                A.trace[((size_t)blockIdx.x * 8 + it) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+        }                                                                                    \
+    } while (0)
+#if SKDSP_OLS_PREFETCH
+#define SK_WAIT "s_waitcnt lgkmcnt(0)"
+#else
+#define SK_WAIT "s_waitcnt vmcnt(0) lgkmcnt(0)"
+#endif
+    // This thread's 32 bins of H stay in registers for every tile it processes: streaming
+    // them per tile cost 64 KiB of L2->CU traffic per tile, a third of everything the CU's
+    // vector-memory pipe (~10 B/clk) had to move, and that pipe is what bounds the kernel.
+    float4 hh[16];
+    load_H(t, A.Hp, hh);
+    int64_t tile = blockIdx.x;
+    cf v[32];
+#if SKDSP_OLS_PREFETCH
+    if (tile < A.ntiles) load_tile(A, tile, t, v);
+#endif
+    for (; tile < A.ntiles; tile += gridDim.x, ++it) {
+        SK_STAMP(0);
+#if !SKDSP_OLS_PREFETCH
         load_tile(A, tile, t, v);
-        float4 hh[16];
-        load_H(t, A.Hp, hh);
+#endif
+        SK_STAMP(1);
         fwd_pass1(t, v, tw, lds);
+        SK_STAMP(2);
         __syncthreads();
+        SK_STAMP(3);
         cf Z[32];
         fwd_pass23(t, T2f, lds, Z);
+        SK_STAMP(4);
         mul_H(hh, Z);
+#if SKDSP_OLS_PREFETCH
+        // x of the next tile: requested now (into the registers H just vacated), consumed at
+        // the top of the next iteration -- in flight during the whole inverse FFT
+        const int64_t next = tile + gridDim.x;
+        cf nx[32];
+        if (next < A.ntiles) load_tile(A, next, t, nx);
+#endif
         inv_pass32(t, T2t, lds, Z);
+        SK_STAMP(5);
         __syncthreads();
+        SK_STAMP(6);
         inv_pass1(t, tw, lds, v);
+        SK_STAMP(7);
         store_tile(A, tile, t, v);
+        SK_STAMP(8);
+#if SKDSP_OLS_PREFETCH
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = nx[i];
+#endif
         __syncthreads();  // every wave is done reading the image before the next tile overwrites it
+        SK_STAMP(9);
     }
+#undef SK_STAMP
 }
 
 bool fir_ols_supported(const FirHandle *h)
@@ -201,7 +284,27 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.ntiles = ntiles;
     int64_t grid = 2 * (int64_t)ctx().num_cus;  // 2 resident workgroups per CU (76 KiB LDS each)
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(ols_tile_kernel, dim3((unsigned)grid), dim3(256), 0, s, A);
+    A.trace = nullptr;
+    if (const char *tp = getenv("SKDSP_OLS_TRACE")) {  // developer diagnostics: dump phase stamps of one launch
+        const size_t nw = 16 * 8 * 16;
+        unsigned long long *d = nullptr;
+        SK_HIP(hipMalloc((void **)&d, nw * 8));
+        SK_HIP(hipMemsetAsync(d, 0, nw * 8, s));
+        A.trace = d;
+        hipLaunchKernelGGL(ols_tile_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, A);
+        std::vector<unsigned long long> hbuf(nw);
+        SK_HIP(hipMemcpyAsync(hbuf.data(), d, nw * 8, hipMemcpyDeviceToHost, s));
+        SK_HIP(hipStreamSynchronize(s));
+        SK_HIP(hipFree(d));
+        if (FILE *f = fopen(tp, "w")) {
+            for (size_t r = 0; r < 16 * 8; ++r) {
+                for (int k = 0; k < 10; ++k) fprintf(f, "%llu%s", hbuf[r * 16 + k], k == 9 ? "\n" : ",");
+            }
+            fclose(f);
+        }
+        return SKDSP_OK;
+    }
+    hipLaunchKernelGGL(ols_tile_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, A);
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
 }

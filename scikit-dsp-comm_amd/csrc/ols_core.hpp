@@ -68,41 +68,105 @@ constexpr int kT2Units = 256;              // one 16 x 16 float4 twiddle table =
      -0.98078528040323032f, -1.0f, -0.98078528040323043f, -0.92387953251128663f, -0.83146961230254546f,    \
      -0.70710678118654768f, -0.55557023301960218f, -0.38268343236509039f, -0.19509032201612872f}
 
+// ----------------------------------------------------------------------------
+// Complex arithmetic.  On the device every operation is ONE or TWO packed-f32
+// instructions on the (re,im) register pair: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32
+// with op_sel (half swap / broadcast) and neg_lo / neg_hi source modifiers doing the
+// swaps and sign flips of complex multiplication for free.  gfx950 issues a wave64
+// VALU instruction in 4 cycles whether it is packed or not (the FP32 peak needs packed
+// math), and the scalar-f32 version of this kernel was VALU-bound (78 % busy), so
+// halving the instruction count is the lever.  hipcc's own SLP packing cannot use the
+// modifiers and paid ~800 v_mov per tile instead.  Host build: plain C++ (same maths).
+// ----------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float v2f __attribute__((ext_vector_type(2)));
+SK_HD v2f V(cf a) { v2f r; r.x = a.x; r.y = a.y; return r; }
+SK_HD cf C(v2f a) { return make_float2(a.x, a.y); }
+SK_HD cf cadd(cf a, cf b) { return C(V(a) + V(b)); }
+SK_HD cf csub(cf a, cf b) { return C(V(a) - V(b)); }
+// a * w
+SK_HD cf cmul(cf a, cf w)
+{
+    v2f p, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(V(a)), "v"(V(w)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(V(a)), "v"(V(w)), "v"(p));
+    return C(r);
+}
+// a * conj(w)
+SK_HD cf cmulc(cf a, cf w)
+{
+    v2f p, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(V(a)), "v"(V(w)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(V(a)), "v"(V(w)), "v"(p));
+    return C(r);
+}
+// a * (c - i s) forward, a * (c + i s) inverse; (c, s) compile-time -> one SGPR pair
+template <bool INV> SK_HD cf cmul_k(cf a, float c, float s)
+{
+    v2f K;
+    K.x = c; K.y = s;
+    v2f p, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(V(a)), "s"(K));
+    if (INV) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(V(a)), "s"(K), "v"(p));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(V(a)), "s"(K), "v"(p));
+    return C(r);
+}
+// p + (-i) d forward, p + (+i) d inverse
+template <bool INV> SK_HD cf madd_mi(cf p, cf d)
+{
+    v2f r;
+    if (INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(V(p)), "v"(V(d)));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(V(p)), "v"(V(d)));
+    return C(r);
+}
+SK_HD cf cneg(cf a) { return C(-V(a)); }
+#else
 SK_HD cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
 SK_HD cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
-// a * b
 SK_HD cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-// a * conj(b)
 SK_HD cf cmulc(cf a, cf b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
-template <bool INV> SK_HD cf cmul_dir(cf a, cf w) { return INV ? cmulc(a, w) : cmul(a, w); }
+template <bool INV> SK_HD cf cmul_k(cf a, float c, float s)
+{
+    return INV ? make_float2(a.x * c - a.y * s, a.y * c + a.x * s) : make_float2(a.x * c + a.y * s, a.y * c - a.x * s);
+}
+template <bool INV> SK_HD cf madd_mi(cf p, cf d)
+{
+    return INV ? make_float2(p.x - d.y, p.y + d.x) : make_float2(p.x + d.y, p.y - d.x);
+}
+SK_HD cf cneg(cf a) { return make_float2(-a.x, -a.y); }
+#endif
+// p - (-i) d forward == p + (+i) d
+template <bool INV> SK_HD cf msub_mi(cf p, cf d) { return madd_mi<!INV>(p, d); }
 // a * (-i) forward, a * (+i) inverse
-template <bool INV> SK_HD cf mul_mi(cf a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+template <bool INV> SK_HD cf mul_mi(cf a) { return madd_mi<INV>(make_float2(0.f, 0.f), a); }
 
 // a * W_N^K  (forward, W = exp(-2 pi i / N)) or a * conj(W_N^K) (INV); K compile-time
 template <int N, int K, bool INV> SK_HD cf twmul(cf a)
 {
     constexpr int k32 = ((K % N) * (32 / N)) & 31;
-    constexpr float C[32] = SK_C32;
-    constexpr float S[32] = SK_S32;
+    constexpr float Ct[32] = SK_C32;
+    constexpr float St[32] = SK_S32;
     if constexpr (k32 == 0) return a;
     else if constexpr (k32 == 8) return mul_mi<INV>(a);
-    else if constexpr (k32 == 16) return make_float2(-a.x, -a.y);
+    else if constexpr (k32 == 16) return cneg(a);
     else if constexpr (k32 == 24) return mul_mi<!INV>(a);
-    else if constexpr (k32 == 4) {   // (1 - i)/sqrt2 forward, (1 + i)/sqrt2 inverse
-        constexpr float r = 0.70710678118654757f;
-        return INV ? make_float2((a.x - a.y) * r, (a.x + a.y) * r) : make_float2((a.x + a.y) * r, (a.y - a.x) * r);
-    } else if constexpr (k32 == 12) {  // (-1 - i)/sqrt2 forward, (-1 + i)/sqrt2 inverse
-        constexpr float r = 0.70710678118654757f;
-        return INV ? make_float2(-(a.x + a.y) * r, (a.x - a.y) * r) : make_float2((a.y - a.x) * r, -(a.x + a.y) * r);
-    } else if constexpr (k32 == 20) {  // (-1 + i)/sqrt2 forward
-        constexpr float r = 0.70710678118654757f;
-        return INV ? make_float2((a.y - a.x) * r, -(a.x + a.y) * r) : make_float2(-(a.x + a.y) * r, (a.x - a.y) * r);
-    } else if constexpr (k32 == 28) {  // (1 + i)/sqrt2 forward
-        constexpr float r = 0.70710678118654757f;
-        return INV ? make_float2((a.x + a.y) * r, (a.y - a.x) * r) : make_float2((a.x - a.y) * r, (a.x + a.y) * r);
+    else return cmul_k<INV>(a, Ct[k32], St[k32]);
+}
+
+// Xa = E + W_N^K O,  Xb = E - W_N^K O   (the -i / +i cases fold into the add)
+template <int N, int K, bool INV> SK_HD void bfly_tw(cf E, cf O, cf &Xa, cf &Xb)
+{
+    constexpr int k32 = ((K % N) * (32 / N)) & 31;
+    if constexpr (k32 == 8) {
+        Xa = madd_mi<INV>(E, O);
+        Xb = msub_mi<INV>(E, O);
+    } else if constexpr (k32 == 24) {
+        Xa = msub_mi<INV>(E, O);
+        Xb = madd_mi<INV>(E, O);
     } else {
-        constexpr float c = C[k32], s = S[k32];  // W = c - i s (forward)
-        return INV ? make_float2(a.x * c - a.y * s, a.y * c + a.x * s) : make_float2(a.x * c + a.y * s, a.y * c - a.x * s);
+        const cf t = twmul<N, K, INV>(O);
+        Xa = cadd(E, t);
+        Xb = csub(E, t);
     }
 }
 
@@ -128,20 +192,18 @@ template <int N, int S, bool INV> struct Dft {
             X[1] = csub(x[0], x[S]);
         } else if constexpr (N == 4) {
             const cf s02 = cadd(x[0], x[2 * S]), d02 = csub(x[0], x[2 * S]);
-            const cf s13 = cadd(x[S], x[3 * S]), d13 = mul_mi<INV>(csub(x[S], x[3 * S]));
+            const cf s13 = cadd(x[S], x[3 * S]), d13 = csub(x[S], x[3 * S]);
             X[0] = cadd(s02, s13);
             X[2] = csub(s02, s13);
-            X[1] = cadd(d02, d13);
-            X[3] = csub(d02, d13);
+            X[1] = madd_mi<INV>(d02, d13);
+            X[3] = msub_mi<INV>(d02, d13);
         } else if constexpr (N == 8) {
             cf E[4], O[4];
             Dft<4, 2 * S, INV>::run(x, E);
             Dft<4, 2 * S, INV>::run(x + S, O);
             static_for<0, 4>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                const cf t = twmul<8, k, INV>(O[k]);
-                X[k] = cadd(E[k], t);
-                X[k + 4] = csub(E[k], t);
+                bfly_tw<8, k, INV>(E[k], O[k], X[k], X[k + 4]);
             });
         } else {
             constexpr int M = N / 4;
@@ -157,11 +219,11 @@ template <int N, int S, bool INV> struct Dft {
                 const cf t2 = twmul<N, 2 * k, INV>(S2[k]);
                 const cf t3 = twmul<N, 3 * k, INV>(S3[k]);
                 const cf s02 = cadd(t0, t2), d02 = csub(t0, t2);
-                const cf s13 = cadd(t1, t3), d13 = mul_mi<INV>(csub(t1, t3));
+                const cf s13 = cadd(t1, t3), d13 = csub(t1, t3);
                 X[k] = cadd(s02, s13);
                 X[k + 2 * M] = csub(s02, s13);
-                X[k + M] = cadd(d02, d13);
-                X[k + 3 * M] = csub(d02, d13);
+                X[k + M] = madd_mi<INV>(d02, d13);
+                X[k + 3 * M] = msub_mi<INV>(d02, d13);
             });
         }
     }
@@ -186,9 +248,8 @@ template <int K, bool INV> SK_HD cf mul_w8192(cf a)
     // cos/sin(2 pi k / 8192), k = 0..15
     constexpr float C[16] = {1.0f, 0.99999970586288223f, 0.99999882345170188f, 0.99999735276697821f, 0.99999529380957619f, 0.99999264658070719f, 0.9999894110819284f, 0.9999855873151432f, 0.99998117528260111f, 0.99997617498689761f, 0.99997058643097414f, 0.99996440961811828f, 0.9999576445519639f, 0.99995029123649048f, 0.99994234967602391f, 0.999933819875236f};
     constexpr float S[16] = {0.0f, 0.00076699031874270449f, 0.0015339801862847655f, 0.002300969151425805f, 0.0030679567629659761f, 0.0038349425697062275f, 0.0046019261204485705f, 0.0053689069639963425f, 0.0061358846491544753f, 0.0069028587247297558f, 0.007669828739531097f, 0.0084367942423697988f, 0.0092037547820598194f, 0.0099707099074180308f, 0.010737659167264491f, 0.011504602110422714f};
-    constexpr float c = C[K], sn = S[K];
     if constexpr (K == 0) return a;
-    else return INV ? make_float2(a.x * c - a.y * sn, a.y * c + a.x * sn) : make_float2(a.x * c + a.y * sn, a.y * c - a.x * sn);
+    else return cmul_k<INV>(a, C[K], S[K]);
 }
 
 // pass 1 + twiddle + exchange-1 write.  thread t = 16 b + q.

@@ -31,7 +31,7 @@ SYMBOLS = [
     "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev",
     "skdsp_upsample", "skdsp_upsample_dev", "skdsp_downsample", "skdsp_downsample_dev", "skdsp_destroy",
     "skdsp_dist_unique_id", "skdsp_dist_init", "skdsp_dist_shutdown", "skdsp_dist_barrier",
-    "skdsp_dist_allreduce_max", "skdsp_dist_allreduce_sum", "skdsp_dist_halo_exchange", "skdsp_fir_filter_shard_dev",
+    "skdsp_dist_allreduce_max", "skdsp_dist_allreduce_sum", "skdsp_dist_sendrecv", "skdsp_dist_halo_exchange", "skdsp_fir_filter_shard_dev",
 ]
 
 _lib = None
@@ -101,6 +101,7 @@ def load():
         L.skdsp_dist_init.argtypes = [ci, ci, vp]
         L.skdsp_dist_allreduce_max.argtypes = [ctypes.POINTER(ctypes.c_double)]
         L.skdsp_dist_allreduce_sum.argtypes = [ctypes.POINTER(ctypes.c_double)]
+        L.skdsp_dist_sendrecv.argtypes = [vp, ci, vp, ci, i64]
         L.skdsp_dist_halo_exchange.argtypes = [vp, i64, i64, ci]
         L.skdsp_fir_filter_shard_dev.argtypes = [vp, vp, i64, vp]
         _lib = L

@@ -117,6 +117,8 @@ class RcclTransport:
         self.rank = er if rank is None else rank
         self.world = ew if world is None else world
         local_rank = el if local_rank is None else local_rank
+        if "SKDSP_DEVICE" in os.environ:  # explicit override (e.g. several ranks on one GPU for debugging)
+            local_rank = int(os.environ["SKDSP_DEVICE"])
         _ffi.init(local_rank)
         L = _ffi.load()
         import ctypes

@@ -371,3 +371,45 @@ def test_updn_full_size_config3():
         skip = ((s_in - lo) * 4) // 3
         w = 4000
         assert_close(yd.to_host(m0, w), ref[skip:skip + w], TOL32, "updn window @%d" % s_in)
+
+
+# ------------------------------------------------------------- RCCL plumbing on one GPU
+def test_rccl_single_rank_communicator_p2p_and_allreduce():
+    """The 8-GPU halo path cannot run on a 1-GPU box, but everything except the peer hop can:
+    dlopen(librccl), unique id, ncclCommInitRank (1 rank), a grouped send+recv to self on the
+    library stream with the exact halo size of config 5 (1023 complex64 = 8184 B, 8-byte
+    aligned only), and the 1-element all-reduces bench.py uses for barrier / max."""
+    import ctypes
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, ctypes
+import numpy as np
+sys.path.insert(0, os.path.join(%r, 'scikit-dsp-comm_amd'))
+os.environ['SKDSP_DIST_FORCE_COMM'] = '1'
+from sk_dsp_comm_amd import _ffi
+_ffi.init(0)
+L = _ffi.load()
+buf = ctypes.create_string_buffer(128)
+_ffi.check(L.skdsp_dist_unique_id(buf))
+_ffi.check(L.skdsp_dist_init(0, 1, ctypes.c_char_p(buf.raw)))
+rng = np.random.default_rng(0)
+x = (rng.standard_normal(5000) + 1j * rng.standard_normal(5000)).astype(np.complex64)
+xd = _ffi.DeviceArray.from_host(x, headroom=1023)
+n_halo = 1023
+src = xd.ptr + (x.size - n_halo) * 8
+dst = xd.ptr - n_halo * 8
+_ffi.check(L.skdsp_dist_sendrecv(ctypes.c_void_p(src), 0, ctypes.c_void_p(dst), 0, n_halo * 8))
+_ffi.sync()
+got = np.empty(n_halo, np.complex64)
+_ffi.check(L.skdsp_memcpy_d2h(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(dst), got.nbytes))
+assert np.array_equal(got, x[-n_halo:]), 'self send/recv mismatch'
+d = ctypes.c_double(3.5)
+_ffi.check(L.skdsp_dist_allreduce_max(ctypes.byref(d))); assert d.value == 3.5
+_ffi.check(L.skdsp_dist_allreduce_sum(ctypes.byref(d))); assert d.value == 3.5
+_ffi.check(L.skdsp_dist_barrier())
+_ffi.check(L.skdsp_dist_shutdown())
+print('RCCL_OK')
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert b"RCCL_OK" in out.stdout, out.stdout.decode()[-3000:]
