@@ -23,6 +23,9 @@
 #include <cstdlib>
 #include <cstdio>
 
+#ifndef SKDSP_OLS_HREG
+#define SKDSP_OLS_HREG 1  // this thread's 32 bins of H stay in registers across tiles
+#endif
 #ifndef SKDSP_OLS_NT
 #define SKDSP_OLS_NT 1  // nontemporal x loads / y stores (streamed once): 0.300 -> 0.295 ms
 #endif
@@ -69,7 +72,9 @@ __device__ __forceinline__ void load_tile(const OlsArgs &A, int64_t tile, int t,
         // were then spilled and reloaded in front of every load)
         int tt = t;
         asm volatile("" : "+v"(tt));
+#if !SKDSP_OLS_NT
         const volatile float4 *xp = reinterpret_cast<const volatile float4 *>(A.x + in0);
+#endif
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
 #if SKDSP_OLS_NT
@@ -174,8 +179,10 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
     // This thread's 32 bins of H stay in registers for every tile it processes: streaming
     // them per tile cost 64 KiB of L2->CU traffic per tile, a third of everything the CU's
     // vector-memory pipe (~10 B/clk) had to move, and that pipe is what bounds the kernel.
+#if SKDSP_OLS_HREG
     float4 hh[16];
     load_H(t, A.Hp, hh);
+#endif
     int64_t tile = blockIdx.x;
     cf v[32];
 #if SKDSP_OLS_PREFETCH
@@ -185,6 +192,16 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         SK_STAMP(0);
 #if !SKDSP_OLS_PREFETCH
         load_tile(A, tile, t, v);
+#endif
+#if !SKDSP_OLS_HREG
+        float4 hh[16];
+        {
+            int tt = t;
+            asm volatile("" : "+v"(tt));
+            const volatile float4 *hp = reinterpret_cast<const volatile float4 *>(A.Hp);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) hh[j] = vld(hp + (unsigned)(j * 256 + tt));
+        }
 #endif
         SK_STAMP(1);
         fwd_pass1(t, v, tw, lds);

@@ -35,7 +35,9 @@ namespace skdsp {
 
 constexpr int kIirThreads = 256;
 constexpr int kPiece = 32;          // samples per thread per staged piece
-constexpr int kMaxChunks = 131072;  // J cap: 512 workgroups of 256 chunks
+constexpr int kMaxPairs = 12288;    // K2 capacity: workgroups x state dimension (one 96 KiB LDS image)
+constexpr int kMaxW = 512;          // workgroups (of 256 chunks) per vector (1024 measured slower: more scan, same occupancy)
+constexpr int kPowers = 19;         // M^(2^l), l = 0..18
 
 struct IirPlan {
     int nsec, order, D;
@@ -43,9 +45,9 @@ struct IirPlan {
     double *A = nullptr;         // host: one-step transition D x D (row-major)
     // per call geometry is recomputed; matrix powers are cached per chunk length T
     int64_t cached_T = -1;
-    double *pw_dev = nullptr;    // 17 matrices M^(2^l), l = 0..16, each D x D row-major
+    double *pw_dev = nullptr;    // kPowers matrices M^(2^l), each D x D row-major
     double *v_dev = nullptr;     // [D][J] chunk end states (SoA), capacity below
-    double *agg_dev = nullptr;   // [2][512][D] workgroup aggregates / carries (ping-pong) + carry
+    double *agg_dev = nullptr;   // [2][kMaxW][D] workgroup aggregates / carries (ping-pong) + carry
     size_t v_cap = 0;
     std::vector<double> A_host;
 };
@@ -282,15 +284,15 @@ template <int D>
 __global__ __launch_bounds__(1024) void iir_wg_scan_kernel(const double *__restrict__ agg, const double *__restrict__ pw,
                                                            int W, double *__restrict__ carry)
 {
-    constexpr int kPer = (512 * D + 1023) / 1024;  // (item,row) pairs per thread
-    __shared__ double vb[512 * D];
+    constexpr int kPer = kMaxPairs / 1024;  // (item,row) pairs per thread
+    __shared__ double vb[kMaxPairs];
     __shared__ double Ml[D * (D + 1)];  // row pitch D+1: rows land on distinct banks
     const int tid = threadIdx.x;
     const double *in = agg + (size_t)blockIdx.x * W * D;
     double *out = carry + (size_t)blockIdx.x * W * D;
     const int npairs = W * D;
     for (int p = tid; p < npairs; p += 1024) vb[p] = in[p];
-    for (int l = 0; l < 9 && (1 << l) < W; ++l) {
+    for (int l = 0; l < 10 && (1 << l) < W; ++l) {
         const int s = 1 << l;
         for (int e = tid; e < D * D; e += 1024) Ml[(e / D) * (D + 1) + (e % D)] = pw[(size_t)(8 + l) * D * D + e];
         __syncthreads();
@@ -385,8 +387,8 @@ static int ensure_plan(IirHandle *h)
     }
     hipError_t e;
     if ((e = hipMalloc((void **)&p->coef_dev, h->coef.size() * 8)) != hipSuccess ||
-        (e = hipMalloc((void **)&p->pw_dev, (size_t)17 * D * D * 8)) != hipSuccess ||
-        (e = hipMalloc((void **)&p->agg_dev, (size_t)2 * 2 * 512 * D * 8)) != hipSuccess) {
+        (e = hipMalloc((void **)&p->pw_dev, (size_t)kPowers * D * D * 8)) != hipSuccess ||
+        (e = hipMalloc((void **)&p->agg_dev, (size_t)2 * 2 * kMaxW * D * 8)) != hipSuccess) {
         iir_free(p);
         return hip_fail(e, "hipMalloc(iir plan)", __FILE__, __LINE__);
     }
@@ -411,14 +413,14 @@ static int ensure_powers(IirHandle *h, int64_t T, hipStream_t s)
         e >>= 1;
         if (e) matmul_ld(sq, sq, sq, D);
     }
-    std::vector<double> pw((size_t)17 * D * D);
-    for (int l = 0; l < 17; ++l) {
+    std::vector<double> pw((size_t)kPowers * D * D);
+    for (int l = 0; l < kPowers; ++l) {
         for (size_t i = 0; i < (size_t)D * D; ++i) {
             long double v = M[i];
             if (!std::isfinite((double)v)) v = 0.0L;  // unstable filter overflow: the reference overflows too
             pw[(size_t)l * D * D + i] = (double)v;
         }
-        if (l < 16) matmul_ld(M, M, M, D);
+        if (l + 1 < kPowers) matmul_ld(M, M, M, D);
     }
     SK_HIP(hipMemcpyAsync(p->pw_dev, pw.data(), pw.size() * 8, hipMemcpyHostToDevice, s));
     SK_HIP(hipStreamSynchronize(s));  // pw is a stack-lifetime host buffer
@@ -434,7 +436,7 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
     std::memcpy(cf.c, h->coef.data(), sizeof(cf.c));
     IirPlan *p = h->plan;
     double *agg = p->agg_dev;
-    double *carry = p->agg_dev + (size_t)2 * 512 * D;
+    double *carry = p->agg_dev + (size_t)2 * kMaxW * D;
     a.agg = agg;
     a.carry = carry;
     hipLaunchKernelGGL((iir_chunk_kernel<NSEC, ORD, IO, false>), dim3(W, nbatch), dim3(kIirThreads), 0, s, a, cf);
@@ -468,7 +470,10 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     if (rc) return rc;
     IirPlan *p = h->plan;
     const int D = p->D;
-    int64_t T = (n + kMaxChunks - 1) / kMaxChunks;
+    int maxW = kMaxPairs / D;
+    if (maxW > kMaxW) maxW = kMaxW;
+    const int64_t maxChunks = (int64_t)maxW * kIirThreads;
+    int64_t T = (n + maxChunks - 1) / maxChunks;
     T = ((T + kPiece - 1) / kPiece) * kPiece;
     if (T < kPiece) T = kPiece;
     const int64_t J = (n + T - 1) / T;
