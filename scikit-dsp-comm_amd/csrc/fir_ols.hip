@@ -23,6 +23,9 @@
 #include <cstdlib>
 #include <cstdio>
 
+#ifndef SKDSP_OLS_NOMEM
+#define SKDSP_OLS_NOMEM 0  // diagnostic: FFT/LDS work only, no x/y traffic (wrong results)
+#endif
 #ifndef SKDSP_OLS_HREG
 #define SKDSP_OLS_HREG 1  // this thread's 32 bins of H stay in registers across tiles
 #endif
@@ -67,6 +70,13 @@ __device__ __forceinline__ void load_tile(const OlsArgs &A, int64_t tile, int t,
 {
     const int64_t in0 = tile * A.V - A.ov;
     const bool interior = A.aligned && in0 >= -A.n_hist && in0 + kN <= A.n;
+#if SKDSP_OLS_NOMEM
+    if (A.n != -12345) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = make_float2(t * 0.001f + i, (float)tile * 0.5f);
+        return;
+    }
+#endif
     if (interior) {
         // opaque copy of t: stops LICM from hoisting 16 loop-invariant 64-bit addresses (which
         // were then spilled and reloaded in front of every load)
@@ -104,6 +114,9 @@ __device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t
 {
     const int64_t out0 = tile * A.V;
     const bool full = A.aligned && out0 + A.V <= A.n;
+#if SKDSP_OLS_NOMEM
+    if (A.n != -12345) return;
+#endif
     if (full) {
         float4 *yp = reinterpret_cast<float4 *>(A.y + out0 + 2 * t);
 #pragma unroll
@@ -130,6 +143,80 @@ __device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t
     }
 }
 
+// ---- float32 signals with real taps: two real tiles ride in one complex tile ----------
+// A real-tap FIR commutes with taking real/imaginary parts, so real tile 2p goes in as
+// the real part and real tile 2p+1 as the imaginary part of complex tile p; the FFT work
+// per real sample halves and the same kernel body serves both dtypes.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void load_tile_real(const OlsArgs &A, int64_t pair, int t, cf *v)
+{
+    const float *xr = reinterpret_cast<const float *>(A.x);
+    const int64_t inA = (2 * pair) * A.V - A.ov, inB = inA + A.V;
+    const bool interior = A.aligned && inA >= -A.n_hist && inB + kN <= A.n;
+    if (interior) {
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const v2f_t ra = __builtin_nontemporal_load(reinterpret_cast<const v2f_t *>(xr + inA) + (unsigned)(a * 256 + tt));
+            const v2f_t rb = __builtin_nontemporal_load(reinterpret_cast<const v2f_t *>(xr + inB) + (unsigned)(a * 256 + tt));
+            v[2 * a] = make_float2(ra.x, rb.x);
+            v[2 * a + 1] = make_float2(ra.y, rb.y);
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int64_t ga = inA + 512 * a + 2 * t + e, gb = ga + A.V;
+                float re = 0.f, im = 0.f;
+                if (ga >= -A.n_hist && ga < A.n) re = xr[ga];
+                if (gb >= -A.n_hist && gb < A.n) im = xr[gb];
+                v[2 * a + e] = make_float2(re, im);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void store_tile_real(const OlsArgs &A, int64_t pair, int t, const cf *v)
+{
+    float *yr = reinterpret_cast<float *>(A.y);
+    const int64_t outA = (2 * pair) * A.V, outB = outA + A.V;
+    const bool full = A.aligned && outB + A.V <= A.n;
+    if (full) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a)
+            if (a >= A.a0) {
+                v2f_t ra, rb;
+                ra.x = v[2 * a].x; ra.y = v[2 * a + 1].x;
+                rb.x = v[2 * a].y; rb.y = v[2 * a + 1].y;
+                __builtin_nontemporal_store(ra, reinterpret_cast<v2f_t *>(yr + outA + 2 * t) + (a - A.a0) * 256);
+                __builtin_nontemporal_store(rb, reinterpret_cast<v2f_t *>(yr + outB + 2 * t) + (a - A.a0) * 256);
+            }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            if (a < A.a0) continue;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int64_t ga = outA + 512 * (a - A.a0) + 2 * t + e, gb = ga + A.V;
+                if (ga < A.n) yr[ga] = v[2 * a + e].x;
+                if (gb < A.n) yr[gb] = v[2 * a + e].y;
+            }
+        }
+    }
+}
+
+template <bool REAL> __device__ __forceinline__ void load_any(const OlsArgs &A, int64_t tile, int t, cf *v)
+{
+    if (REAL) load_tile_real(A, tile, t, v); else load_tile(A, tile, t, v);
+}
+template <bool REAL> __device__ __forceinline__ void store_any(const OlsArgs &A, int64_t tile, int t, const cf *v)
+{
+    if (REAL) store_tile_real(A, tile, t, v); else store_tile(A, tile, t, v);
+}
+
 // Persistent: gridDim.x = 2 workgroups per CU, each walks tiles blockIdx.x, +gridDim.x, ...
 // Per tile the only vector-memory traffic is [H: 16 loads at tile start, consumed after
 // the forward FFT] [next tile's x: 16 loads issued after the H multiply, consumed at the
@@ -137,7 +224,7 @@ __device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t
 // tile-invariant inter-pass twiddles never touch the VM path (T1 as 15 register-resident
 // powers of W_4096^t, T2 as two 4 KiB LDS tables): vmcnt retires in order, so any table
 // load issued after a prefetch would force the prefetch to land first.
-template <bool TRACE>
+template <bool TRACE, bool REAL>
 __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 {
     __shared__ float4 lds[kLdsUnits + 2 * kT2Units];
@@ -186,12 +273,12 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
     int64_t tile = blockIdx.x;
     cf v[32];
 #if SKDSP_OLS_PREFETCH
-    if (tile < A.ntiles) load_tile(A, tile, t, v);
+    if (tile < A.ntiles) load_any<REAL>(A, tile, t, v);
 #endif
     for (; tile < A.ntiles; tile += gridDim.x, ++it) {
         SK_STAMP(0);
 #if !SKDSP_OLS_PREFETCH
-        load_tile(A, tile, t, v);
+        load_any<REAL>(A, tile, t, v);
 #endif
 #if !SKDSP_OLS_HREG
         float4 hh[16];
@@ -217,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         // the top of the next iteration -- in flight during the whole inverse FFT
         const int64_t next = tile + gridDim.x;
         cf nx[32];
-        if (next < A.ntiles) load_tile(A, next, t, nx);
+        if (next < A.ntiles) load_any<REAL>(A, next, t, nx);
 #endif
         inv_pass32(t, T2t, lds, Z);
         SK_STAMP(5);
@@ -225,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         SK_STAMP(6);
         inv_pass1(t, tw, lds, v);
         SK_STAMP(7);
-        store_tile(A, tile, t, v);
+        store_any<REAL>(A, tile, t, v);
         SK_STAMP(8);
 #if SKDSP_OLS_PREFETCH
 #pragma unroll
@@ -240,7 +327,9 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 bool fir_ols_supported(const FirHandle *h)
 {
     // complex64 signal; overlap must leave at least half the tile as useful output
-    return h->dtype == SKDSP_C64 && h->ntaps >= 2 && h->ntaps - 1 <= 4096;
+    if (h->ntaps < 2 || h->ntaps - 1 > 4096) return false;
+    // complex64 with any taps; float32 with real taps (two real tiles per complex tile)
+    return h->dtype == SKDSP_C64 || (h->dtype == SKDSP_F32 && !h->taps_complex);
 }
 
 static int ensure_plan(FirHandle *h)
@@ -284,7 +373,7 @@ void fir_ols_free(OlsPlan *p)
 int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s)
 {
     if (n <= 0) return SKDSP_OK;
-    SK_CHECK(fir_ols_supported(h), SKDSP_ERR_UNSUPPORTED, "fir_ols: needs a complex64 signal and 2..4097 taps");
+    SK_CHECK(fir_ols_supported(h), SKDSP_ERR_UNSUPPORTED, "fir_ols: needs complex64 (or float32 with real taps) and 2..4097 taps");
     int rc = ensure_plan(h);
     if (rc) return rc;
     OlsPlan *p = h->ols;
@@ -295,8 +384,10 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.n_hist = n_hist;
     A.T1 = p->T1; A.T2 = p->T2; A.Hp = p->Hp;
     A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512;
+    const bool real = h->dtype == SKDSP_F32;
     A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
-    const int64_t ntiles = (n + p->V - 1) / p->V;
+    int64_t ntiles = (n + p->V - 1) / p->V;
+    if (real) ntiles = (ntiles + 1) / 2;  // pairs of real tiles
     SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols: too many tiles");
     A.ntiles = ntiles;
     int64_t grid = 2 * (int64_t)ctx().num_cus;  // 2 resident workgroups per CU (76 KiB LDS each)
@@ -308,7 +399,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
         SK_HIP(hipMalloc((void **)&d, nw * 8));
         SK_HIP(hipMemsetAsync(d, 0, nw * 8, s));
         A.trace = d;
-        hipLaunchKernelGGL(ols_tile_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, A);
+        hipLaunchKernelGGL((ols_tile_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
         std::vector<unsigned long long> hbuf(nw);
         SK_HIP(hipMemcpyAsync(hbuf.data(), d, nw * 8, hipMemcpyDeviceToHost, s));
         SK_HIP(hipStreamSynchronize(s));
@@ -321,7 +412,8 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
         }
         return SKDSP_OK;
     }
-    hipLaunchKernelGGL(ols_tile_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, A);
+    if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL((ols_tile_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
 }

@@ -84,20 +84,22 @@ SK_HD v2f V(cf a) { v2f r; r.x = a.x; r.y = a.y; return r; }
 SK_HD cf C(v2f a) { return make_float2(a.x, a.y); }
 SK_HD cf cadd(cf a, cf b) { return C(V(a) + V(b)); }
 SK_HD cf csub(cf a, cf b) { return C(V(a) - V(b)); }
-// a * w
+// a * w   (two instructions in ONE asm statement: hipcc pads every asm boundary with s_nop)
 SK_HD cf cmul(cf a, cf w)
 {
-    v2f p, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(V(a)), "v"(V(w)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(V(a)), "v"(V(w)), "v"(p));
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(V(a)), "v"(V(w)));
     return C(r);
 }
 // a * conj(w)
 SK_HD cf cmulc(cf a, cf w)
 {
-    v2f p, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(V(a)), "v"(V(w)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(V(a)), "v"(V(w)), "v"(p));
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=&v"(r) : "v"(V(a)), "v"(V(w)));
     return C(r);
 }
 // a * (c - i s) forward, a * (c + i s) inverse; (c, s) compile-time -> one SGPR pair
@@ -105,10 +107,15 @@ template <bool INV> SK_HD cf cmul_k(cf a, float c, float s)
 {
     v2f K;
     K.x = c; K.y = s;
-    v2f p, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(V(a)), "s"(K));
-    if (INV) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(V(a)), "s"(K), "v"(p));
-    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(V(a)), "s"(K), "v"(p));
+    v2f r;
+    if (INV)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+            : "=&v"(r) : "v"(V(a)), "s"(K));
+    else
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+            : "=&v"(r) : "v"(V(a)), "s"(K));
     return C(r);
 }
 // p + (-i) d forward, p + (+i) d inverse

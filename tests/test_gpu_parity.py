@@ -148,6 +148,30 @@ def test_fir_ols_edges_vs_oracle(n, P):
     assert_close(k.filter(x), ref, TOL32, "direct n=%d P=%d" % (n, P))
 
 
+@pytest.mark.parametrize("n,P", [(4096, 48), (7168, 127), (7169, 127), (2 * 7680 + 3, 127), (3 * 7168 + 1, 1024),
+                                 (50001, 513), (100000, 1025), (1 << 20, 2000)])
+def test_fir_ols_real_pairs_vs_oracle(n, P):
+    """float32 signals: two real tiles per complex tile (odd tile counts, ragged tails)"""
+    rng = np.random.default_rng(n + P)
+    x = rng.standard_normal(n).astype(np.float32)
+    b = rng.standard_normal(P) / np.sqrt(P)
+    ref = orc.fir_filter(b, x)
+    k = _ffi.FirKernel(b, _ffi.F32)
+    k.set_algo(_ffi.FIR_OLS)
+    assert k.algo_for(n) == _ffi.FIR_OLS
+    assert_close(k.filter(x), ref, TOL32, "ols real n=%d P=%d" % (n, P))
+    # history for the sharded path
+    if n > 3 * P:
+        cut = n // 3 + 1
+        import ctypes
+        xd = _ffi.DeviceArray.from_host(x[cut:], headroom=P - 1)
+        hist = np.ascontiguousarray(x[cut - (P - 1):cut])
+        _ffi.check(_ffi.load().skdsp_memcpy_h2d(ctypes.c_void_p(xd.ptr - hist.nbytes), ctypes.c_void_p(hist.ctypes.data), hist.nbytes))
+        yd = _ffi.DeviceArray(n - cut, np.float32)
+        k.filter_dev(xd, yd, n_hist=P - 1)
+        assert_close(yd.to_host(), ref[cut:], TOL32, "ols real history")
+
+
 @pytest.mark.parametrize("L,M", [(1, 1), (2, 1), (1, 2), (4, 3), (3, 4), (12, 1), (1, 12), (6, 4), (5, 5), (7, 24)])
 def test_fir_polyphase_all_ratios_vs_oracle(L, M):
     rng = np.random.default_rng(L * 100 + M)
