@@ -217,8 +217,17 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
             X mid[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) mid[r] = zero_of<X>();
+            // taps are wave-uniform (scalar loads); request block beta+1 while block beta is
+            // being applied -- a load-then-wait per block left every wave stalled ~85 % of the time
+            B tcur[R];
+#pragma unroll
+            for (int u_ = 0; u_ < R; ++u_) tcur[u_] = tb[u_];
             for (int beta = 0; beta < a.nB; ++beta) {
                 grp -= (P + 1);
+                B tnext[R];
+                const B *__restrict__ tbn = tb + (size_t)(beta + 1 < a.nB ? beta + 1 : beta) * R;
+#pragma unroll
+                for (int u_ = 0; u_ < R; ++u_) tnext[u_] = tbn[u_];
                 X nw[R];
 #pragma unroll
                 for (int i = 0; i < R; ++i) nw[i] = grp[q * i];
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
                 for (int r = 0; r < R; ++r) part[r] = zero_of<X>();
 #pragma unroll
                 for (int u_ = 0; u_ < R; ++u_) {
-                    const B b = tb[beta * R + u_];
+                    const B b = tcur[u_];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int e = r - u_;
@@ -239,6 +248,8 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
                     mid[r] = add_of(mid[r], part[r]);
                     wr[r] = nw[r];
                 }
+#pragma unroll
+                for (int u_ = 0; u_ < R; ++u_) tcur[u_] = tnext[u_];
                 if ((beta & 15) == 15) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {

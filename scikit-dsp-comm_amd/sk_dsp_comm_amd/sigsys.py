@@ -4,6 +4,9 @@
   downsample(x, M, p)  /root/reference/src/sk_dsp_comm/sigsys.py:3056-3083
   cic(m, k)            /root/reference/src/sk_dsp_comm/sigsys.py:62-93
 
+  os_filter(x,h,N,mode) /root/reference/src/sk_dsp_comm/sigsys.py:482-540   ("next" row)
+  oa_filter(x,h,N,mode) /root/reference/src/sk_dsp_comm/sigsys.py:543-598
+
 upsample/downsample run on the GPU (resample.hip) and are bit-exact index moves; cic
 is host-side coefficient generation (a few dozen float64 taps) and stays in NumPy.
 Error conventions follow the reference (tests/golden/g10_conventions.json).
@@ -94,3 +97,38 @@ def downsample(x, M, p=0):
         wide = src.astype(np.float32 if src.dtype == np.float16 else np.int32)
         y = _ffi.downsample(wide.view(np.float32), M, p).view(wide.dtype).astype(src.dtype)
     return y
+
+
+def _transform_domain_fir(x, h, N, mode, name):
+    """Shared body of os_filter / oa_filter: both return real(lfilter(h, 1, x)) as float64
+    (the reference takes np.real of every inverse FFT frame).  The frame size N only
+    parameterises the reference's Python frame loop; here the filtering runs in the GPU
+    overlap-save engine (fir_ols.hip) with its own 8192-point tiles."""
+    from . import multirate_helper as mrh
+    P = len(h)
+    L = int(N) - P + 1
+    if L <= 0:
+        raise ValueError("%s: FFT size N=%d must exceed the filter length P=%d - 1" % (name, int(N), P))
+    if mode == 1:
+        raise NotImplementedError("%s(mode=1): the per-frame diagnostic matrix is a teaching aid of the "
+                                  "reference's Python loop and is not produced by the GPU path" % name)
+    x = np.asarray(x)
+    if len(x) == 0:
+        return np.zeros(0)
+    saved = config.strict_dtype
+    config.strict_dtype = True
+    try:
+        y = mrh.multirate_FIR(np.asarray(h)).filter(x)
+    finally:
+        config.strict_dtype = saved
+    return np.ascontiguousarray(np.real(y), dtype=np.float64)
+
+
+def os_filter(x, h, N, mode=0):
+    """Overlap-and-save FIR filtering (sigsys.py:482-540): y = real(lfilter(h, 1, x))."""
+    return _transform_domain_fir(x, h, N, mode, "os_filter")
+
+
+def oa_filter(x, h, N, mode=0):
+    """Overlap-and-add FIR filtering (sigsys.py:543-598): y = real(lfilter(h, 1, x))."""
+    return _transform_domain_fir(x, h, N, mode, "oa_filter")

@@ -173,8 +173,12 @@ d24 = ss.deci24(y24b)
 n = np.arange(0, 20)
 xos = np.cos(2 * np.pi * 0.05 * n)
 yos = ss.os_filter(xos, np.ones(10), 2 ** 10)
+# os_filter / oa_filter on a longer complex input (the reference keeps only the real part)
+xosc = cplx(3000, np.complex128)
+hos = fir_d.firwin_lpf(65, 0.15)
 save("g9_kat.npz", m2=m2, m3=m3, interp24_m2=y24, interp24_m3=y24b, deci24=np.ascontiguousarray(d24),
-     os_x=xos, os_b=np.ones(10), os_y=yos)
+     os_x=xos, os_b=np.ones(10), os_y=yos, oa_y=ss.oa_filter(xos, np.ones(10), 2 ** 10),
+     osc_x=xosc, osc_h=hos, osc_os=ss.os_filter(xosc, hos, 256), osc_oa=ss.oa_filter(xosc, hos, 256))
 
 # ------------------------------------------------------------ G10 dtype matrix
 dtm = {}

@@ -292,6 +292,24 @@ def test_g9_kats_interp24_deci24_through_gpu():
     np.testing.assert_almost_equal(mrh.multirate_FIR(g["os_b"]).filter(g["os_x"]), g["os_y"])
 
 
+def test_os_oa_filter_next_row():
+    """sigsys.os_filter / oa_filter (sigsys.py:482-598) on the OLS engine."""
+    g = load("g9_kat.npz")
+    for fn, k in ((ss.os_filter, "os_y"), (ss.oa_filter, "oa_y")):
+        y = fn(g["os_x"], g["os_b"], 2 ** 10)
+        assert y.dtype == np.float64
+        np.testing.assert_almost_equal(y, g[k])
+    y = ss.os_filter(g["osc_x"], g["osc_h"], 256)
+    assert y.dtype == np.float64 and y.shape == g["osc_os"].shape
+    assert_close(y, g["osc_os"], TOL64, "os_filter complex in")
+    assert_close(ss.oa_filter(g["osc_x"].astype(np.complex64), g["osc_h"], 256), g["osc_oa"], TOL32, "oa_filter c64")
+    with pytest.raises(NotImplementedError):
+        ss.os_filter(g["os_x"], g["os_b"], 1024, mode=1)
+    with pytest.raises(ValueError):
+        ss.oa_filter(g["os_x"], g["os_b"], 4)
+    assert ss.os_filter(np.zeros(0), g["os_b"], 64).shape == (0,)
+
+
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 8191, 8192 * 3 + 17, 300_001, 2 ** 22 + 5])
 def test_iir_scan_lengths_vs_oracle(n):
     """chunk / workgroup / tail boundaries of the scan"""

@@ -61,6 +61,8 @@ def test_signatures_match_reference():
     assert str(inspect.signature(ss.downsample)) == "(x, M, p=0)"
     assert str(inspect.signature(ss.upsample)) == "(x, L)"
     assert str(inspect.signature(ss.cic)) == "(m, k)"
+    assert str(inspect.signature(ss.os_filter)) == "(x, h, N, mode=0)"
+    assert str(inspect.signature(ss.oa_filter)) == "(x, h, N, mode=0)"
 
 
 def test_constructors_and_logging(caplog):

@@ -140,6 +140,10 @@ def test_g9_kats():
     assert rel_err(yd, g["deci24"])[0] < 1e-10
     # os_filter KAT == plain FIR of ones(10) over a cosine
     np.testing.assert_almost_equal(orc.fir_filter(g["os_b"], g["os_x"]), g["os_y"])
+    np.testing.assert_almost_equal(orc.fir_filter(g["os_b"], g["os_x"]), g["oa_y"])
+    # os_filter / oa_filter keep only the real part of a complex result (sigsys.py:534,592)
+    ref = np.real(orc.fir_filter(g["osc_h"], g["osc_x"]))
+    assert rel_err(ref, g["osc_os"])[0] < 1e-12 and rel_err(ref, g["osc_oa"])[0] < 1e-12
 
 
 def test_oracle_vs_scipy_when_available():
