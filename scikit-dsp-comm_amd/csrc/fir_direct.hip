@@ -282,7 +282,6 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
 // ------------------------------------------------------------------ host side
 FirHandle::~FirHandle()
 {
-    if (taps_dev) (void)hipFree(taps_dev);
     for (auto &p : poly) if (p.dev) (void)hipFree(p.dev);
     for (auto &t : sw) { if (t.taps) (void)hipFree(t.taps); if (t.rho) (void)hipFree(t.rho); }
     if (ols) fir_ols_free(ols);

@@ -41,8 +41,6 @@ constexpr int kPowers = 19;         // M^(2^l), l = 0..18
 
 struct IirPlan {
     int nsec, order, D;
-    double *coef_dev = nullptr;  // nsec * (2*order+1)
-    double *A = nullptr;         // host: one-step transition D x D (row-major)
     // per call geometry is recomputed; matrix powers are cached per chunk length T
     int64_t cached_T = -1;
     double *pw_dev = nullptr;    // kPowers matrices M^(2^l), each D x D row-major
@@ -338,7 +336,6 @@ IirHandle::~IirHandle() { if (plan) iir_free(plan); }
 void iir_free(IirPlan *p)
 {
     if (!p) return;
-    if (p->coef_dev) (void)hipFree(p->coef_dev);
     if (p->pw_dev) (void)hipFree(p->pw_dev);
     if (p->v_dev) (void)hipFree(p->v_dev);
     if (p->agg_dev) (void)hipFree(p->agg_dev);
@@ -386,8 +383,7 @@ static int ensure_plan(IirHandle *h)
         for (int r = 0; r < D; ++r) p->A_host[(size_t)r * D + i] = (double)z[r];
     }
     hipError_t e;
-    if ((e = hipMalloc((void **)&p->coef_dev, h->coef.size() * 8)) != hipSuccess ||
-        (e = hipMalloc((void **)&p->pw_dev, (size_t)kPowers * D * D * 8)) != hipSuccess ||
+    if ((e = hipMalloc((void **)&p->pw_dev, (size_t)kPowers * D * D * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&p->agg_dev, (size_t)2 * 2 * kMaxW * D * 8)) != hipSuccess) {
         iir_free(p);
         return hip_fail(e, "hipMalloc(iir plan)", __FILE__, __LINE__);

@@ -70,8 +70,6 @@ struct FirHandle : HandleBase {
     bool taps_complex = false;
     int algo = SKDSP_FIR_AUTO;
     std::vector<double> taps_host;  // ntaps (real) or 2*ntaps (complex, interleaved)
-    // device taps in the compute precision, natural order: real -> T[ntaps], complex -> T[2*ntaps]
-    void *taps_dev = nullptr;
     // polyphase tap banks, keyed by L (lazy): bank[phase][t] = b[phase + L*t], T = ceil(P/L)
     struct Poly { int L; int T; void *dev; };
     std::vector<Poly> poly;

@@ -455,3 +455,70 @@ print('RCCL_OK')
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert b"RCCL_OK" in out.stdout, out.stdout.decode()[-3000:]
+
+
+def test_sharded_fir_eight_shards_emulated_on_one_gpu():
+    """BASELINE config 5 semantics on one GPU: the 8-way sample-block sharding of
+    sk_dsp_comm_amd.sharding (shard_bounds, headroom layout, Ntaps-1 halo in front of the
+    shard, n_hist) with the halo hop done by a device copy instead of RCCL.  The sharded
+    outputs must equal the single-vector filter (spot-checked against the oracle too)."""
+    import ctypes
+    from sk_dsp_comm_amd import sharding
+    g = load("g5_fir1024.npz")
+    b = g["b"]
+    P = len(b)
+    n, world = 2 ** 23 + 12345, 8
+    L = _ffi.load()
+    k = _ffi.FirKernel(b, _ffi.C64)
+    xd = _ffi.DeviceArray(n, np.complex64).fill_noise(99)
+    yd = _ffi.DeviceArray(n, np.complex64)
+    k.filter_dev(xd, yd)
+    y_full = yd.to_host()
+    bounds = sharding.shard_bounds(n, world)
+    y_parts = []
+    for r, (s0, s1) in enumerate(bounds):
+        nl = s1 - s0
+        sh = _ffi.DeviceArray(nl, np.complex64, headroom=P - 1)
+        _ffi.check(L.skdsp_memcpy_d2d(ctypes.c_void_p(sh.ptr), ctypes.c_void_p(xd.ptr + s0 * 8), nl * 8))
+        if r == 0:
+            _ffi.check(L.skdsp_dist_halo_exchange(ctypes.c_void_p(sh.ptr), nl, P - 1, _ffi.C64))  # world 1: zero fill
+        else:  # what rank r-1 would send: its last P-1 samples
+            _ffi.check(L.skdsp_memcpy_d2d(ctypes.c_void_p(sh.ptr - (P - 1) * 8), ctypes.c_void_p(xd.ptr + (s0 - (P - 1)) * 8), (P - 1) * 8))
+        yo = _ffi.DeviceArray(nl, np.complex64)
+        k.filter_dev(sh, yo, n_hist=P - 1)
+        y_parts.append(yo.to_host())
+    y_sh = np.concatenate(y_parts)
+    assert y_sh.shape == y_full.shape
+    assert_close(y_sh, y_full, 5e-7, "sharded vs single vector")
+    for r in (1, 4, 7):  # oracle across a shard boundary
+        s0 = bounds[r][0]
+        xs = xd.to_host(s0 - 3000, 6000)
+        ref = orc.fir_filter(b, xs)[P - 1:]
+        assert_close(y_sh[s0 - 3000 + P - 1:s0 + 3000], ref, TOL32, "boundary of shard %d" % r)
+
+
+def test_ols_512_thread_variant_in_subprocess():
+    """The alternative 16-points-per-thread tile (SKDSP_OLS_THREADS=512, kept selectable
+    because it was measured) must stay parity-correct."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'scikit-dsp-comm_amd'))
+from sk_dsp_comm_amd import _ffi
+from oracle import oracle as orc
+rng = np.random.default_rng(12)
+for n, P, dt in ((30001, 1024, np.complex64), (7168 * 3, 300, np.complex64), (50000, 127, np.float32)):
+    x = rng.standard_normal(n).astype(np.float32) if dt == np.float32 else ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2)).astype(dt)
+    b = rng.standard_normal(P) / np.sqrt(P)
+    k = _ffi.FirKernel(b, _ffi.code_of(dt)); k.set_algo(_ffi.FIR_OLS)
+    y = k.filter(x); ref = orc.fir_filter(b, x)
+    e = float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))
+    assert e < 1e-6, (n, P, e)
+print('OLS512_OK')
+""" % (root, root)
+    env = dict(os.environ, SKDSP_OLS_THREADS="512")
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, env=env)
+    assert b"OLS512_OK" in out.stdout, out.stdout.decode()[-3000:]
