@@ -11,7 +11,9 @@
 //     s_out = M s_in + v ,   M = A^T (one-chunk transition),  v = zero-state end state
 //   K1  every thread runs the cascade over its chunk from zero state -> v_j ; the
 //       workgroup tree-reduces its 256 v_j (matrix powers M^(2^l)) into one aggregate
-//   K2  one workgroup scans the <=512 workgroup aggregates (powers M^(256*2^l))
+//   K2  one workgroup scans the <=512 workgroup aggregates (powers M^(256*2^l)); skipped when
+//       (M^256)^k underflows within 8 powers (any ordinary stable filter): K3 then sums the
+//       few significant look-back terms itself
 //   K3  every workgroup scans its 256 v_j seeded with its carry-in, then every thread
 //       re-runs the cascade from its now-exact initial state and writes y
 // Nothing is approximated (no "warm-up overlap"): marginally stable / slowly decaying
@@ -44,6 +46,8 @@ struct IirPlan {
     // per call geometry is recomputed; matrix powers are cached per chunk length T
     int64_t cached_T = -1;
     double *pw_dev = nullptr;    // kPowers matrices M^(2^l), each D x D row-major
+    double *lb_dev = nullptr;    // look-back matrices (M^256)^k, k = 1..7
+    int n_lb = 0;                // terms of the in-kernel carry look-back (0 = use the K2 scan)
     double *v_dev = nullptr;     // [D][J] chunk end states (SoA), capacity below
     double *agg_dev = nullptr;   // [2][kMaxW][D] workgroup aggregates / carries (ping-pong) + carry
     size_t v_cap = 0;
@@ -105,7 +109,9 @@ struct IirArgs {
     const double *pw; // matrix powers
     double *v;        // [batch][D][J]
     double *agg;      // [batch][W][D]  workgroup aggregates (K1 out)
-    const double *carry;  // [batch][W][D]  workgroup carry-in (K3 in)
+    const double *carry;  // [batch][W][D]  workgroup carry-in (K3 in), used when n_lb == 0
+    const double *lbmat;  // [n_lb-1][D][D]: (M^256)^k, k = 1..n_lb-1
+    int n_lb;             // > 0: carry = sum_{k<n_lb} (M^256)^k agg[wg-1-k] computed in K3 (no K2 launch)
 };
 
 // Kernel body shared by K1 (WRITE=false) and K3 (WRITE=true).
@@ -139,11 +145,30 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
         double v[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) v[d] = (cj < a.J) ? vbase[(size_t)d * a.J + cj] : 0.0;
-        if (tid == 0) {
-            double c0[D];
-            const double *cin = a.carry + ((size_t)bat * W + wg) * D;
+        double c0[D];  // carry-in of this workgroup (only thread 0 needs it)
 #pragma unroll
-            for (int d = 0; d < D; ++d) c0[d] = cin[d];
+        for (int d = 0; d < D; ++d) c0[d] = 0.0;
+        if (tid == 0) {
+            if (a.n_lb > 0) {
+                // short look-back: the workgroup-level transition (M^256) of a stable filter
+                // underflows after a few powers, so the carry is a handful of terms
+                const double *ag = a.agg + (size_t)bat * W * D;
+                if (wg >= 1) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) c0[d] = ag[(size_t)(wg - 1) * D + d];
+                }
+                for (int k = 1; k < a.n_lb; ++k) {
+                    if (wg - 1 - k < 0) break;
+                    double tmp[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) tmp[d] = ag[(size_t)(wg - 1 - k) * D + d];
+                    matvec_acc<D>(a.lbmat + (size_t)(k - 1) * D * D, tmp, c0);
+                }
+            } else {
+                const double *cin = a.carry + ((size_t)bat * W + wg) * D;
+#pragma unroll
+                for (int d = 0; d < D; ++d) c0[d] = cin[d];
+            }
             matvec_acc<D>(a.pw, c0, v);  // v0' = M carry + v0
         }
 #pragma unroll 1
@@ -165,9 +190,8 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
         for (int d = 0; d < D; ++d) sc[d * kIirThreads + tid] = v[d];
         __syncthreads();
         if (tid == 0) {
-            const double *cin = a.carry + ((size_t)bat * W + wg) * D;
 #pragma unroll
-            for (int d = 0; d < D; ++d) z[d] = cin[d];
+            for (int d = 0; d < D; ++d) z[d] = c0[d];
         } else {
 #pragma unroll
             for (int d = 0; d < D; ++d) z[d] = sc[d * kIirThreads + tid - 1];
@@ -337,6 +361,7 @@ void iir_free(IirPlan *p)
 {
     if (!p) return;
     if (p->pw_dev) (void)hipFree(p->pw_dev);
+    if (p->lb_dev) (void)hipFree(p->lb_dev);
     if (p->v_dev) (void)hipFree(p->v_dev);
     if (p->agg_dev) (void)hipFree(p->agg_dev);
     delete p;
@@ -384,6 +409,7 @@ static int ensure_plan(IirHandle *h)
     }
     hipError_t e;
     if ((e = hipMalloc((void **)&p->pw_dev, (size_t)kPowers * D * D * 8)) != hipSuccess ||
+        (e = hipMalloc((void **)&p->lb_dev, (size_t)8 * D * D * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&p->agg_dev, (size_t)2 * 2 * kMaxW * D * 8)) != hipSuccess) {
         iir_free(p);
         return hip_fail(e, "hipMalloc(iir plan)", __FILE__, __LINE__);
@@ -418,6 +444,25 @@ static int ensure_powers(IirHandle *h, int64_t T, hipStream_t s)
         }
         if (l + 1 < kPowers) matmul_ld(M, M, M, D);
     }
+    // carry look-back: (M^256)^k until every entry is below 1e-30 (its contribution is then far
+    // under one ulp of anything the float64 recurrence itself could resolve)
+    {
+        std::vector<long double> Mw((size_t)D * D), Pk;
+        for (size_t i = 0; i < (size_t)D * D; ++i) Mw[i] = pw[(size_t)8 * D * D + i];
+        Pk = Mw;
+        std::vector<double> lb((size_t)8 * D * D, 0.0);
+        p->n_lb = 0;
+        for (int k = 1; k <= 8; ++k) {  // Pk = Mw^k
+            long double mx = 0.0L;
+            for (auto v : Pk) mx = fabsl(v) > mx ? fabsl(v) : mx;
+            if (!(mx >= 1e-30L)) { p->n_lb = k; break; }  // terms k.. are negligible: keep k terms (0..k-1)
+            if (k == 8) break;
+            for (size_t i = 0; i < (size_t)D * D; ++i) lb[(size_t)(k - 1) * D * D + i] = (double)Pk[i];
+            matmul_ld(Pk, Mw, Pk, D);
+        }
+        SK_HIP(hipMemcpyAsync(p->lb_dev, lb.data(), lb.size() * 8, hipMemcpyHostToDevice, s));
+        SK_HIP(hipStreamSynchronize(s));
+    }
     SK_HIP(hipMemcpyAsync(p->pw_dev, pw.data(), pw.size() * 8, hipMemcpyHostToDevice, s));
     SK_HIP(hipStreamSynchronize(s));  // pw is a stack-lifetime host buffer
     p->cached_T = T;
@@ -435,10 +480,14 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
     double *carry = p->agg_dev + (size_t)2 * kMaxW * D;
     a.agg = agg;
     a.carry = carry;
+    a.lbmat = p->lb_dev;
+    a.n_lb = p->n_lb;
     hipLaunchKernelGGL((iir_chunk_kernel<NSEC, ORD, IO, false>), dim3(W, nbatch), dim3(kIirThreads), 0, s, a, cf);
     SK_HIP(hipGetLastError());
-    hipLaunchKernelGGL((iir_wg_scan_kernel<D>), dim3(nbatch), dim3(1024), 0, s, (const double *)agg, (const double *)p->pw_dev, W, carry);
-    SK_HIP(hipGetLastError());
+    if (p->n_lb == 0) {  // slowly decaying / marginally stable filter: full scan of the workgroup aggregates
+        hipLaunchKernelGGL((iir_wg_scan_kernel<D>), dim3(nbatch), dim3(1024), 0, s, (const double *)agg, (const double *)p->pw_dev, W, carry);
+        SK_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL((iir_chunk_kernel<NSEC, ORD, IO, true>), dim3(W, nbatch), dim3(kIirThreads), 0, s, a, cf);
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
@@ -485,7 +534,7 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     }
     IirArgs a;
     a.x = x; a.y = y; a.n = n; a.T = T; a.J = J; a.batch_stride = batch_stride;
-    a.pw = p->pw_dev; a.v = p->v_dev; a.agg = nullptr; a.carry = nullptr;
+    a.pw = p->pw_dev; a.v = p->v_dev; a.agg = nullptr; a.carry = nullptr; a.lbmat = nullptr; a.n_lb = 0;
     SK_CHECK(nbatch >= 1 && nbatch <= 2, SKDSP_ERR_BADARG, "iir: batch must be 1 or 2");
     if (dtype_double(h->dtype)) return dispatch_shape<double>(h, a, nbatch, W, s);
     return dispatch_shape<float>(h, a, nbatch, W, s);
