@@ -251,11 +251,49 @@ class ShardedFIR:
         """Device buffer for a shard with headroom for the halo in front of x[0]."""
         return _ffi.DeviceArray(n_local, self.dtype, headroom=max(self.halo, 1))
 
+    # ---- device-resident shards (production path) ---------------------------------------
+    # Every method: (1) the transport fills x[-halo..-1] from the left neighbour (zeros on rank
+    # 0 == the zero initial state of lfilter), (2) the single-GPU kernel runs with n_hist=halo.
+    # Outputs need no exchange: rank r produces the outputs that belong to its input block.
+    def _check(self, n_local, halo):
+        if self.transport.world > 1 and n_local < halo:
+            raise ValueError("shard of %d samples is shorter than the %d-sample halo" % (n_local, halo))
+
     def filter_local_dev(self, xd, yd, n_local=None):
+        """.filter: halo Ntaps-1; outputs [start_r, stop_r)."""
         n_local = xd.n if n_local is None else n_local
-        if self.transport.world > 1 and n_local < self.halo:
-            raise ValueError("shard of %d samples is shorter than the %d-sample halo" % (n_local, self.halo))
-        self._hip().filter_shard_dev(xd, yd, n_local)
+        self._check(n_local, self.halo)
+        self.transport.halo_exchange_dev(xd, n_local, self.halo)
+        self._hip().filter_dev(xd, yd, n_local, n_hist=self.halo)
+
+    def up_halo(self, L):
+        """input samples of history .up(x, L) needs: ceil((Ntaps-1)/L)"""
+        return -(-(self.ntaps - 1) // L)
+
+    def up_local_dev(self, xd, yd, L, n_local=None):
+        """.up(x, L): outputs [start_r*L, stop_r*L)."""
+        n_local = xd.n if n_local is None else n_local
+        halo = self.up_halo(L)
+        self._check(n_local, halo)
+        self.transport.halo_exchange_dev(xd, n_local, halo)
+        self._hip().up_dev(xd, yd, L, n_local, n_hist=halo)
+
+    def dn_local_dev(self, xd, yd, M, n_local=None):
+        """.dn(x, M): shard starts must be multiples of M (shard_bounds(n, world, multiple=M));
+        outputs [start_r/M, stop_r/M)."""
+        n_local = xd.n if n_local is None else n_local
+        self._check(n_local, self.halo)
+        self.transport.halo_exchange_dev(xd, n_local, self.halo)
+        self._hip().dn_dev(xd, yd, M, n_local, n_hist=self.halo)
+
+    def updn_local_dev(self, xd, yd, L, M, n_local=None):
+        """downsample(.up(x, L), M): shard starts must be multiples of M/gcd(L, M);
+        outputs [start_r*L/M, stop_r*L/M)."""
+        n_local = xd.n if n_local is None else n_local
+        halo = self.up_halo(L)
+        self._check(n_local, halo)
+        self.transport.halo_exchange_dev(xd, n_local, halo)
+        self._hip().updn_dev(xd, yd, L, M, n_local, n_hist=halo)
 
     def filter_local_host(self, x_local):
         x_local = np.ascontiguousarray(x_local, dtype=self.dtype)

@@ -522,3 +522,68 @@ print('OLS512_OK')
     env = dict(os.environ, SKDSP_OLS_THREADS="512")
     out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, env=env)
     assert b"OLS512_OK" in out.stdout, out.stdout.decode()[-3000:]
+
+
+class _CopyTransport:
+    """Stands in for RcclTransport on one GPU: the halo hop is a device copy out of the
+    full vector (what rank r-1 would have sent), rank 0 gets zeros."""
+
+    def __init__(self, rank, world, full_xd, start):
+        self.rank, self.world, self.full, self.start = rank, world, full_xd, start
+
+    def halo_exchange_dev(self, xd, n, n_halo):
+        import ctypes
+        L = _ffi.load()
+        esz = xd.dtype.itemsize
+        if n_halo == 0:
+            return
+        if self.rank == 0:
+            _ffi.check(L.skdsp_memset(ctypes.c_void_p(xd.ptr - n_halo * esz), 0, n_halo * esz))
+        else:
+            _ffi.check(L.skdsp_memcpy_d2d(ctypes.c_void_p(xd.ptr - n_halo * esz),
+                                          ctypes.c_void_p(self.full.ptr + (self.start - n_halo) * esz), n_halo * esz))
+
+
+@pytest.mark.parametrize("mode,L,M", [("filter", 1, 1), ("up", 4, 1), ("dn", 1, 3), ("updn", 4, 3), ("up", 12, 1), ("dn", 1, 12)])
+def test_sharded_fir_driver_all_modes_emulated(mode, L, M):
+    """sharding.ShardedFIR (.filter/.up/.dn/updn shards, halo lengths, shard alignment) against
+    the single-vector result, 5 ranks emulated on one GPU."""
+    import ctypes
+    import math
+    from sk_dsp_comm_amd import sharding
+    g = load("g6_fir512_updn.npz")
+    b = g["b"]
+    n, world = 600_011, 5
+    lib = _ffi.load()
+    xd = _ffi.DeviceArray(n, np.complex64).fill_noise(5)
+    k = _ffi.FirKernel(b, _ffi.C64)
+    n_out = n if mode == "filter" else (n * L) // M
+    yd = _ffi.DeviceArray(n_out, np.complex64)
+    if mode == "filter":
+        k.filter_dev(xd, yd)
+    else:
+        k.updn_dev(xd, yd, L, M)
+    y_full = yd.to_host()
+    mult = M // math.gcd(L, M)
+    bounds = sharding.shard_bounds(n, world, multiple=mult)
+    parts = []
+    for r, (s0, s1) in enumerate(bounds):
+        nl = s1 - s0
+        fir = sharding.ShardedFIR(b, _CopyTransport(r, world, xd, s0), dtype=np.complex64)
+        halo = fir.halo if mode in ("filter", "dn") else fir.up_halo(L)
+        sh = _ffi.DeviceArray(nl, np.complex64, headroom=halo)
+        _ffi.check(lib.skdsp_memcpy_d2d(ctypes.c_void_p(sh.ptr), ctypes.c_void_p(xd.ptr + s0 * 8), nl * 8))
+        nlo = nl if mode == "filter" else (nl * L) // M
+        yo = _ffi.DeviceArray(max(nlo, 1), np.complex64)
+        if mode == "filter":
+            fir.filter_local_dev(sh, yo)
+        elif mode == "up":
+            fir.up_local_dev(sh, yo, L)
+        elif mode == "dn":
+            fir.dn_local_dev(sh, yo, M)
+        else:
+            fir.updn_local_dev(sh, yo, L, M)
+        parts.append(yo.to_host(0, nlo))
+    y_sh = np.concatenate(parts)
+    assert y_sh.shape == y_full.shape, (y_sh.shape, y_full.shape)
+    assert_close(y_sh, y_full, 5e-7, "sharded %s L=%d M=%d" % (mode, L, M))
