@@ -109,6 +109,14 @@ int skdsp_tf2sos(const double *b, int nb, const double *a, int na, double *sos_o
 /* .filter: sosfilt(sos,x) (:169-174) / lfilter(b,a,x) */
 int skdsp_iir_filter(skdsp_handle h, const void *x, int64_t n, void *y);
 int skdsp_iir_filter_dev(skdsp_handle h, const void *x_dev, int64_t n, void *y_dev);
+/* Streaming state (NOT reference behaviour: the reference always starts from
+ * rest).  zi / zf are host arrays of skdsp_iir_state_len() doubles: for a real signal the DF2T
+ * delays in scipy.signal.sosfilt's zi layout (n_sections x 2); for a complex signal the states of
+ * the real-part stream followed by those of the imaginary-part stream.  Handles made by
+ * skdsp_tf_create use the layout of their internal biquad cascade (opaque: feed a zf back as zi).
+ * zi == NULL means rest; zf == NULL means "not wanted" (no stream synchronisation). */
+int skdsp_iir_state_len(skdsp_handle h, int *len);
+int skdsp_iir_filter_state_dev(skdsp_handle h, const void *x_dev, int64_t n, const double *zi, double *zf, void *y_dev);
 /* .up: filter(L*upsample(x,L)) (:69-75, :177-183); y has n*L samples */
 int skdsp_iir_up(skdsp_handle h, const void *x, int64_t n, int L, void *y);
 int skdsp_iir_up_dev(skdsp_handle h, const void *x_dev, int64_t n, int L, void *y_dev);

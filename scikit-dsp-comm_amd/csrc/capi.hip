@@ -147,11 +147,14 @@ static int stage_out(void *y_host, const void *y_dev, size_t bytes)
 
 // IIR on an interleaved-or-real device vector (handles the complex -> 2 planes detour).
 // tmp slot 3 holds the planes.  y may alias x.
-static int iir_any_dev(IirHandle *h, const void *x_dev, int64_t n, void *y_dev)
+static int iir_any_dev(IirHandle *h, const void *x_dev, int64_t n, void *y_dev, const double *zi = nullptr, double *zf = nullptr)
 {
     hipStream_t s = ctx().stream;
-    if (n <= 0) return SKDSP_OK;
-    if (!dtype_complex(h->dtype)) return iir_launch_planar(h, x_dev, n, 1, 0, y_dev, s);
+    if (n <= 0) {
+        if (zi && zf) memcpy(zf, zi, (size_t)(dtype_complex(h->dtype) ? 2 : 1) * h->nsec * h->order * 8);
+        return SKDSP_OK;
+    }
+    if (!dtype_complex(h->dtype)) return iir_launch_planar(h, x_dev, n, 1, 0, y_dev, s, zi, zf);
     const size_t rsz = dtype_double(h->dtype) ? 8 : 4;
     const int64_t stride = (int64_t)round_up((size_t)n, 64);
     void *planes = nullptr;
@@ -159,7 +162,7 @@ static int iir_any_dev(IirHandle *h, const void *x_dev, int64_t n, void *y_dev)
     if (rc) return rc;
     void *re = planes, *im = (char *)planes + (size_t)stride * rsz;
     if ((rc = deinterleave_launch(x_dev, n, h->dtype, re, im, s))) return rc;
-    if ((rc = iir_launch_planar(h, planes, n, 2, stride, planes, s))) return rc;
+    if ((rc = iir_launch_planar(h, planes, n, 2, stride, planes, s, zi, zf))) return rc;
     return interleave_launch(re, im, n, h->dtype, y_dev, s);
 }
 
@@ -683,6 +686,23 @@ int skdsp_iir_filter_dev(skdsp_handle hh, const void *x_dev, int64_t n, void *y_
     SK_CHECK(h, SKDSP_ERR_BADARG, "iir_filter: not an IIR handle");
     std::lock_guard<std::mutex> lk(h->mu);
     return iir_any_dev(h, x_dev, n, y_dev);
+}
+
+int skdsp_iir_state_len(skdsp_handle hh, int *len)
+{
+    IirHandle *h = as_handle<IirHandle>(hh, H_IIR);
+    SK_CHECK(h && len, SKDSP_ERR_BADARG, "iir_state_len: not an IIR handle");
+    *len = (dtype_complex(h->dtype) ? 2 : 1) * h->nsec * h->order;
+    return SKDSP_OK;
+}
+
+int skdsp_iir_filter_state_dev(skdsp_handle hh, const void *x_dev, int64_t n, const double *zi, double *zf, void *y_dev)
+{
+    API_BEGIN;
+    IirHandle *h = as_handle<IirHandle>(hh, H_IIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "iir_filter_state: not an IIR handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return iir_any_dev(h, x_dev, n, y_dev, zi, zf);
 }
 
 int skdsp_iir_up_dev(skdsp_handle hh, const void *x_dev, int64_t n, int L, void *y_dev)

@@ -30,6 +30,7 @@
 // FP64 VALU is the busy unit (40 dependent-ish v_fma_f64 per sample for 8 biquads);
 // algorithmic bytes = 8 B per f32 sample (4 in + 4 out).
 #include "skdsp_internal.hpp"
+#include <type_traits>
 #include <cmath>
 #include <cstring>
 
@@ -48,6 +49,7 @@ struct IirPlan {
     double *pw_dev = nullptr;    // kPowers matrices M^(2^l), each D x D row-major
     double *lb_dev = nullptr;    // look-back matrices (M^256)^k, k = 1..7
     int n_lb = 0;                // terms of the in-kernel carry look-back (0 = use the K2 scan)
+    double *state_dev = nullptr; // [2][2][D]: zi and zf for up to two planes
     double *v_dev = nullptr;     // [D][J] chunk end states (SoA), capacity below
     double *agg_dev = nullptr;   // [2][kMaxW][D] workgroup aggregates / carries (ping-pong) + carry
     size_t v_cap = 0;
@@ -112,6 +114,8 @@ struct IirArgs {
     const double *carry;  // [batch][W][D]  workgroup carry-in (K3 in), used when n_lb == 0
     const double *lbmat;  // [n_lb-1][D][D]: (M^256)^k, k = 1..n_lb-1
     int n_lb;             // > 0: carry = sum_{k<n_lb} (M^256)^k agg[wg-1-k] computed in K3 (no K2 launch)
+    const double *zi;     // [batch][D] initial state (streaming; null = rest, what the reference uses)
+    double *zf;           // [batch][D] state after sample n-1 (null = not wanted)
 };
 
 // Kernel body shared by K1 (WRITE=false) and K3 (WRITE=true).
@@ -164,6 +168,17 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
                     for (int d = 0; d < D; ++d) tmp[d] = ag[(size_t)(wg - 1 - k) * D + d];
                     matvec_acc<D>(a.lbmat + (size_t)(k - 1) * D * D, tmp, c0);
                 }
+                if (a.zi && wg < a.n_lb) {  // the initial state reaches workgroup wg as (M^256)^wg zi
+                    double tmp[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) tmp[d] = a.zi[(size_t)bat * D + d];
+                    if (wg == 0) {
+#pragma unroll
+                        for (int d = 0; d < D; ++d) c0[d] += tmp[d];
+                    } else {
+                        matvec_acc<D>(a.lbmat + (size_t)(wg - 1) * D * D, tmp, c0);
+                    }
+                }
             } else {
                 const double *cin = a.carry + ((size_t)bat * W + wg) * D;
 #pragma unroll
@@ -199,6 +214,11 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
         __syncthreads();
     }
 
+    // streaming: the thread that owns sample n-1 publishes its state right after that sample
+    const bool zf_owner = WRITE && a.zf != nullptr && cj == (a.n - 1) / a.T;
+    const int zf_off = (int)((a.n - 1) % a.T);
+    const int zf_piece = (WRITE && a.zf != nullptr) ? zf_off / kPiece : -1;  // uniform
+
     // ---- walk the chunk in staged pieces of 32 samples per thread ----
     const int64_t row0 = wg * kIirThreads;  // first chunk (row) of this workgroup
     const int npieces = (int)(a.T / kPiece);
@@ -233,17 +253,25 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
         __syncthreads();
         if (p + 1 < npieces) load_piece(p + 1);  // in flight while this piece is computed
         IO *myrow = stage + tid * St::pitch;
+        auto run_piece = [&](auto capture) {
 #pragma unroll
-        for (int sgi = 0; sgi < St::segs; ++sgi) {
-            float4 raw = *reinterpret_cast<const float4 *>(myrow + sgi * St::elems);
-            IO *e4 = reinterpret_cast<IO *>(&raw);
+            for (int sgi = 0; sgi < St::segs; ++sgi) {
+                float4 raw = *reinterpret_cast<const float4 *>(myrow + sgi * St::elems);
+                IO *e4 = reinterpret_cast<IO *>(&raw);
 #pragma unroll
-            for (int e = 0; e < St::elems; ++e) {
-                const double yv = cascade_step<NSEC, ORD>(cf, z, (double)e4[e]);
-                if (WRITE) e4[e] = (IO)yv;
+                for (int e = 0; e < St::elems; ++e) {
+                    const double yv = cascade_step<NSEC, ORD>(cf, z, (double)e4[e]);
+                    if (WRITE) e4[e] = (IO)yv;
+                    if (decltype(capture)::value && zf_owner && sgi * St::elems + e == zf_off % kPiece) {
+#pragma unroll
+                        for (int d = 0; d < D; ++d) a.zf[(size_t)bat * D + d] = z[d];
+                    }
+                }
+                if (WRITE) *reinterpret_cast<float4 *>(myrow + sgi * St::elems) = raw;
             }
-            if (WRITE) *reinterpret_cast<float4 *>(myrow + sgi * St::elems) = raw;
-        }
+        };
+        if (WRITE && p == zf_piece) run_piece(std::true_type{});  // the one piece that holds sample n-1
+        else run_piece(std::false_type{});
         if (WRITE) {
             __syncthreads();
 #pragma unroll
@@ -304,7 +332,7 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
 // (the first version -- one item per thread, matrix through the scalar cache -- took 78 us).
 template <int D>
 __global__ __launch_bounds__(1024) void iir_wg_scan_kernel(const double *__restrict__ agg, const double *__restrict__ pw,
-                                                           int W, double *__restrict__ carry)
+                                                           int W, double *__restrict__ carry, const double *__restrict__ zi)
 {
     constexpr int kPer = kMaxPairs / 1024;  // (item,row) pairs per thread
     __shared__ double vb[kMaxPairs];
@@ -313,7 +341,8 @@ __global__ __launch_bounds__(1024) void iir_wg_scan_kernel(const double *__restr
     const double *in = agg + (size_t)blockIdx.x * W * D;
     double *out = carry + (size_t)blockIdx.x * W * D;
     const int npairs = W * D;
-    for (int p = tid; p < npairs; p += 1024) vb[p] = in[p];
+    // items: [zi, agg[0], ..., agg[W-2]]; their inclusive scan IS the carry of workgroups 0..W-1
+    for (int p = tid; p < npairs; p += 1024) vb[p] = (p < D) ? (zi ? zi[(size_t)blockIdx.x * D + p] : 0.0) : in[p - D];
     for (int l = 0; l < 10 && (1 << l) < W; ++l) {
         const int s = 1 << l;
         for (int e = tid; e < D * D; e += 1024) Ml[(e / D) * (D + 1) + (e % D)] = pw[(size_t)(8 + l) * D * D + e];
@@ -343,10 +372,7 @@ __global__ __launch_bounds__(1024) void iir_wg_scan_kernel(const double *__restr
         __syncthreads();
     }
     __syncthreads();
-    for (int p = tid; p < npairs; p += 1024) {
-        const int i = p / D;
-        out[p] = (i == 0) ? 0.0 : vb[p - D];
-    }
+    for (int p = tid; p < npairs; p += 1024) out[p] = vb[p];
 }
 
 // ------------------------------------------------------------------ host side
@@ -362,6 +388,7 @@ void iir_free(IirPlan *p)
     if (!p) return;
     if (p->pw_dev) (void)hipFree(p->pw_dev);
     if (p->lb_dev) (void)hipFree(p->lb_dev);
+    if (p->state_dev) (void)hipFree(p->state_dev);
     if (p->v_dev) (void)hipFree(p->v_dev);
     if (p->agg_dev) (void)hipFree(p->agg_dev);
     delete p;
@@ -410,6 +437,7 @@ static int ensure_plan(IirHandle *h)
     hipError_t e;
     if ((e = hipMalloc((void **)&p->pw_dev, (size_t)kPowers * D * D * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&p->lb_dev, (size_t)8 * D * D * 8)) != hipSuccess ||
+        (e = hipMalloc((void **)&p->state_dev, (size_t)4 * D * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&p->agg_dev, (size_t)2 * 2 * kMaxW * D * 8)) != hipSuccess) {
         iir_free(p);
         return hip_fail(e, "hipMalloc(iir plan)", __FILE__, __LINE__);
@@ -485,7 +513,7 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
     hipLaunchKernelGGL((iir_chunk_kernel<NSEC, ORD, IO, false>), dim3(W, nbatch), dim3(kIirThreads), 0, s, a, cf);
     SK_HIP(hipGetLastError());
     if (p->n_lb == 0) {  // slowly decaying / marginally stable filter: full scan of the workgroup aggregates
-        hipLaunchKernelGGL((iir_wg_scan_kernel<D>), dim3(nbatch), dim3(1024), 0, s, (const double *)agg, (const double *)p->pw_dev, W, carry);
+        hipLaunchKernelGGL((iir_wg_scan_kernel<D>), dim3(nbatch), dim3(1024), 0, s, (const double *)agg, (const double *)p->pw_dev, W, carry, a.zi);
         SK_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL((iir_chunk_kernel<NSEC, ORD, IO, true>), dim3(W, nbatch), dim3(kIirThreads), 0, s, a, cf);
@@ -508,9 +536,13 @@ static int dispatch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream
 
 // x_dev/y_dev: real planar arrays (float or double per h->dtype's precision); complex
 // callers deinterleave first (capi) and pass nbatch = 2 with batch_stride.
-int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, hipStream_t s)
+int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, hipStream_t s,
+                      const double *zi_host, double *zf_host)
 {
-    if (n <= 0) return SKDSP_OK;
+    if (n <= 0) {
+        if (zi_host && zf_host) memcpy(zf_host, zi_host, (size_t)nbatch * h->nsec * h->order * 8);
+        return SKDSP_OK;
+    }
     int rc = ensure_plan(h);
     if (rc) return rc;
     IirPlan *p = h->plan;
@@ -535,9 +567,20 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     IirArgs a;
     a.x = x; a.y = y; a.n = n; a.T = T; a.J = J; a.batch_stride = batch_stride;
     a.pw = p->pw_dev; a.v = p->v_dev; a.agg = nullptr; a.carry = nullptr; a.lbmat = nullptr; a.n_lb = 0;
+    a.zi = nullptr; a.zf = nullptr;
+    if (zi_host) {
+        SK_HIP(hipMemcpyAsync(p->state_dev, zi_host, (size_t)nbatch * D * 8, hipMemcpyHostToDevice, s));
+        a.zi = p->state_dev;
+    }
+    if (zf_host) a.zf = p->state_dev + 2 * D;
     SK_CHECK(nbatch >= 1 && nbatch <= 2, SKDSP_ERR_BADARG, "iir: batch must be 1 or 2");
-    if (dtype_double(h->dtype)) return dispatch_shape<double>(h, a, nbatch, W, s);
-    return dispatch_shape<float>(h, a, nbatch, W, s);
+    rc = dtype_double(h->dtype) ? dispatch_shape<double>(h, a, nbatch, W, s) : dispatch_shape<float>(h, a, nbatch, W, s);
+    if (rc) return rc;
+    if (zf_host) {
+        SK_HIP(hipMemcpyAsync(zf_host, p->state_dev + 2 * D, (size_t)nbatch * D * 8, hipMemcpyDeviceToHost, s));
+        SK_HIP(hipStreamSynchronize(s));
+    }
+    return SKDSP_OK;
 }
 
 }  // namespace skdsp

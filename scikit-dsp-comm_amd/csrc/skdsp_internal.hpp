@@ -100,7 +100,8 @@ struct IirHandle : HandleBase {
 };
 // x/y: real planar arrays in the handle's precision; complex callers pass nbatch=2 planes
 // (re, im) batch_stride elements apart.  In-place (y == x) is allowed.
-int iir_launch_planar(IirHandle *h, const void *x_dev, int64_t n, int nbatch, int64_t batch_stride, void *y_dev, hipStream_t s);
+int iir_launch_planar(IirHandle *h, const void *x_dev, int64_t n, int nbatch, int64_t batch_stride, void *y_dev, hipStream_t s,
+                      const double *zi_host = nullptr, double *zf_host = nullptr);  // [nbatch][D] states (streaming)
 void iir_free(IirPlan *p);
 bool iir_shape_supported(int nsec, int order);
 

@@ -28,7 +28,7 @@ SYMBOLS = [
     "skdsp_fir_create", "skdsp_fir_set_algo", "skdsp_fir_get_algo", "skdsp_fir_filter", "skdsp_fir_filter_dev",
     "skdsp_fir_up", "skdsp_fir_up_dev", "skdsp_fir_dn", "skdsp_fir_dn_dev", "skdsp_fir_updn", "skdsp_fir_updn_dev",
     "skdsp_sos_create", "skdsp_tf_create", "skdsp_tf2sos", "skdsp_iir_filter", "skdsp_iir_filter_dev", "skdsp_iir_up",
-    "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev",
+    "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev", "skdsp_iir_state_len", "skdsp_iir_filter_state_dev",
     "skdsp_upsample", "skdsp_upsample_dev", "skdsp_downsample", "skdsp_downsample_dev", "skdsp_destroy",
     "skdsp_dist_unique_id", "skdsp_dist_init", "skdsp_dist_shutdown", "skdsp_dist_barrier",
     "skdsp_dist_allreduce_max", "skdsp_dist_allreduce_sum", "skdsp_dist_sendrecv", "skdsp_dist_halo_exchange", "skdsp_fir_filter_shard_dev",
@@ -88,6 +88,8 @@ def load():
         L.skdsp_tf2sos.argtypes = [vp, ci, vp, ci, vp, ctypes.POINTER(ci)]
         L.skdsp_iir_filter.argtypes = [vp, vp, i64, vp]
         L.skdsp_iir_filter_dev.argtypes = [vp, vp, i64, vp]
+        L.skdsp_iir_state_len.argtypes = [vp, ctypes.POINTER(ci)]
+        L.skdsp_iir_filter_state_dev.argtypes = [vp, vp, i64, vp, vp, vp]
         L.skdsp_iir_up.argtypes = [vp, vp, i64, ci, vp]
         L.skdsp_iir_up_dev.argtypes = [vp, vp, i64, ci, vp]
         L.skdsp_iir_dn.argtypes = [vp, vp, i64, ci, vp]
@@ -177,6 +179,14 @@ class DeviceArray:
         d = cls(a.size, a.dtype, headroom)
         check(load().skdsp_memcpy_h2d(ctypes.c_void_p(d.ptr), _ptr(a), a.nbytes))
         return d
+
+    def write(self, a, at=0):
+        """Copy host samples to x[at .. at+len(a)); negative `at` addresses the headroom."""
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if at < -self.headroom or at + a.size > self.n:
+            raise ValueError("write outside the device array")
+        if a.size:
+            check(load().skdsp_memcpy_h2d(ctypes.c_void_p(self.ptr + at * self.dtype.itemsize), _ptr(a), a.nbytes))
 
     def to_host(self, start=0, count=None):
         count = self.n - start if count is None else count
@@ -326,6 +336,31 @@ class IirKernel:
     def filter_dev(self, xd, yd, n=None):
         n = xd.n if n is None else n
         check(load().skdsp_iir_filter_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, ctypes.c_void_p(yd.ptr)))
+
+    def state_len(self):
+        k = ctypes.c_int(0)
+        check(load().skdsp_iir_state_len(ctypes.c_void_p(self.h), ctypes.byref(k)))
+        return k.value
+
+    def filter_state(self, x, zi=None):
+        """Block streaming: (y, zf) with the filter state carried in / out (float64 vector of
+        state_len() entries; None = rest)."""
+        x = np.ascontiguousarray(x)
+        xd = DeviceArray.from_host(x)
+        yd = DeviceArray(x.size, x.dtype)
+        zf = np.zeros(self.state_len())
+        zi_p = None
+        if zi is not None:
+            zi = np.ascontiguousarray(zi, dtype=np.float64)
+            if zi.size != zf.size:
+                raise ValueError("zi must have %d entries" % zf.size)
+            zi_p = _ptr(zi)
+        check(load().skdsp_iir_filter_state_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), x.size, zi_p,
+                                                 _ptr(zf), ctypes.c_void_p(yd.ptr)))
+        y = yd.to_host()
+        xd.free()
+        yd.free()
+        return y, zf
 
 
 def tf2sos(b, a):

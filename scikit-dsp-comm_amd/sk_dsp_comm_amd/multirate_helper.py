@@ -136,6 +136,37 @@ class multirate_FIR(object):
         return _delegate_plot("multirate_FIR", self.b, "zplane", auto_scale, size, detect_mult, tol)
 
 
+    # --- extension: block streaming (the reference always restarts from rest) ---
+    def filter_stream(self, x, zi=None):
+        """(y, zf): filter one block of a longer signal.  zi / zf are the LAST len(b)-1 INPUT samples
+        before the block (None = rest), so concatenated block outputs equal filter(whole signal)."""
+        xg, ref_dt = _signal(x, self._bc)
+        if xg.ndim != 1:
+            raise ValueError("filter_stream works on 1-D blocks")
+        nh = self.N_forder - 1
+        hist = np.zeros(nh, dtype=xg.dtype)
+        if zi is not None:
+            zi = np.asarray(zi)
+            if zi.shape != (nh,):
+                raise ValueError("zi must hold the previous %d input samples" % nh)
+            hist[:] = zi
+        if xg.size == 0:
+            return _finish(xg.copy(), ref_dt), hist
+        k = self._kern.get(xg.dtype)
+        xd = _ffi.DeviceArray(xg.size, xg.dtype, headroom=max(nh, 1))
+        yd = _ffi.DeviceArray(xg.size, xg.dtype)
+        try:
+            xd.write(xg)
+            xd.write(hist, at=-nh)
+            k.filter_dev(xd, yd, n=xg.size, n_hist=nh)
+            y = yd.to_host()
+        finally:
+            xd.free()
+            yd.free()
+        zf = np.concatenate([hist, xg])[xg.size:]
+        return _finish(y, ref_dt), zf
+
+
 class multirate_IIR(object):
     """SOS IIR filter / interpolator / decimator (multirate_helper.py:146-208)."""
 
@@ -181,6 +212,39 @@ class multirate_IIR(object):
         """y = sosfilt(sos, x)  (multirate_helper.py:169-174)"""
         xg, ref_dt = self._prep(x)
         return _finish(_rows(lambda r: self._chain(r, lambda k, v: k.filter(v)), xg), ref_dt)
+
+    # --- extension: block streaming (SURVEY.md 8f-3; the reference always restarts from rest) ---
+    def filter_stream(self, x, zi=None):
+        """(y, zf) == scipy.signal.sosfilt(sos, x, zi=zi): zi / zf have shape (n_sections, 2)
+        (complex for a complex signal); None = rest."""
+        if np.asarray(x).size:
+            xg, ref_dt = self._prep(x)
+        else:
+            xg, ref_dt = _signal(x)
+        if xg.ndim != 1:
+            raise ValueError("filter_stream works on 1-D blocks")
+        nsec = self._validated().shape[0]
+        cplx = np.iscomplexobj(xg)
+        z = np.zeros((nsec, 2), dtype=np.complex128 if cplx else np.float64)
+        if zi is not None:
+            zi = np.asarray(zi)
+            if zi.shape != (nsec, 2):
+                raise ValueError("zi must have shape (%d, 2)" % nsec)
+            if np.iscomplexobj(zi) and not cplx:
+                raise ValueError("complex zi needs a complex signal")
+            z[...] = zi
+        if xg.size == 0:
+            return _finish(xg.copy(), ref_dt), z
+        zf = np.empty_like(z)
+        y = xg
+        for i, k in enumerate(self._kern.get(xg.dtype)):
+            lo, hi = i * _MAX_SOS, min((i + 1) * _MAX_SOS, nsec)
+            part = z[lo:hi]
+            flat = np.concatenate([part.real.ravel(), part.imag.ravel()]) if cplx else part.ravel()
+            y, out = k.filter_state(y, flat)
+            h = (hi - lo) * 2
+            zf[lo:hi] = (out[:h] + 1j * out[h:]).reshape(-1, 2) if cplx else out.reshape(-1, 2)
+        return _finish(y, ref_dt), zf
 
     def up(self, x, L_change=12):
         """y = sosfilt(sos, L*upsample(x, L))  (multirate_helper.py:177-183)"""

@@ -587,3 +587,89 @@ def test_sharded_fir_driver_all_modes_emulated(mode, L, M):
     y_sh = np.concatenate(parts)
     assert y_sh.shape == y_full.shape, (y_sh.shape, y_full.shape)
     assert_close(y_sh, y_full, 5e-7, "sharded %s L=%d M=%d" % (mode, L, M))
+
+
+# ---------------------------------------------------------------------------
+# block streaming: state in / state out
+# ---------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [np.float32, np.complex64, np.float64, np.complex128])
+def test_iir_stream_matches_sosfilt_zi(dt):
+    """filter_stream(x, zi) == scipy sosfilt(sos, x, zi=zi), and block-wise == one shot."""
+    from scipy import signal
+    import sk_dsp_comm_amd.multirate_helper as mrh
+    rng = np.random.default_rng(41)
+    sos = signal.butter(8, 0.2, output="sos")
+    cplx = np.dtype(dt).kind == "c"
+    n = 300_000
+    x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+    x = x.astype(dt)
+    zi = rng.standard_normal((4, 2)) + (1j * rng.standard_normal((4, 2)) if cplx else 0)
+    y_ref, zf_ref = signal.sosfilt(sos, x.astype(np.complex128 if cplx else np.float64), zi=zi)
+    f = mrh.multirate_IIR(sos)
+    y, zf = f.filter_stream(x, zi)
+    tol = 1e-6 if np.dtype(dt).itemsize in (4, 8) and dt in (np.float32, np.complex64) else 1e-11
+    assert max(rel_err(y, y_ref)) <= tol
+    assert max(rel_err(zf, zf_ref)) <= tol
+    # ragged blocks, including one shorter than a chunk and an empty one
+    cuts = [0, 17, 17, 5000, 130_001, n]
+    zs, outs = None, []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        yb, zs = f.filter_stream(x[lo:hi], zs)
+        outs.append(yb)
+    y_blocks = np.concatenate(outs)
+    y_one = f.filter(x)
+    assert max(rel_err(y_blocks, y_one)) <= tol
+    assert max(rel_err(zs, signal.sosfilt(sos, x.astype(np.complex128 if cplx else np.float64),
+                                      zi=np.zeros((4, 2)))[1])) <= tol
+
+
+@pytest.mark.gpu
+def test_iir_stream_slow_decay_scan_path():
+    """A pole at radius 0.99999 keeps the workgroup-aggregate scan (K2) in play: zi must ride it."""
+    from scipy import signal
+    import sk_dsp_comm_amd.multirate_helper as mrh
+    r = 0.99999
+    sos = np.array([[1.0, 0.5, 0.0, 1.0, -2 * r * np.cos(0.3), r * r]])
+    rng = np.random.default_rng(42)
+    x = rng.standard_normal(1 << 20)
+    zi = np.array([[0.7, -0.3]])
+    y_ref, zf_ref = signal.sosfilt(sos, x, zi=zi)
+    y, zf = mrh.multirate_IIR(sos).filter_stream(x, zi)
+    assert max(rel_err(y, y_ref)) <= 1e-9
+    assert max(rel_err(zf, zf_ref)) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_iir_stream_long_cascade_split():
+    from scipy import signal
+    import sk_dsp_comm_amd.multirate_helper as mrh
+    sos = signal.butter(30, 0.3, output="sos")  # 15 sections -> two chained device cascades
+    rng = np.random.default_rng(43)
+    x = rng.standard_normal(50_000)
+    zi = 0.1 * rng.standard_normal((15, 2))
+    y_ref, zf_ref = signal.sosfilt(sos, x, zi=zi)
+    y, zf = mrh.multirate_IIR(sos).filter_stream(x, zi)
+    assert max(rel_err(y, y_ref)) <= 1e-9
+    assert max(rel_err(zf, zf_ref)) <= 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,ntaps", [(np.complex64, 1024), (np.float32, 127), (np.float64, 33)])
+def test_fir_stream_blocks_equal_one_shot(dt, ntaps):
+    import sk_dsp_comm_amd.multirate_helper as mrh
+    rng = np.random.default_rng(44)
+    b = rng.standard_normal(ntaps) / ntaps
+    n = 200_000
+    x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if np.dtype(dt).kind == "c" else 0)
+    x = x.astype(dt)
+    f = mrh.multirate_FIR(b)
+    y_one = f.filter(x)
+    cuts = [0, 5, 5, 3000, 70_001, n]
+    zs, outs = None, []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        yb, zs = f.filter_stream(x[lo:hi], zs)
+        outs.append(yb)
+    tol = 1e-6 if np.dtype(dt).itemsize <= 8 and dt != np.float64 else 1e-12
+    assert max(rel_err(np.concatenate(outs), y_one)) <= tol
+    assert np.array_equal(zs, x[n - (ntaps - 1):])
