@@ -112,10 +112,14 @@ def main():
     else:
         sos = elliptic_bpf_sos()
         dtype, arith = np.float32, "f32 I/O, f64 state"
-        k = _ffi.IirKernel(_ffi.F32, sos=sos)
-        xd = _ffi.DeviceArray(n, dtype).fill_noise(2026)
+        xd = _ffi.DeviceArray(n, dtype).fill_noise(2026, first_index=rank * n)
         yd = _ffi.DeviceArray(n, dtype)
-        step = lambda: k.filter_dev(xd, yd)                      # noqa: E731
+        if world == 1:
+            k = _ffi.IirKernel(_ffi.F32, sos=sos)
+            step = lambda: k.filter_dev(xd, yd)                  # noqa: E731
+        else:  # contiguous sample blocks, exact state hand-off rank r -> r+1 (16 doubles per hop)
+            iir = sharding.ShardedIIR(sos, tr, dtype=dtype)
+            step = lambda: iir.filter_local_dev(xd, yd, n)       # noqa: E731
         units, alg_bytes = n, 8.0 * n
         kern = "iir_chunk_kernel x2 + iir_wg_scan_kernel"
         wl = "multirate_IIR.filter: 8-biquad elliptic bandpass, float32, 2^%d samples, affine scan" % args.log2n
@@ -172,7 +176,11 @@ def main():
             "dtype": arith,
             "data": "synthetic",
             "config": {"workload": wl, "samples_per_gpu": n, "total_samples": n * world,
-                       "sharding": "contiguous sample blocks, %d-sample RCCL halo" % 1023 if world > 1 else "single GPU",
+                       "sharding": "single GPU" if world == 1 else
+                                   ("contiguous sample blocks, RCCL state hand-off (2 x sections doubles per hop)"
+                                    if args.workload == "iir8" else
+                                    "contiguous sample blocks, %d-sample RCCL halo" % (len(b) - 1)
+                                    if args.workload == "fir1024" else "independent replicas"),
                        "device": info["name"], "compute_units": info["compute_units"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kern,

@@ -145,6 +145,9 @@ int skdsp_dist_allreduce_sum(double *value);
 /* one grouped RCCL point-to-point step on the library stream: send `bytes` to rank dst and
  * receive `bytes` from rank src (either may be -1 = none).  The halo exchange is built on it. */
 int skdsp_dist_sendrecv(const void *send_dev, int dst, void *recv_dev, int src, int64_t bytes);
+/* every rank contributes `bytes` bytes; recv_dev holds world*bytes, rank-major (IIR end states:
+ * sharding.ShardedIIR).  One rank / no communicator: a device copy. */
+int skdsp_dist_allgather(const void *send_dev, void *recv_dev, int64_t bytes);
 /* Halo exchange for a contiguous sample-block shard: send my LAST n_halo samples of
  * x_dev (n local samples) to rank+1, receive rank-1's into x_dev[-n_halo..-1]
  * (rank 0 zero-fills).  x_dev must have n_halo samples of headroom before it. */

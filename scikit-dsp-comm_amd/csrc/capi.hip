@@ -151,7 +151,9 @@ static int iir_any_dev(IirHandle *h, const void *x_dev, int64_t n, void *y_dev, 
 {
     hipStream_t s = ctx().stream;
     if (n <= 0) {
-        if (zi && zf) memcpy(zf, zi, (size_t)(dtype_complex(h->dtype) ? 2 : 1) * h->nsec * h->order * 8);
+        const size_t zb = (size_t)(dtype_complex(h->dtype) ? 2 : 1) * h->nsec * h->order * 8;
+        if (zf && zi) memcpy(zf, zi, zb);
+        else if (zf) memset(zf, 0, zb);
         return SKDSP_OK;
     }
     if (!dtype_complex(h->dtype)) return iir_launch_planar(h, x_dev, n, 1, 0, y_dev, s, zi, zf);

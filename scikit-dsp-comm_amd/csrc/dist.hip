@@ -9,6 +9,9 @@
 // The halo lands in the headroom directly in front of the shard, so the filter
 // kernels simply see n_hist = Ntaps-1 valid samples before x[0].
 //
+// The IIR shards by the same blocks; its exchange is one all-gather of every rank's end state
+// (2 x sections doubles), from which each rank folds its own true initial state (sharding.py).
+//
 // RCCL is bound lazily (dlopen) so that single-GPU users never load it.
 #include "skdsp_internal.hpp"
 #include <rccl/rccl.h>
@@ -28,6 +31,7 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -57,6 +61,7 @@ static int rccl_load()
     SK_SYM(GroupStart, "ncclGroupStart");
     SK_SYM(GroupEnd, "ncclGroupEnd");
     SK_SYM(AllReduce, "ncclAllReduce");
+    SK_SYM(AllGather, "ncclAllGather");
     SK_SYM(GetErrorString, "ncclGetErrorString");
 #undef SK_SYM
     return SKDSP_OK;
@@ -216,6 +221,21 @@ int skdsp_dist_sendrecv(const void *send_dev, int dst, void *recv_dev, int src, 
     SK_CHECK(dst < r.world && src < r.world, SKDSP_ERR_BADARG, "sendrecv: peer out of range");
     if (bytes == 0) return SKDSP_OK;
     return sendrecv_locked(send_dev, dst, recv_dev, src, (size_t)bytes);
+}
+
+int skdsp_dist_allgather(const void *send_dev, void *recv_dev, int64_t bytes)
+{
+    API_BEGIN;
+    SK_CHECK(bytes >= 0 && (bytes == 0 || (send_dev && recv_dev)), SKDSP_ERR_BADARG, "allgather: bad buffers");
+    if (bytes == 0) return SKDSP_OK;
+    Rccl &r = rc();
+    hipStream_t s = ctx().stream;
+    if (!r.comm) {  // one rank: the gather is a copy
+        SK_HIP(hipMemcpyAsync(recv_dev, send_dev, (size_t)bytes, hipMemcpyDeviceToDevice, s));
+        return SKDSP_OK;
+    }
+    SK_NCCL(r.AllGather(send_dev, recv_dev, (size_t)bytes, ncclUint8, r.comm, s));
+    return SKDSP_OK;
 }
 
 int skdsp_dist_halo_exchange(void *x_dev, int64_t n, int64_t n_halo, int dtype)

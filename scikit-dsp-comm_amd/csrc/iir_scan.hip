@@ -540,7 +540,10 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
                       const double *zi_host, double *zf_host)
 {
     if (n <= 0) {
-        if (zi_host && zf_host) memcpy(zf_host, zi_host, (size_t)nbatch * h->nsec * h->order * 8);
+        if (zf_host) {
+            if (zi_host) memcpy(zf_host, zi_host, (size_t)nbatch * h->nsec * h->order * 8);
+            else memset(zf_host, 0, (size_t)nbatch * h->nsec * h->order * 8);
+        }
         return SKDSP_OK;
     }
     int rc = ensure_plan(h);

@@ -31,7 +31,7 @@ SYMBOLS = [
     "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev", "skdsp_iir_state_len", "skdsp_iir_filter_state_dev",
     "skdsp_upsample", "skdsp_upsample_dev", "skdsp_downsample", "skdsp_downsample_dev", "skdsp_destroy",
     "skdsp_dist_unique_id", "skdsp_dist_init", "skdsp_dist_shutdown", "skdsp_dist_barrier",
-    "skdsp_dist_allreduce_max", "skdsp_dist_allreduce_sum", "skdsp_dist_sendrecv", "skdsp_dist_halo_exchange", "skdsp_fir_filter_shard_dev",
+    "skdsp_dist_allreduce_max", "skdsp_dist_allreduce_sum", "skdsp_dist_sendrecv", "skdsp_dist_allgather", "skdsp_dist_halo_exchange", "skdsp_fir_filter_shard_dev",
 ]
 
 _lib = None
@@ -103,7 +103,9 @@ def load():
         L.skdsp_dist_init.argtypes = [ci, ci, vp]
         L.skdsp_dist_allreduce_max.argtypes = [ctypes.POINTER(ctypes.c_double)]
         L.skdsp_dist_allreduce_sum.argtypes = [ctypes.POINTER(ctypes.c_double)]
+        L.skdsp_dist_allgather.argtypes = [vp, vp, i64]
         L.skdsp_dist_sendrecv.argtypes = [vp, ci, vp, ci, i64]
+        L.skdsp_dist_allgather.argtypes = [vp, vp, i64]
         L.skdsp_dist_halo_exchange.argtypes = [vp, i64, i64, ci]
         L.skdsp_fir_filter_shard_dev.argtypes = [vp, vp, i64, vp]
         _lib = L
@@ -342,24 +344,32 @@ class IirKernel:
         check(load().skdsp_iir_state_len(ctypes.c_void_p(self.h), ctypes.byref(k)))
         return k.value
 
-    def filter_state(self, x, zi=None):
-        """Block streaming: (y, zf) with the filter state carried in / out (float64 vector of
-        state_len() entries; None = rest)."""
-        x = np.ascontiguousarray(x)
-        xd = DeviceArray.from_host(x)
-        yd = DeviceArray(x.size, x.dtype)
-        zf = np.zeros(self.state_len())
+    def filter_state_dev(self, xd, yd, n=None, zi=None, want_zf=True):
+        """Device-resident block streaming: y_dev[0:n] and (returned) the state after sample n-1.
+        zi: float64 vector of state_len() entries, None = rest."""
+        n = xd.n if n is None else n
+        zf = np.zeros(self.state_len()) if want_zf else None
         zi_p = None
         if zi is not None:
             zi = np.ascontiguousarray(zi, dtype=np.float64)
-            if zi.size != zf.size:
-                raise ValueError("zi must have %d entries" % zf.size)
+            if zi.size != self.state_len():
+                raise ValueError("zi must have %d entries" % self.state_len())
             zi_p = _ptr(zi)
-        check(load().skdsp_iir_filter_state_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), x.size, zi_p,
-                                                 _ptr(zf), ctypes.c_void_p(yd.ptr)))
-        y = yd.to_host()
-        xd.free()
-        yd.free()
+        check(load().skdsp_iir_filter_state_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, zi_p,
+                                                 _ptr(zf) if want_zf else None, ctypes.c_void_p(yd.ptr)))
+        return zf
+
+    def filter_state(self, x, zi=None):
+        """Block streaming from host memory: (y, zf)."""
+        x = np.ascontiguousarray(x)
+        xd = DeviceArray.from_host(x)
+        yd = DeviceArray(x.size, x.dtype)
+        try:
+            zf = self.filter_state_dev(xd, yd, x.size, zi)
+            y = yd.to_host()
+        finally:
+            xd.free()
+            yd.free()
         return y, zf
 
 

@@ -6,6 +6,11 @@ shard, which rank r-1 sends from the END of its own shard (rank 0 uses zeros == 
 zero initial state of lfilter).  Outputs need no exchange: rank r's outputs are the
 samples [start_r, stop_r) of the full-length result.
 
+The SOS IIR shards the same way (ShardedIIR): every rank filters its block from rest, the
+end states are all-gathered (2*n_sections doubles per rank) and folded locally into each rank's
+true initial state (s_{k+1} = f_k + A^{n_k} s_k), and each rank re-filters only the head of its block -- as far as its true initial state
+is still visible -- from that state.
+
 Transports
   RcclTransport  device buffers, RCCL send/recv over xGMI inside libskdsp_hip.so
                  (the production path; rendezvous of the RCCL unique id through a
@@ -156,6 +161,19 @@ class RcclTransport:
         import ctypes
         _ffi.check(_ffi.load().skdsp_dist_halo_exchange(ctypes.c_void_p(xd.ptr), n, n_halo, xd.code))
 
+    def allgather_state(self, vec):
+        """Every rank contributes a small float64 vector; returns the (world, len) table.  One RCCL
+        all-gather on the compute stream through persistent staging buffers."""
+        import ctypes
+        vec = np.ascontiguousarray(vec, dtype=np.float64)
+        st = getattr(self, "_stage", None)
+        if st is None or st[0].n < vec.size:
+            cap = max(64, vec.size)
+            st = self._stage = (_ffi.DeviceArray(cap, np.float64), _ffi.DeviceArray(cap * self.world, np.float64))
+        st[0].write(vec)
+        _ffi.check(_ffi.load().skdsp_dist_allgather(ctypes.c_void_p(st[0].ptr), ctypes.c_void_p(st[1].ptr), vec.nbytes))
+        return st[1].to_host(0, vec.size * self.world).reshape(self.world, vec.size)
+
     def close(self):
         _ffi.load().skdsp_dist_shutdown()
         if self._rdzv is not None:
@@ -180,6 +198,13 @@ class GlooTransport:
         t = torch.tensor([float(v)], dtype=torch.float64)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t[0])
+
+    def allgather_state(self, vec):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64).copy())
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(out, t)
+        return np.stack([o.numpy() for o in out])
 
     def halo_exchange_host(self, x_local, n_halo):
         """Send my last n_halo samples right, receive the left neighbour's; rank 0 gets zeros."""
@@ -300,3 +325,142 @@ class ShardedFIR:
         hist = self.transport.halo_exchange_host(x_local, self.halo)
         kernel = self._kernel or hip_fir_kernel(self._hip())
         return kernel(x_local, hist)
+
+
+def sos_state_matrix(sos):
+    """State-transition matrix A (zero input) of the DF2T biquad cascade in scipy.signal.sosfilt's
+    zi coordinates (n_sections x 2, flattened): state_after = A @ state_before for x = 0."""
+    sos = np.atleast_2d(np.asarray(sos, dtype=np.float64))
+    ns = sos.shape[0]
+    D = 2 * ns
+    A = np.zeros((D, D))
+    for j in range(D):
+        z = np.zeros(D)
+        z[j] = 1.0
+        x = 0.0
+        for k in range(ns):
+            b0, b1, b2, _, a1, a2 = sos[k]
+            y = b0 * x + z[2 * k]
+            z[2 * k] = b1 * x - a1 * y + z[2 * k + 1]
+            z[2 * k + 1] = b2 * x - a2 * y
+            x = y
+        A[:, j] = z
+    return A
+
+
+def hip_iir_kernel(iir_kernel):
+    """kernel(x_local, zi) -> (y_local, zf) on the GPU for host-buffer transports; zi / zf are
+    (n_sections, 2) arrays (complex for a complex signal), None = rest."""
+    def run(x_local, zi):
+        cplx = np.iscomplexobj(x_local)
+        flat = None
+        if zi is not None:
+            zi = np.asarray(zi)
+            flat = np.concatenate([zi.real.ravel(), zi.imag.ravel()]) if cplx else zi.real.ravel()
+        y, out = iir_kernel.filter_state(x_local, flat)
+        h = out.size // 2
+        zf = (out[:h] + 1j * out[h:]).reshape(-1, 2) if cplx else out.reshape(-1, 2)
+        return y, zf
+    return run
+
+
+class ShardedIIR:
+    """multirate_IIR.filter (multirate_helper.py:169-174) on a sample-block shard: EXACT state
+    hand-off, no approximation of the recursion.
+
+      1. every rank filters its block from rest -> y0, end state f_r        (parallel, one pass)
+      2. ONE all-gather of (n_r, f_r) (1 + 2*n_sections doubles per rank); each rank folds its
+         own true initial state: s_0 = zi (rest), s_{k+1} = f_k + A^{n_k} s_k for k < r
+      3. by linearity only the zero-input response of s_r is missing from y0; it is below
+         `decay_tol` after K samples (max |A^K| <= decay_tol), so the first K samples are
+         re-filtered from s_r; K = n_r (a second full pass) for a filter that never decays
+         (integrators).
+    """
+
+    def __init__(self, sos, transport, dtype=np.float32, kernel=None, decay_tol=1e-18, head_quantum=4096):
+        self.sos = np.atleast_2d(np.asarray(sos, dtype=np.float64))
+        if self.sos.ndim != 2 or self.sos.shape[1] != 6:
+            raise ValueError('sos array must be shape (n_sections, 6)')
+        self.nsec = self.sos.shape[0]
+        self.transport = transport
+        self.dtype = np.dtype(dtype)
+        self.cplx = self.dtype.kind == "c"
+        self.decay_tol = float(decay_tol)
+        self.head_quantum = int(head_quantum)
+        self.A = sos_state_matrix(self.sos)
+        self._pow = {}
+        self._head = {}
+        self._kernel = kernel
+        self._iir = None
+
+    def _hip(self):
+        if self._iir is None:
+            if self.nsec > 12:
+                raise ValueError("ShardedIIR: at most 12 sections per device cascade")
+            self._iir = _ffi.IirKernel(_ffi.code_of(self.dtype), sos=self.sos)
+        return self._iir
+
+    def _power(self, n):
+        P = self._pow.get(n)
+        if P is None:
+            P = self._pow[n] = np.linalg.matrix_power(self.A, int(n))
+        return P
+
+    def head_length(self, n_local):
+        """Smallest K (head_quantum * 2^k, capped at n_local) with max|A^K| <= decay_tol."""
+        K = self._head.get(n_local)
+        if K is None:
+            K = self.head_quantum
+            P = np.linalg.matrix_power(self.A, K)
+            while K < n_local and np.max(np.abs(P)) > self.decay_tol:
+                P = P @ P
+                K *= 2
+            K = self._head[n_local] = min(K, n_local)
+        return K
+
+    # ---- step 2 -------------------------------------------------------------------------
+    def _pack(self, f, n_local):
+        f = np.asarray(f).ravel()
+        return np.concatenate([[float(n_local)], f.real, f.imag if self.cplx else []])
+
+    def initial_state(self, table, rank, zi=None):
+        """table: (world, 1 + D[*2]) rows [n_k, f_k] from the all-gather -> state before my block."""
+        D = 2 * self.nsec
+        ctype = np.complex128 if self.cplx else np.float64
+        s = np.zeros(D, dtype=ctype) if zi is None else np.asarray(zi, dtype=ctype).ravel().copy()
+        for k in range(rank):
+            row = table[k]
+            f = row[1:1 + D] + 1j * row[1 + D:1 + 2 * D] if self.cplx else row[1:1 + D]
+            s = f + self._power(int(row[0])) @ s
+        return s.reshape(self.nsec, 2)
+
+    def exchange(self, f, n_local, zi=None):
+        tr = self.transport
+        table = tr.allgather_state(self._pack(f, n_local))
+        return self.initial_state(table, tr.rank, zi)
+
+    # ---- drivers ------------------------------------------------------------------------
+    def filter_local_host(self, x_local, zi=None):
+        """y for my block [start_r, stop_r); zi = state before sample 0 of the WHOLE signal."""
+        x_local = np.ascontiguousarray(x_local, dtype=self.dtype)
+        kernel = self._kernel or hip_iir_kernel(self._hip())
+        y, f = kernel(x_local, None)
+        s = self.exchange(f, x_local.size, zi)
+        if np.any(s != 0) and x_local.size:
+            K = self.head_length(x_local.size)
+            y = np.array(y, copy=True)
+            y[:K], _ = kernel(x_local[:K], s)
+        return y
+
+    def filter_local_dev(self, xd, yd, n_local=None, zi=None):
+        """Device-resident shard: two launches of the scan (whole block from rest, head from s_r)."""
+        n_local = xd.n if n_local is None else n_local
+        k = self._hip()
+        out = k.filter_state_dev(xd, yd, n_local, None)
+        D = 2 * self.nsec
+        f = out[:D] + 1j * out[D:] if self.cplx else out
+        s = self.exchange(f, n_local, zi)
+        if np.any(s != 0) and n_local:
+            K = self.head_length(n_local)
+            flat = np.concatenate([s.real.ravel(), s.imag.ravel()]) if self.cplx else s.ravel()
+            k.filter_state_dev(xd, yd, K, flat, want_zf=False)
