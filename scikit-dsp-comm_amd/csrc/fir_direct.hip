@@ -23,6 +23,7 @@
 // c64 sample); long .filter calls go to fir_ols.hip instead.  It is the HBM-bound
 // choice only for short filters.
 #include "skdsp_internal.hpp"
+#include <type_traits>
 #include <cstring>
 #include <numeric>
 #include <cstdlib>
@@ -88,11 +89,21 @@ __global__ __launch_bounds__(256) void fir_poly_kernel(const X *__restrict__ x, 
     const int64_t w0 = (int64_t)a.q * s0 - (a.T - 1);  // global input index of win[0]
 
     // ---- stage the window (coalesced; zero outside [-n_hist, n)) ----
-    for (int i = tid; i < a.win; i += 256) {
-        const int64_t g = w0 + i;
-        X v = zero_of<X>();
-        if (g >= -a.n_hist && g < a.n) v = x[g];
-        win[i] = v;
+    // eight loads in flight per thread: a load-wait-store loop costs one HBM round trip per 256 samples
+    for (int i0 = tid; i0 < a.win; i0 += 256 * 8) {
+        X v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            const int64_t g = w0 + i;
+            v[u] = zero_of<X>();
+            if (i < a.win && g >= -a.n_hist && g < a.n) v[u] = x[g];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < a.win) win[i] = v[u];
+        }
     }
     __syncthreads();
 
@@ -177,7 +188,79 @@ struct SwArgs {
     int G;      // groups staged to the left of the first output group
     int nB;     // tap blocks per (class, residue) = table pitch / R
     int win;    // logical window length = (G + 256) * q * R
+    int tap_off;  // byte offset of the tap-table copy in LDS (-1: none, taps come through scalar loads)
+    int tap_cnt;  // floats in that copy = Lp * q * nB * R
 };
+
+
+// ---- complex64 x real taps, R = 8: packed FP32 with the tap broadcast done by op_sel ----------
+// v_pk_fma_f32 multiplies (re, im) by (tap, tap); hipcc builds that pair with two v_mov per tap and
+// rotates the register window with 16 more per block (46 v_mov per 64 useful v_pk_fma).  Here one
+// 64-bit register pair holds two consecutive taps and op_sel picks the half, and the window ping-pongs
+// between two register sets, so a block is 64 v_pk_fma/mul + 8 v_pk_add.  One asm statement covers
+// a tap pair x 8 outputs (hipcc pads every asm boundary with s_nop).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef v2f tap2_t;  // two consecutive taps in one 64-bit VGPR pair
+
+// p[r] (+)= t_lo * w[r+1] + t_hi * w[r],  r = 0..7  (w = 9 consecutive window registers, oldest first)
+__device__ __forceinline__ void pair_first(v2f (&p)[8], const v2f w0, const v2f w1, const v2f w2, const v2f w3, const v2f w4,
+                                           const v2f w5, const v2f w6, const v2f w7, const v2f w8, const tap2_t tt)
+{
+    asm("v_pk_mul_f32 %0, %9,  %16 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %1, %10, %16 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %2, %11, %16 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %3, %12, %16 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %4, %13, %16 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %5, %14, %16 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %6, %15, %16 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %7, %17, %16 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %8,  %16, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %1, %9,  %16, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %2, %10, %16, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %3, %11, %16, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %4, %12, %16, %4 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %5, %13, %16, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %6, %14, %16, %6 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %7, %15, %16, %7 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7])
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7), "v"(tt), "v"(w8));
+}
+
+__device__ __forceinline__ void pair_next(v2f (&p)[8], const v2f w0, const v2f w1, const v2f w2, const v2f w3, const v2f w4,
+                                          const v2f w5, const v2f w6, const v2f w7, const v2f w8, const tap2_t tt)
+{
+    asm("v_pk_fma_f32 %0, %9,  %16, %0 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %10, %16, %1 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %2, %11, %16, %2 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %3, %12, %16, %3 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %4, %13, %16, %4 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %5, %14, %16, %5 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %6, %15, %16, %6 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %7, %17, %16, %7 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %8,  %16, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %1, %9,  %16, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %2, %10, %16, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %3, %11, %16, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %4, %12, %16, %4 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %5, %13, %16, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %6, %14, %16, %6 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %7, %15, %16, %7 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7])
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7), "v"(tt), "v"(w8));
+}
+
+// one block of 8 taps (4 SGPR pairs) over the window {nxt[0..7] (older), cur[0..7]}: tap u feeds
+// output r from W[8 + r - u]
+__device__ __forceinline__ void sw_block8(v2f (&mid)[8], const v2f (&cur)[8], const v2f (&nxt)[8], const tap2_t (&tt)[4])
+{
+    v2f p[8];
+    pair_first(p, nxt[7], cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7], tt[0]);
+    pair_next(p, nxt[5], nxt[6], nxt[7], cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], tt[1]);
+    pair_next(p, nxt[3], nxt[4], nxt[5], nxt[6], nxt[7], cur[0], cur[1], cur[2], cur[3], tt[2]);
+    pair_next(p, nxt[1], nxt[2], nxt[3], nxt[4], nxt[5], nxt[6], nxt[7], cur[0], cur[1], tt[3]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mid[r] += p[r];
+}
 
 template <typename X, typename B, int R, int Q>
 __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, const B *__restrict__ taps,
@@ -192,11 +275,56 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
     const int64_t s0 = (int64_t)blockIdx.x * (256 * R);
     const int64_t w0 = (int64_t)q * s0 - (int64_t)P * a.G;
 
-    for (int i = tid; i < a.win; i += 256) {
-        const int64_t g = w0 + i;
-        X v = zero_of<X>();
-        if (g >= -a.n_hist && g < a.n) v = x[g];
-        win[i + i / P] = v;
+    // ---- stage the window.  Interior workgroups (the whole window inside [-n_hist, n), 16-byte
+    // aligned) take 16-byte loads with no per-sample bounds logic; eight loads are in flight per
+    // thread either way (a load-wait-store loop costs one HBM round trip per 256 samples).
+    constexpr int VEC = 16 / (int)sizeof(X);
+    const X *src = x + w0;
+    const bool interior = w0 >= -a.n_hist && w0 + a.win <= a.n && (P % VEC) == 0 && (a.win % VEC) == 0 &&
+                          (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    if (interior) {
+        const int nv = a.win / VEC;
+        const float4 *src4 = reinterpret_cast<const float4 *>(src);
+        for (int k0 = tid; k0 < nv; k0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 256 * u;
+                if (k < nv) v[u] = src4[k];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 256 * u;
+                if (k < nv) {
+                    const int i = k * VEC;
+                    X *dst = win + i + i / P;  // the VEC samples share a group (P % VEC == 0)
+                    const X *e = reinterpret_cast<const X *>(&v[u]);
+#pragma unroll
+                    for (int t = 0; t < VEC; ++t) dst[t] = e[t];
+                }
+            }
+        }
+    } else {
+        for (int i0 = tid; i0 < a.win; i0 += 256 * 8) {
+            X v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u;
+                const int64_t g = w0 + i;
+                v[u] = zero_of<X>();
+                if (i < a.win && g >= -a.n_hist && g < a.n) v[u] = x[g];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < a.win) win[i + i / P] = v[u];
+            }
+        }
+    }
+    if (a.tap_off >= 0) {  // LDS copy of the whole (class, residue) tap table (complex64 x real taps path)
+        float4 *dst = reinterpret_cast<float4 *>(smem_raw + a.tap_off);
+        const float4 *src = reinterpret_cast<const float4 *>(taps);
+        for (int i = tid; i < a.tap_cnt / 4; i += 256) dst[i] = src[i];
     }
     __syncthreads();
 
@@ -211,6 +339,60 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
             if (rho < 0) continue;  // residue j has no taps
             const B *__restrict__ tb = taps + (size_t)cj * a.nB * R;
             const X *grp = win + (size_t)(a.G + tid) * (P + 1) + rho;
+            if constexpr (std::is_same<X, float2>::value && std::is_same<B, float>::value && R == 8) if (a.tap_off >= 0) {
+                const v2f *g2 = reinterpret_cast<const v2f *>(grp);
+                const tap2_t *tq = reinterpret_cast<const tap2_t *>(smem_raw + a.tap_off) + (size_t)cj * a.nB * 4;
+                v2f wa[8], wb[8], wc[8], mid2[8], acc2[8];
+                tap2_t ta[4], tb2[4], tc[4];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    wa[e] = g2[q * e];
+                    wb[e] = g2[q * e - (P + 1)];
+                    mid2[e] = v2f{0.f, 0.f};
+                    acc2[e] = v2f{0.f, 0.f};
+                }
+#pragma unroll
+                for (int u_ = 0; u_ < 4; ++u_) ta[u_] = tq[u_];
+                // software pipeline, three register windows: while block beta runs on (W_beta, W_beta+1),
+                // the LDS reads of W_beta+2 and of block beta+1's taps are in flight.  The taps come from
+                // an LDS copy of the table, not from scalar loads: lgkmcnt counts SMEM and LDS together and
+                // SMEM returns out of order, so any pending s_load forces a full drain before the math.
+                int beta = 0;
+#define SK_SW_STEP(CUR, NXT, PRE, TCUR, TPRE)                                                        \
+    {                                                                                                \
+        /* what this block consumes was requested one block ago: have hipcc wait for it HERE, before */ \
+        /* the next requests go out, instead of draining those too right before the math            */ \
+        asm volatile("" ::"v"(TCUR[0]), "v"(TCUR[1]), "v"(TCUR[2]), "v"(TCUR[3]), "v"(NXT[0]), "v"(NXT[1]), "v"(NXT[2]),   \
+                     "v"(NXT[3]), "v"(NXT[4]), "v"(NXT[5]), "v"(NXT[6]), "v"(NXT[7]));                \
+        const int kw = beta + 2 <= a.nB ? beta + 2 : a.nB;                                           \
+        const v2f *gp = g2 - (size_t)kw * (P + 1);                                                   \
+        const tap2_t *tqn = tq + (size_t)(beta + 1 < a.nB ? beta + 1 : beta) * 4;                    \
+        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) TPRE[u_] = tqn[u_];                         \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) PRE[i] = gp[q * i];                            \
+        sw_block8(mid2, CUR, NXT, TCUR);                                                             \
+        ++beta;                                                                                      \
+        if ((beta & 15) == 0) {                                                                      \
+            _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                          \
+                acc2[r] += mid2[r];                                                                  \
+                mid2[r] = v2f{0.f, 0.f};                                                             \
+            }                                                                                        \
+        }                                                                                            \
+        if (beta >= a.nB) break;                                                                     \
+    }
+                for (;;) {
+                    SK_SW_STEP(wa, wb, wc, ta, tb2)
+                    SK_SW_STEP(wb, wc, wa, tb2, tc)
+                    SK_SW_STEP(wc, wa, wb, tc, ta)
+                }
+#undef SK_SW_STEP
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    acc2[r] += mid2[r];
+                    acc[r].x += acc2[r].x;
+                    acc[r].y += acc2[r].y;
+                }
+                continue;
+            }
             X wr[R];
 #pragma unroll
             for (int e = 0; e < R; ++e) wr[e] = grp[q * e];
@@ -417,7 +599,13 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
             SwArgs w;
             w.n = n; w.n_hist = n_hist; w.n_out = n_out;
             w.L = L; w.Lp = a.Lp; w.q = q; w.G = G; w.nB = nB; w.win = (int)win;
-            const size_t lds = (size_t)phys * esz;
+            size_t lds = (size_t)phys * esz;
+            w.tap_off = -1; w.tap_cnt = 0;
+            if (h->dtype == SKDSP_C64 && !h->taps_complex && R == 8) {
+                const size_t tbytes = (size_t)a.Lp * q * nB * R * 4;
+                const size_t off = (lds + 15) & ~(size_t)15;
+                if (off + tbytes <= lds_cap) { w.tap_off = (int)off; w.tap_cnt = (int)(tbytes / 4); lds = off + tbytes; }
+            }
 #define SK_SWQ(XT, BT, RR, QQ) \
     hipLaunchKernelGGL((fir_sw_kernel<XT, BT, RR, QQ>), dim3((unsigned)nb), dim3(256), lds, s, (const XT *)x, (const BT *)tab->taps, (const int *)tab->rho, w, (XT *)y)
 #define SK_SWR(XT, BT, RR)                                   \
