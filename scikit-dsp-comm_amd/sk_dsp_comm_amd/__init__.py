@@ -7,11 +7,12 @@ from . import _ffi
 from . import config
 from . import sigsys
 from . import multirate_helper
+from . import digitalcom
 from .multirate_helper import rate_change, multirate_FIR, multirate_IIR
 from .sigsys import upsample, downsample, cic
 
 __version__ = "0.1.0"
-__all__ = ["sigsys", "multirate_helper", "rate_change", "multirate_FIR", "multirate_IIR", "upsample", "downsample",
+__all__ = ["sigsys", "multirate_helper", "digitalcom", "rate_change", "multirate_FIR", "multirate_IIR", "upsample", "downsample",
            "cic", "config", "install"]
 
 

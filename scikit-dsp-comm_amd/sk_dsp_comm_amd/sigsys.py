@@ -7,6 +7,13 @@
   os_filter(x,h,N,mode) /root/reference/src/sk_dsp_comm/sigsys.py:482-540   ("next" row)
   oa_filter(x,h,N,mode) /root/reference/src/sk_dsp_comm/sigsys.py:543-598
 
+Callers around the hot path, same signatures, the filtering on the GPU:
+  interp24(x) / deci24(x)         sigsys.py:2945-3028   3-stage (b,a) Butterworth x24 / /24
+  ten_band_eq_filt(x, GdB, Q)     sigsys.py:96-141      ten peaking biquads -> one SOS scan
+  peaking(GdB, fc, Q, fs)         sigsys.py:202-260     (host design)
+  rc_imp / sqrt_rc_imp            sigsys.py:1847-1945   (host pulse design)
+  nrz_bits / nrz_bits2            sigsys.py:2120-2211   lfilter(b, 1, zero-stuffed data) -> polyphase .up
+
 upsample/downsample run on the GPU (resample.hip) and are bit-exact index moves; cic
 is host-side coefficient generation (a few dozen float64 taps) and stays in NumPy.
 Error conventions follow the reference (tests/golden/g10_conventions.json).
@@ -132,3 +139,151 @@ def os_filter(x, h, N, mode=0):
 def oa_filter(x, h, N, mode=0):
     """Overlap-and-add FIR filtering (sigsys.py:543-598): y = real(lfilter(h, 1, x))."""
     return _transform_domain_fir(x, h, N, mode, "oa_filter")
+
+
+# ---------------------------------------------------------------------------------------------
+# callers around the hot path (SURVEY.md 8f-2)
+# ---------------------------------------------------------------------------------------------
+def _lfilter_dtype(x):
+    """(device array, result dtype) for scipy.signal.lfilter(b, a, x) with float64 coefficients."""
+    from . import multirate_helper as mrh
+    return mrh._signal(np.asarray(x))
+
+
+def _butter_stage(order, wn, dtype):
+    import scipy.signal as signal
+    b, a = signal.butter(order, wn)
+    return _ffi.IirKernel(_ffi.code_of(dtype), b=b, a=a)
+
+
+def interp24(x):
+    """Interpolate by 24 in three stages x2, x3, x4, each lfilter(b, a, L*upsample(., L)) with a
+    10th-order Butterworth at 1/L (sigsys.py:2945-2985).  One fused zero-stuff + scan per stage."""
+    from . import multirate_helper as mrh
+    x = np.asarray(x)
+    if x.ndim != 1:
+        raise ValueError("cannot reshape array of size %d into shape (%d,1)" % (x.size, len(x)))
+    xg, ref_dt = _lfilter_dtype(x)
+    if xg.size == 0:
+        return np.zeros(0, dtype=ref_dt)
+    y = xg
+    for L in (2, 3, 4):
+        y = _butter_stage(10, 1.0 / L, y.dtype).up(y, L)
+    return mrh._finish(y, ref_dt)
+
+
+def deci24(x):
+    """Decimate by 24 in three stages /2, /3, /4, each downsample(lfilter(b, a, .), M) with a
+    10th-order Butterworth at 1/M (sigsys.py:2988-3028); only the kept samples are written."""
+    from . import multirate_helper as mrh
+    x = np.asarray(x)
+    if x.ndim != 1:
+        raise ValueError("deci24 expects a 1-D signal")
+    xg, ref_dt = _lfilter_dtype(x)
+    y = xg
+    for M in (2, 3, 4):
+        if len(y) // M == 0:
+            return np.zeros(0, dtype=ref_dt if config.strict_dtype else xg.dtype)
+        y = _butter_stage(10, 1.0 / M, y.dtype).dn(y, M)
+    return mrh._finish(y, ref_dt)
+
+
+def peaking(GdB, fc, Q=3.5, fs=44100.):
+    """Second-order peaking (bell) equaliser section, gain GdB at fc (sigsys.py:202-260).
+    Returns (b, a) with a[0] = 1."""
+    mu = 10.0 ** (GdB / 20.0)
+    w0 = 2.0 * np.pi * fc / fs
+    kq = 4.0 / (1.0 + mu) * np.tan(w0 / (2.0 * Q))
+    c0 = np.cos(w0)
+    den_b, den_a = 1.0 + kq * mu, 1.0 + kq
+    b = (den_b / den_a) * np.array([1.0, -2.0 * c0 / den_b, (1.0 - kq * mu) / den_b])
+    a = np.array([1.0, -2.0 * c0 / den_a, (1.0 - kq) / den_a])
+    return b, a
+
+
+def ten_band_eq_filt(x, GdB, Q=3.5):
+    """Ten octave-spaced peaking filters (31.25 Hz ... 16 kHz at fs = 44.1 kHz) in cascade
+    (sigsys.py:96-141).  The reference runs ten lfilter passes; here the ten biquads are one
+    SOS cascade in a single exact scan."""
+    from . import multirate_helper as mrh
+    nb = len(GdB)
+    if not nb == 10:
+        raise ValueError("GdB length not equal to ten")
+    fc = 31.25 * 2.0 ** np.arange(nb)
+    sos = np.zeros((nb, 6))
+    for k in range(nb):
+        sos[k, :3], sos[k, 3:] = peaking(GdB[k], fc[k], Q)
+    xg, ref_dt = _lfilter_dtype(x)
+    if xg.size == 0:
+        return np.zeros(0)
+    y = _ffi.IirKernel(_ffi.code_of(xg.dtype), sos=sos).filter(xg)
+    return mrh._finish(y, ref_dt)
+
+
+def rc_imp(Ns, alpha, M=6):
+    """Truncated raised-cosine pulse, 2*M*Ns+1 samples (sigsys.py:1847-1891)."""
+    n = np.arange(-M * Ns, M * Ns + 1)
+    t = n / float(Ns)
+    den = 1.0 - 4.0 * (alpha * t) ** 2
+    sing = den == 0
+    b = np.sinc(t) * np.cos(np.pi * alpha * t) / np.where(sing, 1.0, den)
+    if np.any(sing):
+        b[sing] = np.pi / 4.0 * np.sinc(1.0 / (2.0 * alpha))
+    return b
+
+
+def sqrt_rc_imp(Ns, alpha, M=6):
+    """Truncated square-root raised-cosine pulse, 2*M*Ns+1 samples (sigsys.py:1894-1945)."""
+    n = np.arange(-M * Ns, M * Ns + 1)
+    t = n / float(Ns)
+    a = alpha
+    den = 1.0 - 16.0 * a ** 2 * t ** 2
+    sing = np.abs(den) <= np.finfo(np.float32).eps / 2
+    b = 4.0 * a / (np.pi * np.where(sing, 1.0, den)) * (np.cos((1.0 + a) * np.pi * t)
+                                                    + np.sinc((1.0 - a) * t) * (1.0 - a) * np.pi / (4.0 * a))
+    if np.any(sing):
+        b[sing] = 0.5 * ((1.0 + a) * np.sin((1.0 + a) * np.pi / (4.0 * a))
+                         - (1.0 - a) * np.cos((1.0 - a) * np.pi / (4.0 * a))
+                         + (4.0 * a) / np.pi * np.sin((1.0 - a) * np.pi / (4.0 * a)))
+    return b
+
+
+def _pulse(pulse, ns, alpha, m, err='pulse type must be rec, rc, or src'):
+    kind = pulse.lower()
+    if kind == 'rect':
+        return np.ones(int(ns))
+    if kind == 'rc':
+        return rc_imp(ns, alpha, m)
+    if kind == 'src':
+        return sqrt_rc_imp(ns, alpha, m)
+    raise ValueError(err)
+
+
+def pulse_shape(symbols, b, ns):
+    """lfilter(b, 1, upsample(symbols, ns)) -- the pulse-shaping step of nrz_bits*, the *_bb
+    transmitters of digitalcom (digitalcom.py:1676, 1821) -- as ONE polyphase interpolation:
+    only the ns-th of the products that do not multiply a stuffed zero is computed."""
+    from . import multirate_helper as mrh
+    ns = int(ns)
+    sym = np.asarray(symbols)
+    if sym.size == 0:
+        return np.zeros(0, dtype=np.complex128 if np.iscomplexobj(sym) else np.float64)
+    if ns == 1:
+        return mrh.multirate_FIR(np.asarray(b, dtype=np.float64)).filter(sym)
+    # multirate_FIR.up applies the interpolation gain ns to the stuffed signal; lfilter here does not
+    return mrh.multirate_FIR(np.asarray(b, dtype=np.float64) / ns).up(sym.astype(np.result_type(sym.dtype, np.float64)), ns)
+
+
+def nrz_bits2(data, Ns, pulse='rect', alpha=0.25, M=6):
+    """NRZ +-1 waveform from user bits with pulse shaping (sigsys.py:2163-2211): (x, b/Ns)."""
+    data = np.asarray(data)
+    b = _pulse(pulse, Ns, alpha, M)
+    x = pulse_shape(2 * data - 1, b, Ns)
+    return x, b / float(Ns)
+
+
+def nrz_bits(n_bits, ns, pulse='rect', alpha=0.25, m=6):
+    """NRZ +-1 waveform from random bits (sigsys.py:2120-2160): (x, b/ns, data)."""
+    data = np.random.randint(0, 2, n_bits)
+    x, b = nrz_bits2(data, ns, pulse, alpha, m)
+    return x, b, data

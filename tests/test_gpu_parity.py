@@ -732,3 +732,67 @@ def test_sharded_iir_emulated_ranks(dt, path):
                 xd.free()
                 yd.free()
         assert max(rel_err(np.concatenate(got), want)) <= tol
+
+
+# ---------------------------------------------------------------------------------------------
+# callers around the hot path against vectors captured from the reference (G11)
+# ---------------------------------------------------------------------------------------------
+def _g11():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g11_callers.npz"))
+
+
+@pytest.mark.gpu
+def test_interp24_deci24_match_reference():
+    from sk_dsp_comm_amd import sigsys, config
+    g = _g11()
+    config.strict_dtype = True
+    try:
+        y = sigsys.interp24(g["i24_x"])
+        assert y.dtype == np.float64 and max(rel_err(y, g["i24_y"])) <= 1e-9
+        yc = sigsys.interp24(g["i24c_x"])
+        assert yc.dtype == np.complex128 and max(rel_err(yc, g["i24c_y"])) <= 1e-9
+        d = sigsys.deci24(g["d24_x"])
+        assert max(rel_err(d, g["d24_y"])) <= 1e-9
+        y32 = sigsys.interp24(g["i24_x"].astype(np.float32))  # float32 signal: float32 I/O kernels
+        assert y32.dtype == np.float64 and max(rel_err(y32, g["i24_y"])) <= 2e-6
+    finally:
+        config.strict_dtype = False
+
+
+@pytest.mark.gpu
+def test_ten_band_eq_matches_reference():
+    from sk_dsp_comm_amd import sigsys
+    g = _g11()
+    assert max(rel_err(sigsys.ten_band_eq_filt(g["eq_x"], g["eq_gdb"]), g["eq_y"])) <= 1e-9
+    assert max(rel_err(sigsys.ten_band_eq_filt(g["eq_x"], g["eq_gdb"], Q=2.0), g["eq_y_q2"])) <= 1e-9
+    with pytest.raises(ValueError):
+        sigsys.ten_band_eq_filt(g["eq_x"], g["eq_gdb"][:9])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pulse", ["rect", "rc", "src"])
+def test_nrz_bits2_matches_reference(pulse):
+    from sk_dsp_comm_amd import sigsys
+    g = _g11()
+    x, b = sigsys.nrz_bits2(g["nrz_bits"], 10, pulse, 0.25, 6)
+    assert np.allclose(b, g["nrz_b_" + pulse], rtol=1e-13, atol=1e-16)
+    assert x.shape == g["nrz_x_" + pulse].shape and max(rel_err(x, g["nrz_x_" + pulse])) <= 1e-11
+
+
+@pytest.mark.gpu
+def test_gray_transmitters_match_reference():
+    from sk_dsp_comm_amd import digitalcom as dc
+    g = _g11()
+    data = g["tx_data"]
+    for mod in (2, 4, 16, 64, 256):
+        for pulse, ns in (("src", 8), ("rect", 4)):
+            x, b, d = dc.qam_gray_encode_bb(None, ns, mod, pulse, 0.35, 6, data)
+            ref = g["qam%d_%s_x" % (mod, pulse)]
+            assert x.shape == ref.shape and max(rel_err(x, ref)) <= 1e-11, (mod, pulse)
+            assert np.allclose(b, g["qam%d_%s_b" % (mod, pulse)], rtol=1e-13)
+    for mod in (2, 4, 8, 16, 32):
+        x, b, d = dc.mpsk_gray_encode_bb(None, 8, mod, "src", 0.25, 6, data)
+        assert max(rel_err(x, g["mpsk%d_x" % mod])) <= 1e-11, mod
+        assert np.allclose(b, g["mpsk%d_b" % mod], rtol=1e-13)
+    x, b, d = dc.mpsk_gray_encode_bb(None, 5, 8, "rc", 0.35, 4, data)
+    assert max(rel_err(x, g["mpsk8_rc_x"])) <= 1e-11
