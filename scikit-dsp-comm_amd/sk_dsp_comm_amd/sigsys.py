@@ -13,6 +13,7 @@ Callers around the hot path, same signatures, the filtering on the
   peaking(GdB, fc, Q, fs)         sigsys.py:202-260     (host design)
   rc_imp / sqrt_rc_imp            sigsys.py:1847-1945   (host pulse design)
   nrz_bits / nrz_bits2            sigsys.py:2120-2211   lfilter(b, 1, zero-stuffed data) -> polyphase .up
+  fft_filt_bank(x, h, ...)        sigsys.py:2588-2694   (8f-4) one FIR per band with frequency-shifted taps
 
 upsample/downsample run on the GPU (resample.hip) and are bit-exact index moves; cic
 is host-side coefficient generation (a few dozen float64 taps) and stays in NumPy.
@@ -287,3 +288,52 @@ def nrz_bits(n_bits, ns, pulse='rect', alpha=0.25, m=6):
     data = np.random.randint(0, 2, n_bits)
     x, b = nrz_bits2(data, ns, pulse, alpha, m)
     return x, b, data
+
+
+def fft_filt_bank(x_in, h_filt, n_fft2=512, n_bands2=0, bs=0.2, fs=1.0, n_band_odd=True):
+    """Streaming filter bank of 2*n_bands2+1 (or 2*n_bands2) bands spaced by ~bs Hz
+    (sigsys.py:2588-2694).  The reference overlap-saves with a 2*n_fft2 FFT and rolls H by whole
+    bins per band; rolling H by s bins IS the filter h[n]*exp(j*2*pi*s*n/(2*n_fft2)), so every band
+    is one complex-tap FIR over the same device-resident input (fir_ols.hip / fir_direct.hip).
+    Like the reference only whole blocks of n_fft2 samples are produced; the tail stays zero.
+    Returns (y_filt_bank[bands, len(x)], freq_axis, freq_axis_desired)."""
+    h_filt = np.asarray(h_filt)
+    if len(h_filt) > n_fft2:
+        raise ValueError('Error: Must have Nfft2 = %d >= %d = len(h_ref)' % (n_fft2, len(h_filt)))
+    x_in = np.asarray(x_in)
+    n_x = len(x_in)
+    if n_band_odd:
+        n_tot = 2 * n_bands2 + 1
+        step = int(round(bs * 2 * n_fft2 / fs))
+        shifts = [j * step - n_bands2 * step for j in range(n_tot)]
+    else:
+        n_tot = 2 * n_bands2
+        step = int(round(bs / 2 * 2 * n_fft2 / fs))
+        shifts = [j * 2 * step - (2 * n_bands2 - 1) * step for j in range(n_tot)]
+    bs_actual = step * fs / (2 * n_fft2)
+    print('N_band_step = %d' % (step,))
+    print('N_band_step = %d and BS_Hz_actual = %3.2f Hz' % (step, bs_actual))
+    print('N_bands_tot = %d and span_Hz = +/- %4.2f Hz' % (n_tot, n_bands2 * bs_actual))
+    y = np.zeros((n_tot, n_x), dtype=complex)
+    n_use = (n_x // n_fft2) * n_fft2
+    if n_use and n_tot:
+        single = x_in.dtype in (np.float32, np.complex64) and not config.strict_dtype
+        cdt = np.complex64 if single else np.complex128
+        xd = _ffi.DeviceArray.from_host(np.ascontiguousarray(x_in[:n_use], dtype=cdt))
+        yd = _ffi.DeviceArray(n_use, cdt)
+        try:
+            n = np.arange(len(h_filt))
+            for j, sft in enumerate(shifts):
+                taps = h_filt * np.exp(2j * np.pi * sft * n / (2 * n_fft2))
+                _ffi.FirKernel(taps, _ffi.code_of(cdt)).filter_dev(xd, yd)
+                y[j, :n_use] = yd.to_host()
+        finally:
+            xd.free()
+            yd.free()
+    if n_band_odd:
+        freq_axis = np.arange(-n_bands2 * step, n_bands2 * step + step, step) * fs / 2 / n_fft2
+        freq_axis_desired = np.rint(freq_axis / bs) * bs
+    else:
+        freq_axis = np.arange(-(2 * n_bands2 - 1) * step, n_bands2 * step + 2 * (step + 1), 2 * step) * fs / 2 / n_fft2
+        freq_axis_desired = np.rint(freq_axis / (bs / 2)) * (bs / 2)
+    return y, freq_axis, freq_axis_desired

@@ -796,3 +796,42 @@ def test_gray_transmitters_match_reference():
         assert np.allclose(b, g["mpsk%d_b" % mod], rtol=1e-13)
     x, b, d = dc.mpsk_gray_encode_bb(None, 5, 8, "rc", 0.35, 4, data)
     assert max(rel_err(x, g["mpsk8_rc_x"])) <= 1e-11
+
+
+@pytest.mark.gpu
+def test_fft_filt_bank_matches_reference(capsys):
+    from sk_dsp_comm_amd import sigsys
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g13_filtbank.npz"))
+    y, f, fd = sigsys.fft_filt_bank(g["xr"], g["h"] + 0j, n_fft2=128, n_bands2=2, bs=200, fs=1000)
+    assert y.shape == g["odd_y"].shape and y.dtype == np.complex128
+    assert max(rel_err(y, g["odd_y"])) <= 1e-11 and np.all(y[:, 2944:] == 0)
+    assert np.allclose(f, g["odd_f"]) and np.allclose(fd, g["odd_fd"])
+    y, f, fd = sigsys.fft_filt_bank(g["xr"], g["h"] + 0j, n_fft2=128, n_bands2=2, bs=200, fs=1000, n_band_odd=False)
+    assert max(rel_err(y, g["even_y"])) <= 1e-11 and np.allclose(f, g["even_f"]) and np.allclose(fd, g["even_fd"])
+    y, f, fd = sigsys.fft_filt_bank(g["xc"], g["hc"], n_fft2=100, n_bands2=1, bs=130, fs=1000)
+    assert max(rel_err(y, g["cplx_y"])) <= 1e-11 and np.allclose(f, g["cplx_f"]) and np.allclose(fd, g["cplx_fd"])
+    assert capsys.readouterr().out == str(g["stdout"])
+    y32, _, _ = sigsys.fft_filt_bank(g["xr"].astype(np.float32), g["h"], n_fft2=128, n_bands2=2, bs=200, fs=1000)
+    assert max(rel_err(y32, g["odd_y"])) <= 2e-6
+    with pytest.raises(ValueError):
+        sigsys.fft_filt_bank(g["xr"], g["h"], n_fft2=32)
+
+
+@pytest.mark.gpu
+def test_header_taps_drive_the_gpu_filter(tmp_path):
+    """coeff2header round trip into the filter objects (8f-4): Q15 header -> multirate_FIR, SOS header -> multirate_IIR."""
+    from scipy import signal
+    from sk_dsp_comm_amd import coeff2header as c2h
+    import sk_dsp_comm_amd.multirate_helper as mrh
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal(20000)
+    h = signal.firwin(64, 0.25)
+    fn = str(tmp_path / "h.h")
+    c2h.fir_fix_header(fn, h)
+    hq = c2h.read_fir_header(fn)
+    assert max(rel_err(mrh.multirate_FIR(hq).filter(x), signal.lfilter(hq, 1, x))) <= 1e-11
+    sos = signal.ellip(6, 0.5, 60, 0.3, output="sos")
+    fs = str(tmp_path / "s.h")
+    c2h.iir_sos_header(fs, sos)
+    sos_r = c2h.read_sos_header(fs)
+    assert max(rel_err(mrh.multirate_IIR(sos_r).filter(x), signal.sosfilt(sos_r, x))) <= 1e-9

@@ -209,3 +209,31 @@ def test_gray_symbol_mapping_matches_reference_without_gpu():
         dc.qam_gray_encode_bb(None, 4, 8, ext_data=g["tx_data"])
     with pytest.raises(ValueError):
         dc.mpsk_gray_encode_bb(None, 4, 64, ext_data=g["tx_data"])
+
+
+# ---------------------------------------------------------------------------------------------
+# coefficient header formats against the text the reference itself wrote (G12)
+# ---------------------------------------------------------------------------------------------
+def test_coefficient_headers_byte_exact_and_round_trip(tmp_path):
+    import json
+    from sk_dsp_comm_amd import coeff2header as c2h
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "g12_headers.json")))
+    assert {c["kind"] for c in cases} == {"fir", "fix", "sos"}
+    for c in cases:
+        fn = str(tmp_path / (c["kind"] + "_" + c["name"] + ".h"))
+        if c["kind"] == "fir":
+            h = np.array(c["h"])
+            c2h.fir_header(fn, h)
+            assert open(fn).read() == c["text"], c["name"]
+            assert np.allclose(c2h.read_fir_header(fn), h, rtol=0, atol=0.5e-12)
+        elif c["kind"] == "fix":
+            h = np.array(c["h"])
+            c2h.fir_fix_header(fn, h)
+            assert open(fn).read() == c["text"], c["name"]
+            assert np.array_equal(c2h.read_fir_header(fn) * 2 ** 15, np.rint(h * 2 ** 15))
+        else:
+            sos = np.array(c["sos"])
+            c2h.iir_sos_header(fn, sos)
+            assert open(fn).read() == c["text"], c["name"]
+            back = c2h.read_sos_header(fn)
+            assert back.shape == sos.shape and np.allclose(back, sos / sos[:, 3:4], rtol=1e-6, atol=1e-12)
