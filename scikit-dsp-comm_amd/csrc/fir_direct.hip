@@ -188,8 +188,9 @@ struct SwArgs {
     int G;      // groups staged to the left of the first output group
     int nB;     // tap blocks per (class, residue) = table pitch / R
     int win;    // logical window length = (G + 256) * q * R
-    int tap_off;  // byte offset of the tap-table copy in LDS (-1: none, taps come through scalar loads)
-    int tap_cnt;  // floats in that copy = Lp * q * nB * R
+    int tap_off;  // byte offset of the two per-class tap buffers in LDS (-1: none, taps come through scalar loads)
+    int tap_cnt;  // floats per class = q * nB * R
+    int out_off;  // byte offset of the four wave-private output transposition tiles (-1: store directly)
 };
 
 
@@ -262,7 +263,11 @@ __device__ __forceinline__ void sw_block8(v2f (&mid)[8], const v2f (&cur)[8], co
     for (int r = 0; r < 8; ++r) mid[r] += p[r];
 }
 
-template <typename X, typename B, int R, int Q>
+// LPT > 0 (= Lp, complex64 x real taps only): the class loop is unrolled and all Lp classes of a
+// thread's slots stay in registers, so that the epilogue can write the interleaved output as full
+// 512-byte rows (per-class stores fill a quarter of every line at a time; L2 merges them, but at
+// the price of 0.15 ms of config 3's 0.97).
+template <typename X, typename B, int R, int Q, int LPT = 0>
 __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, const B *__restrict__ taps,
                                                      const int *__restrict__ rho_tab, SwArgs a, X *__restrict__ y)
 {
@@ -321,16 +326,24 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
             }
         }
     }
-    if (a.tap_off >= 0) {  // LDS copy of the whole (class, residue) tap table (complex64 x real taps path)
-        float4 *dst = reinterpret_cast<float4 *>(smem_raw + a.tap_off);
-        const float4 *src = reinterpret_cast<const float4 *>(taps);
+    // LDS copy of ONE class's tap table at a time, double-buffered (complex64 x real taps path):
+    // class c+1's taps are staged while class c is computed; the barrier on top of every class
+    // publishes them and retires the buffer they replace.  (The whole table would push the
+    // workgroup past a third of the CU's LDS for the config-3 shape.)
+    auto stage_taps = [&](int c) {
+        float4 *dst = reinterpret_cast<float4 *>(smem_raw + a.tap_off + (c & 1) * a.tap_cnt * 4);
+        const float4 *src = reinterpret_cast<const float4 *>(taps + (size_t)c * a.tap_cnt);
         for (int i = tid; i < a.tap_cnt / 4; i += 256) dst[i] = src[i];
-    }
+    };
+    if (a.tap_off >= 0) stage_taps(0);
     __syncthreads();
 
     const S gain = (S)a.L;
-    for (int c = 0; c < a.Lp; ++c) {
-        X acc[R];
+    auto class_body = [&](const int c, X (&acc)[R]) __attribute__((always_inline)) {
+        if (a.tap_off >= 0) {
+            if (c > 0) __syncthreads();
+            if (c + 1 < a.Lp) stage_taps(c + 1);
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = zero_of<X>();
         for (int j = 0; j < q; ++j) {
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
             const X *grp = win + (size_t)(a.G + tid) * (P + 1) + rho;
             if constexpr (std::is_same<X, float2>::value && std::is_same<B, float>::value && R == 8) if (a.tap_off >= 0) {
                 const v2f *g2 = reinterpret_cast<const v2f *>(grp);
-                const tap2_t *tq = reinterpret_cast<const tap2_t *>(smem_raw + a.tap_off) + (size_t)cj * a.nB * 4;
+                const tap2_t *tq = reinterpret_cast<const tap2_t *>(smem_raw + a.tap_off + (c & 1) * a.tap_cnt * 4) + (size_t)j * a.nB * 4;
                 v2f wa[8], wb[8], wc[8], mid2[8], acc2[8];
                 tap2_t ta[4], tb2[4], tc[4];
 #pragma unroll
@@ -443,9 +456,64 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = add_of(acc[r], mid[r]);
         }
+    };
+
+    if constexpr (LPT > 0) {
+        X accs[LPT][R];
+#pragma unroll
+        for (int c = 0; c < LPT; ++c) class_body(c, accs[c]);
+        // element e of a wave's output run = LPT * slot + class; 16 lanes (16*LPT*R consecutive
+        // elements) go through the wave-private tile per pass and leave as 512-byte rows
+        static_assert(16 * (LPT * R + 1) <= 64 * (R + 1), "output tile too small");
+        const int wave = tid >> 6, lane = tid & 63;
+        X *ot = reinterpret_cast<X *>(smem_raw + a.out_off) + (size_t)wave * (64 * (R + 1));
+        const int64_t mw = (int64_t)LPT * (s0 + (int64_t)R * 64 * wave);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if ((lane >> 4) == p) {
+                X *row = ot + (lane & 15) * (LPT * R + 1);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int c = 0; c < LPT; ++c) row[LPT * r + c] = (a.L == 1) ? accs[c][r] : scl(accs[c][r], gain);
+            }
+#pragma unroll
+            for (int k = 0; k < LPT * R / 4; ++k) {
+                const int e = lane + 64 * k;
+                const X v = ot[e + e / (LPT * R)];
+                const int64_t m = mw + (int64_t)p * (16 * LPT * R) + e;
+                if (m < a.n_out) y[m] = v;
+            }
+        }
+        return;
+    }
+    for (int c = 0; c < a.Lp; ++c) {
+        X acc[R];
+        class_body(c, acc);
         const int64_t sb = s0 + (int64_t)R * tid;
-        if (a.Lp == 1 && a.L == 1 && sb + R <= a.n_out && (R * sizeof(X)) % 16 == 0 &&
-            (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+        if (a.out_off >= 0) {
+            // a thread's R outputs of a class sit Lp*R elements apart from its neighbour's, so a direct
+            // store touches 64 lines per instruction.  Transpose through a wave-private LDS tile
+            // (pitch R+1) so that consecutive lanes hold consecutive slots: 64*Lp elements per
+            // instruction instead (config 3: 16 lines x 32 B, and 0.25 ms of 0.97 back).
+            const int wave = tid >> 6, lane = tid & 63;
+            X *ot = reinterpret_cast<X *>(smem_raw + a.out_off) + (size_t)wave * (64 * (R + 1));
+#pragma unroll
+            for (int r = 0; r < R; ++r) ot[lane * (R + 1) + r] = (a.L == 1) ? acc[r] : scl(acc[r], gain);
+            const int64_t wb = s0 + (int64_t)R * 64 * wave;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int sl = lane + 64 * k;
+                const X v = ot[sl + sl / R];
+#ifdef SKDSP_SW_PLANAR
+                const int64_t m = (int64_t)c * (a.n_out / a.Lp) + (wb + sl);  // timing experiment only: wrong layout
+#else
+                const int64_t m = (int64_t)c + (int64_t)a.Lp * (wb + sl);
+#endif
+                if (m < a.n_out) y[m] = v;
+            }
+        } else if (a.Lp == 1 && a.L == 1 && sb + R <= a.n_out && (R * sizeof(X)) % 16 == 0 &&
+                   (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
             constexpr int NV = (R * (int)sizeof(X)) / 16;
             float4 *dst = reinterpret_cast<float4 *>(y + sb);
             const float4 *src = reinterpret_cast<const float4 *>(acc);
@@ -577,7 +645,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     a.n_s = (n_out + a.Lp - 1) / a.Lp;
 
     const size_t esz = dtype_size(h->dtype);
-    const size_t lds_cap = 64 * 1024;  // <= 2 workgroups per CU of the 160 KiB LDS
+    const size_t lds_cap = 80 * 1024;  // <= 2 workgroups per CU of the 160 KiB LDS
 
     // ---- preferred: register sliding window (R consecutive outputs per thread) ----
     static const bool no_sw = getenv("SKDSP_FIR_NO_SW") != nullptr;  // developer A/B switch
@@ -602,12 +670,24 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
             size_t lds = (size_t)phys * esz;
             w.tap_off = -1; w.tap_cnt = 0;
             if (h->dtype == SKDSP_C64 && !h->taps_complex && R == 8) {
-                const size_t tbytes = (size_t)a.Lp * q * nB * R * 4;
+                const size_t tbytes = (size_t)q * nB * R * 4;  // one class; two buffers
                 const size_t off = (lds + 15) & ~(size_t)15;
-                if (off + tbytes <= lds_cap) { w.tap_off = (int)off; w.tap_cnt = (int)(tbytes / 4); lds = off + tbytes; }
+                if (off + 2 * tbytes <= lds_cap) { w.tap_off = (int)off; w.tap_cnt = (int)(tbytes / 4); lds = off + 2 * tbytes; }
             }
-#define SK_SWQ(XT, BT, RR, QQ) \
-    hipLaunchKernelGGL((fir_sw_kernel<XT, BT, RR, QQ>), dim3((unsigned)nb), dim3(256), lds, s, (const XT *)x, (const BT *)tab->taps, (const int *)tab->rho, w, (XT *)y)
+            w.out_off = -1;
+            {
+                const size_t off = (lds + 15) & ~(size_t)15;
+                const size_t obytes = (size_t)4 * 64 * (R + 1) * esz;
+                if (off + obytes <= lds_cap) { w.out_off = (int)off; lds = off + obytes; }
+            }
+#define SK_SWQ(XT, BT, RR, QQ)                                                                                        \
+    do {                                                                                                              \
+        if (lds > 64 * 1024)                                                                                          \
+            (void)hipFuncSetAttribute((const void *)fir_sw_kernel<XT, BT, RR, QQ>,                                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+        hipLaunchKernelGGL((fir_sw_kernel<XT, BT, RR, QQ>), dim3((unsigned)nb), dim3(256), lds, s, (const XT *)x,     \
+                           (const BT *)tab->taps, (const int *)tab->rho, w, (XT *)y);                                 \
+    } while (0)
 #define SK_SWR(XT, BT, RR)                                   \
     do {                                                     \
         if (q == 1) SK_SWQ(XT, BT, RR, 1);                   \
@@ -621,6 +701,31 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
         else if (R == 4) SK_SWR(XT, BT, 4);                  \
         else SK_SWR(XT, BT, 2);                              \
     } while (0)
+#define SK_SWL(QQ, LL)                                                                                                 \
+    do {                                                                                                               \
+        if (lds > 64 * 1024)                                                                                           \
+            (void)hipFuncSetAttribute((const void *)fir_sw_kernel<float2, float, 8, QQ, LL>,                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+        hipLaunchKernelGGL((fir_sw_kernel<float2, float, 8, QQ, LL>), dim3((unsigned)nb), dim3(256), lds, s,           \
+                           (const float2 *)x, (const float *)tab->taps, (const int *)tab->rho, w, (float2 *)y);        \
+    } while (0)
+#define SK_SWLQ(LL)                                   \
+    do {                                              \
+        if (q == 1) SK_SWL(1, LL);                    \
+        else if (q == 2) SK_SWL(2, LL);               \
+        else if (q == 3) SK_SWL(3, LL);               \
+        else SK_SWL(0, LL);                           \
+    } while (0)
+            if (h->dtype == SKDSP_C64 && !h->taps_complex && R == 8 && w.tap_off >= 0 && w.out_off >= 0 && a.Lp >= 2 &&
+                a.Lp <= 4 && !getenv("SKDSP_SW_NO_LPT")) {
+                if (a.Lp == 2) SK_SWLQ(2);
+                else if (a.Lp == 3) SK_SWLQ(3);
+                else SK_SWLQ(4);
+                SK_HIP(hipGetLastError());
+                return SKDSP_OK;
+            }
+#undef SK_SWLQ
+#undef SK_SWL
             switch (h->dtype) {
             case SKDSP_F32: SK_SW(float, float); break;
             case SKDSP_F64: SK_SW(double, double); break;
@@ -636,7 +741,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     }
 
     // ---- generic fallback: one LDS read per FMA, any stride ----
-    const int64_t cap_elems = (int64_t)(lds_cap / esz);
+    const int64_t cap_elems = (int64_t)((size_t)64 * 1024 / esz);
     // window = q*s_tile + T + q  <=  cap_elems
     int64_t s_tile = (cap_elems - T - a.q) / a.q;
     SK_CHECK(s_tile >= 1, SKDSP_ERR_UNSUPPORTED,

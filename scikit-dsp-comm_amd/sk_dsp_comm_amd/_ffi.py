@@ -191,7 +191,8 @@ class DeviceArray:
             check(load().skdsp_memcpy_h2d(ctypes.c_void_p(self.ptr + at * self.dtype.itemsize), _ptr(a), a.nbytes))
 
     def to_host(self, start=0, count=None):
-        count = self.n - start if count is None else count
+        start = int(start)
+        count = self.n - start if count is None else int(count)
         out = np.empty(count, dtype=self.dtype)
         esz = self.dtype.itemsize
         check(load().skdsp_memcpy_d2h(_ptr(out), ctypes.c_void_p(self.ptr + start * esz), out.nbytes))

@@ -835,3 +835,32 @@ def test_header_taps_drive_the_gpu_filter(tmp_path):
     c2h.iir_sos_header(fs, sos)
     sos_r = c2h.read_sos_header(fs)
     assert max(rel_err(mrh.multirate_IIR(sos_r).filter(x), signal.sosfilt(sos_r, x))) <= 1e-9
+
+
+@pytest.mark.parametrize("L,M", [(2, 1), (3, 1), (4, 1), (3, 2), (2, 3), (4, 5), (4, 3), (5, 3)])
+def test_c64_polyphase_large_tiles(L, M):
+    """complex64 x real taps at sizes where the R=8 sliding-window tiles (and for Lp = 2..4 the
+    unrolled-class kernel with full-row interleaved stores) are selected: windows against the oracle,
+    including the very first and the very last outputs."""
+    g = load("g6_fir512_updn.npz")
+    b = g["b"]
+    n = 3 * 2 ** 20 + 1234  # ragged: last workgroup and last rows are partial
+    n -= n % M
+    k = _ffi.FirKernel(b, _ffi.C64)
+    xd = _ffi.DeviceArray(n, np.complex64).fill_noise(23)
+    n_out = (n * L) // M
+    yd = _ffi.DeviceArray(n_out, np.complex64)
+    k.updn_dev(xd, yd, L, M)
+    _ffi.sync()
+    q = M // int(np.gcd(L, M))
+    for s_in in (0, 700_000, n - 5000):
+        s_in -= s_in % q
+        lo = max(0, s_in - 600)
+        lo -= lo % M
+        xs = xd.to_host(lo, min(5000, n - lo))
+        ref = orc.downsample(orc.fir_up(b, xs, L), M) if M > 1 else orc.fir_up(b, xs, L)
+        m0 = (s_in * L) // M
+        skip = ((s_in - lo) * L) // M
+        w = min(len(ref) - skip, n_out - m0, 4000)
+        assert w > 1000
+        assert_close(yd.to_host(m0, w), ref[skip:skip + w], TOL32, "L=%d M=%d window @%d" % (L, M, s_in))
