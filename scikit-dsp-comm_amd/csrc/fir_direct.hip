@@ -678,7 +678,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
             {
                 const size_t off = (lds + 15) & ~(size_t)15;
                 const size_t obytes = (size_t)4 * 64 * (R + 1) * esz;
-                if (off + obytes <= lds_cap) { w.out_off = (int)off; lds = off + obytes; }
+                if (a.Lp > 1 && off + obytes <= lds_cap) { w.out_off = (int)off; lds = off + obytes; }  // Lp == 1 stores 16-byte vectors directly
             }
 #define SK_SWQ(XT, BT, RR, QQ)                                                                                        \
     do {                                                                                                              \
