@@ -125,7 +125,12 @@ __device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t
     if (A.n != -12345) return;
 #endif
     if (full) {
-        float4 *yp = reinterpret_cast<float4 *>(A.y + out0 + 2 * t);
+        // recompute the per-thread offset here: hoisted out of the tile loop it is a 64-bit VGPR pair
+        // that hipcc spills, and the scratch reload's s_waitcnt vmcnt(0) then drains the whole
+        // x(tile+1) prefetch in front of the stores (vmcnt retires in order)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        float4 *yp = reinterpret_cast<float4 *>(A.y + out0 + 2 * tt);
 #pragma unroll
         for (int a = 0; a < 16; ++a)
 #if SKDSP_OLS_NT
@@ -281,6 +286,14 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
     cf v[32];
 #if SKDSP_OLS_PREFETCH
     if (tile < A.ntiles) load_any<REAL>(A, tile, t, v);
+    // the loop is entered with no load pending on either edge (see the note in front of the stores):
+    // waits placed at the loop top for THIS load would otherwise also be paid by every later tile,
+    // where the only pending vector-memory operations are the previous tile's stores
+#pragma unroll
+    for (int i = 0; i < 32; i += 8)
+        asm volatile("" ::"v"(v[i].x), "v"(v[i].y), "v"(v[i + 1].x), "v"(v[i + 1].y), "v"(v[i + 2].x), "v"(v[i + 2].y),
+                     "v"(v[i + 3].x), "v"(v[i + 3].y), "v"(v[i + 4].x), "v"(v[i + 4].y), "v"(v[i + 5].x), "v"(v[i + 5].y),
+                     "v"(v[i + 6].x), "v"(v[i + 6].y), "v"(v[i + 7].x), "v"(v[i + 7].y));
 #endif
     for (; tile < A.ntiles; tile += gridDim.x, ++it) {
         SK_STAMP(0);
@@ -319,6 +332,17 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         SK_STAMP(6);
         inv_pass1(t, tw, lds, v);
         SK_STAMP(7);
+#if SKDSP_OLS_PREFETCH
+        // Have hipcc wait for the prefetch HERE, while only loads are outstanding (they have had the
+        // whole inverse FFT to land).  Otherwise the wait sits at the top of the next tile, behind the
+        // stores below, and vmcnt -- which retires in order -- makes every tile start with a full
+        // round trip of its predecessor's stores.
+#pragma unroll
+        for (int i = 0; i < 32; i += 8)
+            asm volatile("" ::"v"(nx[i].x), "v"(nx[i].y), "v"(nx[i + 1].x), "v"(nx[i + 1].y), "v"(nx[i + 2].x), "v"(nx[i + 2].y),
+                         "v"(nx[i + 3].x), "v"(nx[i + 3].y), "v"(nx[i + 4].x), "v"(nx[i + 4].y), "v"(nx[i + 5].x), "v"(nx[i + 5].y),
+                         "v"(nx[i + 6].x), "v"(nx[i + 6].y), "v"(nx[i + 7].x), "v"(nx[i + 7].y));
+#endif
         store_any<REAL>(A, tile, t, v);
         SK_STAMP(8);
 #if SKDSP_OLS_PREFETCH
