@@ -355,14 +355,14 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
             if constexpr (std::is_same<X, float2>::value && std::is_same<B, float>::value && R == 8) if (a.tap_off >= 0) {
                 const v2f *g2 = reinterpret_cast<const v2f *>(grp);
                 const tap2_t *tq = reinterpret_cast<const tap2_t *>(smem_raw + a.tap_off + (c & 1) * a.tap_cnt * 4) + (size_t)j * a.nB * 4;
-                v2f wa[8], wb[8], wc[8], mid2[8], acc2[8];
+                v2f wa[8], wb[8], wc[8], mid2[8];
+                v2f *acc2 = reinterpret_cast<v2f *>(acc);  // the class accumulator itself (X = float2)
                 tap2_t ta[4], tb2[4], tc[4];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     wa[e] = g2[q * e];
                     wb[e] = g2[q * e - (P + 1)];
                     mid2[e] = v2f{0.f, 0.f};
-                    acc2[e] = v2f{0.f, 0.f};
                 }
 #pragma unroll
                 for (int u_ = 0; u_ < 4; ++u_) ta[u_] = tq[u_];
@@ -401,8 +401,6 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     acc2[r] += mid2[r];
-                    acc[r].x += acc2[r].x;
-                    acc[r].y += acc2[r].y;
                 }
                 continue;
             }
@@ -465,6 +463,7 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
         // element e of a wave's output run = LPT * slot + class; 16 lanes (16*LPT*R consecutive
         // elements) go through the wave-private tile per pass and leave as 512-byte rows
         static_assert(16 * (LPT * R + 1) <= 64 * (R + 1), "output tile too small");
+        __syncthreads();  // the tiles reuse the front of the window image: every wave is done with it
         const int wave = tid >> 6, lane = tid & 63;
         X *ot = reinterpret_cast<X *>(smem_raw + a.out_off) + (size_t)wave * (64 * (R + 1));
         const int64_t mw = (int64_t)LPT * (s0 + (int64_t)R * 64 * wave);
@@ -475,7 +474,7 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int c = 0; c < LPT; ++c) row[LPT * r + c] = (a.L == 1) ? accs[c][r] : scl(accs[c][r], gain);
+                    for (int c = 0; c < LPT; ++c) row[LPT * r + c] = scl(accs[c][r], gain);  // LPT > 1 means L > 1
             }
 #pragma unroll
             for (int k = 0; k < LPT * R / 4; ++k) {
@@ -675,7 +674,11 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
                 if (off + 2 * tbytes <= lds_cap) { w.tap_off = (int)off; w.tap_cnt = (int)(tbytes / 4); lds = off + 2 * tbytes; }
             }
             w.out_off = -1;
-            {
+            const bool lpt_ok = h->dtype == SKDSP_C64 && !h->taps_complex && R == 8 && w.tap_off >= 0 && a.Lp >= 2 && a.Lp <= 4 &&
+                                !getenv("SKDSP_SW_NO_LPT");
+            if (lpt_ok) {
+                w.out_off = 0;  // unrolled-class kernel: its output tiles alias the (finished) window image
+            } else {
                 const size_t off = (lds + 15) & ~(size_t)15;
                 const size_t obytes = (size_t)4 * 64 * (R + 1) * esz;
                 if (a.Lp > 1 && off + obytes <= lds_cap) { w.out_off = (int)off; lds = off + obytes; }  // Lp == 1 stores 16-byte vectors directly
@@ -716,8 +719,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
         else if (q == 3) SK_SWL(3, LL);               \
         else SK_SWL(0, LL);                           \
     } while (0)
-            if (h->dtype == SKDSP_C64 && !h->taps_complex && R == 8 && w.tap_off >= 0 && w.out_off >= 0 && a.Lp >= 2 &&
-                a.Lp <= 4 && !getenv("SKDSP_SW_NO_LPT")) {
+            if (lpt_ok) {
                 if (a.Lp == 2) SK_SWLQ(2);
                 else if (a.Lp == 3) SK_SWLQ(3);
                 else SK_SWLQ(4);
