@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         for (int i = 0; i < 32; i += 8)
             asm volatile("" ::"v"(nx[i].x), "v"(nx[i].y), "v"(nx[i + 1].x), "v"(nx[i + 1].y), "v"(nx[i + 2].x), "v"(nx[i + 2].y),
                          "v"(nx[i + 3].x), "v"(nx[i + 3].y), "v"(nx[i + 4].x), "v"(nx[i + 4].y), "v"(nx[i + 5].x), "v"(nx[i + 5].y),
-                         "v"(nx[i + 6].x), "v"(nx[i + 6].y), "v"(nx[i + 7].x), "v"(nx[i + 7].y));
+                         "v"(nx[i + 6].x), "v"(nx[i + 6].y), "v"(nx[i + 7].x), "v"(nx[i + 7].y)
+                         : "memory");
 #endif
         store_any<REAL>(A, tile, t, v);
         SK_STAMP(8);
