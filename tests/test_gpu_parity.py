@@ -864,3 +864,54 @@ def test_c64_polyphase_large_tiles(L, M):
         w = min(len(ref) - skip, n_out - m0, 4000)
         assert w > 1000
         assert_close(yd.to_host(m0, w), ref[skip:skip + w], TOL32, "L=%d M=%d window @%d" % (L, M, s_in))
+
+
+# ---------------------------------------------------------------------------------------------
+# C-ABI error behaviour on a live device: status codes + messages, no crashes, no side effects
+# ---------------------------------------------------------------------------------------------
+def test_c_abi_rejects_bad_arguments():
+    import ctypes
+    L = _ffi.load()
+    vp = ctypes.c_void_p
+    b = np.ones(8)
+    fir = _ffi.FirKernel(b, _ffi.C64)
+    iir = _ffi.IirKernel(_ffi.F32, sos=np.array([[1.0, 0, 0, 1, -0.5, 0]]))
+    x = _ffi.DeviceArray(1024, np.complex64).fill_noise(1)
+    y = _ffi.DeviceArray(4096, np.complex64)
+
+    def code(rc):
+        assert rc != 0
+        msg = L.skdsp_last_error().decode()
+        assert msg, "an error status must come with a message"
+        return rc
+
+    # wrong handle kind, factors < 1, null handle
+    assert code(L.skdsp_fir_filter_dev(vp(iir.h), vp(x.ptr), 1024, 0, vp(y.ptr))) == -1
+    assert code(L.skdsp_iir_filter_dev(vp(fir.h), vp(x.ptr), 1024, vp(y.ptr))) == -1
+    assert code(L.skdsp_fir_up_dev(vp(fir.h), vp(x.ptr), 1024, 0, 0, vp(y.ptr))) == -1
+    assert code(L.skdsp_fir_dn_dev(vp(fir.h), vp(x.ptr), 1024, 0, 0, vp(y.ptr))) == -1
+    assert code(L.skdsp_fir_filter_dev(vp(0), vp(x.ptr), 1024, 0, vp(y.ptr))) == -1
+    # creation: no taps, bad dtype, complex taps for a real signal, sos without a0 == 1
+    h = vp(0)
+    assert code(L.skdsp_fir_create(_ffi._ptr(b), 0, 0, _ffi.C64, ctypes.byref(h))) == -1
+    assert code(L.skdsp_fir_create(_ffi._ptr(b), 8, 0, 99, ctypes.byref(h))) == -1
+    bad_sos = np.array([[1.0, 0, 0, 2.0, -0.5, 0]])
+    assert code(L.skdsp_sos_create(_ffi._ptr(bad_sos), 1, _ffi.F32, ctypes.byref(h))) == -1
+    bc = np.ones(4, dtype=np.complex128)
+    rc = L.skdsp_fir_create(_ffi._ptr(bc), 4, 1, _ffi.F32, ctypes.byref(h))
+    if rc == 0:  # creation may defer the check to the first launch
+        xr = _ffi.DeviceArray(64, np.float32).fill_noise(2)
+        yr = _ffi.DeviceArray(64, np.float32)
+        assert code(L.skdsp_fir_filter_dev(h, vp(xr.ptr), 64, 0, vp(yr.ptr))) == -1
+        L.skdsp_destroy(h)
+    else:
+        assert rc == -1
+    # zero-length work is a no-op, not an error
+    assert L.skdsp_fir_filter_dev(vp(fir.h), vp(x.ptr), 0, 0, vp(y.ptr)) == 0
+    assert L.skdsp_iir_filter_dev(vp(iir.h), vp(x.ptr), 0, vp(y.ptr)) == 0
+    assert L.skdsp_upsample_dev(vp(x.ptr), 0, 3, _ffi.C64, ctypes.c_double(1.0), vp(y.ptr)) == 0
+    # the library still works after all of that
+    fir.filter_dev(x, y, 1024)
+    _ffi.sync()
+    ref = orc.fir_filter(b, x.to_host())
+    assert_close(y.to_host(0, 1024), ref, TOL32, "after errors")
