@@ -132,6 +132,10 @@ int skdsp_upsample_dev(const void *x_dev, int64_t n, int L, int dtype, double sc
 int skdsp_downsample(const void *x, int64_t n, int M, int p, int dtype, void *y);
 int skdsp_downsample_dev(const void *x_dev, int64_t n, int M, int p, int dtype, void *y_dev);
 
+/* Host-pointer entry points of a float32/complex64 handle deliver y as float64/complex128 (the
+ * reference's result dtype, multirate_helper.py:108 etc.): widened on the device before the copy
+ * back, so y must hold twice the bytes.  Device-pointer (_dev) entry points are not affected. */
+int skdsp_set_wide_output(skdsp_handle h, int on);
 int skdsp_destroy(skdsp_handle h);
 
 /* ---- sample-block sharding across GPUs (one process per GPU, RCCL) ------- */

@@ -138,8 +138,17 @@ static int stage_in(const void *x_host, size_t bytes, void **x_dev)
     return SKDSP_OK;
 }
 
-static int stage_out(void *y_host, const void *y_dev, size_t bytes)
+static int stage_out(void *y_host, const void *y_dev, size_t bytes, const HandleBase *h = nullptr)
 {
+    if (bytes && h && h->wide_out && !dtype_double(h->dtype)) {
+        // widen on the device (slot 0 held x, which the kernels are done with in stream order)
+        void *wide = nullptr;
+        int rc = ws_reserve(0, 2 * bytes + 256, &wide);
+        if (rc) return rc;
+        if ((rc = widen_launch(y_dev, (int64_t)(bytes / 4), wide, ctx().stream))) return rc;
+        y_dev = wide;
+        bytes *= 2;
+    }
     if (bytes) SK_HIP(hipMemcpyAsync(y_host, y_dev, bytes, hipMemcpyDeviceToHost, ctx().stream));
     SK_HIP(hipStreamSynchronize(ctx().stream));
     return SKDSP_OK;
@@ -610,7 +619,7 @@ static int fir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M
     if (mode == 0) rc = fir_filter_any(h, x_dev, n, 0, y_dev);
     else rc = fir_direct_launch(h, x_dev, n, 0, L, M, n_out, y_dev, ctx().stream);
     if (rc) return rc;
-    return stage_out(y, y_dev, (size_t)n_out * esz);
+    return stage_out(y, y_dev, (size_t)n_out * esz, h);
 }
 
 int skdsp_fir_filter(skdsp_handle h, const void *x, int64_t n, void *y) { return fir_host_call(h, x, n, 1, 1, 0, y); }
@@ -764,7 +773,7 @@ static int iir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M
         if ((rc = ws_reserve(1, (size_t)n * esz + 256, &y_dev))) return rc;
         if ((rc = iir_any_dev(h, x_dev, n, y_dev))) return rc;
     }
-    return stage_out(y, y_dev, (size_t)n_out * esz);
+    return stage_out(y, y_dev, (size_t)n_out * esz, h);
 }
 
 int skdsp_iir_filter(skdsp_handle h, const void *x, int64_t n, void *y) { return iir_host_call(h, x, n, 1, 1, y); }
@@ -814,6 +823,15 @@ int skdsp_downsample(const void *x, int64_t n, int M, int p, int dtype, void *y)
     if ((rc = ws_reserve(1, (size_t)n_out * esz + 256, &y_dev))) return rc;
     if ((rc = downsample_launch(x_dev, n, M, p, dtype, y_dev, ctx().stream))) return rc;
     return stage_out(y, y_dev, (size_t)n_out * esz);
+}
+
+int skdsp_set_wide_output(skdsp_handle hh, int on)
+{
+    HandleBase *b = reinterpret_cast<HandleBase *>(hh);
+    SK_CHECK(b && (b->kind == H_FIR || b->kind == H_IIR), SKDSP_ERR_BADARG, "set_wide_output: not a filter handle");
+    std::lock_guard<std::mutex> lk(b->mu);
+    b->wide_out = on != 0;
+    return SKDSP_OK;
 }
 
 int skdsp_destroy(skdsp_handle hh)

@@ -59,6 +59,7 @@ enum HandleKind { H_FIR = 1, H_IIR = 2 };
 struct HandleBase {
     int kind;
     int dtype;
+    bool wide_out = false;  // host-pointer entry points deliver float64/complex128 (skdsp_set_wide_output)
     std::mutex mu;
     virtual ~HandleBase() {}
 };
@@ -110,6 +111,7 @@ int upsample_launch(const void *x_dev, int64_t n, int L, int dtype, double scale
 int downsample_launch(const void *x_dev, int64_t n, int M, int p, int dtype, void *y_dev, hipStream_t s);
 int deinterleave_launch(const void *x_dev, int64_t n, int dtype_complex_in, void *re_dev, void *im_dev, hipStream_t s);
 int interleave_launch(const void *re_dev, const void *im_dev, int64_t n, int dtype_complex_out, void *y_dev, hipStream_t s);
+int widen_launch(const void *src_dev, int64_t nscalars, void *dst_dev, hipStream_t s);  // float32 -> float64
 int fill_noise_launch(void *x_dev, int64_t n, int dtype, uint64_t seed, int64_t first, hipStream_t s);
 
 }  // namespace skdsp

@@ -29,7 +29,7 @@ SYMBOLS = [
     "skdsp_fir_up", "skdsp_fir_up_dev", "skdsp_fir_dn", "skdsp_fir_dn_dev", "skdsp_fir_updn", "skdsp_fir_updn_dev",
     "skdsp_sos_create", "skdsp_tf_create", "skdsp_tf2sos", "skdsp_iir_filter", "skdsp_iir_filter_dev", "skdsp_iir_up",
     "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev", "skdsp_iir_state_len", "skdsp_iir_filter_state_dev",
-    "skdsp_upsample", "skdsp_upsample_dev", "skdsp_downsample", "skdsp_downsample_dev", "skdsp_destroy",
+    "skdsp_upsample", "skdsp_upsample_dev", "skdsp_downsample", "skdsp_downsample_dev", "skdsp_set_wide_output", "skdsp_destroy",
     "skdsp_dist_unique_id", "skdsp_dist_init", "skdsp_dist_shutdown", "skdsp_dist_barrier",
     "skdsp_dist_allreduce_max", "skdsp_dist_allreduce_sum", "skdsp_dist_sendrecv", "skdsp_dist_allgather", "skdsp_dist_halo_exchange", "skdsp_fir_filter_shard_dev",
 ]
@@ -103,6 +103,7 @@ def load():
         L.skdsp_dist_init.argtypes = [ci, ci, vp]
         L.skdsp_dist_allreduce_max.argtypes = [ctypes.POINTER(ctypes.c_double)]
         L.skdsp_dist_allreduce_sum.argtypes = [ctypes.POINTER(ctypes.c_double)]
+        L.skdsp_set_wide_output.argtypes = [vp, ci]
         L.skdsp_dist_allgather.argtypes = [vp, vp, i64]
         L.skdsp_dist_sendrecv.argtypes = [vp, ci, vp, ci, i64]
         L.skdsp_dist_allgather.argtypes = [vp, vp, i64]
@@ -237,7 +238,25 @@ def _destroy(h):
         pass
 
 
-class FirKernel:
+_WIDE = {np.dtype(np.float32): np.dtype(np.float64), np.dtype(np.complex64): np.dtype(np.complex128)}
+
+
+class _HostCalls:
+    """Shared by FirKernel / IirKernel: output allocation for the host-pointer entry points.
+    wide=True asks the library for float64/complex128 results from a float32/complex64 handle
+    (widened on the device: skdsp_set_wide_output)."""
+    _wide_state = False
+
+    def _out(self, count, dtype, wide):
+        dtype = np.dtype(dtype)
+        wide = bool(wide) and dtype in _WIDE
+        if wide != self._wide_state:
+            check(load().skdsp_set_wide_output(ctypes.c_void_p(self.h), int(wide)))
+            self._wide_state = wide
+        return np.empty(count, dtype=_WIDE[dtype] if wide else dtype)
+
+
+class FirKernel(_HostCalls):
     """A device FIR handle for one (taps, signal dtype) pair."""
 
     def __init__(self, taps, code):
@@ -261,23 +280,23 @@ class FirKernel:
         return a.value
 
     # host vectors ------------------------------------------------------
-    def filter(self, x):
-        y = np.empty(x.size, dtype=x.dtype)
+    def filter(self, x, wide=False):
+        y = self._out(x.size, x.dtype, wide)
         check(load().skdsp_fir_filter(ctypes.c_void_p(self.h), _ptr(x), x.size, _ptr(y)))
         return y
 
-    def up(self, x, L):
-        y = np.empty(x.size * L, dtype=x.dtype)
+    def up(self, x, L, wide=False):
+        y = self._out(x.size * L, x.dtype, wide)
         check(load().skdsp_fir_up(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), _ptr(y)))
         return y
 
-    def dn(self, x, M):
-        y = np.empty(x.size // M, dtype=x.dtype)
+    def dn(self, x, M, wide=False):
+        y = self._out(x.size // M, x.dtype, wide)
         check(load().skdsp_fir_dn(ctypes.c_void_p(self.h), _ptr(x), x.size, int(M), _ptr(y)))
         return y
 
-    def updn(self, x, L, M):
-        y = np.empty((x.size * L) // M, dtype=x.dtype)
+    def updn(self, x, L, M, wide=False):
+        y = self._out((x.size * L) // M, x.dtype, wide)
         check(load().skdsp_fir_updn(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), int(M), _ptr(y)))
         return y
 
@@ -304,7 +323,7 @@ class FirKernel:
         check(load().skdsp_fir_filter_shard_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, ctypes.c_void_p(yd.ptr)))
 
 
-class IirKernel:
+class IirKernel(_HostCalls):
     """A device IIR handle: cascaded biquads (sos) or a transfer function (b, a)."""
 
     def __init__(self, code, sos=None, b=None, a=None):
@@ -321,18 +340,18 @@ class IirKernel:
         self.h = h.value
         self._fin = weakref.finalize(self, _destroy, self.h)
 
-    def filter(self, x):
-        y = np.empty(x.size, dtype=x.dtype)
+    def filter(self, x, wide=False):
+        y = self._out(x.size, x.dtype, wide)
         check(load().skdsp_iir_filter(ctypes.c_void_p(self.h), _ptr(x), x.size, _ptr(y)))
         return y
 
-    def up(self, x, L):
-        y = np.empty(x.size * L, dtype=x.dtype)
+    def up(self, x, L, wide=False):
+        y = self._out(x.size * L, x.dtype, wide)
         check(load().skdsp_iir_up(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), _ptr(y)))
         return y
 
-    def dn(self, x, M):
-        y = np.empty(x.size // M, dtype=x.dtype)
+    def dn(self, x, M, wide=False):
+        y = self._out(x.size // M, x.dtype, wide)
         check(load().skdsp_iir_dn(ctypes.c_void_p(self.h), _ptr(x), x.size, int(M), _ptr(y)))
         return y
 

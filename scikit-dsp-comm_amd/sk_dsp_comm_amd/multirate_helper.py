@@ -44,6 +44,12 @@ def _finish(y, ref_dt):
     return y.astype(ref_dt, copy=False) if config.strict_dtype else y
 
 
+def _wide():
+    """strict_dtype: float32/complex64 kernels hand back float64/complex128 (widened on the device,
+    which is 6x cheaper than astype() on the host); _finish() is then a no-op."""
+    return bool(config.strict_dtype)
+
+
 def _rows(fn, xg):
     """Apply a 1-D kernel call along the last axis (lfilter/sosfilt semantics for N-D)."""
     if xg.ndim == 1:
@@ -85,7 +91,7 @@ class multirate_FIR(object):
         if xg.size == 0:
             raise ValueError("v cannot be empty")
         k = self._kern.get(xg.dtype)
-        return _finish(_rows(k.filter, xg), ref_dt)
+        return _finish(_rows(lambda r: k.filter(r, wide=_wide()), xg), ref_dt)
 
     def up(self, x, L_change=12):
         """y = lfilter(b, [1], L*upsample(x, L))  (multirate_helper.py:112-118), polyphase on the GPU."""
@@ -94,7 +100,7 @@ class multirate_FIR(object):
         if xg.size == 0:
             raise ValueError("v cannot be empty")
         k = self._kern.get(xg.dtype)
-        y = k.up(xg, Li)
+        y = k.up(xg, Li, wide=_wide())
         if gain_fix != 1.0:
             y = y * y.dtype.type(gain_fix) if not np.iscomplexobj(y) else y * gain_fix
         return _finish(y, ref_dt)
@@ -113,7 +119,7 @@ class multirate_FIR(object):
         if nk == 0:
             return np.zeros(0, dtype=ref_dt if config.strict_dtype else xg.dtype)
         k = self._kern.get(xg.dtype)
-        return _finish(k.dn(xg, M_change), ref_dt)
+        return _finish(k.dn(xg, M_change, wide=_wide()), ref_dt)
 
     # --- extension: fused rational resampler (BASELINE.json config 3) --------
     def updn(self, x, L_change, M_change):
@@ -123,7 +129,7 @@ class multirate_FIR(object):
         Li, gain_fix = _stuff_factor(x, L_change)
         xg, ref_dt = _signal(x, self._bc)
         k = self._kern.get(xg.dtype)
-        y = k.updn(xg, Li, M_change)
+        y = k.updn(xg, Li, M_change, wide=_wide())
         if gain_fix != 1.0:
             y = y * gain_fix
         return _finish(y, ref_dt)
@@ -203,15 +209,15 @@ class multirate_IIR(object):
 
     def _chain(self, xg, first):
         ks = self._kern.get(xg.dtype)
-        y = first(ks[0], xg)
-        for k in ks[1:]:
-            y = k.filter(y)
+        y = first(ks[0], xg, _wide() and len(ks) == 1)
+        for i, k in enumerate(ks[1:]):
+            y = k.filter(y, wide=_wide() and i == len(ks) - 2)
         return y
 
     def filter(self, x):
         """y = sosfilt(sos, x)  (multirate_helper.py:169-174)"""
         xg, ref_dt = self._prep(x)
-        return _finish(_rows(lambda r: self._chain(r, lambda k, v: k.filter(v)), xg), ref_dt)
+        return _finish(_rows(lambda r: self._chain(r, lambda k, v, w: k.filter(v, wide=w)), xg), ref_dt)
 
     # --- extension: block streaming (SURVEY.md 8f-3; the reference always restarts from rest) ---
     def filter_stream(self, x, zi=None):
@@ -250,7 +256,7 @@ class multirate_IIR(object):
         """y = sosfilt(sos, L*upsample(x, L))  (multirate_helper.py:177-183)"""
         Li, gain_fix = _stuff_factor(x, L_change)
         xg, ref_dt = self._prep(x)
-        y = self._chain(xg, lambda k, v: k.up(v, Li))
+        y = self._chain(xg, lambda k, v, w: k.up(v, Li, wide=w))
         if gain_fix != 1.0:
             y = y * gain_fix
         return _finish(y, np.result_type(ref_dt, np.float64))
@@ -267,7 +273,7 @@ class multirate_IIR(object):
         y = xg
         for k in ks[:-1]:
             y = k.filter(y)
-        return _finish(ks[-1].dn(y, M_change), ref_dt)
+        return _finish(ks[-1].dn(y, M_change, wide=_wide()), ref_dt)
 
     def freq_resp(self, mode='dB', fs=8000, ylim=[-100, 2]):
         return _delegate_plot("multirate_IIR", self.sos, "freq_resp", mode, fs, ylim)
@@ -304,7 +310,7 @@ class rate_change(object):
         xg, ref_dt = _signal(x)
         if xg.size == 0:
             return np.zeros(0, dtype=ref_dt)
-        y = self._kern.get(xg.dtype).up(xg, Li)
+        y = self._kern.get(xg.dtype).up(xg, Li, wide=_wide())
         if gain_fix != 1.0:
             y = y * gain_fix
         return _finish(y, ref_dt)
@@ -320,7 +326,7 @@ class rate_change(object):
                              % (xg.size, int(np.floor(len(xg) / self.M)), self.M))
         if len(xg) // self.M == 0:
             return np.zeros(0, dtype=ref_dt)
-        return _finish(self._kern.get(xg.dtype).dn(xg, self.M), ref_dt)
+        return _finish(self._kern.get(xg.dtype).dn(xg, self.M, wide=_wide()), ref_dt)
 
 
 # ------------------------------------------------------------------ helpers

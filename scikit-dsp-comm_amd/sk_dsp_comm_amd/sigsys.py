@@ -169,7 +169,7 @@ def interp24(x):
         return np.zeros(0, dtype=ref_dt)
     y = xg
     for L in (2, 3, 4):
-        y = _butter_stage(10, 1.0 / L, y.dtype).up(y, L)
+        y = _butter_stage(10, 1.0 / L, y.dtype).up(y, L, wide=config.strict_dtype and L == 4)
     return mrh._finish(y, ref_dt)
 
 
@@ -185,7 +185,7 @@ def deci24(x):
     for M in (2, 3, 4):
         if len(y) // M == 0:
             return np.zeros(0, dtype=ref_dt if config.strict_dtype else xg.dtype)
-        y = _butter_stage(10, 1.0 / M, y.dtype).dn(y, M)
+        y = _butter_stage(10, 1.0 / M, y.dtype).dn(y, M, wide=config.strict_dtype and M == 4)
     return mrh._finish(y, ref_dt)
 
 
@@ -217,7 +217,7 @@ def ten_band_eq_filt(x, GdB, Q=3.5):
     xg, ref_dt = _lfilter_dtype(x)
     if xg.size == 0:
         return np.zeros(0)
-    y = _ffi.IirKernel(_ffi.code_of(xg.dtype), sos=sos).filter(xg)
+    y = _ffi.IirKernel(_ffi.code_of(xg.dtype), sos=sos).filter(xg, wide=config.strict_dtype)
     return mrh._finish(y, ref_dt)
 
 

@@ -1,14 +1,53 @@
-import sys, time, numpy as np
-sys.path.insert(0,'scikit-dsp-comm_amd'); sys.path.insert(0,'.')
-import bench
-from sk_dsp_comm_amd import multirate_helper as mrh, config
-b=bench.firwin_lowpass(1024,0.2)
-f=mrh.multirate_FIR(b)
-rng=np.random.default_rng(0)
-n=1<<24
-x=((rng.standard_normal(n)+1j*rng.standard_normal(n))/np.sqrt(2)).astype(np.complex64)
+"""Where the time of the NumPy-in / NumPy-out API goes (PCIe-inclusive; never bench.py's `value`).
+    python tools/host_api_time.py        (on a GPU box, from the repo root)"""
+import ctypes
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, 'scikit-dsp-comm_amd')
+sys.path.insert(0, '.')
+import bench  # noqa: E402
+from sk_dsp_comm_amd import _ffi, multirate_helper as mrh, config  # noqa: E402
+
+b = bench.firwin_lowpass(1024, 0.2)
+f = mrh.multirate_FIR(b)
+rng = np.random.default_rng(0)
+n = 1 << 24
+x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2)).astype(np.complex64)
 f.filter(x[:100000])
-for strict in (True, False):
-    config.strict_dtype=strict
-    t0=time.perf_counter(); y=f.filter(x); dt=time.perf_counter()-t0
-    print("host API 2^24 c64, strict_dtype=%s: %.1f ms -> %.1f MS/s (dtype %s)"%(strict, dt*1e3, n/dt/1e6, y.dtype))
+
+
+def best(fn, reps=5):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = fn()
+        ts.append(time.perf_counter() - t0)
+    return min(ts) * 1e3, r
+
+
+for strict in (False, True, False):
+    config.strict_dtype = strict
+    ms, y = best(lambda: f.filter(x))
+    print("multirate_FIR.filter, 2^24 c64, strict_dtype=%s: %.1f ms -> %.0f MS/s (result %s)" % (strict, ms, n / ms / 1e3, y.dtype))
+
+# the pieces, through the C ABI directly
+k = _ffi.FirKernel(b, _ffi.C64)
+L = _ffi.load()
+y = np.empty_like(x)
+ms, _ = best(lambda: _ffi.check(L.skdsp_fir_filter(ctypes.c_void_p(k.h), _ffi._ptr(x), n, _ffi._ptr(y))))
+print("skdsp_fir_filter (host pointers, output array already touched): %.1f ms" % ms)
+ms, _ = best(lambda: np.empty_like(x).fill(0))
+print("first touch of a fresh 128 MiB output array (np.empty + fill): %.1f ms" % ms)
+xd = _ffi.DeviceArray(n, np.complex64)
+yd = _ffi.DeviceArray(n, np.complex64)
+ms, _ = best(lambda: xd.write(x))
+print("H2D 128 MiB: %.1f ms" % ms)
+ms, _ = best(lambda: (k.filter_dev(xd, yd), _ffi.sync()))
+print("kernel: %.2f ms" % ms)
+ms, _ = best(lambda: _ffi.check(L.skdsp_memcpy_d2h(_ffi._ptr(y), ctypes.c_void_p(yd.ptr), y.nbytes)))
+print("D2H 128 MiB into a touched array: %.1f ms" % ms)
+ms, _ = best(lambda: x.astype(np.complex128))
+print("astype(complex128) of the result (strict_dtype): %.1f ms" % ms)
