@@ -114,6 +114,8 @@ static int pick_fir_algo(const FirHandle *h, int64_t n)
     return SKDSP_FIR_DIRECT;
 }
 
+int fir_algo_for(const FirHandle *h, int64_t n) { return pick_fir_algo(h, n); }
+
 static int fir_filter_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev)
 {
     if (pick_fir_algo(h, n) == SKDSP_FIR_OLS) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream);

@@ -78,11 +78,11 @@ static int rccl_load()
 
 // one grouped point-to-point step on the compute stream: send `bytes` to rank dst (if >= 0),
 // receive `bytes` from rank src (if >= 0)
-static int sendrecv_locked(const void *sendbuf, int dst, void *recvbuf, int src, size_t bytes)
+static int sendrecv_locked(const void *sendbuf, int dst, void *recvbuf, int src, size_t bytes, hipStream_t s = nullptr)
 {
     Rccl &r = rc();
     SK_CHECK(r.comm, SKDSP_ERR_RCCL, "dist: no communicator (call skdsp_dist_init first)");
-    hipStream_t s = ctx().stream;
+    if (!s) s = ctx().stream;
     SK_NCCL(r.GroupStart());
     if (dst >= 0) SK_NCCL(r.Send(sendbuf, bytes, ncclUint8, dst, r.comm, s));
     if (src >= 0) SK_NCCL(r.Recv(recvbuf, bytes, ncclUint8, src, r.comm, s));
@@ -90,10 +90,10 @@ static int sendrecv_locked(const void *sendbuf, int dst, void *recvbuf, int src,
     return SKDSP_OK;
 }
 
-static int halo_exchange_locked(void *x_dev, int64_t n, int64_t n_halo, int dtype)
+static int halo_exchange_locked(void *x_dev, int64_t n, int64_t n_halo, int dtype, hipStream_t s = nullptr)
 {
     Rccl &r = rc();
-    hipStream_t s = ctx().stream;
+    if (!s) s = ctx().stream;
     const size_t esz = dtype_size(dtype);
     SK_CHECK(n_halo >= 0 && n_halo <= n, SKDSP_ERR_BADARG,
              "halo_exchange: halo of %lld samples needs a shard of at least that many (got %lld)", (long long)n_halo,
@@ -108,7 +108,7 @@ static int halo_exchange_locked(void *x_dev, int64_t n, int64_t n_halo, int dtyp
     const size_t bytes = (size_t)n_halo * esz;
     if (r.rank == 0) SK_HIP(hipMemsetAsync(halo, 0, bytes, s));  // zero initial state
     return sendrecv_locked(x0 + (size_t)(n - n_halo) * esz, r.rank + 1 < r.world ? r.rank + 1 : -1, halo,
-                           r.rank > 0 ? r.rank - 1 : -1, bytes);
+                           r.rank > 0 ? r.rank - 1 : -1, bytes, s);
 }
 
 static int allreduce_locked(double *value, ncclRedOp_t op)
@@ -255,6 +255,34 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
         SK_CHECK(b && b->kind == H_FIR, SKDSP_ERR_BADARG, "fir_filter_shard: not a FIR handle");
         h = static_cast<FirHandle *>(b);
         halo = h->ntaps - 1;
+        // Overlap-save shards: only tile 0 reads the halo.  Tiles 1.. are the same problem started
+        // V samples in (their history is local), so they run on the compute stream while the
+        // 8 KB halo crosses xGMI on a second stream; tile 0 follows once it has landed.
+        int V = 0;
+        if (h->dtype == SKDSP_C64 && rc().comm && fir_algo_for(h, n_local) == SKDSP_FIR_OLS &&
+            !getenv("SKDSP_SHARD_NO_OVERLAP")) {
+            int r0 = fir_ols_tile_outputs(h, &V);
+            if (r0) return r0;
+        }
+        if (V > 0 && n_local >= 4 * (int64_t)V && V >= halo) {
+            Context &c = ctx();
+            if (!c.comm_stream) {
+                SK_HIP(hipStreamCreateWithFlags(&c.comm_stream, hipStreamNonBlocking));
+                SK_HIP(hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
+                SK_HIP(hipEventCreateWithFlags(&c.ev_halo, hipEventDisableTiming));
+            }
+            std::lock_guard<std::mutex> lk(h->mu);
+            const size_t esz = dtype_size(h->dtype);
+            SK_HIP(hipEventRecord(c.ev_in, c.stream));            // x (and its tail, which is sent) is ready
+            SK_HIP(hipStreamWaitEvent(c.comm_stream, c.ev_in, 0));
+            int r1 = halo_exchange_locked(x_dev, n_local, halo, h->dtype, c.comm_stream);
+            if (r1) return r1;
+            SK_HIP(hipEventRecord(c.ev_halo, c.comm_stream));
+            r1 = fir_ols_launch(h, (char *)x_dev + (size_t)V * esz, n_local - V, V, (char *)y_dev + (size_t)V * esz, c.stream);
+            if (r1) return r1;
+            SK_HIP(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
+            return fir_ols_launch(h, x_dev, V, halo, y_dev, c.stream);
+        }
         int r = halo_exchange_locked(x_dev, n_local, halo, h->dtype);
         if (r) return r;
     }

@@ -59,7 +59,7 @@ struct OlsArgs {
     const float4 *Hh;
     unsigned long long *trace;  // developer phase timing (SKDSP_OLS_TRACE), else null
     int ov, V, a0;  // a0 = ov / 512: first stored 512-block
-    int aligned;    // x and y 16-byte aligned
+    int aligned;    // x and y element-aligned (8 bytes complex64, 4 bytes float32)
     int64_t ntiles;
 };
 
@@ -559,6 +559,14 @@ void fir_ols_free(OlsPlan *p)
     delete p;
 }
 
+int fir_ols_tile_outputs(FirHandle *h, int *V)
+{
+    int rc = ensure_plan(h);
+    if (rc) return rc;
+    *V = h->ols->V;
+    return SKDSP_OK;
+}
+
 int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s)
 {
     if (n <= 0) return SKDSP_OK;
@@ -574,7 +582,9 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.T1 = p->T1; A.T2 = p->T2; A.Hp = p->Hp; A.T1h = p->T1h; A.Hh = p->Hh;
     A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512;
     const bool real = h->dtype == SKDSP_F32;
-    A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    // element alignment is all the vector accesses need: tile starts are odd multiples of the
+    // element size anyway (V = 8192 - (Ntaps-1) is odd for even tap counts)
+    A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & (real ? 3 : 7)) == 0;
     int64_t ntiles = (n + p->V - 1) / p->V;
     if (real) ntiles = (ntiles + 1) / 2;  // pairs of real tiles
     SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols: too many tiles");

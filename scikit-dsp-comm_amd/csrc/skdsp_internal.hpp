@@ -36,6 +36,8 @@ struct Context {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     // grow-only device workspaces used by the host-pointer entry points
+    hipStream_t comm_stream = nullptr;   // halo traffic of a sharded FIR, overlapped with the interior tiles
+    hipEvent_t ev_in = nullptr, ev_halo = nullptr;
     void *ws[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t ws_bytes[4] = {0, 0, 0, 0};
     std::mutex mu;
@@ -87,6 +89,8 @@ int fir_direct_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
                       void *y_dev, hipStream_t s);
 // FFT overlap-save (fir_ols.hip): c64 (and packed f32) .filter
 bool fir_ols_supported(const FirHandle *h);
+int fir_ols_tile_outputs(FirHandle *h, int *V);  // outputs per overlap-save tile (builds the plan if needed)
+int fir_algo_for(const FirHandle *h, int64_t n);  // SKDSP_FIR_OLS / SKDSP_FIR_DIRECT as skdsp_fir_filter_dev would pick
 int fir_ols_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, hipStream_t s);
 void fir_ols_free(OlsPlan *p);
 

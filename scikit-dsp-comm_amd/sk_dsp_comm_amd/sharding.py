@@ -288,6 +288,11 @@ class ShardedFIR:
         """.filter: halo Ntaps-1; outputs [start_r, stop_r)."""
         n_local = xd.n if n_local is None else n_local
         self._check(n_local, self.halo)
+        if isinstance(self.transport, RcclTransport):
+            # one library call: the halo crosses xGMI on a second stream while the overlap-save tiles
+            # that do not need it already run (skdsp_fir_filter_shard_dev)
+            self._hip().filter_shard_dev(xd, yd, n_local)
+            return
         self.transport.halo_exchange_dev(xd, n_local, self.halo)
         self._hip().filter_dev(xd, yd, n_local, n_hist=self.halo)
 

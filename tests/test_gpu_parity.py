@@ -428,6 +428,7 @@ def test_rccl_single_rank_communicator_p2p_and_allreduce():
 import os, sys, ctypes
 import numpy as np
 sys.path.insert(0, os.path.join(%r, 'scikit-dsp-comm_amd'))
+sys.path.insert(0, %r)
 os.environ['SKDSP_DIST_FORCE_COMM'] = '1'
 from sk_dsp_comm_amd import _ffi
 _ffi.init(0)
@@ -466,9 +467,21 @@ zi = rng.standard_normal((8, 2))
 iir.filter_local_dev(xd2, yd2, zi=zi)
 want = signal.sosfilt(sos, xr.astype(np.float64), zi=zi)[0]
 assert np.max(np.abs(yd2.to_host() - want)) / np.max(np.abs(want)) < 1e-6, 'sharded IIR via RCCL transport'
+# fused sharded FIR: halo on the comm stream, tiles 1.. on the compute stream, tile 0 after the halo
+from oracle import oracle as orc
+bl = np.hanning(1024) / 512
+xs = (rng.standard_normal(200000) + 1j * rng.standard_normal(200000)).astype(np.complex64)
+fir = sharding.ShardedFIR(bl, tr, dtype=np.complex64)
+xsd = fir.new_shard_buffer(xs.size); xsd.write(xs)
+ysd = _ffi.DeviceArray(xs.size, np.complex64)
+for _ in range(3):
+    fir.filter_local_dev(xsd, ysd)
+_ffi.sync()
+ref = orc.fir_filter(bl, xs)
+assert np.max(np.abs(ysd.to_host() - ref)) / np.max(np.abs(ref)) < 1e-6, 'overlapped shard filter'
 _ffi.check(L.skdsp_dist_shutdown())
 print('RCCL_OK')
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+""" % ((os.path.dirname(os.path.dirname(os.path.abspath(__file__))),) * 2)
     out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert b"RCCL_OK" in out.stdout, out.stdout.decode()[-3000:]
 
