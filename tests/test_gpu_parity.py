@@ -928,3 +928,42 @@ def test_c_abi_rejects_bad_arguments():
     _ffi.sync()
     ref = orc.fir_filter(b, x.to_host())
     assert_close(y.to_host(0, 1024), ref, TOL32, "after errors")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
+@pytest.mark.parametrize("L,M", [(1, 1), (3, 1), (1, 4), (2, 3)])
+def test_direct_fir_large_tiles_all_dtypes(dt, L, M):
+    """Direct/polyphase kernels at sizes where the big sliding-window tiles and the vectorised
+    interior staging (16-byte loads: 4 float32 / 2 complex64 or float64 / 1 complex128 per load) are
+    taken, for every signal dtype; real and complex taps; windows at the start, middle and end."""
+    rng = np.random.default_rng(61)
+    n = 3 * 2 ** 20 + 777
+    n -= n % M
+    cplx = np.dtype(dt).kind == "c"
+    tol = TOL32 if np.dtype(dt).itemsize // (2 if cplx else 1) == 4 else 1e-12
+    for taps in (rng.standard_normal(33) / 6, (rng.standard_normal(21) + 1j * rng.standard_normal(21)) / 5):
+        if np.iscomplexobj(taps) and not cplx:
+            continue
+        k = _ffi.FirKernel(taps, _ffi.code_of(dt))
+        k.set_algo(_ffi.FIR_DIRECT)
+        xd = _ffi.DeviceArray(n, dt).fill_noise(29)
+        n_out = (n * L) // M
+        yd = _ffi.DeviceArray(n_out, dt)
+        k.updn_dev(xd, yd, L, M)
+        _ffi.sync()
+        q = M // int(np.gcd(L, M))
+        for s_in in (0, 1_500_000, n - 4000):
+            s_in -= s_in % q
+            lo = max(0, s_in - 300)
+            lo -= lo % M
+            xs = xd.to_host(lo, min(4000, n - lo))
+            ref = orc.fir_up(taps, xs, L)
+            if M > 1:
+                ref = orc.downsample(ref, M)
+            m0 = (s_in * L) // M
+            skip = ((s_in - lo) * L) // M
+            w = min(len(ref) - skip, n_out - m0, 3000)
+            assert w > 500
+            assert_close(yd.to_host(m0, w), ref[skip:skip + w], tol, "%s L=%d M=%d @%d" % (np.dtype(dt).name, L, M, s_in))
+        xd.free()
+        yd.free()
