@@ -504,11 +504,7 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
             for (int k = 0; k < R; ++k) {
                 const int sl = lane + 64 * k;
                 const X v = ot[sl + sl / R];
-#ifdef SKDSP_SW_PLANAR
-                const int64_t m = (int64_t)c * (a.n_out / a.Lp) + (wb + sl);  // timing experiment only: wrong layout
-#else
                 const int64_t m = (int64_t)c + (int64_t)a.Lp * (wb + sl);
-#endif
                 if (m < a.n_out) y[m] = v;
             }
         } else if (a.Lp == 1 && a.L == 1 && sb + R <= a.n_out && (R * sizeof(X)) % 16 == 0 &&
