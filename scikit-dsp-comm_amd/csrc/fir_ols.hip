@@ -318,6 +318,17 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         }
 #endif
         SK_STAMP(1);
+#if defined(SKDSP_OLS_COPYONLY)
+        {   // measurement aid: the tile walk's memory traffic alone (loads, prefetch, stores)
+            const int64_t next = tile + gridDim.x;
+            cf nx[32];
+            if (next < A.ntiles) load_any<REAL>(A, next, t, nx);
+            store_any<REAL>(A, tile, t, v);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v[i] = nx[i];
+            continue;
+        }
+#endif
         fwd_pass1(t, v, tw, lds);
         SK_STAMP(2);
         __syncthreads();
