@@ -132,11 +132,17 @@ def main():
     # for the first 50-launch window of the headline kernel, 0.236 ms from the second window on,
     # flat for as long as the launches continue: profiles/r01/README.md).  Steady state is what a
     # streaming job sees, so the clock is settled first, untimed, whatever W is.
+    # (the number of settle passes is agreed between the ranks: every pass of a sharded workload
+    # contains a send/recv pair, so a per-rank time-based loop would deadlock)
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle_seconds:
-        for _ in range(10):
-            step()
-        _ffi.sync()
+    for _ in range(10):
+        step()
+    _ffi.sync()
+    per_pass = max((time.perf_counter() - t_settle) / 10, 1e-6)
+    n_settle = int(tr.allreduce_max(float(min(20000, int(args.settle_seconds / per_pass) + 1)))) if args.settle_seconds > 0 else 0
+    for _ in range(n_settle):
+        step()
+    _ffi.sync()
     for _ in range(W):
         step()
     _ffi.sync()
