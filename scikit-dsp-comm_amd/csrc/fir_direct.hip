@@ -190,6 +190,7 @@ struct SwArgs {
     int win;    // logical window length = (G + 256) * q * R
     int tap_off;  // byte offset of the two per-class tap buffers in LDS (-1: none, taps come through scalar loads)
     int tap_cnt;  // floats per class = q * nB * R
+    int half_last;  // taps 4..7 of the last block of every (class, residue) row are zero padding
     int out_off;  // byte offset of the four wave-private output transposition tiles (-1: store directly)
 };
 
@@ -252,13 +253,17 @@ __device__ __forceinline__ void pair_next(v2f (&p)[8], const v2f w0, const v2f w
 
 // one block of 8 taps (4 SGPR pairs) over the window {nxt[0..7] (older), cur[0..7]}: tap u feeds
 // output r from W[8 + r - u]
-__device__ __forceinline__ void sw_block8(v2f (&mid)[8], const v2f (&cur)[8], const v2f (&nxt)[8], const tap2_t (&tt)[4])
+// `half`: only taps 0..3 of the block are non-zero (the zero-padded tail of a tap table) -- uniform
+__device__ __forceinline__ void sw_block8(v2f (&mid)[8], const v2f (&cur)[8], const v2f (&nxt)[8], const tap2_t (&tt)[4],
+                                          const bool half)
 {
     v2f p[8];
     pair_first(p, nxt[7], cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7], tt[0]);
     pair_next(p, nxt[5], nxt[6], nxt[7], cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], tt[1]);
-    pair_next(p, nxt[3], nxt[4], nxt[5], nxt[6], nxt[7], cur[0], cur[1], cur[2], cur[3], tt[2]);
-    pair_next(p, nxt[1], nxt[2], nxt[3], nxt[4], nxt[5], nxt[6], nxt[7], cur[0], cur[1], tt[3]);
+    if (!half) {
+        pair_next(p, nxt[3], nxt[4], nxt[5], nxt[6], nxt[7], cur[0], cur[1], cur[2], cur[3], tt[2]);
+        pair_next(p, nxt[1], nxt[2], nxt[3], nxt[4], nxt[5], nxt[6], nxt[7], cur[0], cur[1], tt[3]);
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) mid[r] += p[r];
 }
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
         const tap2_t *tqn = tq + (size_t)(beta + 1 < a.nB ? beta + 1 : beta) * 4;                    \
         _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) TPRE[u_] = tqn[u_];                         \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) PRE[i] = gp[q * i];                            \
-        sw_block8(mid2, CUR, NXT, TCUR);                                                             \
+        sw_block8(mid2, CUR, NXT, TCUR, a.half_last && beta == a.nB - 1);                            \
         ++beta;                                                                                      \
         if ((beta & 15) == 0) {                                                                      \
             _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                          \
@@ -662,6 +667,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
             SwArgs w;
             w.n = n; w.n_hist = n_hist; w.n_out = n_out;
             w.L = L; w.Lp = a.Lp; w.q = q; w.G = G; w.nB = nB; w.win = (int)win;
+            w.half_last = (R == 8 && (Tq + 1) - (nB - 1) * R <= R / 2) ? 1 : 0;
             size_t lds = (size_t)phys * esz;
             w.tap_off = -1; w.tap_cnt = 0;
             if (h->dtype == SKDSP_C64 && !h->taps_complex && R == 8) {
