@@ -191,6 +191,7 @@ struct SwArgs {
     int tap_off;  // byte offset of the two per-class tap buffers in LDS (-1: none, taps come through scalar loads)
     int tap_cnt;  // floats per class = q * nB * R
     int half_last;  // taps 4..7 of the last block of every (class, residue) row are zero padding
+    int out_tile;  // 1: out_off is ONE image of all Lp classes of the workgroup's slots (256*R*Lp elements)
     int out_off;  // byte offset of the four wave-private output transposition tiles (-1: store directly)
 };
 
@@ -495,7 +496,13 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
         X acc[R];
         class_body(c, acc);
         const int64_t sb = s0 + (int64_t)R * tid;
-        if (a.out_off >= 0) {
+        if (a.out_tile) {
+            // every class of the workgroup's slots is parked in one LDS image laid out like the
+            // output run itself (slot-major, class-minor); it leaves as full rows after the loop
+            X *tile = reinterpret_cast<X *>(smem_raw + a.out_off);
+#pragma unroll
+            for (int r = 0; r < R; ++r) tile[(size_t)(R * tid + r) * a.Lp + c] = scl(acc[r], gain);
+        } else if (a.out_off >= 0) {
             // a thread's R outputs of a class sit Lp*R elements apart from its neighbour's, so a direct
             // store touches 64 lines per instruction.  Transpose through a wave-private LDS tile
             // (pitch R+1) so that consecutive lanes hold consecutive slots: 64*Lp elements per
@@ -525,6 +532,25 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
                 const int64_t m = (int64_t)c + (int64_t)a.Lp * (sb + r);
                 if (m < a.n_out) y[m] = (a.L == 1) ? acc[r] : scl(acc[r], gain);
             }
+        }
+    }
+    if (a.out_tile) {
+        // Lp > 4 (e.g. the reference's default L = 12): a per-class store would fill 8 of every 8*Lp
+        // bytes per pass (0.72 TB/s at L = 12); the staged image goes out in 16-byte pieces, 1 KiB per
+        // wave-instruction
+        __syncthreads();
+        const int64_t m0 = (int64_t)a.Lp * s0;
+        const int64_t total = (int64_t)a.Lp * 256 * R;
+        constexpr int VEC = 16 / (int)sizeof(X) > 0 ? 16 / (int)sizeof(X) : 1;
+        const char *tile = smem_raw + a.out_off;
+        if (m0 + total <= a.n_out && (total % VEC) == 0 && ((reinterpret_cast<uintptr_t>(y + m0)) & 15) == 0) {
+            const float4 *src = reinterpret_cast<const float4 *>(tile);
+            float4 *dst = reinterpret_cast<float4 *>(y + m0);
+            for (int i = tid; i < (int)(total / VEC); i += 256) dst[i] = src[i];
+        } else {
+            const X *src = reinterpret_cast<const X *>(tile);
+            for (int64_t i = tid; i < total; i += 256)
+                if (m0 + i < a.n_out) y[m0 + i] = src[i];
         }
     }
 }
@@ -661,6 +687,12 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
             if ((size_t)phys * esz > lds_cap) continue;
             const int64_t nb = (a.n_s + 256 * R - 1) / (256 * R);
             if (nb < ctx().num_cus && R > 2) continue;  // small problems: smaller tiles
+            // interpolation by more than 4 classes: the whole output run of the workgroup is staged
+            // in LDS (needs 256*R*Lp elements next to the window) -- prefer a smaller R that fits
+            const size_t tile_bytes = (size_t)256 * R * a.Lp * esz;
+            const bool want_tile = a.Lp > 4 && !getenv("SKDSP_SW_NO_TILE");  // up to 4 classes the per-class row transposition measured faster
+            const bool tile_fits = (size_t)phys * esz + 4096 + tile_bytes <= lds_cap;
+            if (want_tile && !tile_fits && R > 2) continue;
             const FirHandle::SwTab *tab = nullptr;
             int rc2 = get_sw_table(h, L, M, R, nB, &tab);
             if (rc2) return rc2;
@@ -676,10 +708,16 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
                 if (off + 2 * tbytes <= lds_cap) { w.tap_off = (int)off; w.tap_cnt = (int)(tbytes / 4); lds = off + 2 * tbytes; }
             }
             w.out_off = -1;
+            w.out_tile = 0;
             const bool lpt_ok = h->dtype == SKDSP_C64 && !h->taps_complex && R == 8 && w.tap_off >= 0 && a.Lp >= 2 && a.Lp <= 4 &&
                                 !getenv("SKDSP_SW_NO_LPT");
             if (lpt_ok) {
                 w.out_off = 0;  // unrolled-class kernel: its output tiles alias the (finished) window image
+            } else if (want_tile && tile_fits) {
+                const size_t off = (lds + 15) & ~(size_t)15;
+                w.out_off = (int)off;
+                w.out_tile = 1;
+                lds = off + tile_bytes;
             } else {
                 const size_t off = (lds + 15) & ~(size_t)15;
                 const size_t obytes = (size_t)4 * 64 * (R + 1) * esz;

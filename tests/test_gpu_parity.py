@@ -931,7 +931,7 @@ def test_c_abi_rejects_bad_arguments():
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
-@pytest.mark.parametrize("L,M", [(1, 1), (3, 1), (1, 4), (2, 3)])
+@pytest.mark.parametrize("L,M", [(1, 1), (3, 1), (1, 4), (2, 3), (12, 1), (6, 4), (5, 2)])
 def test_direct_fir_large_tiles_all_dtypes(dt, L, M):
     """Direct/polyphase kernels at sizes where the big sliding-window tiles and the vectorised
     interior staging (16-byte loads: 4 float32 / 2 complex64 or float64 / 1 complex128 per load) are
