@@ -116,6 +116,17 @@ static int pick_fir_algo(const FirHandle *h, int64_t n)
 
 int fir_algo_for(const FirHandle *h, int64_t n) { return pick_fir_algo(h, n); }
 
+// .dn: long filters with a modest M go through the overlap-save engine with a decimating store, which
+// beats Ntaps/M direct taps per kept sample (2^24 complex64, 512 taps, M = 3: 0.163 -> 0.085 ms)
+static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev)
+{
+    if (M > 1 && fir_ols_supported(h) && pick_fir_algo(h, n) == SKDSP_FIR_OLS &&
+        h->ntaps / M >= (h->dtype == SKDSP_C64 ? 24 : 64) &&  // the two-real-tiles store pays two divides per sample
+        !getenv("SKDSP_DN_NO_OLS"))
+        return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
+    return fir_direct_launch(h, x_dev, n, n_hist, 1, M, n / M, y_dev, ctx().stream);
+}
+
 static int fir_filter_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev)
 {
     if (pick_fir_algo(h, n) == SKDSP_FIR_OLS) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream);
@@ -590,7 +601,7 @@ int skdsp_fir_dn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int64_t n_hi
     SK_CHECK(h, SKDSP_ERR_BADARG, "fir_dn: not a FIR handle");
     SK_CHECK(M >= 1, SKDSP_ERR_BADARG, "fir_dn: M must be >= 1");
     std::lock_guard<std::mutex> lk(h->mu);
-    return fir_direct_launch(h, x_dev, n, n_hist, 1, M, n / M, y_dev, ctx().stream);
+    return fir_dn_any(h, x_dev, n, n_hist, M, y_dev);
 }
 
 int skdsp_fir_updn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev)
@@ -619,6 +630,7 @@ static int fir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M
     if (rc) return rc;
     if ((rc = ws_reserve(1, (size_t)n_out * esz + 256, &y_dev))) return rc;
     if (mode == 0) rc = fir_filter_any(h, x_dev, n, 0, y_dev);
+    else if (L == 1) rc = fir_dn_any(h, x_dev, n, 0, M, y_dev);
     else rc = fir_direct_launch(h, x_dev, n, 0, L, M, n_out, y_dev, ctx().stream);
     if (rc) return rc;
     return stage_out(y, y_dev, (size_t)n_out * esz, h);

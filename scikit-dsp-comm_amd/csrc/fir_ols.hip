@@ -61,6 +61,8 @@ struct OlsArgs {
     int ov, V, a0;  // a0 = ov / 512: first stored 512-block
     int aligned;    // x and y element-aligned (8 bytes complex64, 4 bytes float32)
     int64_t ntiles;
+    int dec;        // > 1: keep every dec-th output only (multirate_FIR.dn): y[g / dec] = out[g] for g % dec == 0
+    int64_t n_keep; // dec * floor(n / dec)
 };
 
 // volatile 16-byte load: keeps the request at its program position (the scheduler would
@@ -124,6 +126,24 @@ __device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t
 #if SKDSP_OLS_NOMEM
     if (A.n != -12345) return;
 #endif
+    if (A.dec > 1) {
+        // decimating store: the full-rate convolution is computed (it is memory-bound, and cheaper than
+        // Ntaps/dec direct taps per kept sample once Ntaps/dec exceeds a few dozen), 1/dec of it leaves
+        const unsigned M = (unsigned)A.dec;
+        const int64_t q0 = out0 / A.dec;                 // uniform
+        const unsigned r0 = (unsigned)(out0 - q0 * A.dec);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            if (a < A.a0) continue;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const unsigned gl = r0 + 512u * (unsigned)(a - A.a0) + 2u * (unsigned)t + (unsigned)e;
+                const unsigned q = gl / M;
+                if (q * M == gl && out0 + (int64_t)(gl - r0) < A.n_keep) A.y[q0 + q] = v[2 * a + e];
+            }
+        }
+        return;
+    }
     if (full) {
         // recompute the per-thread offset here: hoisted out of the tile loop it is a 64-bit VGPR pair
         // that hipcc spills, and the scratch reload's s_waitcnt vmcnt(0) then drains the whole
@@ -196,6 +216,24 @@ __device__ __forceinline__ void store_tile_real(const OlsArgs &A, int64_t pair, 
     float *yr = reinterpret_cast<float *>(A.y);
     const int64_t outA = (2 * pair) * A.V, outB = outA + A.V;
     const bool full = A.aligned && outB + A.V <= A.n;
+    if (A.dec > 1) {  // decimating store, see store_tile
+        const unsigned M = (unsigned)A.dec;
+        const int64_t qa = outA / A.dec, qb = outB / A.dec;
+        const unsigned ra0 = (unsigned)(outA - qa * A.dec), rb0 = (unsigned)(outB - qb * A.dec);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            if (a < A.a0) continue;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const unsigned loc = 512u * (unsigned)(a - A.a0) + 2u * (unsigned)t + (unsigned)e;
+                const unsigned ga = ra0 + loc, gb = rb0 + loc;
+                const unsigned ka = ga / M, kb = gb / M;
+                if (ka * M == ga && outA + (int64_t)loc < A.n_keep) yr[qa + ka] = v[2 * a + e].x;
+                if (kb * M == gb && outB + (int64_t)loc < A.n_keep) yr[qb + kb] = v[2 * a + e].y;
+            }
+        }
+        return;
+    }
     if (full) {
 #pragma unroll
         for (int a = 0; a < 16; ++a)
@@ -578,8 +616,10 @@ int fir_ols_tile_outputs(FirHandle *h, int *V)
     return SKDSP_OK;
 }
 
-int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s)
+int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s, int dec)
 {
+    if (n <= 0) return SKDSP_OK;
+    if (dec > 1) n = (n / dec) * dec;  // the dropped tail is never computed
     if (n <= 0) return SKDSP_OK;
     SK_CHECK(fir_ols_supported(h), SKDSP_ERR_UNSUPPORTED, "fir_ols: needs complex64 (or float32 with real taps) and 2..4097 taps");
     int rc = ensure_plan(h);
@@ -600,6 +640,8 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     if (real) ntiles = (ntiles + 1) / 2;  // pairs of real tiles
     SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols: too many tiles");
     A.ntiles = ntiles;
+    A.dec = dec > 1 ? dec : 1;
+    A.n_keep = n;
     int64_t grid = 2 * (int64_t)ctx().num_cus;  // 2 resident workgroups per CU (76 KiB LDS each)
     if (grid > ntiles) grid = ntiles;
     A.trace = nullptr;

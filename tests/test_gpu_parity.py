@@ -967,3 +967,40 @@ def test_direct_fir_large_tiles_all_dtypes(dt, L, M):
             assert_close(yd.to_host(m0, w), ref[skip:skip + w], tol, "%s L=%d M=%d @%d" % (np.dtype(dt).name, L, M, s_in))
         xd.free()
         yd.free()
+
+
+@pytest.mark.parametrize("dt", [np.complex64, np.float32])
+@pytest.mark.parametrize("M,ntaps", [(2, 512), (3, 512), (12, 768), (5, 1024), (7, 200)])
+def test_fir_dn_overlap_save_decimating_store(M, ntaps, dt):
+    """.dn of a long filter runs in the overlap-save engine and stores every M-th output: identical
+    (to float32 rounding) to the direct polyphase kernel, ragged length, with history; complex64 and
+    the float32 two-real-tiles variant."""
+    rng = np.random.default_rng(71)
+    b = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+    n = 2 ** 20 + 12345
+    esz = np.dtype(dt).itemsize
+    k = _ffi.FirKernel(b, _ffi.code_of(dt))
+    xd = _ffi.DeviceArray(n, dt, headroom=ntaps).fill_noise(31)
+    xd.write(cnoise(rng, ntaps - 1) if dt == np.complex64 else rng.standard_normal(ntaps - 1).astype(np.float32), at=-(ntaps - 1))
+    yd = _ffi.DeviceArray(n // M, dt)
+    k.dn_dev(xd, yd, M, n_hist=ntaps - 1)
+    y = yd.to_host()
+    os.environ["SKDSP_DN_NO_OLS"] = "1"
+    try:
+        y2 = _ffi.DeviceArray(n // M, dt)
+        k.dn_dev(xd, y2, M, n_hist=ntaps - 1)
+        y_direct = y2.to_host()
+    finally:
+        del os.environ["SKDSP_DN_NO_OLS"]
+    assert_close(y, y_direct, 2e-6, "ols-dn vs direct M=%d" % M)
+    # and against the oracle on windows (incl. the history at the start and the ragged end)
+    hist = np.empty(ntaps - 1, dt)
+    import ctypes
+    _ffi.check(_ffi.load().skdsp_memcpy_d2h(_ffi._ptr(hist), ctypes.c_void_p(xd.ptr - (ntaps - 1) * esz), hist.nbytes))
+    head = np.concatenate([hist, xd.to_host(0, 6000)])
+    ref = orc.fir_filter(b, head)[ntaps - 1:][::M]
+    assert_close(y[:len(ref)], ref, TOL32, "ols-dn head M=%d" % M)
+    lo = (n - 9000) - (n - 9000) % M
+    tail = xd.to_host(lo - (ntaps - 1), n - lo + ntaps - 1)
+    ref = orc.fir_filter(b, tail)[ntaps - 1:][::M][:n // M - lo // M]
+    assert_close(y[lo // M:], ref, TOL32, "ols-dn tail M=%d" % M)
