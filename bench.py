@@ -211,22 +211,23 @@ def main():
 
 
 def measured_traffic(args):
-    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE,
+    """HBM bytes per step from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE,
     WRITE_SIZE; separate --pmc runs, read side doubled per the gfx950 correction of
-    MI355X_MICROARCH.md).  PMC counters cannot be read inside an un-profiled run, so this is the
-    committed measurement of the same kernel/workload, or null when none applies."""
-    if args.workload != "fir1024" or args.log2n != 26:
+    MI355X_MICROARCH.md; tools/collect_profiles.sh + tools/reduce_pmc.py).  PMC counters cannot be
+    read inside an un-profiled run, so this is the committed measurement of the same workload at
+    the same size, or null when none applies."""
+    if args.log2n != 26:
         return None
     prof = os.path.join(ROOT, "profiles")
     best = None
     for d in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
-        f = os.path.join(prof, d, "pmc_ols_tile_kernel.json")
+        f = os.path.join(prof, d, "pmc_%s.json" % args.workload)
         if os.path.exists(f):
             best = f
     if best is None:
         return None
     try:
-        return float(json.load(open(best))["derived"]["hbm_total_bytes_per_launch"])
+        return float(json.load(open(best))["derived"]["hbm_total_bytes_per_step"])
     except Exception:
         return None
 

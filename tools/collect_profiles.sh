@@ -13,13 +13,16 @@ for w in fir1024 updn43 iir8 fir127; do
   cp $OUT/trace_$w/*/*kernel_stats.csv $OUT/kernel_stats_$w.csv
   rm -rf $OUT/trace_$w
 done
-# PMC passes for the headline kernel, each counter group in its own run
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES"; do
-  tag=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$tag -- python $ROOT/bench.py --no-cpu-baseline > /dev/null 2>&1
-  cp $OUT/pmc_$tag/*/*counter_collection.csv $OUT/pmc_fir1024_$tag.csv 2>/dev/null
-  cp $OUT/pmc_$tag/*/*kernel_trace.csv $OUT/pmc_fir1024_${tag}_trace.csv 2>/dev/null
-  rm -rf $OUT/pmc_$tag
+# PMC passes, each counter group in its own run (never combined with other trace domains)
+for w in fir1024 updn43 iir8 fir127; do
+  sets=("FETCH_SIZE" "WRITE_SIZE")
+  [ $w = fir1024 ] && sets+=("SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES")
+  for set in "${sets[@]}"; do
+    tag=$(echo $set | cut -d' ' -f1)
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$tag -- python $ROOT/bench.py --workload $w --steps 100 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
+    cp $OUT/pmc_$tag/*/*counter_collection.csv $OUT/pmc_${w}_$tag.csv 2>/dev/null
+    rm -rf $OUT/pmc_$tag
+  done
 done
 cd $ROOT
 python bench.py > $OUT/bench_fir1024.json 2>$OUT/bench_fir1024.err

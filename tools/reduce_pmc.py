@@ -1,43 +1,48 @@
 #!/usr/bin/env python3
 """Reduce the rocprofv3 --pmc CSVs that tools/collect_profiles.sh wrote into
-profiles/<round>/pmc_ols_tile_kernel.json (per-launch means + the derived HBM bytes that
-bench.py reports as roofline.traffic).
+profiles/<round>/pmc_<workload>.json: per-dispatch means per kernel plus the HBM bytes of ONE
+bench step (what bench.py reports as roofline.traffic).
 
     python tools/reduce_pmc.py gpurun_out/profiles_r01 profiles/r01
 
 FETCH_SIZE / WRITE_SIZE are in KiB; the read side is doubled per the gfx950 correction of
-MI355X_MICROARCH.md (HBM section); the passes are separate rocprofv3 runs.
+MI355X_MICROARCH.md (HBM section); every counter group comes from its own rocprofv3 run.
+A "step" is one bench.py pass: one dispatch of the FIR kernels, K1 + K3 for the IIR.
 """
 import collections
 import csv
-import glob
 import json
 import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-out = {}
-for f in sorted(glob.glob(os.path.join(src, "pmc_fir1024_*.csv"))):
-    if f.endswith("_trace.csv"):
-        continue
-    acc = collections.defaultdict(list)
-    dur = []
-    for r in csv.DictReader(open(f)):
-        if "ols_tile_kernel" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    for k, v in acc.items():
-        out[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
-    if dur:
-        out["kernel_us_in_pass_" + os.path.basename(f)[len("pmc_fir1024_"):-4]] = sum(dur) / len(dur)
-rd = out["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
-wr = out["WRITE_SIZE"]["mean_per_launch"] * 1024
-alg = 16 * 2 ** 26
-out["derived"] = {
-    "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_total_bytes_per_launch": rd + wr,
-    "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (rd + wr) / alg,
-    "note": "FETCH_SIZE/WRITE_SIZE are in KiB; read side doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM); "
-            "separate --pmc passes; kernel = skdsp::ols_tile_kernel<false,false> on 2^26 c64 samples, 1024 taps",
+WORK = {  # workload -> (kernel substring, algorithmic bytes per step, dispatches per step)
+    "fir1024": ("ols_tile_kernel", 16 * 2 ** 26, 1),
+    "fir127": ("ols_tile_kernel", 8 * 2 ** 26, 1),
+    "updn43": ("fir_sw_kernel", 8 * 2 ** 26 + 8 * ((2 ** 26 * 4) // 3), 1),
+    "iir8": ("iir_chunk_kernel", 8 * 2 ** 26, 2),
 }
-json.dump(out, open(os.path.join(dst, "pmc_ols_tile_kernel.json"), "w"), indent=1)
-print(json.dumps(out["derived"], indent=1))
+for w, (pat, alg, per_step) in WORK.items():
+    out = {}
+    for tag in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+        f = os.path.join(src, "pmc_%s_%s.csv" % (w, tag))
+        if not os.path.exists(f):
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if pat in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            out[k] = {"dispatches": len(v), "mean_per_dispatch": sum(v) / len(v), "per_step": sum(v) / len(v) * per_step}
+    if "FETCH_SIZE" not in out or "WRITE_SIZE" not in out:
+        continue
+    rd = out["FETCH_SIZE"]["per_step"] * 1024 * 2
+    wr = out["WRITE_SIZE"]["per_step"] * 1024
+    out["derived"] = {
+        "hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr, "hbm_total_bytes_per_step": rd + wr,
+        "algorithmic_bytes_per_step": alg, "traffic_over_algorithmic": (rd + wr) / alg,
+        "note": "FETCH_SIZE/WRITE_SIZE in KiB; read side doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM); "
+                "separate --pmc passes of `bench.py --workload %s`; kernels matching '%s', %d dispatch(es) per step" % (w, pat, per_step),
+    }
+    json.dump(out, open(os.path.join(dst, "pmc_%s.json" % w), "w"), indent=1)
+    print(w, "traffic/algorithmic = %.3f  (%.1f MB read + %.1f MB written per step)" % ((rd + wr) / alg, rd / 1e6, wr / 1e6))
