@@ -436,6 +436,14 @@ int skdsp_shutdown(void)
     }
     (void)hipEventDestroy(c.ev_start);
     (void)hipEventDestroy(c.ev_stop);
+    if (c.comm_stream) {
+        (void)hipStreamSynchronize(c.comm_stream);
+        (void)hipEventDestroy(c.ev_in);
+        (void)hipEventDestroy(c.ev_halo);
+        (void)hipStreamDestroy(c.comm_stream);
+        c.comm_stream = nullptr;
+        c.ev_in = c.ev_halo = nullptr;
+    }
     (void)hipStreamDestroy(c.stream);
     c.ready = false;
     c.device = -1;
