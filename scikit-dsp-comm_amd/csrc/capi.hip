@@ -190,6 +190,30 @@ static int iir_any_dev(IirHandle *h, const void *x_dev, int64_t n, void *y_dev, 
     return interleave_launch(re, im, n, h->dtype, y_dev, s);
 }
 
+// y = filter(L * upsample(x, L)).  Real: zero-stuff straight into y, then filter in place.  Complex:
+// zero-stuff straight into the two planes the scan works on (no stuffed interleaved copy, no
+// deinterleave pass), filter, interleave into y.
+static int iir_up_any(IirHandle *h, const void *x_dev, int64_t n, int L, void *y_dev)
+{
+    hipStream_t s = ctx().stream;
+    const int64_t nl = n * L;
+    if (nl <= 0) return SKDSP_OK;
+    int rc;
+    if (!dtype_complex(h->dtype)) {
+        if ((rc = upsample_launch(x_dev, n, L, h->dtype, (double)L, y_dev, s))) return rc;
+        return iir_any_dev(h, y_dev, nl, y_dev);
+    }
+    const size_t rsz = dtype_double(h->dtype) ? 8 : 4;
+    const int64_t stride = (int64_t)round_up((size_t)nl, 64);
+    void *planes = nullptr;
+    if ((rc = ws_reserve(3, (size_t)2 * stride * rsz, &planes))) return rc;
+    void *re = planes, *im = (char *)planes + (size_t)stride * rsz;
+    if ((rc = upsample_planes_launch(x_dev, n, L, h->dtype, (double)L, re, im, s))) return rc;
+    if ((rc = iir_launch_planar(h, planes, nl, 2, stride, planes, s))) return rc;
+    return interleave_launch(re, im, nl, h->dtype, y_dev, s);
+}
+
+
 // ---------------------------------------------------------------------------
 // (b, a) -> cascaded biquads.  scipy.signal.lfilter runs a transfer function as ONE
 // direct-form-II-transposed section of order N.  In those state coordinates the
@@ -745,10 +769,7 @@ int skdsp_iir_up_dev(skdsp_handle hh, const void *x_dev, int64_t n, int L, void 
     SK_CHECK(h, SKDSP_ERR_BADARG, "iir_up: not an IIR handle");
     SK_CHECK(L >= 1, SKDSP_ERR_BADARG, "iir_up: L must be >= 1");
     std::lock_guard<std::mutex> lk(h->mu);
-    // y = filter(L * upsample(x, L)): zero-stuff straight into y, then filter in place
-    int rc = upsample_launch(x_dev, n, L, h->dtype, (double)L, y_dev, ctx().stream);
-    if (rc) return rc;
-    return iir_any_dev(h, y_dev, n * L, y_dev);
+    return iir_up_any(h, x_dev, n, L, y_dev);
 }
 
 int skdsp_iir_dn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int M, void *y_dev)
@@ -783,8 +804,7 @@ static int iir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M
     hipStream_t s = ctx().stream;
     if (L > 1) {
         if ((rc = ws_reserve(1, (size_t)n * L * esz + 256, &y_dev))) return rc;
-        if ((rc = upsample_launch(x_dev, n, L, h->dtype, (double)L, y_dev, s))) return rc;
-        if ((rc = iir_any_dev(h, y_dev, n * L, y_dev))) return rc;
+        if ((rc = iir_up_any(h, x_dev, n, L, y_dev))) return rc;
     } else if (M > 1) {
         void *full = nullptr;
         if ((rc = ws_reserve(2, (size_t)n * esz + 256, &full))) return rc;

@@ -264,4 +264,55 @@ int widen_launch(const void *src, int64_t nscalars, void *dst, hipStream_t s)
     return SKDSP_OK;
 }
 
+// Zero-stuffing of an interleaved complex vector straight into the two real planes the IIR scan works
+// on (re[o] = scale * Re x[o / L] for o % L == 0, else 0): saves writing and re-reading the stuffed
+// interleaved vector in front of rate_change.up / multirate_IIR.up on complex data.
+template <typename C, typename R, int VEC>
+__global__ __launch_bounds__(256) void upsample_planes_kernel(const C *__restrict__ x, int64_t n_out, int L, R scale,
+                                                              R *__restrict__ re, R *__restrict__ im)
+{
+    const int64_t nvec = (n_out + VEC - 1) / VEC;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o0 = v * VEC;
+        int64_t q = o0 / L;
+        int64_t r = o0 - q * L;
+        R a[VEC], b[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            a[e] = R(0);
+            b[e] = R(0);
+            if (r == 0 && o0 + e < n_out) {
+                const C val = x[q];
+                a[e] = val.x * scale;
+                b[e] = val.y * scale;
+            }
+            if (++r == L) { r = 0; ++q; }
+        }
+        if (o0 + VEC <= n_out) {
+            *reinterpret_cast<float4 *>(re + o0) = *reinterpret_cast<const float4 *>(a);
+            *reinterpret_cast<float4 *>(im + o0) = *reinterpret_cast<const float4 *>(b);
+        } else {
+            for (int e = 0; e < VEC && o0 + e < n_out; ++e) {
+                re[o0 + e] = a[e];
+                im[o0 + e] = b[e];
+            }
+        }
+    }
+}
+
+int upsample_planes_launch(const void *x, int64_t n, int L, int dtype, double scale, void *re, void *im, hipStream_t s)
+{
+    SK_CHECK(L >= 1 && dtype_complex(dtype), SKDSP_ERR_BADARG, "upsample_planes: needs a complex dtype and L >= 1");
+    const int64_t n_out = n * L;
+    if (n_out <= 0) return SKDSP_OK;
+    if (dtype == SKDSP_C64)
+        hipLaunchKernelGGL((upsample_planes_kernel<float2, float, 4>), dim3(grid_for((n_out + 3) / 4)), dim3(256), 0, s,
+                           (const float2 *)x, n_out, L, (float)scale, (float *)re, (float *)im);
+    else
+        hipLaunchKernelGGL((upsample_planes_kernel<double2, double, 2>), dim3(grid_for((n_out + 1) / 2)), dim3(256), 0, s,
+                           (const double2 *)x, n_out, L, scale, (double *)re, (double *)im);
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
 }  // namespace skdsp

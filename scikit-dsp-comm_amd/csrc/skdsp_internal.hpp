@@ -113,6 +113,8 @@ bool iir_shape_supported(int nsec, int order);
 
 // ---- resamplers (resample.hip) ---------------------------------------------
 int upsample_launch(const void *x_dev, int64_t n, int L, int dtype, double scale, void *y_dev, hipStream_t s);
+int upsample_planes_launch(const void *x_dev, int64_t n, int L, int dtype_complex_in, double scale, void *re_dev, void *im_dev,
+                           hipStream_t s);  // complex zero-stuffing straight into two real planes
 int downsample_launch(const void *x_dev, int64_t n, int M, int p, int dtype, void *y_dev, hipStream_t s);
 int deinterleave_launch(const void *x_dev, int64_t n, int dtype_complex_in, void *re_dev, void *im_dev, hipStream_t s);
 int interleave_launch(const void *re_dev, const void *im_dev, int64_t n, int dtype_complex_out, void *y_dev, hipStream_t s);
