@@ -108,6 +108,7 @@ def main():
         yd = _ffi.DeviceArray(n_out, dtype)
         step = lambda: k.updn_dev(xd, yd, 4, 3)                  # noqa: E731
         units, alg_bytes = n, 8.0 * n + 8.0 * n_out              # 18.67 B per input sample
+        compute = ("FP32 vector (packed v_pk_fma_f32)", 157.3, 4.0 * 512 / 4 * n_out)  # 4*Ntaps/L flop per c64 output
         kern = "fir_sw_kernel"
         wl = "downsample(multirate_FIR.up(x,4),3): 512-tap prototype, complex64, 2^%d input samples, fused polyphase" % args.log2n
         metric = "complex64 input MSamples/s (polyphase L=4/M=3, 512 taps)"
@@ -123,10 +124,13 @@ def main():
             iir = sharding.ShardedIIR(sos, tr, dtype=dtype)
             step = lambda: iir.filter_local_dev(xd, yd, n)       # noqa: E731
         units, alg_bytes = n, 8.0 * n
+        compute = ("FP64 vector (v_fma_f64)", 78.6, 72.0 * n)     # 9 flop per biquad per sample
         kern = "iir_chunk_kernel x2 + iir_wg_scan_kernel"
         wl = "multirate_IIR.filter: 8-biquad elliptic bandpass, float32, 2^%d samples, affine scan" % args.log2n
         metric = "float32 MSamples/s (8-biquad SOS IIR)"
 
+    if args.workload in ("fir1024", "fir127"):
+        compute = None
     # --------------------------------------------------------------- timing
     # The chip idles at ~160 MHz; the first ~50 launches after idle run on a ramping clock (0.28 ms
     # for the first 50-launch window of the headline kernel, 0.236 ms from the second window on,
@@ -204,6 +208,12 @@ def main():
                          "kernel_ms": t_kernel * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
         }
+        if compute is not None:
+            # these two workloads are bound by vector arithmetic, not by HBM: useful
+            # flops of the reference formulation against the vector peak (the IIR scan executes 2.2x them)
+            tf = compute[2] / t_kernel / 1e12
+            out["compute"] = {"unit": "TFLOP/s", "what": compute[0], "useful_flop_per_step": compute[2], "achieved": tf,
+                              "peak": compute[1], "frac": tf / compute[1]}
         if check is not None:
             out["parity_spot_check_max_err"] = check
         print(json.dumps(out))
