@@ -11,6 +11,8 @@
 //     s_out = M s_in + v ,   M = A^T (one-chunk transition),  v = zero-state end state
 //   K1  every thread runs the cascade over its chunk from zero state -> v_j ; the
 //       workgroup tree-reduces its 256 v_j (matrix powers M^(2^l)) into one aggregate
+//       (decaying filters with <= 8 biquads: v = G x on the FP64 matrix pipe instead, and the
+//       carries straight from the v_j -- iir_k1_mfma_kernel / iir_carry_kernel below)
 //   K2  one workgroup scans the <=512 workgroup aggregates (powers M^(256*2^l)); skipped when
 //       (M^256)^k underflows within 8 powers (any ordinary stable filter): K3 then sums the
 //       few significant look-back terms itself
@@ -51,6 +53,9 @@ struct IirPlan {
     int64_t cached_T = -1;
     double *pw_dev = nullptr;    // kPowers matrices M^(2^l), each D x D row-major
     double *lb_dev = nullptr;    // look-back matrices (M^256)^k, k = 1..7
+    double *lbk_dev = nullptr;   // chunk look-back powers M^k, k = 0..31, lane-contiguous (aggregate-free mode)
+    double *gt_dev = nullptr;    // G = [A^(T-1-k) b]_k in MFMA A-operand order: [T/4][64], grown on demand
+    size_t gt_cap = 0;
     int n_lb = 0;                // terms of the in-kernel carry look-back (0 = use the K2 scan)
     int n_lv = kPowers;          // first l with max|M^(2^l)| < 1e-30 (chunk-level scan depth that matters)
     double *state_dev = nullptr; // [2][2][D]: zi and zf for up to two planes
@@ -333,6 +338,127 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
     }
 }
 
+// K1 as a matrix product (aggregate-free mode only).  From rest, the state at the end of a chunk is
+// linear in its T samples:  v = sum_k A^(T-1-k) b x_k = G x  with G a D x T matrix that depends on the
+// filter and on T alone -- 2*D flop per sample instead of the 5 dependent FMA per biquad of the
+// recurrence, and a dense FP64 contraction, so it runs on the matrix pipe: one wave owns 16 chunks and
+// accumulates  V[16 states x 16 chunks] += G[:, 4 samples] * X[4 samples, 16 chunks]  with
+// v_mfma_f64_16x16x4_f64 (A operand: lane l holds G[l & 15][k0 + (l >> 4)], B operand: lane l holds
+// x[chunk l & 15][k0 + (l >> 4)]; C: col = lane & 15, row = (lane >> 4) + 4 reg).  The samples of the
+// wave's 16 chunks are staged per 128-sample piece in a wave-private LDS image (row pitch 132 words:
+// the 64 B-operand reads of a step hit 64 distinct banks), so there is no workgroup barrier at all.
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+constexpr int kMmPiece = 128;                 // samples of every chunk staged at a time
+constexpr int kMmPitch = kMmPiece + 4;        // in 4-byte words (float); doubles use 2 words per sample
+
+template <typename IO>
+__global__ __launch_bounds__(256) void iir_k1_mfma_kernel(const IO *__restrict__ xin, int64_t n, int64_t T, int64_t J,
+                                                          int64_t batch_stride, const double *__restrict__ Gt,
+                                                          double *__restrict__ vout, int D)
+{
+    constexpr int E = 16 / (int)sizeof(IO);               // samples per 16-byte load
+    constexpr int W = (int)sizeof(IO) / 4;                // 4-byte words per sample
+    constexpr int kLoads = 16 * kMmPiece / E / 64;        // 16-byte loads per lane per piece
+    __shared__ __attribute__((aligned(16))) float lds[4 * 16 * kMmPitch * W];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bat = blockIdx.y;
+    const IO *x = xin + (size_t)bat * batch_stride;
+    double *vbase = vout + (size_t)bat * D * J;
+    float *img = lds + wave * (16 * kMmPitch * W);
+    const int64_t chunk0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+    if (chunk0 >= J) return;
+    const int npieces = (int)(T / kMmPiece);
+    float4 pre[kLoads];
+    auto load_piece = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int idx = i * 64 + lane;                    // 16-byte segment of the 16 x piece image
+            const int row = idx / (kMmPiece / E), seg = idx % (kMmPiece / E);
+            const int64_t g = (chunk0 + row) * T + (int64_t)p * kMmPiece + (int64_t)seg * E;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g + E <= n) {
+                val = *reinterpret_cast<const float4 *>(x + g);
+            } else if (g < n) {
+                IO tmp[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) tmp[e] = (g + e < n) ? x[g + e] : IO(0);
+                val = *reinterpret_cast<const float4 *>(tmp);
+            }
+            pre[i] = val;
+        }
+    };
+    v4d_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+    const int c = lane & 15, j = lane >> 4;
+    load_piece(0);
+    for (int p = 0; p < npieces; ++p) {
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int idx = i * 64 + lane;
+            const int row = idx / (kMmPiece / E), seg = idx % (kMmPiece / E);
+            *reinterpret_cast<float4 *>(img + (row * kMmPitch + seg * E) * W) = pre[i];
+        }
+        // The A operands stream from the L2-resident table inside the step loop; the HBM loads of the next
+        // piece are requested only AFTER the loop: vmcnt retires in order, so table loads queued behind a
+        // prefetch would wait for HBM at every step.  Four waves per SIMD cover the exposed latency.
+        const double *gt = Gt + ((size_t)p * (kMmPiece / 4)) * 64 + lane;
+        const IO *xs = reinterpret_cast<const IO *>(img) + c * kMmPitch + j;
+#pragma unroll 8
+        for (int s = 0; s < kMmPiece / 4; s += 2) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(gt[(size_t)s * 64], (double)xs[4 * s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(gt[(size_t)(s + 1) * 64], (double)xs[4 * s + 4], acc1, 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+        if (p + 1 < npieces) load_piece(p + 1);
+    }
+    const int64_t cj = chunk0 + c;
+    if (cj < J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = j + 4 * r;
+            if (d < D) vbase[(size_t)d * J + cj] = acc0[r] + acc1[r];
+        }
+    }
+}
+
+// Aggregate-free carries: when M^32 is negligible the state entering workgroup w is
+//   carry[w] = sum_{k<32} M^k v[256 w - 1 - k]        (chunk -1 holds the caller's initial state)
+// One small workgroup per w: thread (k = tid & 31, row pair tid >> 5) applies two rows of its own power
+// M^k from the lane-contiguous table lbk[i][j][k]; a half-wave shuffle tree sums over k.
+template <int D, int ORD>
+__global__ __launch_bounds__(256) void iir_carry_kernel(const double *__restrict__ v, const double *__restrict__ lbk, int64_t J,
+                                                        const double *__restrict__ zi, double *__restrict__ carry)
+{
+    const int tid = threadIdx.x, k = tid & 31, i0 = (tid >> 5) * ORD;
+    const int64_t w = blockIdx.x, W = gridDim.x;
+    const int bat = blockIdx.y;
+    const double *vbase = v + (size_t)bat * D * J;
+    const int64_t ck = w * kIirThreads - 1 - k;
+    double r[ORD];
+#pragma unroll
+    for (int q = 0; q < ORD; ++q) r[q] = 0.0;
+    if (i0 < D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (j < i0 + ORD) {
+                double u = 0.0;
+                if (ck >= 0) u = vbase[(size_t)j * J + ck];
+                else if (ck == -1 && zi) u = zi[(size_t)bat * D + j];
+#pragma unroll
+                for (int q = 0; q < ORD; ++q) r[q] = fma(lbk[((size_t)(i0 + q) * D + j) * 32 + k], u, r[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ORD; ++q) {
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) r[q] += __shfl_xor(r[q], m);
+    }
+    if (k == 0 && i0 < D) {
+#pragma unroll
+        for (int q = 0; q < ORD; ++q) carry[((size_t)bat * W + w) * D + i0 + q] = r[q];
+    }
+}
+
 // K2: exclusive scan of W <= 512 workgroup aggregates, one workgroup per batch item:
 //   carry[w] = sum_{u<w} (M^256)^(w-1-u) agg[u]
 // Hillis-Steele over items with the D x D matvec spread over (item,row) pairs: thread p
@@ -397,6 +523,8 @@ void iir_free(IirPlan *p)
     if (!p) return;
     if (p->pw_dev) (void)hipFree(p->pw_dev);
     if (p->lb_dev) (void)hipFree(p->lb_dev);
+    if (p->lbk_dev) (void)hipFree(p->lbk_dev);
+    if (p->gt_dev) (void)hipFree(p->gt_dev);
     if (p->state_dev) (void)hipFree(p->state_dev);
     if (p->v_dev) (void)hipFree(p->v_dev);
     if (p->agg_dev) (void)hipFree(p->agg_dev);
@@ -446,6 +574,7 @@ static int ensure_plan(IirHandle *h)
     hipError_t e;
     if ((e = hipMalloc((void **)&p->pw_dev, (size_t)kPowers * D * D * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&p->lb_dev, (size_t)8 * D * D * 8)) != hipSuccess ||
+        (e = hipMalloc((void **)&p->lbk_dev, (size_t)32 * D * D * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&p->state_dev, (size_t)4 * D * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&p->agg_dev, (size_t)2 * 2 * kMaxW * D * 8)) != hipSuccess) {
         iir_free(p);
@@ -471,6 +600,39 @@ static int ensure_powers(IirHandle *h, int64_t T, hipStream_t s)
         if (e & 1) matmul_ld(M, sq, M, D);
         e >>= 1;
         if (e) matmul_ld(sq, sq, sq, D);
+    }
+    {   // M^k, k = 0..31, transposed so that lane k reads entry (i,j) at [(i*D+j)*32 + k]
+        std::vector<long double> Pk((size_t)D * D, 0.0L);
+        for (int i = 0; i < D; ++i) Pk[(size_t)i * D + i] = 1.0L;
+        std::vector<double> lbk((size_t)32 * D * D);
+        for (int k = 0; k < 32; ++k) {
+            for (size_t i = 0; i < (size_t)D * D; ++i) lbk[i * 32 + k] = std::isfinite((double)Pk[i]) ? (double)Pk[i] : 0.0;
+            matmul_ld(Pk, M, Pk, D);
+        }
+        SK_HIP(hipMemcpyAsync(p->lbk_dev, lbk.data(), lbk.size() * 8, hipMemcpyHostToDevice, s));
+        SK_HIP(hipStreamSynchronize(s));
+    }
+    if (D <= 16 && T % kMmPiece == 0) {
+        // G[:, k] = A^(T-1-k) b, b = the state one sample x = 1 leaves behind; stored as the MFMA A operand
+        // of step s = k / 4: lane l holds row l & 15, column 4 s + (l >> 4)
+        std::vector<long double> g(D, 0.0L);
+        host_step(h, g, 1.0L);
+        std::vector<double> gt((size_t)T * 16, 0.0);
+        for (int64_t k = T - 1; k >= 0; --k) {
+            for (int d = 0; d < D; ++d) {
+                const long double v = g[d];
+                gt[(size_t)(k / 4) * 64 + (size_t)(k % 4) * 16 + d] = std::isfinite((double)v) ? (double)v : 0.0;
+            }
+            host_step(h, g, 0.0L);  // g <- A g
+        }
+        if (gt.size() * 8 > p->gt_cap) {
+            if (p->gt_dev) SK_HIP(hipFree(p->gt_dev));
+            p->gt_dev = nullptr; p->gt_cap = 0;
+            SK_HIP(hipMalloc((void **)&p->gt_dev, gt.size() * 8));
+            p->gt_cap = gt.size() * 8;
+        }
+        SK_HIP(hipMemcpyAsync(p->gt_dev, gt.data(), gt.size() * 8, hipMemcpyHostToDevice, s));
+        SK_HIP(hipStreamSynchronize(s));
     }
     std::vector<double> pw((size_t)kPowers * D * D);
     p->n_lv = kPowers;
@@ -524,9 +686,21 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
     a.lbmat = p->lb_dev;
     a.n_lb = p->n_lb;
     a.n_lv = p->n_lv < 8 ? p->n_lv : 8;
-    hipLaunchKernelGGL((iir_chunk_kernel<NSEC, ORD, IO, false>), dim3(W, nbatch), dim3(kIirThreads), 0, s, a, cf);
+    // aggregate-free mode: matrix-pipe K1, carries from the chunk states themselves, unchanged K3
+    const bool fast = p->n_lv <= 5 && D <= 16 && ORD == 2 && a.T % kMmPiece == 0 && p->gt_dev && !getenv("SKDSP_IIR_NO_MFMA");
+    if (fast) {
+        const int64_t waves = (a.J + 15) / 16;
+        hipLaunchKernelGGL((iir_k1_mfma_kernel<IO>), dim3((unsigned)((waves + 3) / 4), nbatch), dim3(256), 0, s, (const IO *)a.x, a.n,
+                           a.T, a.J, a.batch_stride, (const double *)p->gt_dev, a.v, D);
+        SK_HIP(hipGetLastError());
+        hipLaunchKernelGGL((iir_carry_kernel<D, ORD>), dim3(W, nbatch), dim3(256), 0, s, (const double *)a.v, (const double *)p->lbk_dev,
+                           a.J, a.zi, carry);
+        a.n_lb = 0;  // K3 reads the carries
+    } else {
+        hipLaunchKernelGGL((iir_chunk_kernel<NSEC, ORD, IO, false>), dim3(W, nbatch), dim3(kIirThreads), 0, s, a, cf);
+    }
     SK_HIP(hipGetLastError());
-    if (p->n_lb == 0) {  // slowly decaying / marginally stable filter: full scan of the workgroup aggregates
+    if (p->n_lb == 0 && !fast) {  // slowly decaying / marginally stable filter: full scan of the workgroup aggregates
         hipLaunchKernelGGL((iir_wg_scan_kernel<D>), dim3(nbatch), dim3(1024), 0, s, (const double *)agg, (const double *)p->pw_dev, W, carry, a.zi);
         SK_HIP(hipGetLastError());
     }
@@ -570,6 +744,7 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     int64_t T = (n + maxChunks - 1) / maxChunks;
     T = ((T + kPiece - 1) / kPiece) * kPiece;
     if (T < kPiece) T = kPiece;
+    if (T >= kMmPiece) T = ((T + kMmPiece - 1) / kMmPiece) * kMmPiece;  // whole 128-sample pieces for the matrix-pipe K1
     const int64_t J = (n + T - 1) / T;
     const int W = (int)((J + kIirThreads - 1) / kIirThreads);
     rc = ensure_powers(h, T, s);
