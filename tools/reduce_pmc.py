@@ -16,24 +16,27 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-WORK = {  # workload -> (kernel substring, algorithmic bytes per step, dispatches per step)
-    "fir1024": ("ols_tile_kernel", 16 * 2 ** 26, 1),
-    "fir127": ("ols_tile_kernel", 8 * 2 ** 26, 1),
-    "updn43": ("fir_sw_kernel", 8 * 2 ** 26 + 8 * ((2 ** 26 * 4) // 3), 1),
-    "iir8": ("iir_chunk_kernel", 8 * 2 ** 26, 2),
+WORK = {  # workload -> (substring of every kernel of a step, substring of the kernel that runs once per step, algorithmic bytes)
+    "fir1024": ("ols_tile_kernel", "ols_tile_kernel", 16 * 2 ** 26),
+    "fir127": ("ols_tile_kernel", "ols_tile_kernel", 8 * 2 ** 26),
+    "updn43": ("fir_sw_kernel", "fir_sw_kernel", 8 * 2 ** 26 + 8 * ((2 ** 26 * 4) // 3)),
+    "iir8": ("skdsp::iir_", "float, true>", 8 * 2 ** 26),  # K1 (matrix pipe or recurrence) + carries/K2 + K3
 }
-for w, (pat, alg, per_step) in WORK.items():
+for w, (pat, marker, alg) in WORK.items():
     out = {}
     for tag in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         f = os.path.join(src, "pmc_%s_%s.csv" % (w, tag))
         if not os.path.exists(f):
             continue
         acc = collections.defaultdict(list)
+        steps = collections.defaultdict(int)
         for r in csv.DictReader(open(f)):
             if pat in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                if marker in r["Kernel_Name"]:
+                    steps[r["Counter_Name"]] += 1
         for k, v in acc.items():
-            out[k] = {"dispatches": len(v), "mean_per_dispatch": sum(v) / len(v), "per_step": sum(v) / len(v) * per_step}
+            out[k] = {"dispatches": len(v), "steps": steps[k], "per_step": sum(v) / max(steps[k], 1)}
     if "FETCH_SIZE" not in out or "WRITE_SIZE" not in out:
         continue
     rd = out["FETCH_SIZE"]["per_step"] * 1024 * 2
@@ -42,7 +45,7 @@ for w, (pat, alg, per_step) in WORK.items():
         "hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr, "hbm_total_bytes_per_step": rd + wr,
         "algorithmic_bytes_per_step": alg, "traffic_over_algorithmic": (rd + wr) / alg,
         "note": "FETCH_SIZE/WRITE_SIZE in KiB; read side doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM); "
-                "separate --pmc passes of `bench.py --workload %s`; kernels matching '%s', %d dispatch(es) per step" % (w, pat, per_step),
+                "separate --pmc passes of `bench.py --workload %s`; all kernels matching '%s' summed per bench step" % (w, pat),
     }
     json.dump(out, open(os.path.join(dst, "pmc_%s.json" % w), "w"), indent=1)
     print(w, "traffic/algorithmic = %.3f  (%.1f MB read + %.1f MB written per step)" % ((rd + wr) / alg, rd / 1e6, wr / 1e6))
