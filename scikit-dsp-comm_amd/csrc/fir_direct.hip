@@ -560,6 +560,7 @@ FirHandle::~FirHandle()
 {
     for (auto &p : poly) if (p.dev) (void)hipFree(p.dev);
     for (auto &t : sw) { if (t.taps) (void)hipFree(t.taps); if (t.rho) (void)hipFree(t.rho); }
+    for (auto &t : mm) if (t.At) (void)hipFree(t.At);
     if (ols) fir_ols_free(ols);
 }
 
@@ -659,6 +660,8 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     if (n_out <= 0) return SKDSP_OK;
     SK_CHECK(!(h->taps_complex && !dtype_complex(h->dtype)), SKDSP_ERR_BADARG,
              "fir: complex taps need a complex signal dtype (promote x first)");
+    static const int mm_mode = getenv("SKDSP_FIR_MM") ? atoi(getenv("SKDSP_FIR_MM")) : 1;  // 0: never (developer A/B)
+    if (mm_mode && fir_mm_supported(h, L, M, n_out)) return fir_mm_launch(h, x, n, n_hist, L, M, n_out, y, s);
     void *bank = nullptr;
     int T = 0;
     int rc = get_bank(h, L, &bank, &T);

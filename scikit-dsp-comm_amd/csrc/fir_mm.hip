@@ -1,0 +1,245 @@
+// fir_mm.hip -- direct / polyphase FIR of float32 or complex64 signals with real taps as a Toeplitz
+// matrix product on the FP32 matrix pipe (gfx950: v_mfma_f32_16x16x4_f32, exact f32 FMA chains at the
+// FP32 vector peak -- which a v_pk_fma_f32 sliding-window kernel reaches to ~40 % at best).
+//
+// Serves the same reference calls as fir_direct.hip (multirate_helper.py:104-127 and
+// downsample(up(x,L),M)):   y[m] = L * sum_t b[phi_c + L t] * x[i_c + q s - t],
+//     m = c + L' s,  c = m mod L' (class),  L' = L/gcd, q = M/gcd,  phi_c = (c M) mod L, i_c = (c M) div L.
+//
+// 16 output ROWS are formed from DS = floor(16 / L') consecutive slots of all L' classes,
+//     row r = L' ds + c  (ds < DS),   column N = slot block,   slot s = DS N + ds,
+// so that the output index is  m = RS N + r  (RS = L' DS rows in use: a column block IS a contiguous run of
+// the output) and the input index is  q DS N + U0 - u  with a lag u = t + U0 - i_c - q ds >= 0 that no
+// longer depends on N.  Hence
+//     Y[16 x N] = A[16 x K] * W[K x N],   A[r][u] = L b[phi_c + L (u - U0 + i_c + q ds)]  (0 outside the taps),
+//                                          W[u][N] = x[q DS N + U0 - u],     K = T + U0,  T = ceil(P / L)
+// A depends on the filter only: each lane keeps its K/4 A-operands (row l & 15, lag 4 ks + (l >> 4)) in
+// registers for the whole launch.  W is read straight out of the LDS window (lane l: column l & 15, lag
+// l >> 4 of the step), complex samples as one 8-byte read feeding two MFMAs (re, im).  The accumulator
+// layout (col = lane & 15, row = 4 (lane >> 4) + reg) puts 4 consecutive outputs in every lane and a
+// wave's 16 x 16 tile in 256 consecutive outputs: stores are full 2 KiB rows with no transposition.
+// The window is stored with one pad element after every 8 (physical = e + (e >> 3)): the 16 columns of a
+// B read are q DS elements apart, which without the skew lands them on a few banks for most strides
+// (12 complex elements: 2-way, 16: 8-way; with it at most 2-way for every stride, none for 12).
+#include "skdsp_internal.hpp"
+#include <numeric>
+#include <vector>
+
+namespace skdsp {
+
+typedef float v4f_mm __attribute__((ext_vector_type(4)));
+
+struct MmArgs {
+    int64_t n, n_hist, n_out;
+    int q_ds;   // q * DS: input samples per column block
+    int RS;     // rows in use = L' * DS (<= 16): outputs per column block
+    int K4;     // K / 4 MFMA steps (K padded to a multiple of 4)
+    int U0;     // lag offset (see above)
+    int NS;     // column blocks per workgroup (multiple of 64)
+    int win;    // staged samples per workgroup = q_ds * (NS - 1) + 4 * K4
+};
+
+__device__ __forceinline__ int mm_phys(int e) { return e + (e >> 3); }
+
+template <typename X> struct MmIo;
+template <> struct MmIo<float> { static constexpr int C = 1; };
+template <> struct MmIo<float2> { static constexpr int C = 2; };
+
+template <typename X, int K4B>
+__global__ __launch_bounds__(256) void fir_mm_kernel(const X *__restrict__ x, const float *__restrict__ At, MmArgs a,
+                                                     X *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    X *win = reinterpret_cast<X *>(smem_raw);
+    constexpr bool CPLX = MmIo<X>::C == 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = 4 * a.K4;
+    const int64_t S0 = (int64_t)blockIdx.x * a.NS;                 // first column block of this workgroup
+    const int64_t g0 = (int64_t)a.q_ds * S0 + a.U0 - (K - 1);       // input index of win[0]
+
+    // A operands of this lane for every step (zero beyond K4)
+    float areg[K4B];  // a.K4 == K4B: the host pads the lag range with zero taps up to the instantiated size
+#pragma unroll
+    for (int ks = 0; ks < K4B; ++ks) areg[ks] = At[ks * 64 + lane];
+
+    // ---- stage the window (zero outside [-n_hist, n)); 16-byte loads for interior workgroups ----
+    {
+        constexpr int VEC = 16 / (int)sizeof(X);
+        const X *src = x + g0;
+        const bool interior = g0 >= -a.n_hist && g0 + a.win <= a.n && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+        if (interior) {
+            const int nv = a.win / VEC;
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            for (int k0 = tid; k0 < nv; k0 += 256 * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + 256 * u < nv) v[u] = s4[k0 + 256 * u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + 256 * u < nv) {
+                        const int i = (k0 + 256 * u) * VEC;  // VEC <= 4 elements starting at a multiple of VEC share a pad group
+                        X *dst = win + mm_phys(i);
+                        const X *e = reinterpret_cast<const X *>(&v[u]);
+#pragma unroll
+                        for (int t = 0; t < VEC; ++t) dst[t] = e[t];
+                    }
+            }
+            for (int i = nv * VEC + tid; i < a.win; i += 256) win[mm_phys(i)] = src[i];
+        } else {
+            for (int i0 = tid; i0 < a.win; i0 += 256 * 8) {
+                X v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 256 * u;
+                    const int64_t g = g0 + i;
+                    X z;
+                    if constexpr (CPLX) z = make_float2(0.f, 0.f); else z = 0.f;
+                    v[u] = z;
+                    if (i < a.win && g >= -a.n_hist && g < a.n) v[u] = x[g];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + 256 * u < a.win) win[mm_phys(i0 + 256 * u)] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int ncol = lane & 15, klane = lane >> 4;
+    const int ntiles = a.NS / 16;
+    for (int tile = wave; tile < ntiles; tile += 4) {
+        // W[u][N]: window index of (column N, lag u) = q_ds * Nloc + (K - 1) - u
+        const int eb = a.q_ds * (tile * 16 + ncol) + (K - 1) - klane;
+        // four interleaved accumulator sets: independent MFMA chains, and partial sums of K/4 terms each
+        // (a single f32 chain over all lags sits at 5e-7 of the float64 result for ~150 lags)
+        v4f_mm ar[4], ai[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ar[c] = ai[c] = v4f_mm{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < K4B; ++ks) {
+            const X b = win[mm_phys(eb - 4 * ks)];
+            if constexpr (CPLX) {
+                ar[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ks], b.x, ar[ks & 3], 0, 0, 0);
+                ai[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ks], b.y, ai[ks & 3], 0, 0, 0);
+            } else {
+                ar[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ks], b, ar[ks & 3], 0, 0, 0);
+            }
+        }
+        v4f_mm ar0 = (ar[0] + ar[1]) + (ar[2] + ar[3]);
+        v4f_mm ai0 = (ai[0] + ai[1]) + (ai[2] + ai[3]);
+        // rows 4 (lane >> 4) + i of column N: outputs m = RS N + row
+        const int64_t N = S0 + tile * 16 + ncol;
+        const int row0 = 4 * klane;
+        const int64_t m0 = (int64_t)a.RS * N + row0;
+        if (a.RS == 16 && m0 + 4 <= a.n_out && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+            if constexpr (CPLX) {
+                float4 *dst = reinterpret_cast<float4 *>(y + m0);
+                dst[0] = make_float4(ar0[0], ai0[0], ar0[1], ai0[1]);
+                dst[1] = make_float4(ar0[2], ai0[2], ar0[3], ai0[3]);
+            } else {
+                *reinterpret_cast<float4 *>(y + m0) = make_float4(ar0[0], ar0[1], ar0[2], ar0[3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (row0 + i < a.RS && m0 + i < a.n_out) {
+                    if constexpr (CPLX) y[m0 + i] = make_float2(ar0[i], ai0[i]);
+                    else y[m0 + i] = ar0[i];
+                }
+            }
+        }
+    }
+}
+
+// A-operand table of one (L, M): At[ks][lane] = A[row = lane & 15][u = 4 ks + (lane >> 4)]
+static int get_mm_table(FirHandle *h, int L, int M, const FirHandle::MmTab **out)
+{
+    for (auto &t : h->mm)
+        if (t.L == L && t.M == M) { *out = &t; return SKDSP_OK; }
+    const int g = std::gcd(L, M), Lp = L / g, q = M / g;
+    const int P = h->ntaps, T = (P + L - 1) / L;
+    const int DS = 16 / Lp, RS = Lp * DS;
+    int imax = 0;
+    for (int c = 0; c < Lp; ++c) imax = std::max(imax, (int)(((int64_t)c * M) / L));
+    const int U0 = imax + q * (DS - 1);
+    const int K4 = ((T + U0 + 3) / 4 + 7) / 8 * 8;  // padded to the kernel instantiations (multiples of 8 steps)
+    std::vector<float> host((size_t)K4 * 64, 0.f);
+    for (int r = 0; r < RS; ++r) {
+        const int ds = r / Lp, c = r % Lp;
+        const int64_t cm = (int64_t)c * M;
+        const int phi = (int)(cm % L), ic = (int)(cm / L);
+        for (int u = 0; u < 4 * K4; ++u) {
+            const int t = u - U0 + ic + q * ds;
+            if (t < 0 || t >= T) continue;
+            const int k = phi + L * t;
+            if (k >= P) continue;
+            host[(size_t)(u / 4) * 64 + (size_t)(u % 4) * 16 + r] = (float)((double)L * h->taps_host[k]);
+        }
+    }
+    FirHandle::MmTab t;
+    t.L = L; t.M = M; t.Lp = Lp; t.q = q; t.DS = DS; t.RS = RS; t.U0 = U0; t.K4 = K4; t.At = nullptr;
+    SK_HIP(hipMalloc(&t.At, host.size() * 4));
+    SK_HIP(hipMemcpy(t.At, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    h->mm.push_back(t);
+    *out = &h->mm.back();
+    return SKDSP_OK;
+}
+
+bool fir_mm_supported(const FirHandle *h, int L, int M, int64_t n_out)
+{
+    if (h->taps_complex || (h->dtype != SKDSP_F32 && h->dtype != SKDSP_C64)) return false;
+    const int g = std::gcd(L, M), Lp = L / g, q = M / g;
+    if (Lp > 16) return false;
+    const int T = (h->ntaps + L - 1) / L, DS = 16 / Lp;
+    const int64_t imax = ((int64_t)(Lp - 1) * M) / L;
+    const int64_t K = T + imax + (int64_t)q * (DS - 1);
+    if (K > 4 * 96 - 28) return false;                    // A operands must fit the register file
+    const int64_t win = (int64_t)q * DS * 63 + K + 32;    // smallest workgroup tile (NS = 64)
+    if (win * 9 / 8 * (int64_t)dtype_size(h->dtype) > 63 * 1024) return false;
+    return n_out >= 16 * 64;
+}
+
+int fir_mm_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, int M, int64_t n_out, void *y, hipStream_t s)
+{
+    if (n_out <= 0) return SKDSP_OK;
+    const FirHandle::MmTab *t = nullptr;
+    int rc = get_mm_table(h, L, M, &t);
+    if (rc) return rc;
+    const size_t esz = dtype_size(h->dtype);
+    MmArgs a;
+    a.n = n; a.n_hist = n_hist; a.n_out = n_out;
+    a.q_ds = t->q * t->DS; a.RS = t->RS; a.K4 = t->K4; a.U0 = t->U0;
+    // column blocks per workgroup: as many as a 64 KiB window holds (2 workgroups per CU), at most 512
+    int NS = getenv("SKDSP_MM_NS") ? atoi(getenv("SKDSP_MM_NS")) : 256;
+    while (NS > 64 && ((size_t)a.q_ds * (NS - 1) + 4 * a.K4) * 9 / 8 * esz > (size_t)63 * 1024) NS -= 64;
+    const int64_t ncols = (n_out + a.RS - 1) / a.RS;
+    while (NS > 64 && (ncols + NS - 1) / NS < 2 * ctx().num_cus) NS -= 64;  // small problems: more workgroups
+    a.NS = NS;
+    a.win = a.q_ds * (NS - 1) + 4 * a.K4;
+    const size_t lds = ((((size_t)a.win + (size_t)a.win / 8 + 2) * esz + 15) & ~(size_t)15) + 64;
+    const unsigned grid = (unsigned)((ncols + NS - 1) / NS);
+#define SK_MM(XT, KB)                                                                                              \
+    hipLaunchKernelGGL((fir_mm_kernel<XT, KB>), dim3(grid), dim3(256), lds, s, (const XT *)x, (const float *)t->At, a, (XT *)y)
+#define SK_MMK(XT)                                                       \
+    switch (a.K4) {                                                      \
+    case 8: SK_MM(XT, 8); break;   case 16: SK_MM(XT, 16); break;        \
+    case 24: SK_MM(XT, 24); break; case 32: SK_MM(XT, 32); break;        \
+    case 40: SK_MM(XT, 40); break; case 48: SK_MM(XT, 48); break;        \
+    case 56: SK_MM(XT, 56); break; case 64: SK_MM(XT, 64); break;        \
+    case 72: SK_MM(XT, 72); break; case 80: SK_MM(XT, 80); break;        \
+    case 88: SK_MM(XT, 88); break; case 96: SK_MM(XT, 96); break;        \
+    default: SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "fir_mm: %d steps", a.K4); \
+    }
+    if (h->dtype == SKDSP_C64) {
+        SK_MMK(float2)
+    } else {
+        SK_MMK(float)
+    }
+#undef SK_MMK
+#undef SK_MM
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+}  // namespace skdsp

@@ -79,6 +79,9 @@ struct FirHandle : HandleBase {
     // sliding-window tap tables, keyed by (L, M, R)
     struct SwTab { int L, M, R; void *taps; void *rho; };
     std::vector<SwTab> sw;
+    // Toeplitz-product (matrix pipe) A-operand tables, keyed by (L, M)  -- fir_mm.hip
+    struct MmTab { int L, M, Lp, q, DS, RS, U0, K4; void *At; };
+    std::vector<MmTab> mm;
     OlsPlan *ols = nullptr;
     ~FirHandle();
 };
@@ -87,6 +90,10 @@ struct FirHandle : HandleBase {
 //   y[m] = L * sum_t b[phi + L t] * x[i - t],  j = m*M, phi = j mod L, i = j div L,  m in [0, n_out)
 int fir_direct_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, int64_t n_out,
                       void *y_dev, hipStream_t s);
+// Toeplitz product on the FP32 matrix pipe (fir_mm.hip): float32 / complex64 signals, real taps
+bool fir_mm_supported(const FirHandle *h, int L, int M, int64_t n_out);
+int fir_mm_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, int64_t n_out, void *y_dev,
+                  hipStream_t s);
 // FFT overlap-save (fir_ols.hip): c64 (and packed f32) .filter
 bool fir_ols_supported(const FirHandle *h);
 int fir_ols_tile_outputs(FirHandle *h, int *V);  // outputs per overlap-save tile (builds the plan if needed)
