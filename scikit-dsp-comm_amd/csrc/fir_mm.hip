@@ -163,7 +163,7 @@ static int get_mm_table(FirHandle *h, int L, int M, const FirHandle::MmTab **out
     int imax = 0;
     for (int c = 0; c < Lp; ++c) imax = std::max(imax, (int)(((int64_t)c * M) / L));
     const int U0 = imax + q * (DS - 1);
-    const int K4 = ((T + U0 + 3) / 4 + 7) / 8 * 8;  // padded to the kernel instantiations (multiples of 8 steps)
+    const int K4 = ((T + U0 + 3) / 4 + 3) / 4 * 4;  // padded to the kernel instantiations (multiples of 4 steps)
     std::vector<float> host((size_t)K4 * 64, 0.f);
     for (int r = 0; r < RS; ++r) {
         const int ds = r / Lp, c = r % Lp;
@@ -194,7 +194,7 @@ bool fir_mm_supported(const FirHandle *h, int L, int M, int64_t n_out)
     const int T = (h->ntaps + L - 1) / L, DS = 16 / Lp;
     const int64_t imax = ((int64_t)(Lp - 1) * M) / L;
     const int64_t K = T + imax + (int64_t)q * (DS - 1);
-    if (K > 4 * 96 - 28) return false;                    // A operands must fit the register file
+    if (K > 4 * 96 - 12) return false;                    // A operands must fit the register file
     const int64_t win = (int64_t)q * DS * 63 + K + 32;    // smallest workgroup tile (NS = 64)
     if (win * 9 / 8 * (int64_t)dtype_size(h->dtype) > 63 * 1024) return false;
     return n_out >= 16 * 64;
@@ -223,12 +223,30 @@ int fir_mm_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L,
     hipLaunchKernelGGL((fir_mm_kernel<XT, KB>), dim3(grid), dim3(256), lds, s, (const XT *)x, (const float *)t->At, a, (XT *)y)
 #define SK_MMK(XT)                                                       \
     switch (a.K4) {                                                      \
-    case 8: SK_MM(XT, 8); break;   case 16: SK_MM(XT, 16); break;        \
-    case 24: SK_MM(XT, 24); break; case 32: SK_MM(XT, 32); break;        \
-    case 40: SK_MM(XT, 40); break; case 48: SK_MM(XT, 48); break;        \
-    case 56: SK_MM(XT, 56); break; case 64: SK_MM(XT, 64); break;        \
-    case 72: SK_MM(XT, 72); break; case 80: SK_MM(XT, 80); break;        \
-    case 88: SK_MM(XT, 88); break; case 96: SK_MM(XT, 96); break;        \
+    case 4: SK_MM(XT, 4); break;                                      \
+    case 8: SK_MM(XT, 8); break;                                      \
+    case 12: SK_MM(XT, 12); break;                                      \
+    case 16: SK_MM(XT, 16); break;                                      \
+    case 20: SK_MM(XT, 20); break;                                      \
+    case 24: SK_MM(XT, 24); break;                                      \
+    case 28: SK_MM(XT, 28); break;                                      \
+    case 32: SK_MM(XT, 32); break;                                      \
+    case 36: SK_MM(XT, 36); break;                                      \
+    case 40: SK_MM(XT, 40); break;                                      \
+    case 44: SK_MM(XT, 44); break;                                      \
+    case 48: SK_MM(XT, 48); break;                                      \
+    case 52: SK_MM(XT, 52); break;                                      \
+    case 56: SK_MM(XT, 56); break;                                      \
+    case 60: SK_MM(XT, 60); break;                                      \
+    case 64: SK_MM(XT, 64); break;                                      \
+    case 68: SK_MM(XT, 68); break;                                      \
+    case 72: SK_MM(XT, 72); break;                                      \
+    case 76: SK_MM(XT, 76); break;                                      \
+    case 80: SK_MM(XT, 80); break;                                      \
+    case 84: SK_MM(XT, 84); break;                                      \
+    case 88: SK_MM(XT, 88); break;                                      \
+    case 92: SK_MM(XT, 92); break;                                      \
+    case 96: SK_MM(XT, 96); break;                                      \
     default: SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "fir_mm: %d steps", a.K4); \
     }
     if (h->dtype == SKDSP_C64) {

@@ -1029,3 +1029,18 @@ def test_iir_up_dn_complex_vs_scipy(dt):
     ref = signal.sosfilt(sos, 5 * np.kron(xw, np.r_[1.0, np.zeros(4)]))
     assert max(rel_err(f.up(x, 5), ref)) <= tol
     assert max(rel_err(f.dn(x, 7), signal.sosfilt(sos, xw)[::7][:n // 7])) <= tol
+
+
+def test_sliding_window_kernels_without_the_matrix_pipe_path():
+    """float32 / complex64 direct FIRs normally run as Toeplitz products on the matrix pipe (fir_mm.hip);
+    the register sliding-window kernels behind them (still used for float64 / complex128, complex taps
+    and very long lag ranges) are re-checked here on the same float32 / complex64 cases."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SKDSP_FIR_MM="0")
+    here = os.path.abspath(__file__)
+    out = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
+                          "c64_polyphase_large_tiles or fir_polyphase_all_ratios or g6_fir512 or updn_full_size"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = out.stdout.decode()[-600:]
+    assert out.returncode == 0 and " passed" in tail, tail
