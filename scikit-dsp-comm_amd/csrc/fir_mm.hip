@@ -41,16 +41,41 @@ struct MmArgs {
 
 __device__ __forceinline__ int mm_phys(int e) { return e + (e >> 3); }
 
-template <typename X> struct MmIo;
-template <> struct MmIo<float> { static constexpr int C = 1; };
-template <> struct MmIo<float2> { static constexpr int C = 2; };
+typedef double v4d_mm __attribute__((ext_vector_type(4)));
 
+// signal type -> scalar type, components, accumulator vector, MFMA
+template <typename X> struct MmIo;
+template <> struct MmIo<float> { using S = float; using V = v4f_mm; static constexpr int C = 1; };
+template <> struct MmIo<float2> { using S = float; using V = v4f_mm; static constexpr int C = 2; };
+template <> struct MmIo<double> { using S = double; using V = v4d_mm; static constexpr int C = 1; };
+template <> struct MmIo<double2> { using S = double; using V = v4d_mm; static constexpr int C = 2; };
+
+__device__ __forceinline__ v4f_mm mm_mfma(float a, float b, v4f_mm c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ v4d_mm mm_mfma(double a, double b, v4d_mm c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+template <typename S> __device__ __forceinline__ S mm_re(S v) { return v; }
+__device__ __forceinline__ float mm_re(float2 v) { return v.x; }
+__device__ __forceinline__ double mm_re(double2 v) { return v.x; }
+__device__ __forceinline__ float mm_im(float2 v) { return v.y; }
+__device__ __forceinline__ double mm_im(double2 v) { return v.y; }
+template <typename X> __device__ __forceinline__ X mm_zero();
+template <> __device__ __forceinline__ float mm_zero<float>() { return 0.f; }
+template <> __device__ __forceinline__ double mm_zero<double>() { return 0.0; }
+template <> __device__ __forceinline__ float2 mm_zero<float2>() { return make_float2(0.f, 0.f); }
+template <> __device__ __forceinline__ double2 mm_zero<double2>() { return make_double2(0.0, 0.0); }
+template <typename S> __device__ __forceinline__ void mm_put(S *y, S re, S) { *y = re; }
+__device__ __forceinline__ void mm_put(float2 *y, float re, float im) { *y = make_float2(re, im); }
+__device__ __forceinline__ void mm_put(double2 *y, double re, double im) { *y = make_double2(re, im); }
+
+// The f64 MFMA returns rows (lane >> 4) + 4 reg instead of 4 (lane >> 4) + reg; the host permutes the
+// rows of A for float64 / complex128 so that, either way, register i of lane group g is output row 4 g + i.
 template <typename X, int K4B>
-__global__ __launch_bounds__(256) void fir_mm_kernel(const X *__restrict__ x, const float *__restrict__ At, MmArgs a,
+__global__ __launch_bounds__(256) void fir_mm_kernel(const X *__restrict__ x, const typename MmIo<X>::S *__restrict__ At, MmArgs a,
                                                      X *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     X *win = reinterpret_cast<X *>(smem_raw);
+    using S = typename MmIo<X>::S;
+    using V = typename MmIo<X>::V;
     constexpr bool CPLX = MmIo<X>::C == 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = 4 * a.K4;
@@ -58,7 +83,7 @@ __global__ __launch_bounds__(256) void fir_mm_kernel(const X *__restrict__ x, co
     const int64_t g0 = (int64_t)a.q_ds * S0 + a.U0 - (K - 1);       // input index of win[0]
 
     // A operands of this lane for every step (zero beyond K4)
-    float areg[K4B];  // a.K4 == K4B: the host pads the lag range with zero taps up to the instantiated size
+    S areg[K4B];  // a.K4 == K4B: the host pads the lag range with zero taps up to the instantiated size
 #pragma unroll
     for (int ks = 0; ks < K4B; ++ks) areg[ks] = At[ks * 64 + lane];
 
@@ -93,9 +118,7 @@ __global__ __launch_bounds__(256) void fir_mm_kernel(const X *__restrict__ x, co
                 for (int u = 0; u < 8; ++u) {
                     const int i = i0 + 256 * u;
                     const int64_t g = g0 + i;
-                    X z;
-                    if constexpr (CPLX) z = make_float2(0.f, 0.f); else z = 0.f;
-                    v[u] = z;
+                    v[u] = mm_zero<X>();
                     if (i < a.win && g >= -a.n_hist && g < a.n) v[u] = x[g];
                 }
 #pragma unroll
@@ -113,41 +136,37 @@ __global__ __launch_bounds__(256) void fir_mm_kernel(const X *__restrict__ x, co
         const int eb = a.q_ds * (tile * 16 + ncol) + (K - 1) - klane;
         // four interleaved accumulator sets: independent MFMA chains, and partial sums of K/4 terms each
         // (a single f32 chain over all lags sits at 5e-7 of the float64 result for ~150 lags)
-        v4f_mm ar[4], ai[4];
+        V ar[4], ai[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ar[c] = ai[c] = v4f_mm{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 4; ++c) ar[c] = ai[c] = V{0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < K4B; ++ks) {
             const X b = win[mm_phys(eb - 4 * ks)];
-            if constexpr (CPLX) {
-                ar[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ks], b.x, ar[ks & 3], 0, 0, 0);
-                ai[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ks], b.y, ai[ks & 3], 0, 0, 0);
-            } else {
-                ar[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ks], b, ar[ks & 3], 0, 0, 0);
-            }
+            ar[ks & 3] = mm_mfma(areg[ks], mm_re(b), ar[ks & 3]);
+            if constexpr (CPLX) ai[ks & 3] = mm_mfma(areg[ks], mm_im(b), ai[ks & 3]);
         }
-        v4f_mm ar0 = (ar[0] + ar[1]) + (ar[2] + ar[3]);
-        v4f_mm ai0 = (ai[0] + ai[1]) + (ai[2] + ai[3]);
+        const V ar0 = (ar[0] + ar[1]) + (ar[2] + ar[3]);
+        const V ai0 = (ai[0] + ai[1]) + (ai[2] + ai[3]);
         // rows 4 (lane >> 4) + i of column N: outputs m = RS N + row
         const int64_t N = S0 + tile * 16 + ncol;
         const int row0 = 4 * klane;
         const int64_t m0 = (int64_t)a.RS * N + row0;
         if (a.RS == 16 && m0 + 4 <= a.n_out && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
-            if constexpr (CPLX) {
-                float4 *dst = reinterpret_cast<float4 *>(y + m0);
-                dst[0] = make_float4(ar0[0], ai0[0], ar0[1], ai0[1]);
-                dst[1] = make_float4(ar0[2], ai0[2], ar0[3], ai0[3]);
-            } else {
-                *reinterpret_cast<float4 *>(y + m0) = make_float4(ar0[0], ar0[1], ar0[2], ar0[3]);
-            }
-        } else {
+            // 4 consecutive outputs per lane: 16-byte stores
+            S buf[4 * MmIo<X>::C];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (row0 + i < a.RS && m0 + i < a.n_out) {
-                    if constexpr (CPLX) y[m0 + i] = make_float2(ar0[i], ai0[i]);
-                    else y[m0 + i] = ar0[i];
-                }
+                buf[MmIo<X>::C * i] = ar0[i];
+                if constexpr (CPLX) buf[2 * i + 1] = ai0[i];
             }
+            constexpr int NV = 4 * (int)sizeof(X) / 16;
+            float4 *dst = reinterpret_cast<float4 *>(y + m0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) dst[v] = reinterpret_cast<const float4 *>(buf)[v];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (row0 + i < a.RS && m0 + i < a.n_out) mm_put(y + m0 + i, (S)ar0[i], (S)ai0[i]);
         }
     }
 }
@@ -164,7 +183,8 @@ static int get_mm_table(FirHandle *h, int L, int M, const FirHandle::MmTab **out
     for (int c = 0; c < Lp; ++c) imax = std::max(imax, (int)(((int64_t)c * M) / L));
     const int U0 = imax + q * (DS - 1);
     const int K4 = ((T + U0 + 3) / 4 + 3) / 4 * 4;  // padded to the kernel instantiations (multiples of 4 steps)
-    std::vector<float> host((size_t)K4 * 64, 0.f);
+    const bool dbl = dtype_double(h->dtype);
+    std::vector<double> host((size_t)K4 * 64, 0.0);
     for (int r = 0; r < RS; ++r) {
         const int ds = r / Lp, c = r % Lp;
         const int64_t cm = (int64_t)c * M;
@@ -174,13 +194,18 @@ static int get_mm_table(FirHandle *h, int L, int M, const FirHandle::MmTab **out
             if (t < 0 || t >= T) continue;
             const int k = phi + L * t;
             if (k >= P) continue;
-            host[(size_t)(u / 4) * 64 + (size_t)(u % 4) * 16 + r] = (float)((double)L * h->taps_host[k]);
+            // MFMA row that must hold output row r: the f64 instruction returns rows (lane >> 4) + 4 reg
+            const int row = dbl ? (r % 4) * 4 + r / 4 : r;
+            host[(size_t)(u / 4) * 64 + (size_t)(u % 4) * 16 + row] = (double)L * h->taps_host[k];
         }
     }
+    std::vector<float> hostf;
+    if (!dbl) hostf.assign(host.begin(), host.end());
     FirHandle::MmTab t;
     t.L = L; t.M = M; t.Lp = Lp; t.q = q; t.DS = DS; t.RS = RS; t.U0 = U0; t.K4 = K4; t.At = nullptr;
-    SK_HIP(hipMalloc(&t.At, host.size() * 4));
-    SK_HIP(hipMemcpy(t.At, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    const size_t tbytes = host.size() * (dbl ? 8 : 4);
+    SK_HIP(hipMalloc(&t.At, tbytes));
+    SK_HIP(hipMemcpy(t.At, dbl ? (const void *)host.data() : (const void *)hostf.data(), tbytes, hipMemcpyHostToDevice));
     h->mm.push_back(t);
     *out = &h->mm.back();
     return SKDSP_OK;
@@ -188,13 +213,14 @@ static int get_mm_table(FirHandle *h, int L, int M, const FirHandle::MmTab **out
 
 bool fir_mm_supported(const FirHandle *h, int L, int M, int64_t n_out)
 {
-    if (h->taps_complex || (h->dtype != SKDSP_F32 && h->dtype != SKDSP_C64)) return false;
+    if (h->taps_complex || h->dtype == SKDSP_C128) return false;  // complex128: the sliding-window kernel measured faster
+    const int kmax = dtype_double(h->dtype) ? 48 : 96;  // A operands in registers: 1 (float) or 2 (double) VGPRs per step
     const int g = std::gcd(L, M), Lp = L / g, q = M / g;
     if (Lp > 16) return false;
     const int T = (h->ntaps + L - 1) / L, DS = 16 / Lp;
     const int64_t imax = ((int64_t)(Lp - 1) * M) / L;
     const int64_t K = T + imax + (int64_t)q * (DS - 1);
-    if (K > 4 * 96 - 12) return false;                    // A operands must fit the register file
+    if (K > 4 * kmax - 12) return false;                  // A operands must fit the register file
     const int64_t win = (int64_t)q * DS * 63 + K + 32;    // smallest workgroup tile (NS = 64)
     if (win * 9 / 8 * (int64_t)dtype_size(h->dtype) > 63 * 1024) return false;
     return n_out >= 16 * 64;
@@ -220,7 +246,7 @@ int fir_mm_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L,
     const size_t lds = ((((size_t)a.win + (size_t)a.win / 8 + 2) * esz + 15) & ~(size_t)15) + 64;
     const unsigned grid = (unsigned)((ncols + NS - 1) / NS);
 #define SK_MM(XT, KB)                                                                                              \
-    hipLaunchKernelGGL((fir_mm_kernel<XT, KB>), dim3(grid), dim3(256), lds, s, (const XT *)x, (const float *)t->At, a, (XT *)y)
+    hipLaunchKernelGGL((fir_mm_kernel<XT, KB>), dim3(grid), dim3(256), lds, s, (const XT *)x, (const typename MmIo<XT>::S *)t->At, a, (XT *)y)
 #define SK_MMK(XT)                                                       \
     switch (a.K4) {                                                      \
     case 4: SK_MM(XT, 4); break;                                      \
@@ -249,11 +275,29 @@ int fir_mm_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L,
     case 96: SK_MM(XT, 96); break;                                      \
     default: SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "fir_mm: %d steps", a.K4); \
     }
-    if (h->dtype == SKDSP_C64) {
-        SK_MMK(float2)
-    } else {
-        SK_MMK(float)
+#define SK_MMKD(XT)                                                      \
+    switch (a.K4) {                                                      \
+    case 4: SK_MM(XT, 4); break;                                      \
+    case 8: SK_MM(XT, 8); break;                                      \
+    case 12: SK_MM(XT, 12); break;                                      \
+    case 16: SK_MM(XT, 16); break;                                      \
+    case 20: SK_MM(XT, 20); break;                                      \
+    case 24: SK_MM(XT, 24); break;                                      \
+    case 28: SK_MM(XT, 28); break;                                      \
+    case 32: SK_MM(XT, 32); break;                                      \
+    case 36: SK_MM(XT, 36); break;                                      \
+    case 40: SK_MM(XT, 40); break;                                      \
+    case 44: SK_MM(XT, 44); break;                                      \
+    case 48: SK_MM(XT, 48); break;                                      \
+    default: SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "fir_mm: %d steps", a.K4); \
     }
+    switch (h->dtype) {
+    case SKDSP_C64: { SK_MMK(float2) } break;
+    case SKDSP_F32: { SK_MMK(float) } break;
+    case SKDSP_C128: { SK_MMKD(double2) } break;
+    default: { SK_MMKD(double) } break;
+    }
+#undef SK_MMKD
 #undef SK_MMK
 #undef SK_MM
     SK_HIP(hipGetLastError());
