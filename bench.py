@@ -108,9 +108,9 @@ def main():
         yd = _ffi.DeviceArray(n_out, dtype)
         step = lambda: k.updn_dev(xd, yd, 4, 3)                  # noqa: E731
         units, alg_bytes = n, 8.0 * n + 8.0 * n_out              # 18.67 B per input sample
-        compute = ("FP32 vector (packed v_pk_fma_f32)", 157.3, 4.0 * 512 / 4 * n_out)  # 4*Ntaps/L flop per c64 output
-        kern = "fir_sw_kernel"
-        wl = "downsample(multirate_FIR.up(x,4),3): 512-tap prototype, complex64, 2^%d input samples, fused polyphase" % args.log2n
+        compute = ("FP32 matrix pipe (v_mfma_f32_16x16x4_f32, = FP32 vector peak)", 157.3, 4.0 * 512 / 4 * n_out)  # 4*Ntaps/L flop per c64 output
+        kern = "fir_mm_kernel"
+        wl = "downsample(multirate_FIR.up(x,4),3): 512-tap prototype, complex64, 2^%d input samples, fused polyphase (Toeplitz product on the matrix pipe)" % args.log2n
         metric = "complex64 input MSamples/s (polyphase L=4/M=3, 512 taps)"
     else:
         sos = elliptic_bpf_sos()
