@@ -1044,3 +1044,38 @@ def test_sliding_window_kernels_without_the_matrix_pipe_path():
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     tail = out.stdout.decode()[-600:]
     assert out.returncode == 0 and " passed" in tail, tail
+
+
+class _View:
+    """A window of a DeviceArray starting `off` samples in (misaligned device pointers on purpose)."""
+    def __init__(self, base, off, n):
+        self.ptr = base.ptr + off * base.dtype.itemsize
+        self.n = n
+        self.dtype = base.dtype
+        self.code = base.code
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64, np.float64])
+@pytest.mark.parametrize("L,M", [(1, 1), (4, 3), (3, 1)])
+def test_direct_fir_misaligned_device_pointers(dt, L, M):
+    """x and y that are only element-aligned (views into larger device arrays): the 16-byte fast paths
+    of the matrix-pipe and sliding-window kernels must step aside."""
+    rng = np.random.default_rng(91)
+    b = rng.standard_normal(40) / 6
+    n = 300_001
+    n -= n % M
+    big = _ffi.DeviceArray(n + 64, dt).fill_noise(37)
+    ybig = _ffi.DeviceArray((n * L) // M + 64, dt)
+    k = _ffi.FirKernel(b, _ffi.code_of(dt))
+    k.set_algo(_ffi.FIR_DIRECT)
+    for xo, yo in ((1, 0), (3, 1), (0, 1)):
+        xv, yv = _View(big, xo, n), _View(ybig, yo, (n * L) // M)
+        k.updn_dev(xv, yv, L, M, n=n)
+        _ffi.sync()
+        x = big.to_host(xo, 20000)
+        ref = orc.fir_up(b, x, L)
+        if M > 1:
+            ref = orc.downsample(ref, M)
+        got = ybig.to_host(yo, len(ref))
+        tol = TOL32 if np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4 else 1e-12
+        assert_close(got, ref, tol, "%s L=%d M=%d offsets %d/%d" % (np.dtype(dt).name, L, M, xo, yo))
