@@ -1079,3 +1079,32 @@ def test_direct_fir_misaligned_device_pointers(dt, L, M):
         got = ybig.to_host(yo, len(ref))
         tol = TOL32 if np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4 else 1e-12
         assert_close(got, ref, tol, "%s L=%d M=%d offsets %d/%d" % (np.dtype(dt).name, L, M, xo, yo))
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_iir_matrix_pipe_chunk_states_large(dt):
+    """2^24 samples put the scan in its aggregate-free mode (chunk end states from the FP64 matrix pipe,
+    carries straight from them) for both I/O precisions: head and deep windows against the oracle,
+    and the same launch with the recurrence K1 (SKDSP_IIR_NO_MFMA) must agree to rounding."""
+    g = load("g7_iir_sos.npz")
+    sos = g["sos8"]
+    n = 2 ** 24
+    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+    xd = _ffi.DeviceArray(n, dt).fill_noise(17)
+    yd = _ffi.DeviceArray(n, dt)
+    k.filter_dev(xd, yd)
+    _ffi.sync()
+    tol = TOL32 if dt == np.float32 else 1e-9
+    m = 2 ** 19
+    assert_close(yd.to_host(0, m), orc.sos_filter(sos, xd.to_host(0, m)), tol, "head")
+    s0 = n - 2 * m
+    ref = orc.sos_filter(sos, xd.to_host(s0 - 20000, m + 20000))[20000:]
+    assert_close(yd.to_host(s0, m), ref, tol, "deep window")
+    os.environ["SKDSP_IIR_NO_MFMA"] = "1"
+    try:
+        y2 = _ffi.DeviceArray(n, dt)
+        k.filter_dev(xd, y2)
+        _ffi.sync()
+    finally:
+        del os.environ["SKDSP_IIR_NO_MFMA"]
+    assert_close(yd.to_host(s0, m), y2.to_host(s0, m), 1e-6 if dt == np.float32 else 1e-11, "matrix-pipe vs recurrence K1")
