@@ -351,7 +351,8 @@ typedef double v4d_t __attribute__((ext_vector_type(4)));
 constexpr int kMmPiece = 128;                 // samples of every chunk staged at a time
 constexpr int kMmPitch = kMmPiece + 4;        // in 4-byte words (float); doubles use 2 words per sample
 
-template <typename IO>
+// NT = 1: D <= 16 states (<= 8 biquads); NT = 2: up to 32 states in two 16-row tiles sharing the B operand.
+template <typename IO, int NT>
 __global__ __launch_bounds__(256) void iir_k1_mfma_kernel(const IO *__restrict__ xin, int64_t n, int64_t T, int64_t J,
                                                           int64_t batch_stride, const double *__restrict__ Gt,
                                                           double *__restrict__ vout, int D)
@@ -387,8 +388,11 @@ __global__ __launch_bounds__(256) void iir_k1_mfma_kernel(const IO *__restrict__
             pre[i] = val;
         }
     };
-    v4d_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+    v4d_t acc0[NT], acc1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc0[t] = acc1[t] = v4d_t{0.0, 0.0, 0.0, 0.0};
     const int c = lane & 15, j = lane >> 4;
+    const size_t tstride = (size_t)(T / 4) * 64;  // doubles per row tile of the table
     load_piece(0);
     for (int p = 0; p < npieces; ++p) {
 #pragma unroll
@@ -404,8 +408,12 @@ __global__ __launch_bounds__(256) void iir_k1_mfma_kernel(const IO *__restrict__
         const IO *xs = reinterpret_cast<const IO *>(img) + c * kMmPitch + j;
 #pragma unroll 8
         for (int s = 0; s < kMmPiece / 4; s += 2) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(gt[(size_t)s * 64], (double)xs[4 * s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(gt[(size_t)(s + 1) * 64], (double)xs[4 * s + 4], acc1, 0, 0, 0);
+            const double b0 = (double)xs[4 * s], b1 = (double)xs[4 * s + 4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(gt[t * tstride + (size_t)s * 64], b0, acc0[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(gt[t * tstride + (size_t)(s + 1) * 64], b1, acc1[t], 0, 0, 0);
+            }
         }
         asm volatile("" ::: "memory");
         if (p + 1 < npieces) load_piece(p + 1);
@@ -413,10 +421,12 @@ __global__ __launch_bounds__(256) void iir_k1_mfma_kernel(const IO *__restrict__
     const int64_t cj = chunk0 + c;
     if (cj < J) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int d = j + 4 * r;
-            if (d < D) vbase[(size_t)d * J + cj] = acc0[r] + acc1[r];
-        }
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 16 * t + j + 4 * r;
+                if (d < D) vbase[(size_t)d * J + cj] = acc0[t][r] + acc1[t][r];
+            }
     }
 }
 
@@ -428,15 +438,17 @@ template <int D, int ORD>
 __global__ __launch_bounds__(256) void iir_carry_kernel(const double *__restrict__ v, const double *__restrict__ lbk, int64_t J,
                                                         const double *__restrict__ zi, double *__restrict__ carry)
 {
-    const int tid = threadIdx.x, k = tid & 31, i0 = (tid >> 5) * ORD;
+    const int tid = threadIdx.x, k = tid & 31;
     const int64_t w = blockIdx.x, W = gridDim.x;
     const int bat = blockIdx.y;
     const double *vbase = v + (size_t)bat * D * J;
     const int64_t ck = w * kIirThreads - 1 - k;
+#pragma unroll 1
+    for (int i0 = (tid >> 5) * ORD; i0 < D; i0 += 8 * ORD) {
     double r[ORD];
 #pragma unroll
     for (int q = 0; q < ORD; ++q) r[q] = 0.0;
-    if (i0 < D) {
+    {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             if (j < i0 + ORD) {
@@ -453,9 +465,10 @@ __global__ __launch_bounds__(256) void iir_carry_kernel(const double *__restrict
 #pragma unroll
         for (int m = 16; m >= 1; m >>= 1) r[q] += __shfl_xor(r[q], m);
     }
-    if (k == 0 && i0 < D) {
+    if (k == 0) {
 #pragma unroll
         for (int q = 0; q < ORD; ++q) carry[((size_t)bat * W + w) * D + i0 + q] = r[q];
+    }
     }
 }
 
@@ -612,16 +625,18 @@ static int ensure_powers(IirHandle *h, int64_t T, hipStream_t s)
         SK_HIP(hipMemcpyAsync(p->lbk_dev, lbk.data(), lbk.size() * 8, hipMemcpyHostToDevice, s));
         SK_HIP(hipStreamSynchronize(s));
     }
-    if (D <= 16 && T % kMmPiece == 0) {
+    if (D <= 32 && T % kMmPiece == 0) {
         // G[:, k] = A^(T-1-k) b, b = the state one sample x = 1 leaves behind; stored as the MFMA A operand
         // of step s = k / 4: lane l holds row l & 15, column 4 s + (l >> 4)
         std::vector<long double> g(D, 0.0L);
         host_step(h, g, 1.0L);
-        std::vector<double> gt((size_t)T * 16, 0.0);
+        const int NT = D > 16 ? 2 : 1;
+        std::vector<double> gt((size_t)NT * T * 16, 0.0);
         for (int64_t k = T - 1; k >= 0; --k) {
             for (int d = 0; d < D; ++d) {
                 const long double v = g[d];
-                gt[(size_t)(k / 4) * 64 + (size_t)(k % 4) * 16 + d] = std::isfinite((double)v) ? (double)v : 0.0;
+                gt[(size_t)(d / 16) * T * 16 + (size_t)(k / 4) * 64 + (size_t)(k % 4) * 16 + (d % 16)] =
+                    std::isfinite((double)v) ? (double)v : 0.0;
             }
             host_step(h, g, 0.0L);  // g <- A g
         }
@@ -687,11 +702,15 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
     a.n_lb = p->n_lb;
     a.n_lv = p->n_lv < 8 ? p->n_lv : 8;
     // aggregate-free mode: matrix-pipe K1, carries from the chunk states themselves, unchanged K3
-    const bool fast = p->n_lv <= 5 && D <= 16 && ORD == 2 && a.T % kMmPiece == 0 && p->gt_dev && !getenv("SKDSP_IIR_NO_MFMA");
+    const bool fast = p->n_lv <= 5 && D <= 32 && ORD == 2 && a.T % kMmPiece == 0 && p->gt_dev && !getenv("SKDSP_IIR_NO_MFMA");
     if (fast) {
         const int64_t waves = (a.J + 15) / 16;
-        hipLaunchKernelGGL((iir_k1_mfma_kernel<IO>), dim3((unsigned)((waves + 3) / 4), nbatch), dim3(256), 0, s, (const IO *)a.x, a.n,
-                           a.T, a.J, a.batch_stride, (const double *)p->gt_dev, a.v, D);
+        if (D <= 16)
+            hipLaunchKernelGGL((iir_k1_mfma_kernel<IO, 1>), dim3((unsigned)((waves + 3) / 4), nbatch), dim3(256), 0, s, (const IO *)a.x,
+                               a.n, a.T, a.J, a.batch_stride, (const double *)p->gt_dev, a.v, D);
+        else
+            hipLaunchKernelGGL((iir_k1_mfma_kernel<IO, 2>), dim3((unsigned)((waves + 3) / 4), nbatch), dim3(256), 0, s, (const IO *)a.x,
+                               a.n, a.T, a.J, a.batch_stride, (const double *)p->gt_dev, a.v, D);
         SK_HIP(hipGetLastError());
         hipLaunchKernelGGL((iir_carry_kernel<D, ORD>), dim3(W, nbatch), dim3(256), 0, s, (const double *)a.v, (const double *)p->lbk_dev,
                            a.J, a.zi, carry);

@@ -1108,3 +1108,22 @@ def test_iir_matrix_pipe_chunk_states_large(dt):
     finally:
         del os.environ["SKDSP_IIR_NO_MFMA"]
     assert_close(yd.to_host(s0, m), y2.to_host(s0, m), 1e-6 if dt == np.float32 else 1e-11, "matrix-pipe vs recurrence K1")
+
+
+@pytest.mark.parametrize("nsec", [9, 12])
+def test_iir_matrix_pipe_two_row_tiles(nsec):
+    """9..12 biquads (18..24 states): the matrix-pipe K1 runs two 16-row tiles; against scipy."""
+    from scipy import signal
+    sos = signal.butter(2 * nsec, 0.35, output="sos")
+    assert sos.shape[0] == nsec
+    n = 2 ** 24
+    k = _ffi.IirKernel(_ffi.F32, sos=sos)
+    xd = _ffi.DeviceArray(n, np.float32).fill_noise(19)
+    yd = _ffi.DeviceArray(n, np.float32)
+    k.filter_dev(xd, yd)
+    _ffi.sync()
+    m = 2 ** 18
+    assert_close(yd.to_host(0, m), signal.sosfilt(sos, xd.to_host(0, m).astype(np.float64)), TOL32, "head")
+    s0 = n - 2 * m
+    ref = signal.sosfilt(sos, xd.to_host(s0 - 30000, m + 30000).astype(np.float64))[30000:]
+    assert_close(yd.to_host(s0, m), ref, TOL32, "deep window")
