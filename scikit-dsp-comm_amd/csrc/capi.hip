@@ -179,6 +179,12 @@ static int iir_any_dev(IirHandle *h, const void *x_dev, int64_t n, void *y_dev, 
         return SKDSP_OK;
     }
     if (!dtype_complex(h->dtype)) return iir_launch_planar(h, x_dev, n, 1, 0, y_dev, s, zi, zf);
+    const bool planar_only = getenv("SKDSP_IIR_PLANAR") != nullptr;  // developer A/B switch (and the tests)
+    if (!planar_only) {
+        // decaying filters: both components stay interleaved end to end (iir_k1c / iir_k3c kernels)
+        const int r1 = iir_launch_planar(h, x_dev, n, 2, 0, y_dev, s, zi, zf, 1);
+        if (r1 != 1) return r1;
+    }
     const size_t rsz = dtype_double(h->dtype) ? 8 : 4;
     const int64_t stride = (int64_t)round_up((size_t)n, 64);
     void *planes = nullptr;

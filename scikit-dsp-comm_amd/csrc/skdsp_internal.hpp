@@ -114,7 +114,8 @@ struct IirHandle : HandleBase {
 // x/y: real planar arrays in the handle's precision; complex callers pass nbatch=2 planes
 // (re, im) batch_stride elements apart.  In-place (y == x) is allowed.
 int iir_launch_planar(IirHandle *h, const void *x_dev, int64_t n, int nbatch, int64_t batch_stride, void *y_dev, hipStream_t s,
-                      const double *zi_host = nullptr, double *zf_host = nullptr);  // [nbatch][D] states (streaming)
+                      const double *zi_host = nullptr, double *zf_host = nullptr,  // [nbatch][D] states (streaming)
+                      int interleaved = 0);  // 1: x / y interleaved complex, nbatch = 2; returns 1 if not applicable
 void iir_free(IirPlan *p);
 bool iir_shape_supported(int nsec, int order);
 

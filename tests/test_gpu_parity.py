@@ -1127,3 +1127,40 @@ def test_iir_matrix_pipe_two_row_tiles(nsec):
     s0 = n - 2 * m
     ref = signal.sosfilt(sos, xd.to_host(s0 - 30000, m + 30000).astype(np.float64))[30000:]
     assert_close(yd.to_host(s0, m), ref, TOL32, "deep window")
+
+
+@pytest.mark.parametrize("dt,nsec", [(np.complex64, 8), (np.complex128, 8), (np.complex64, 3), (np.complex64, 12), (np.complex128, 10)])
+def test_iir_complex_interleaved_kernels(dt, nsec):
+    """Complex signals stay interleaved end to end in the aggregate-free mode (iir_k1c / iir_k3c): head, deep
+    window and the streaming state against scipy, a ragged length, and agreement with the planar detour."""
+    from scipy import signal
+    sos = signal.butter(2 * nsec, 0.3, output="sos")
+    D = 2 * nsec
+    rng = np.random.default_rng(5)
+    n = 2 ** 22 + 777
+    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+    xd = _ffi.DeviceArray(n, dt).fill_noise(23)
+    yd = _ffi.DeviceArray(n, dt)
+    zi = rng.standard_normal((nsec, 2)) + 1j * rng.standard_normal((nsec, 2))
+    flat = np.concatenate([zi.real.ravel(), zi.imag.ravel()])  # C-ABI layout: [re plane | im plane]
+    zf = k.filter_state_dev(xd, yd, zi=flat)
+    _ffi.sync()
+    zf = (zf[:D] + 1j * zf[D:]).reshape(nsec, 2)
+    tol = TOL32 if dt == np.complex64 else 1e-10
+    m = 2 ** 17
+    ref, _ = signal.sosfilt(sos, xd.to_host(0, m).astype(np.complex128), zi=zi)
+    assert_close(yd.to_host(0, m), ref, tol, "head")
+    w = 40000
+    ref, zf_ref = signal.sosfilt(sos, xd.to_host(n - m - w, m + w).astype(np.complex128), zi=np.zeros((nsec, 2), complex))
+    assert_close(yd.to_host(n - m, m), ref[w:], tol, "tail window")
+    assert_close(zf, zf_ref, tol, "final state")
+    os.environ["SKDSP_IIR_PLANAR"] = "1"
+    try:
+        y2 = _ffi.DeviceArray(n, dt)
+        zf2 = k.filter_state_dev(xd, y2, zi=flat)
+        _ffi.sync()
+        zf2 = (zf2[:D] + 1j * zf2[D:]).reshape(nsec, 2)
+    finally:
+        del os.environ["SKDSP_IIR_PLANAR"]
+    assert_close(yd.to_host(0, n), y2.to_host(0, n), 1e-6 if dt == np.complex64 else 1e-12, "interleaved vs planar")
+    assert_close(zf, zf2, 1e-9, "state: interleaved vs planar")
