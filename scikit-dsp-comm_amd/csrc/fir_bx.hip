@@ -1,0 +1,397 @@
+// fir_bx.hip -- direct / polyphase FIR of float32 or complex64 signals with real taps as a Toeplitz
+// matrix product on the BF16 matrix pipe, in float32 precision: every operand is split into three bf16
+// pieces (x = x1 + x2 + x3, 8 mantissa bits each, exact), and the six partial products down to 2^-18 of
+// the leading one are formed with v_mfma_f32_16x16x32_bf16 (fp32 accumulate; the five small products in
+// their own accumulator).  tools/ubench_bf16x3.hip: max error 1.9e-7 of max|y| over 160 lags, against
+// 5.2e-7 for one v_mfma_f32_16x16x4_f32 chain -- at 6/16 of its pipe time (the bf16 instruction does 8x
+// the lags in half the cycles).
+//
+// Serves the same reference calls as fir_mm.hip / fir_direct.hip (multirate_helper.py:104-127 and
+// downsample(up(x,L),M)):   y[m] = L * sum_t b[phi_c + L t] * x[i_c + q s - t],
+//     m = c + L' s,  c = m mod L',  L' = L/gcd, q = M/gcd,  phi_c = (c M) mod L, i_c = (c M) div L.
+//
+// Output ROWS r = L' ds + c are DS consecutive slots of all L' classes (RS = L' DS rows, RT = ceil(RS/16)
+// row tiles), a COLUMN N is a slot block, so   m = RS N + r   and the input index is
+//     q DS N + U0 - u,   lag u = t + U0 - i_c - q ds >= 0   (independent of N):
+//     Y[RS x N] = A[RS x K] * W[K x N],  A[r][u] = L b[phi_c + L (u - U0 + i_c + q ds)],  W[u][N] = x[q DS N + U0 - u].
+// The bf16 instruction wants 8 consecutive lags per lane.  With k' = K-1-u ascending in x, lane (column n,
+// group j) reads the 8 window elements  q DS n + 32 kb + 8 j + (0..7)  as ONE 16-byte LDS read per bf16
+// piece -- aligned whenever q DS is a multiple of 8, which fixes DS (and with it RS: 32 rows for L/M = 4/3,
+// 16 for a plain filter, 96 for L = 12).  A (three bf16 pieces per row tile and 32-lag block) stays in
+// registers for the whole launch; the window is split once, while it is staged, into 3 (6: re, im) bf16
+// planes in LDS.  The accumulator layout (col = lane & 15, row = 4 (lane >> 4) + reg) leaves 4 consecutive
+// outputs in every lane: 16-byte stores, no transposition.
+#include "skdsp_internal.hpp"
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace skdsp {
+
+typedef float v4f_bx __attribute__((ext_vector_type(4)));
+typedef float v2f_bx __attribute__((ext_vector_type(2)));
+typedef __bf16 v8bf_bx __attribute__((ext_vector_type(8)));
+typedef __bf16 v2bf_bx __attribute__((ext_vector_type(2)));
+
+constexpr int kBxUnits = 512;  // 8-sample units of one window (2 per thread: 32 prefetch VGPRs for complex64)
+
+struct BxArgs {
+    int64_t n, n_hist, n_out;
+    int q_ds;  // q * DS: input samples per column (multiple of 8)
+    int RS;    // rows in use = L' * DS
+    int U0;    // lag offset
+    int NS;    // columns per workgroup (multiple of 16)
+    int win;   // staged samples per workgroup (multiple of 8) >= q_ds * (NS - 1) + 32 KB
+};
+
+// (a, b) -> three packed bf16 pairs, a in the low half: a = a1 + a2 + a3 exactly (24 = 3 x 8 mantissa bits)
+__device__ __forceinline__ void bx_split2(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3)
+{
+    v2f_bx v = {a, b};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, v2bf_bx));
+    v2f_bx r = {a - __uint_as_float(p1 << 16), b - __uint_as_float(p1 & 0xffff0000u)};
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, v2bf_bx));
+    v2f_bx r2 = {r.x - __uint_as_float(p2 << 16), r.y - __uint_as_float(p2 & 0xffff0000u)};
+    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, v2bf_bx));
+}
+
+__device__ __forceinline__ v4f_bx bx_mfma(uint4 a, uint4 b, v4f_bx c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf_bx, a), __builtin_bit_cast(v8bf_bx, b), c, 0, 0, 0);
+}
+
+// Persistent 256-thread workgroups: window w+1 is requested into registers before window w is multiplied, so
+// its HBM latency hides behind the MFMAs of the same workgroup; the workgroups of a CU run out of phase with
+// each other, which is what overlaps the bf16 split / LDS writes / stores of one with the MFMAs of another.
+template <bool CPLX, int KB, int RT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_bx_kernel(const float *__restrict__ x, const uint4 *__restrict__ At, BxArgs a,
+                                                     float *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) char bx_smem[];
+    constexpr int C = CPLX ? 2 : 1;
+    constexpr int K = 32 * KB;
+    constexpr int UPT = kBxUnits / 256;   // staged 8-sample units per thread
+    constexpr int F4 = 2 * C;             // 16-byte loads per unit
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nunits = a.win / 8;
+    const int plane_bytes = a.win * 2 + 16;  // + a dump row for the threads beyond the window
+
+    float4 pre[UPT][F4];
+    auto load_window = [&](int64_t wdx) {
+        const int64_t g0 = (int64_t)a.q_ds * a.NS * wdx + a.U0 - (K - 1);  // input index of window element 0
+        const float *src = x + g0 * C;
+        const bool al16 = (reinterpret_cast<uintptr_t>(src) & 15) == 0;  // the same for every window
+        if (al16 && g0 >= -a.n_hist && g0 + a.win <= a.n) {  // interior window (uniform): 16-byte loads, no guards
+#pragma unroll
+            for (int h = 0; h < UPT; ++h) {
+                const int u = min(tid + 256 * h, nunits - 1);
+                const float4 *s4 = reinterpret_cast<const float4 *>(src + (size_t)u * 8 * C);
+#pragma unroll
+                for (int w = 0; w < F4; ++w) pre[h][w] = s4[w];
+            }
+        } else {  // first / last windows, element-aligned views
+#pragma unroll
+            for (int h = 0; h < UPT; ++h) {
+                const int64_t g = g0 + 8 * (int64_t)(tid + 256 * h);
+#pragma unroll
+                for (int w = 0; w < F4; ++w) {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int64_t ge = g + (4 * w + e) / C;
+                        t[e] = (ge >= -a.n_hist && ge < a.n && tid + 256 * h < nunits) ? x[ge * C + (4 * w + e) % C] : 0.f;
+                    }
+                    pre[h][w] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+        }
+    };
+    auto settle = [&]() {  // pin the wait for the prefetch here (in front of the stores: vmcnt retires in order)
+#pragma unroll
+        for (int h = 0; h < UPT; ++h)
+#pragma unroll
+            for (int w = 0; w < F4; ++w)
+                asm volatile("" ::"v"(pre[h][w].x), "v"(pre[h][w].y), "v"(pre[h][w].z), "v"(pre[h][w].w) : "memory");
+    };
+    auto store_window = [&]() {  // split into bf16 pieces, one 16-byte row of 8 samples per piece (branch-free)
+#pragma unroll
+        for (int h = 0; h < UPT; ++h) {
+            const int u = min(tid + 256 * h, nunits);  // beyond the window: the dump row
+            const float *v = reinterpret_cast<const float *>(&pre[h][0]);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) bx_split2(v[(2 * w) * C + c], v[(2 * w + 1) * C + c], p1[w], p2[w], p3[w]);
+                char *base = bx_smem + (size_t)(3 * c) * plane_bytes + (size_t)u * 16;
+                *reinterpret_cast<uint4 *>(base) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+                *reinterpret_cast<uint4 *>(base + plane_bytes) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+                *reinterpret_cast<uint4 *>(base + 2 * plane_bytes) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+            }
+        }
+    };
+
+    const int64_t ncols = (a.n_out + a.RS - 1) / a.RS;
+    const int64_t nwin = (ncols + a.NS - 1) / a.NS;
+    int64_t wdx = blockIdx.x;
+    if (wdx >= nwin) return;
+    load_window(wdx);  // first: the A operands below queue behind it
+
+    // A operands of this lane: [32-lag block][row tile][bf16 piece]
+    uint4 areg[KB][RT][3];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) areg[kb][rt][p] = At[((kb * RT + rt) * 3 + p) * 64 + lane];
+
+    const int ncol = lane & 15, j = lane >> 4;
+    const int ntiles = a.NS / 16;
+    const bool y16 = (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (a.RS & 3) == 0;
+#pragma unroll 1
+    for (; wdx < nwin; wdx += gridDim.x) {
+        store_window();
+        __syncthreads();
+        if (wdx + gridDim.x < nwin) load_window(wdx + gridDim.x);
+        const int64_t S0 = wdx * a.NS;  // first column of this window
+#pragma unroll 1
+        for (int ct = wave; ct < ntiles; ct += 4) {
+            // window element of (column n, block kb, group j, i): q_ds n + 32 kb + 8 j + i
+            const char *bbase = bx_smem + ((size_t)a.q_ds * (ct * 16 + ncol) + 8 * j) * 2;
+            v4f_bx big[RT][C], small[RT][C];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int c = 0; c < C; ++c) big[rt][c] = small[rt][c] = v4f_bx{0.f, 0.f, 0.f, 0.f};
+            // B operands are re-read for the next block right after their last use in this one (piece 1 is
+            // multiplied first, piece 3 last), so every LDS read has >= 3 products (192 cycles) of cover.
+            // Small products (relative size 2^-9 .. 2^-18) go to their own accumulator; consecutive MFMAs
+            // go to different accumulators (row tile x component).
+            uint4 b[C][3];
+            auto read_b = [&](int kb, int p) {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    b[c][p] = *reinterpret_cast<const uint4 *>(bbase + (size_t)(3 * c + p) * plane_bytes + 64 * kb);
+            };
+            read_b(0, 0);
+            read_b(0, 1);
+            read_b(0, 2);
+#ifdef SK_BX_NOMFMA
+#define SK_BX(PA, PB, ACC)                                                                              \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int c = 0; c < C; ++c)    \
+        ACC[rt][c][0] += __uint_as_float(areg[kb][rt][PA].x ^ b[c][PB].x);
+#else
+#define SK_BX(PA, PB, ACC)                                                                              \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int c = 0; c < C; ++c)    \
+        ACC[rt][c] = bx_mfma(areg[kb][rt][PA], b[c][PB], ACC[rt][c]);
+#endif
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                SK_BX(2, 0, small)
+                SK_BX(1, 0, small)
+                SK_BX(0, 0, big)
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb + 1 < KB) read_b(kb + 1, 0);
+                SK_BX(1, 1, small)
+                SK_BX(0, 1, small)
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb + 1 < KB) read_b(kb + 1, 1);
+                SK_BX(0, 2, small)
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb + 1 < KB) read_b(kb + 1, 2);
+            }
+#undef SK_BX
+            if (ct + 4 >= ntiles) settle();
+            // rows 16 rt + 4 j + i of column N: outputs m = RS N + row
+            const int64_t N = S0 + ct * 16 + ncol;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int row0 = 16 * rt + 4 * j;
+                const int64_t m0 = (int64_t)a.RS * N + row0;
+                float out[4 * C];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) out[i * C + c] = big[rt][c][i] + small[rt][c][i];
+                if (row0 >= a.RS) continue;
+#ifdef SK_BX_NOSTORE
+                if (out[0] != 12345.678f) continue;
+#endif
+                if (y16 && m0 + 4 <= a.n_out) {
+                    float4 *dst = reinterpret_cast<float4 *>(y + m0 * C);
+#pragma unroll
+                    for (int w = 0; w < C; ++w) dst[w] = reinterpret_cast<const float4 *>(out)[w];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (row0 + i < a.RS && m0 + i < a.n_out) {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) y[(m0 + i) * C + c] = out[i * C + c];
+                        }
+                }
+            }
+        }
+        __syncthreads();  // the planes are rewritten next
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+static unsigned short bx_bf16_rne(double v)
+{
+    const float f = (float)v;  // (a piece need not be the nearest bf16: the next piece takes whatever is left)
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static double bx_bf16_val(unsigned short h)
+{
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return (double)f;
+}
+
+// geometry of one (L, M): false if the kernel family does not cover it
+static bool bx_geometry(const FirHandle *h, int L, int M, FirHandle::BxTab *t)
+{
+    const int g = std::gcd(L, M), Lp = L / g, q = M / g;
+    const int P = h->ntaps, T = (P + L - 1) / L;
+    const int ds0 = 8 / std::gcd(q, 8);  // q DS must be a multiple of 8
+    int best_k = 0;
+    double best_util = 0.0;
+    for (int k = 1; k <= 16; ++k) {
+        const int RS = Lp * ds0 * k, RT = (RS + 15) / 16;
+        if (RT > 8) break;
+        const double util = (double)RS / (16.0 * RT);
+        if (util > best_util + 1e-9) { best_util = util; best_k = k; }
+    }
+    if (best_k == 0 || best_util < 0.74) return false;
+    const int DS = ds0 * best_k, RS = Lp * DS, RT = (RS + 15) / 16;
+    int imax = 0;
+    for (int c = 0; c < Lp; ++c) imax = std::max(imax, (int)(((int64_t)c * M) / L));
+    int U0 = imax + q * (DS - 1);
+    // window element 0 is input q_ds S0 + U0 + 1 - 32 KB: a 16-byte boundary of x for U0 + 1 = 0 mod 4 (2 for complex)
+    const int al = dtype_complex(h->dtype) ? 2 : 4;
+    U0 += (al - (U0 + 1) % al) % al;
+    const int KB = (T + U0 + 31) / 32;
+    if (KB * RT > 12) return false;  // A operands: 12 VGPRs per (block, row tile)
+    const int comp = dtype_complex(h->dtype) ? 2 : 1;
+    if (12 * KB * RT + 8 * comp * RT + 28 * comp + 52 > 270) return false;  // 256 VGPRs (2 waves per SIMD), a few spills at most
+    t->L = L; t->M = M; t->Lp = Lp; t->q = q; t->DS = DS; t->RS = RS; t->RT = RT; t->U0 = U0; t->KB = KB; t->At = nullptr;
+    return true;
+}
+
+static int bx_columns(const FirHandle::BxTab *t, int comp, int64_t n_out)
+{
+    // columns per workgroup: what a window of kBxUnits 8-sample units holds (complex64: 48 KiB of bf16 planes, 3 workgroups
+    // per CU by LDS, 2 by registers), multiples of 64 (16 for wide strides), at most 256
+    auto win_of = [&](int NS) { return ((t->q * t->DS * (NS - 1) + 32 * t->KB) + 7) / 8 * 8; };
+    (void)comp;
+    int NS = 256;
+    while (NS > 64 && win_of(NS) > 8 * kBxUnits) NS -= 64;
+    while (NS > 16 && win_of(NS) > 8 * kBxUnits) NS -= 16;
+    if (win_of(NS) > 8 * kBxUnits) return 0;
+    const int64_t ncols = (n_out + t->RS - 1) / t->RS;
+    while (NS > 64 && (ncols + NS - 1) / NS < 2 * ctx().num_cus) NS -= 64;  // small problems: more windows
+    return NS;
+}
+
+bool fir_bx_supported(const FirHandle *h, int L, int M, int64_t n_out)
+{
+    if (h->taps_complex || dtype_double(h->dtype)) return false;
+    FirHandle::BxTab t;
+    if (!bx_geometry(h, L, M, &t)) return false;
+    if (bx_columns(&t, dtype_complex(h->dtype) ? 2 : 1, n_out) == 0) return false;
+    return n_out >= (int64_t)t.RS * 64;
+}
+
+// A-operand table of one (L, M): At[((kb RT + rt) 3 + piece) 64 + lane] = 8 bf16 of row 16 rt + (lane & 15),
+// lags u = K - 1 - (32 kb + 8 (lane >> 4) + i)
+static int get_bx_table(FirHandle *h, int L, int M, const FirHandle::BxTab **out)
+{
+    for (auto &t : h->bx)
+        if (t.L == L && t.M == M) { *out = &t; return SKDSP_OK; }
+    FirHandle::BxTab t;
+    SK_CHECK(bx_geometry(h, L, M, &t), SKDSP_ERR_UNSUPPORTED, "fir_bx: L=%d M=%d not covered", L, M);
+    const int P = h->ntaps, T = (P + L - 1) / L, K = 32 * t.KB;
+    std::vector<unsigned short> host((size_t)t.KB * t.RT * 3 * 64 * 8, 0);
+    for (int kb = 0; kb < t.KB; ++kb)
+        for (int rt = 0; rt < t.RT; ++rt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    const int r = 16 * rt + (lane & 15);
+                    if (r >= t.RS) continue;
+                    const int u = K - 1 - (32 * kb + 8 * (lane >> 4) + i);
+                    const int ds = r / t.Lp, c = r % t.Lp;
+                    const int64_t cm = (int64_t)c * M;
+                    const int phi = (int)(cm % L), ic = (int)(cm / L);
+                    const int tt = u - t.U0 + ic + t.q * ds;
+                    if (tt < 0 || tt >= T) continue;
+                    const int k = phi + L * tt;
+                    if (k >= P) continue;
+                    double v = (double)L * h->taps_host[k];
+                    for (int p = 0; p < 3; ++p) {
+                        const unsigned short piece = bx_bf16_rne(v);
+                        host[((((size_t)kb * t.RT + rt) * 3 + p) * 64 + lane) * 8 + i] = piece;
+                        v -= bx_bf16_val(piece);
+                    }
+                }
+    SK_HIP(hipMalloc(&t.At, host.size() * 2));
+    SK_HIP(hipMemcpy(t.At, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+    h->bx.push_back(t);
+    *out = &h->bx.back();
+    return SKDSP_OK;
+}
+
+template <bool CPLX, int KB, int RT>
+static void bx_launch_one(unsigned grid, size_t lds, hipStream_t s, const void *x, const void *At, const BxArgs &a, void *y)
+{
+    if (lds > (size_t)64 * 1024)
+        (void)hipFuncSetAttribute((const void *)fir_bx_kernel<CPLX, KB, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((fir_bx_kernel<CPLX, KB, RT>), dim3(grid), dim3(256), lds, s, (const float *)x, (const uint4 *)At, a, (float *)y);
+}
+
+template <bool CPLX>
+static bool bx_dispatch(int KB, int RT, unsigned grid, size_t lds, hipStream_t s, const void *x, const void *At, const BxArgs &a, void *y)
+{
+#define SK_BXC(kb, rt) case (kb) * 16 + (rt): bx_launch_one<CPLX, kb, rt>(grid, lds, s, x, At, a, y); return true;
+    switch (KB * 16 + RT) {
+        SK_BXC(1, 1) SK_BXC(1, 2) SK_BXC(1, 3) SK_BXC(1, 4) SK_BXC(1, 5) SK_BXC(1, 6) SK_BXC(1, 7) SK_BXC(1, 8)
+        SK_BXC(2, 1) SK_BXC(2, 2) SK_BXC(2, 3) SK_BXC(2, 4) SK_BXC(2, 5) SK_BXC(2, 6)
+        SK_BXC(3, 1) SK_BXC(3, 2) SK_BXC(3, 3) SK_BXC(3, 4)
+        SK_BXC(4, 1) SK_BXC(4, 2) SK_BXC(4, 3)
+        SK_BXC(5, 1) SK_BXC(5, 2)
+        SK_BXC(6, 1) SK_BXC(6, 2)
+        SK_BXC(7, 1) SK_BXC(8, 1) SK_BXC(9, 1) SK_BXC(10, 1) SK_BXC(11, 1) SK_BXC(12, 1)
+    default: return false;
+    }
+#undef SK_BXC
+}
+
+int fir_bx_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, int M, int64_t n_out, void *y, hipStream_t s)
+{
+    if (n_out <= 0) return SKDSP_OK;
+    const FirHandle::BxTab *t = nullptr;
+    int rc = get_bx_table(h, L, M, &t);
+    if (rc) return rc;
+    const bool cplx = dtype_complex(h->dtype);
+    BxArgs a;
+    a.n = n; a.n_hist = n_hist; a.n_out = n_out;
+    a.q_ds = t->q * t->DS; a.RS = t->RS; a.U0 = t->U0;
+    a.NS = bx_columns(t, cplx ? 2 : 1, n_out);
+    SK_CHECK(a.NS > 0, SKDSP_ERR_UNSUPPORTED, "fir_bx: window does not fit LDS (L=%d M=%d)", L, M);
+    a.win = ((a.q_ds * (a.NS - 1) + 32 * t->KB) + 7) / 8 * 8;
+    const size_t lds = (size_t)(cplx ? 6 : 3) * (a.win * 2 + 16);  // (+ a dump row per plane)
+    const int64_t ncols = (n_out + a.RS - 1) / a.RS;
+    const int64_t nwin = (ncols + a.NS - 1) / a.NS;
+    const unsigned grid = (unsigned)std::min<int64_t>(nwin, (int64_t)2 * ctx().num_cus);  // persistent: two per CU
+    const bool ok = cplx ? bx_dispatch<true>(t->KB, t->RT, grid, lds, s, x, t->At, a, y)
+                         : bx_dispatch<false>(t->KB, t->RT, grid, lds, s, x, t->At, a, y);
+    SK_CHECK(ok, SKDSP_ERR_UNSUPPORTED, "fir_bx: no kernel for %d blocks x %d row tiles", t->KB, t->RT);
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+}  // namespace skdsp

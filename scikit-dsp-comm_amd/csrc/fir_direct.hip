@@ -561,6 +561,7 @@ FirHandle::~FirHandle()
     for (auto &p : poly) if (p.dev) (void)hipFree(p.dev);
     for (auto &t : sw) { if (t.taps) (void)hipFree(t.taps); if (t.rho) (void)hipFree(t.rho); }
     for (auto &t : mm) if (t.At) (void)hipFree(t.At);
+    for (auto &t : bx) if (t.At) (void)hipFree(t.At);
     if (ols) fir_ols_free(ols);
 }
 
@@ -661,6 +662,8 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     SK_CHECK(!(h->taps_complex && !dtype_complex(h->dtype)), SKDSP_ERR_BADARG,
              "fir: complex taps need a complex signal dtype (promote x first)");
     static const int mm_mode = getenv("SKDSP_FIR_MM") ? atoi(getenv("SKDSP_FIR_MM")) : 1;  // 0: never (developer A/B)
+    static const int bx_mode = getenv("SKDSP_FIR_BX") ? atoi(getenv("SKDSP_FIR_BX")) : 1;  // 0: never (developer A/B)
+    if (mm_mode && bx_mode && fir_bx_supported(h, L, M, n_out)) return fir_bx_launch(h, x, n, n_hist, L, M, n_out, y, s);
     if (mm_mode && fir_mm_supported(h, L, M, n_out)) return fir_mm_launch(h, x, n, n_hist, L, M, n_out, y, s);
     void *bank = nullptr;
     int T = 0;

@@ -82,6 +82,9 @@ struct FirHandle : HandleBase {
     // Toeplitz-product (matrix pipe) A-operand tables, keyed by (L, M)  -- fir_mm.hip
     struct MmTab { int L, M, Lp, q, DS, RS, U0, K4; void *At; };
     std::vector<MmTab> mm;
+    // bf16x3 Toeplitz-product A-operand tables, keyed by (L, M)  -- fir_bx.hip
+    struct BxTab { int L, M, Lp, q, DS, RS, RT, U0, KB; void *At; };
+    std::vector<BxTab> bx;
     OlsPlan *ols = nullptr;
     ~FirHandle();
 };
@@ -93,6 +96,10 @@ int fir_direct_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
 // Toeplitz product on the FP32 matrix pipe (fir_mm.hip): float32 / complex64 signals, real taps
 bool fir_mm_supported(const FirHandle *h, int L, int M, int64_t n_out);
 int fir_mm_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, int64_t n_out, void *y_dev,
+                  hipStream_t s);
+// Toeplitz product on the BF16 matrix pipe in float32 precision (3-way bf16 split, fir_bx.hip): same coverage, tried first
+bool fir_bx_supported(const FirHandle *h, int L, int M, int64_t n_out);
+int fir_bx_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, int64_t n_out, void *y_dev,
                   hipStream_t s);
 // FFT overlap-save (fir_ols.hip): c64 (and packed f32) .filter
 bool fir_ols_supported(const FirHandle *h);
