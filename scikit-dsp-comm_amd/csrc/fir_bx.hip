@@ -148,7 +148,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int ncol = lane & 15, j = lane >> 4;
     const int ntiles = a.NS / 16;
-    const bool y16 = (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (a.RS & 3) == 0;
 #pragma unroll 1
     for (; wdx < nwin; wdx += gridDim.x) {
         store_window();
@@ -184,7 +183,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #else
 #define SK_BX(PA, PB, ACC)                                                                              \
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int c = 0; c < C; ++c)    \
-        ACC[rt][c] = bx_mfma(areg[kb][rt][PA], b[c][PB], ACC[rt][c]);
+        ACC[rt][c] = bx_mfma(b[c][PB], areg[kb][rt][PA], ACC[rt][c]);
 #endif
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
@@ -203,32 +202,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
 #undef SK_BX
             if (ct + 4 >= ntiles) settle();
-            // rows 16 rt + 4 j + i of column N: outputs m = RS N + row
-            const int64_t N = S0 + ct * 16 + ncol;
+            // The window fragment is the A operand and the taps are B, so the tile comes out transposed: lane
+            // (r = lane & 15, j) holds row 16 rt + r of the four columns 4 j + i -- the 16 lanes of a group write
+            // 16 consecutive outputs (128 bytes of complex64) per store instead of 16-byte pieces 32 bytes apart.
+            const int64_t m_base = (int64_t)a.RS * (S0 + ct * 16 + 4 * j) + ncol;   // output of (row tile 0, i = 0)
+            float *yb = y + m_base * C;
+            const int64_t left = a.n_out - m_base;
+            const int rem = left > (int64_t)0x7fffffff ? 0x7fffffff : (left < 0 ? 0 : (int)left);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const int row0 = 16 * rt + 4 * j;
-                const int64_t m0 = (int64_t)a.RS * N + row0;
-                float out[4 * C];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int c = 0; c < C; ++c) out[i * C + c] = big[rt][c][i] + small[rt][c][i];
-                if (row0 >= a.RS) continue;
+                for (int i = 0; i < 4; ++i) {
+                    const int off = i * a.RS + 16 * rt;  // uniform
 #ifdef SK_BX_NOSTORE
-                if (out[0] != 12345.678f) continue;
+                    if (big[rt][0][i] != 12345.678f) continue;
 #endif
-                if (y16 && m0 + 4 <= a.n_out) {
-                    float4 *dst = reinterpret_cast<float4 *>(y + m0 * C);
-#pragma unroll
-                    for (int w = 0; w < C; ++w) dst[w] = reinterpret_cast<const float4 *>(out)[w];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (row0 + i < a.RS && m0 + i < a.n_out) {
-#pragma unroll
-                            for (int c = 0; c < C; ++c) y[(m0 + i) * C + c] = out[i * C + c];
-                        }
+                    if (16 * rt + ncol < a.RS && off < rem) {
+                        if (CPLX)
+                            *reinterpret_cast<float2 *>(yb + 2 * off) =
+                                make_float2(big[rt][0][i] + small[rt][0][i], big[rt][C - 1][i] + small[rt][C - 1][i]);
+                        else
+                            yb[off] = big[rt][0][i] + small[rt][0][i];
+                    }
                 }
             }
         }
@@ -278,7 +273,7 @@ static bool bx_geometry(const FirHandle *h, int L, int M, FirHandle::BxTab *t)
     const int KB = (T + U0 + 31) / 32;
     if (KB * RT > 12) return false;  // A operands: 12 VGPRs per (block, row tile)
     const int comp = dtype_complex(h->dtype) ? 2 : 1;
-    if (12 * KB * RT + 8 * comp * RT + 28 * comp + 52 > 270) return false;  // 256 VGPRs (2 waves per SIMD), a few spills at most
+    if (12 * KB * RT + 8 * comp * RT + 28 * comp + 52 > 276) return false;  // 256 VGPRs (2 waves per SIMD), a few spills at most
     t->L = L; t->M = M; t->Lp = Lp; t->q = q; t->DS = DS; t->RS = RS; t->RT = RT; t->U0 = U0; t->KB = KB; t->At = nullptr;
     return true;
 }

@@ -1031,19 +1031,57 @@ def test_iir_up_dn_complex_vs_scipy(dt):
     assert max(rel_err(f.dn(x, 7), signal.sosfilt(sos, xw)[::7][:n // 7])) <= tol
 
 
-def test_sliding_window_kernels_without_the_matrix_pipe_path():
-    """float32 / complex64 direct FIRs normally run as Toeplitz products on the matrix pipe (fir_mm.hip);
-    the register sliding-window kernels behind them (still used for float64 / complex128, complex taps
-    and very long lag ranges) are re-checked here on the same float32 / complex64 cases."""
+@pytest.mark.parametrize("switch", ["SKDSP_FIR_MM", "SKDSP_FIR_BX"])
+def test_direct_fir_kernels_behind_the_default_path(switch):
+    """float32 / complex64 direct FIRs normally run as bf16x3 Toeplitz products on the BF16 matrix pipe
+    (fir_bx.hip).  Behind it sit the FP32 / FP64 matrix-pipe kernels (fir_mm.hip: float64, long lag ranges;
+    SKDSP_FIR_BX=0 forces them) and the register sliding-window kernels (complex128, complex taps;
+    SKDSP_FIR_MM=0 forces them): both are re-checked here on the same float32 / complex64 cases."""
     import subprocess
     import sys
-    env = dict(os.environ, SKDSP_FIR_MM="0")
+    env = dict(os.environ)
+    env[switch] = "0"
     here = os.path.abspath(__file__)
     out = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
                           "c64_polyphase_large_tiles or fir_polyphase_all_ratios or g6_fir512 or updn_full_size"],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     tail = out.stdout.decode()[-600:]
     assert out.returncode == 0 and " passed" in tail, tail
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+@pytest.mark.parametrize("P,L,M", [(40, 1, 1), (301, 1, 1), (192, 12, 1), (192, 1, 12), (75, 5, 1), (96, 3, 2), (64, 2, 1),
+                                   (33, 1, 3), (140, 7, 1), (90, 9, 4), (1024, 4, 3)])
+def test_bf16x3_matrix_pipe_geometries(dt, P, L, M):
+    """Row-tile / lag-block geometries of the bf16x3 Toeplitz kernel (1..7 row tiles, 1..10 lag blocks, shapes it
+    hands on to the kernels behind it), ragged lengths, history: against the oracle at the float32 tolerance."""
+    rng = np.random.default_rng(P + 13 * L + M)
+    b = rng.standard_normal(P) / np.sqrt(P)
+    n = 700_003
+    n -= n % M
+    cplx = np.dtype(dt).kind == "c"
+    x = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dt)
+    k = _ffi.FirKernel(b, _ffi.code_of(dt))
+    k.set_algo(_ffi.FIR_DIRECT)
+    xd = _ffi.DeviceArray.from_host(x)
+    yd = _ffi.DeviceArray(n * L // M, dt)
+    k.updn_dev(xd, yd, L, M)
+    _ffi.sync()
+    got = yd.to_host()
+    m = 60_000  # inputs checked at the head and at the tail
+    ref = orc.fir_up(b, x[:m], L)
+    if M > 1:
+        ref = orc.downsample(ref, M)
+    assert_close(got[:len(ref)], ref, TOL32, "head")
+    lo = n - m
+    lo -= lo % M
+    pad = -(-P // L) + 2
+    lo2 = lo - pad - ((lo - pad) % M)  # start early enough for the filter memory, on an output boundary
+    ref = orc.fir_up(b, x[lo2:], L)
+    if M > 1:
+        ref = orc.downsample(ref, M)
+    skip = (lo - lo2) * L // M
+    assert_close(got[lo * L // M:], ref[skip:], TOL32, "tail")
 
 
 class _View:
