@@ -76,34 +76,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int nunits = a.win / 8;
     const int plane_bytes = a.win * 2 + 16;  // + a dump row for the threads beyond the window
 
+    // Interior windows (16-byte aligned, fully inside [-n_hist, n)) are prefetched into registers one window
+    // ahead; the few others (first / last windows, element-aligned views) are staged synchronously by their own
+    // code, so that `pre` has a single definition and no register copies (= vmcnt waits) follow the prefetch.
     float4 pre[UPT][F4];
-    auto load_window = [&](int64_t wdx) {
-        const int64_t g0 = (int64_t)a.q_ds * a.NS * wdx + a.U0 - (K - 1);  // input index of window element 0
-        const float *src = x + g0 * C;
-        const bool al16 = (reinterpret_cast<uintptr_t>(src) & 15) == 0;  // the same for every window
-        if (al16 && g0 >= -a.n_hist && g0 + a.win <= a.n) {  // interior window (uniform): 16-byte loads, no guards
+    auto window_g0 = [&](int64_t wdx) { return (int64_t)a.q_ds * a.NS * wdx + a.U0 - (K - 1); };  // input index of element 0
+    auto interior = [&](int64_t wdx) {
+        const int64_t g0 = window_g0(wdx);
+        return (reinterpret_cast<uintptr_t>(x + g0 * C) & 15) == 0 && g0 >= -a.n_hist && g0 + a.win <= a.n;
+    };
+    auto load_window = [&](int64_t wdx) {  // interior windows only
+        const float *src = x + window_g0(wdx) * C;
 #pragma unroll
-            for (int h = 0; h < UPT; ++h) {
-                const int u = min(tid + 256 * h, nunits - 1);
-                const float4 *s4 = reinterpret_cast<const float4 *>(src + (size_t)u * 8 * C);
+        for (int h = 0; h < UPT; ++h) {
+            const int u = min(tid + 256 * h, nunits - 1);
+            const float4 *s4 = reinterpret_cast<const float4 *>(src + (size_t)u * 8 * C);
 #pragma unroll
-                for (int w = 0; w < F4; ++w) pre[h][w] = s4[w];
-            }
-        } else {  // first / last windows, element-aligned views
-#pragma unroll
-            for (int h = 0; h < UPT; ++h) {
-                const int64_t g = g0 + 8 * (int64_t)(tid + 256 * h);
-#pragma unroll
-                for (int w = 0; w < F4; ++w) {
-                    float t[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int64_t ge = g + (4 * w + e) / C;
-                        t[e] = (ge >= -a.n_hist && ge < a.n && tid + 256 * h < nunits) ? x[ge * C + (4 * w + e) % C] : 0.f;
-                    }
-                    pre[h][w] = make_float4(t[0], t[1], t[2], t[3]);
-                }
-            }
+            for (int w = 0; w < F4; ++w) pre[h][w] = s4[w];
         }
     };
     auto settle = [&]() {  // pin the wait for the prefetch here (in front of the stores: vmcnt retires in order)
@@ -113,21 +102,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int w = 0; w < F4; ++w)
                 asm volatile("" ::"v"(pre[h][w].x), "v"(pre[h][w].y), "v"(pre[h][w].z), "v"(pre[h][w].w) : "memory");
     };
-    auto store_window = [&]() {  // split into bf16 pieces, one 16-byte row of 8 samples per piece (branch-free)
+    // 8 samples v[0 .. 8 C) -> one 16-byte row per bf16 piece and component at unit u
+    auto split_unit = [&](const float *v, int u) __attribute__((always_inline)) {
 #pragma unroll
-        for (int h = 0; h < UPT; ++h) {
-            const int u = min(tid + 256 * h, nunits);  // beyond the window: the dump row
-            const float *v = reinterpret_cast<const float *>(&pre[h][0]);
+        for (int c = 0; c < C; ++c) {
+            unsigned p1[4], p2[4], p3[4];
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                unsigned p1[4], p2[4], p3[4];
+            for (int w = 0; w < 4; ++w) bx_split2(v[(2 * w) * C + c], v[(2 * w + 1) * C + c], p1[w], p2[w], p3[w]);
+            char *base = bx_smem + (size_t)(3 * c) * plane_bytes + (size_t)u * 16;
+            *reinterpret_cast<uint4 *>(base) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+            *reinterpret_cast<uint4 *>(base + plane_bytes) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+            *reinterpret_cast<uint4 *>(base + 2 * plane_bytes) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+        }
+    };
+    auto store_window = [&]() {  // the prefetched window (branch-free: units beyond the window go to the dump row)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) bx_split2(v[(2 * w) * C + c], v[(2 * w + 1) * C + c], p1[w], p2[w], p3[w]);
-                char *base = bx_smem + (size_t)(3 * c) * plane_bytes + (size_t)u * 16;
-                *reinterpret_cast<uint4 *>(base) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
-                *reinterpret_cast<uint4 *>(base + plane_bytes) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
-                *reinterpret_cast<uint4 *>(base + 2 * plane_bytes) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+        for (int h = 0; h < UPT; ++h) split_unit(reinterpret_cast<const float *>(&pre[h][0]), min(tid + 256 * h, nunits));
+    };
+    auto stage_window_slow = [&](int64_t wdx) {  // guarded scalar loads, zero outside [-n_hist, n)
+        const int64_t g0 = window_g0(wdx);
+#pragma unroll 1
+        for (int u = tid; u < nunits; u += 256) {
+            float v[8 * C];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int64_t g = g0 + 8 * (int64_t)u + e;
+                const bool ok = g >= -a.n_hist && g < a.n;
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[e * C + c] = ok ? x[g * C + c] : 0.f;
             }
+            split_unit(v, u);
         }
     };
 
@@ -135,7 +139,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int64_t nwin = (ncols + a.NS - 1) / a.NS;
     int64_t wdx = blockIdx.x;
     if (wdx >= nwin) return;
-    load_window(wdx);  // first: the A operands below queue behind it
+    bool fast = interior(wdx);
+    if (fast) load_window(wdx);  // first: the A operands below queue behind it
 
     // A operands of this lane: [32-lag block][row tile][bf16 piece]
     uint4 areg[KB][RT][3];
@@ -148,14 +153,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int ncol = lane & 15, j = lane >> 4;
     const int ntiles = a.NS / 16;
+    // Every path into the loop head has the prefetch settled (here, and in front of the last stores of an
+    // iteration), so the split below needs no vmcnt wait -- which, vmcnt retiring in order, would also wait for
+    // the acknowledgement of the stores issued just before the barrier.
+    settle();
+    // (the A operands too: inside the loop the compiler cannot count the loads queued behind them and would
+    // drain the prefetch of every iteration in front of the first MFMA)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                asm volatile("" ::"v"(areg[kb][rt][p].x), "v"(areg[kb][rt][p].y), "v"(areg[kb][rt][p].z), "v"(areg[kb][rt][p].w) : "memory");
 #pragma unroll 1
     for (; wdx < nwin; wdx += gridDim.x) {
-        store_window();
+        if (fast) store_window();
+        else stage_window_slow(wdx);
         __syncthreads();
-        if (wdx + gridDim.x < nwin) load_window(wdx + gridDim.x);
+        const int64_t wnext = wdx + gridDim.x;
+        fast = wnext < nwin && interior(wnext);
+        if (fast) load_window(wnext);
         const int64_t S0 = wdx * a.NS;  // first column of this window
-#pragma unroll 1
-        for (int ct = wave; ct < ntiles; ct += 4) {
+        // one column tile; LAST: the wave's last tile of this window settles the prefetch in front of its stores
+        auto tile = [&](auto last_tag, int ct) __attribute__((always_inline)) {
             // window element of (column n, block kb, group j, i): q_ds n + 32 kb + 8 j + i
             const char *bbase = bx_smem + ((size_t)a.q_ds * (ct * 16 + ncol) + 8 * j) * 2;
             v4f_bx big[RT][C], small[RT][C];
@@ -201,7 +222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (kb + 1 < KB) read_b(kb + 1, 2);
             }
 #undef SK_BX
-            if (ct + 4 >= ntiles) settle();
+            if (decltype(last_tag)::value) settle();
             // The window fragment is the A operand and the taps are B, so the tile comes out transposed: lane
             // (r = lane & 15, j) holds row 16 rt + r of the four columns 4 j + i -- the 16 lanes of a group write
             // 16 consecutive outputs (128 bytes of complex64) per store instead of 16-byte pieces 32 bytes apart.
@@ -209,24 +230,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float *yb = y + m_base * C;
             const int64_t left = a.n_out - m_base;
             const int rem = left > (int64_t)0x7fffffff ? 0x7fffffff : (left < 0 ? 0 : (int)left);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int off = i * a.RS + 16 * rt;  // uniform
+            auto put = [&](int rt, int i, int off) __attribute__((always_inline)) {
+                if (CPLX)
+                    *reinterpret_cast<float2 *>(yb + 2 * off) =
+                        make_float2(big[rt][0][i] + small[rt][0][i], big[rt][C - 1][i] + small[rt][C - 1][i]);
+                else
+                    yb[off] = big[rt][0][i] + small[rt][0][i];
+            };
 #ifdef SK_BX_NOSTORE
-                    if (big[rt][0][i] != 12345.678f) continue;
+            if (big[0][0][0] != 12345.678f) return;
 #endif
-                    if (16 * rt + ncol < a.RS && off < rem) {
-                        if (CPLX)
-                            *reinterpret_cast<float2 *>(yb + 2 * off) =
-                                make_float2(big[rt][0][i] + small[rt][0][i], big[rt][C - 1][i] + small[rt][C - 1][i]);
-                        else
-                            yb[off] = big[rt][0][i] + small[rt][0][i];
+            // whole tile inside the output and all 16 RT rows in use (uniform): no per-store guards
+            if ((a.RS & 15) == 0 && (int64_t)a.RS * (S0 + ct * 16 + 16) <= a.n_out) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) put(rt, i, i * a.RS + 16 * rt);
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int off = i * a.RS + 16 * rt;
+                        if (16 * rt + ncol < a.RS && off < rem) put(rt, i, off);
                     }
-                }
             }
-        }
+        };
+        int ct = wave;
+#pragma unroll 1
+        for (; ct + 4 < ntiles; ct += 4) tile(std::false_type{}, ct);
+        if (ct < ntiles) tile(std::true_type{}, ct);
+        else settle();
         __syncthreads();  // the planes are rewritten next
     }
 }
