@@ -95,13 +95,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int w = 0; w < F4; ++w) pre[h][w] = s4[w];
         }
     };
-    auto settle = [&]() {  // pin the wait for the prefetch here (in front of the stores: vmcnt retires in order)
-#pragma unroll
-        for (int h = 0; h < UPT; ++h)
-#pragma unroll
-            for (int w = 0; w < F4; ++w)
-                asm volatile("" ::"v"(pre[h][w].x), "v"(pre[h][w].y), "v"(pre[h][w].z), "v"(pre[h][w].w) : "memory");
-    };
     // 8 samples v[0 .. 8 C) -> one 16-byte row per bf16 piece and component at unit u
     auto split_unit = [&](const float *v, int u) __attribute__((always_inline)) {
 #pragma unroll
@@ -153,12 +146,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int ncol = lane & 15, j = lane >> 4;
     const int ntiles = a.NS / 16;
-    // Every path into the loop head has the prefetch settled (here, and in front of the last stores of an
-    // iteration), so the split below needs no vmcnt wait -- which, vmcnt retiring in order, would also wait for
-    // the acknowledgement of the stores issued just before the barrier.
-    settle();
-    // (the A operands too: inside the loop the compiler cannot count the loads queued behind them and would
-    // drain the prefetch of every iteration in front of the first MFMA)
+    // The A operands are settled here: inside the loop the compiler cannot count the loads queued behind them and
+    // would drain the prefetch of every iteration in front of the first MFMA.
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -166,20 +155,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 asm volatile("" ::"v"(areg[kb][rt][p].x), "v"(areg[kb][rt][p].y), "v"(areg[kb][rt][p].z), "v"(areg[kb][rt][p].w) : "memory");
-#pragma unroll 1
-    for (; wdx < nwin; wdx += gridDim.x) {
-        if (fast) store_window();
-        else stage_window_slow(wdx);
-        __syncthreads();
+    // Iteration w:  MFMAs of window w (stores of all tiles but the wave's last) | barrier | split window w+1
+    // into the planes | stores of the last tile | barrier | request window w+2.  The split is the only place
+    // that waits on loads, and the only stores still in flight there are a whole tile old (vmcnt retires in
+    // order: a wait behind fresh stores would also wait for their acknowledgement).
+    if (fast) store_window();
+    else stage_window_slow(wdx);
+    __syncthreads();
+    {
         const int64_t wnext = wdx + gridDim.x;
         fast = wnext < nwin && interior(wnext);
         if (fast) load_window(wnext);
+    }
+#pragma unroll 1
+    for (; wdx < nwin; wdx += gridDim.x) {
         const int64_t S0 = wdx * a.NS;  // first column of this window
-        // one column tile; LAST: the wave's last tile of this window settles the prefetch in front of its stores
-        auto tile = [&](auto last_tag, int ct) __attribute__((always_inline)) {
+        v4f_bx big[RT][C], small[RT][C];
+        auto mma_tile = [&](int ct) __attribute__((always_inline)) {
             // window element of (column n, block kb, group j, i): q_ds n + 32 kb + 8 j + i
             const char *bbase = bx_smem + ((size_t)a.q_ds * (ct * 16 + ncol) + 8 * j) * 2;
-            v4f_bx big[RT][C], small[RT][C];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -222,7 +216,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (kb + 1 < KB) read_b(kb + 1, 2);
             }
 #undef SK_BX
-            if (decltype(last_tag)::value) settle();
+        };
+        auto store_tile = [&](int ct) __attribute__((always_inline)) {
             // The window fragment is the A operand and the taps are B, so the tile comes out transposed: lane
             // (r = lane & 15, j) holds row 16 rt + r of the four columns 4 j + i -- the 16 lanes of a group write
             // 16 consecutive outputs (128 bytes of complex64) per store instead of 16-byte pieces 32 bytes apart.
@@ -258,10 +253,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         int ct = wave;
 #pragma unroll 1
-        for (; ct + 4 < ntiles; ct += 4) tile(std::false_type{}, ct);
-        if (ct < ntiles) tile(std::true_type{}, ct);
-        else settle();
-        __syncthreads();  // the planes are rewritten next
+        for (; ct + 4 < ntiles; ct += 4) {
+            mma_tile(ct);
+            store_tile(ct);
+        }
+        const bool has_last = ct < ntiles;
+        if (has_last) mma_tile(ct);
+        __syncthreads();  // everyone is done reading the planes
+        const int64_t wnext = wdx + gridDim.x;
+        if (wnext < nwin) {
+            if (fast) store_window();
+            else stage_window_slow(wnext);
+        }
+        if (has_last) store_tile(ct);
+        __syncthreads();  // the planes hold window w+1
+        const int64_t wnext2 = wnext + gridDim.x;
+        fast = wnext2 < nwin && interior(wnext2);
+        if (fast) load_window(wnext2);
     }
 }
 
