@@ -120,13 +120,18 @@ static int pick_fir_algo(const FirHandle *h, int64_t n)
 int fir_algo_for(const FirHandle *h, int64_t n) { return pick_fir_algo(h, n); }
 
 // .dn: long filters with a modest M go through the overlap-save engine with a decimating store, which
-// beats Ntaps/M direct taps per kept sample (2^24 complex64, 512 taps, M = 3: 0.163 -> 0.085 ms)
+// beats Ntaps/M direct taps per kept sample (2^24 complex64, 512 taps, M = 3: 0.163 -> 0.085 ms).  Where the
+// bf16x3 matrix-pipe kernel covers the geometry it is the faster one up to ~4 M lag blocks for complex64
+// (2^26: 0.14-0.20 ms against a flat 0.24) and always for float32 (0.07-0.15 against 0.26).
 static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev)
 {
-    if (M > 1 && fir_ols_supported(h) && pick_fir_algo(h, n) == SKDSP_FIR_OLS &&
-        h->ntaps / M >= (h->dtype == SKDSP_C64 ? 24 : 64) &&  // the two-real-tiles store pays two divides per sample
-        !getenv("SKDSP_DN_NO_OLS"))
-        return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
+    bool ols = M > 1 && fir_ols_supported(h) && pick_fir_algo(h, n) == SKDSP_FIR_OLS && !getenv("SKDSP_DN_NO_OLS");
+    if (ols) {
+        const int kb = h->algo == SKDSP_FIR_OLS ? 0 : fir_bx_blocks(h, 1, M);
+        if (kb > 0) ols = h->dtype == SKDSP_C64 && kb > 4 * M;
+        else ols = h->ntaps / M >= (h->dtype == SKDSP_C64 ? 24 : 64);  // the two-real-tiles store pays two divides per sample
+    }
+    if (ols) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
     return fir_direct_launch(h, x_dev, n, n_hist, 1, M, n / M, y_dev, ctx().stream);
 }
 

@@ -344,6 +344,16 @@ bool fir_bx_supported(const FirHandle *h, int L, int M, int64_t n_out)
     return n_out >= (int64_t)t.RS * 64;
 }
 
+// 32-lag blocks the kernel would run for (L, M); 0: not covered (cost model of the callers)
+int fir_bx_blocks(const FirHandle *h, int L, int M)
+{
+    if (h->taps_complex || dtype_double(h->dtype)) return 0;
+    static const bool off = (getenv("SKDSP_FIR_BX") && atoi(getenv("SKDSP_FIR_BX")) == 0) || (getenv("SKDSP_FIR_MM") && atoi(getenv("SKDSP_FIR_MM")) == 0);
+    if (off) return 0;
+    FirHandle::BxTab t;
+    return bx_geometry(h, L, M, &t) ? t.KB : 0;
+}
+
 // A-operand table of one (L, M): At[((kb RT + rt) 3 + piece) 64 + lane] = 8 bf16 of row 16 rt + (lane & 15),
 // lags u = K - 1 - (32 kb + 8 (lane >> 4) + i)
 static int get_bx_table(FirHandle *h, int L, int M, const FirHandle::BxTab **out)

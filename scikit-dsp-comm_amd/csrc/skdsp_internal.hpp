@@ -99,6 +99,7 @@ int fir_mm_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, in
                   hipStream_t s);
 // Toeplitz product on the BF16 matrix pipe in float32 precision (3-way bf16 split, fir_bx.hip): same coverage, tried first
 bool fir_bx_supported(const FirHandle *h, int L, int M, int64_t n_out);
+int fir_bx_blocks(const FirHandle *h, int L, int M);  // 32-lag blocks per output tile, 0 = not covered
 int fir_bx_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, int64_t n_out, void *y_dev,
                   hipStream_t s);
 // FFT overlap-save (fir_ols.hip): c64 (and packed f32) .filter

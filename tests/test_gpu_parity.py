@@ -980,6 +980,7 @@ def test_fir_dn_overlap_save_decimating_store(M, ntaps, dt):
     n = 2 ** 20 + 12345
     esz = np.dtype(dt).itemsize
     k = _ffi.FirKernel(b, _ffi.code_of(dt))
+    k.set_algo(_ffi.FIR_OLS)  # (left to itself, .dn prefers the bf16x3 matrix-pipe kernel where that one is faster)
     xd = _ffi.DeviceArray(n, dt, headroom=ntaps).fill_noise(31)
     xd.write(cnoise(rng, ntaps - 1) if dt == np.complex64 else rng.standard_normal(ntaps - 1).astype(np.float32), at=-(ntaps - 1))
     yd = _ffi.DeviceArray(n // M, dt)
