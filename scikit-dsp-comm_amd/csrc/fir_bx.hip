@@ -33,7 +33,8 @@ typedef float v2f_bx __attribute__((ext_vector_type(2)));
 typedef __bf16 v8bf_bx __attribute__((ext_vector_type(8)));
 typedef __bf16 v2bf_bx __attribute__((ext_vector_type(2)));
 
-constexpr int kBxUnits = 512;  // 8-sample units of one window (2 per thread: 32 prefetch VGPRs for complex64)
+constexpr int kBxUnitsC = 512;   // 8-sample units of one complex64 window (2 per thread: 32 prefetch VGPRs)
+constexpr int kBxUnitsR = 1024;  // float32: 4 per thread, the same 32 VGPRs
 
 struct BxArgs {
     int64_t n, n_hist, n_out;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     extern __shared__ __attribute__((aligned(16))) char bx_smem[];
     constexpr int C = CPLX ? 2 : 1;
     constexpr int K = 32 * KB;
-    constexpr int UPT = kBxUnits / 256;   // staged 8-sample units per thread
+    constexpr int UPT = (CPLX ? kBxUnitsC : kBxUnitsR) / 256;   // staged 8-sample units per thread
     constexpr int F4 = 2 * C;             // 16-byte loads per unit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nunits = a.win / 8;
@@ -315,21 +316,22 @@ static bool bx_geometry(const FirHandle *h, int L, int M, FirHandle::BxTab *t)
     const int KB = (T + U0 + 31) / 32;
     if (KB * RT > 12) return false;  // A operands: 12 VGPRs per (block, row tile)
     const int comp = dtype_complex(h->dtype) ? 2 : 1;
-    if (12 * KB * RT + 8 * comp * RT + 28 * comp + 52 > 276) return false;  // 256 VGPRs (2 waves per SIMD), a few spills at most
+    // 256 VGPRs (2 waves per SIMD): A operands + accumulators + B fragments + 32 prefetch registers + ~52 others
+    if (12 * KB * RT + 8 * comp * RT + 12 * comp + 32 + 52 > (comp == 2 ? 276 : 256)) return false;
     t->L = L; t->M = M; t->Lp = Lp; t->q = q; t->DS = DS; t->RS = RS; t->RT = RT; t->U0 = U0; t->KB = KB; t->At = nullptr;
     return true;
 }
 
 static int bx_columns(const FirHandle::BxTab *t, int comp, int64_t n_out)
 {
-    // columns per workgroup: what a window of kBxUnits 8-sample units holds (complex64: 48 KiB of bf16 planes, 3 workgroups
+    // columns per workgroup: what a window of kBxUnitsC / kBxUnitsR 8-sample units holds (complex64: 48 KiB of bf16 planes, 3 workgroups
     // per CU by LDS, 2 by registers), multiples of 64 (16 for wide strides), at most 256
     auto win_of = [&](int NS) { return ((t->q * t->DS * (NS - 1) + 32 * t->KB) + 7) / 8 * 8; };
-    (void)comp;
-    int NS = 256;
-    while (NS > 64 && win_of(NS) > 8 * kBxUnits) NS -= 64;
-    while (NS > 16 && win_of(NS) > 8 * kBxUnits) NS -= 16;
-    if (win_of(NS) > 8 * kBxUnits) return 0;
+    const int cap = 8 * (comp == 2 ? kBxUnitsC : kBxUnitsR);
+    int NS = 512;
+    while (NS > 64 && win_of(NS) > cap) NS -= 64;
+    while (NS > 16 && win_of(NS) > cap) NS -= 16;
+    if (win_of(NS) > cap) return 0;
     const int64_t ncols = (n_out + t->RS - 1) / t->RS;
     while (NS > 64 && (ncols + NS - 1) / NS < 2 * ctx().num_cus) NS -= 64;  // small problems: more windows
     return NS;
