@@ -90,7 +90,8 @@ static int sendrecv_locked(const void *sendbuf, int dst, void *recvbuf, int src,
     return SKDSP_OK;
 }
 
-static int halo_exchange_locked(void *x_dev, int64_t n, int64_t n_halo, int dtype, hipStream_t s = nullptr)
+// zero_first = false: the caller treats the missing history of rank 0 as zeros itself (n_hist = 0) -- no fill launches
+static int halo_exchange_locked(void *x_dev, int64_t n, int64_t n_halo, int dtype, hipStream_t s = nullptr, bool zero_first = true)
 {
     Rccl &r = rc();
     if (!s) s = ctx().stream;
@@ -102,11 +103,11 @@ static int halo_exchange_locked(void *x_dev, int64_t n, int64_t n_halo, int dtyp
     char *x0 = (char *)x_dev;
     void *halo = x0 - (size_t)n_halo * esz;
     if (r.world <= 1 || !r.comm) {
-        SK_HIP(hipMemsetAsync(halo, 0, (size_t)n_halo * esz, s));
+        if (zero_first) SK_HIP(hipMemsetAsync(halo, 0, (size_t)n_halo * esz, s));
         return SKDSP_OK;
     }
     const size_t bytes = (size_t)n_halo * esz;
-    if (r.rank == 0) SK_HIP(hipMemsetAsync(halo, 0, bytes, s));  // zero initial state
+    if (r.rank == 0 && zero_first) SK_HIP(hipMemsetAsync(halo, 0, bytes, s));  // zero initial state
     return sendrecv_locked(x0 + (size_t)(n - n_halo) * esz, r.rank + 1 < r.world ? r.rank + 1 : -1, halo,
                            r.rank > 0 ? r.rank - 1 : -1, bytes, s);
 }
@@ -255,6 +256,9 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
         SK_CHECK(b && b->kind == H_FIR, SKDSP_ERR_BADARG, "fir_filter_shard: not a FIR handle");
         h = static_cast<FirHandle *>(b);
         halo = h->ntaps - 1;
+        // the first shard has no history: its kernels read zeros for x[-k] (n_hist = 0) instead of a halo that
+        // would have to be cleared by two fill launches per call (~10 us of a 0.24 ms step)
+        const bool first = rc().world <= 1 || !rc().comm || rc().rank == 0;
         // Overlap-save shards: only tile 0 reads the halo.  Tiles 1.. are the same problem started
         // V samples in (their history is local), so they run on the compute stream while the
         // 8 KB halo crosses xGMI on a second stream; tile 0 follows once it has landed.
@@ -275,16 +279,17 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
             const size_t esz = dtype_size(h->dtype);
             SK_HIP(hipEventRecord(c.ev_in, c.stream));            // x (and its tail, which is sent) is ready
             SK_HIP(hipStreamWaitEvent(c.comm_stream, c.ev_in, 0));
-            int r1 = halo_exchange_locked(x_dev, n_local, halo, h->dtype, c.comm_stream);
+            int r1 = halo_exchange_locked(x_dev, n_local, halo, h->dtype, c.comm_stream, false);
             if (r1) return r1;
             SK_HIP(hipEventRecord(c.ev_halo, c.comm_stream));
             r1 = fir_ols_launch(h, (char *)x_dev + (size_t)V * esz, n_local - V, V, (char *)y_dev + (size_t)V * esz, c.stream);
             if (r1) return r1;
             SK_HIP(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
-            return fir_ols_launch(h, x_dev, V, halo, y_dev, c.stream);
+            return fir_ols_launch(h, x_dev, V, first ? 0 : halo, y_dev, c.stream);
         }
-        int r = halo_exchange_locked(x_dev, n_local, halo, h->dtype);
+        int r = halo_exchange_locked(x_dev, n_local, halo, h->dtype, nullptr, false);
         if (r) return r;
+        if (first) halo = 0;
     }
     return skdsp_fir_filter_dev(hh, x_dev, n_local, halo, y_dev);
 }
