@@ -17,10 +17,11 @@
 // The bf16 instruction wants 8 consecutive lags per lane.  With k' = K-1-u ascending in x, lane (column n,
 // group j) reads the 8 window elements  q DS n + 32 kb + 8 j + (0..7)  as ONE 16-byte LDS read per bf16
 // piece -- aligned whenever q DS is a multiple of 8, which fixes DS (and with it RS: 32 rows for L/M = 4/3,
-// 16 for a plain filter, 96 for L = 12).  A (three bf16 pieces per row tile and 32-lag block) stays in
+// 16 for a plain filter, 96 for L = 12).  The taps (three bf16 pieces per row tile and 32-lag block) stay in
 // registers for the whole launch; the window is split once, while it is staged, into 3 (6: re, im) bf16
-// planes in LDS.  The accumulator layout (col = lane & 15, row = 4 (lane >> 4) + reg) leaves 4 consecutive
-// outputs in every lane: 16-byte stores, no transposition.
+// planes in LDS.  The MFMA is issued with the window fragment as its A operand and the taps as B, i.e. the
+// tile comes out transposed (col = lane & 15 = row of the tile, the four registers = four columns), so that
+// the 16 lanes of a group store 16 consecutive outputs.
 #include "skdsp_internal.hpp"
 #include <cstring>
 #include <numeric>
