@@ -1203,3 +1203,43 @@ def test_iir_complex_interleaved_kernels(dt, nsec):
         del os.environ["SKDSP_IIR_PLANAR"]
     assert_close(yd.to_host(0, n), y2.to_host(0, n), 1e-6 if dt == np.complex64 else 1e-12, "interleaved vs planar")
     assert_close(zf, zf2, 1e-9, "state: interleaved vs planar")
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_direct_fir_random_geometries(seed):
+    """Randomised (dtype, taps, L, M, length, history) sweep of the direct / polyphase path -- whichever kernel
+    the dispatcher picks (bf16x3 or FP32 matrix pipe, sliding window) -- head and tail windows against the
+    oracle at the float32 tolerance."""
+    rng = np.random.default_rng(seed)
+    for _ in range(40):
+        L, M, P = int(rng.integers(1, 17)), int(rng.integers(1, 17)), int(rng.integers(1, 420))
+        dt = [np.float32, np.complex64][int(rng.integers(0, 2))]
+        n = int(rng.integers(1, 100_000)) if rng.random() < 0.3 else int(rng.integers(100_000, 900_000))
+        n -= n % M
+        if n == 0:
+            continue
+        hist = int(rng.integers(0, 2)) * (-(-(P - 1) // L))
+        b = rng.standard_normal(P) / np.sqrt(P)
+        cplx = np.dtype(dt).kind == "c"
+        xa = (rng.standard_normal(n + hist) + (1j * rng.standard_normal(n + hist) if cplx else 0)).astype(dt)
+        k = _ffi.FirKernel(b, _ffi.code_of(dt))
+        k.set_algo(_ffi.FIR_DIRECT)
+        xd = _ffi.DeviceArray(n, dt, headroom=max(hist, 1))
+        xd.write(xa[hist:], at=0)
+        if hist:
+            xd.write(xa[:hist], at=-hist)
+        yd = _ffi.DeviceArray(n * L // M, dt)
+        k.updn_dev(xd, yd, L, M, n=n, n_hist=hist)
+        _ffi.sync()
+        got = yd.to_host()
+        m = min(n, 20000)
+        m -= m % M
+        pad = -(-P // L) + 2
+        for lo, hi in ((0, m), (n - m, n)):
+            lo -= lo % M
+            lo2 = max(lo - pad, -hist)
+            ref = orc.fir_up(b, xa[hist + lo2: hist + hi], L)[(lo - lo2) * L::M]
+            g = got[lo * L // M: lo * L // M + len(ref)]
+            assert_close(g, ref[:len(g)], TOL32, "%s P=%d L=%d M=%d n=%d hist=%d @%d" % (np.dtype(dt).name, P, L, M, n, hist, lo))
+        xd.free()
+        yd.free()
