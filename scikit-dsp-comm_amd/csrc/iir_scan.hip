@@ -237,36 +237,48 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
     // ---- walk the chunk in staged pieces of 32 samples per thread ----
     const int64_t row0 = wg * kIirThreads;  // first chunk (row) of this workgroup
     const int npieces = (int)(a.T / kPiece);
-    float4 pre[St::per_thread];
-    auto load_piece = [&](int p) {
+    // Workgroups whose 256 chunks lie inside the signal (all but the last one or two) prefetch with unguarded
+    // 16-byte loads; the others stage each piece synchronously by their own code.  (One load routine with
+    // per-lane guards put every prefetch load into its own branch region, and hipcc waits for it at the merge:
+    // vmcnt(0) right behind each load = no prefetch at all.)
+    const bool interior = (row0 + kIirThreads) * a.T <= a.n;
+    typedef float pre_t __attribute__((ext_vector_type(4)));  // (a struct float4 here ends up as memcpy into scratch)
+    pre_t pre[St::per_thread];
+    auto load_piece = [&](int p) {  // interior workgroups only
 #pragma unroll
         for (int i = 0; i < St::per_thread; ++i) {
             const int idx = i * kIirThreads + tid;
             const int row = idx / St::segs, seg = idx % St::segs;
             const int64_t g = (row0 + row) * a.T + (int64_t)p * kPiece + (int64_t)seg * St::elems;  // element index
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g + St::elems <= a.n) {
-                val = *reinterpret_cast<const float4 *>(x + g);
-            } else if (g < a.n) {
-                IO tmp[St::elems];
-#pragma unroll
-                for (int e = 0; e < St::elems; ++e) tmp[e] = (g + e < a.n) ? x[g + e] : IO(0);
-                val = *reinterpret_cast<const float4 *>(tmp);
-            }
-            pre[i] = val;
+            pre[i] = *reinterpret_cast<const pre_t *>(x + g);
         }
     };
-    load_piece(0);
+    auto stage_slow = [&](int p) {  // zero beyond the signal
 #pragma unroll 1
-    for (int p = 0; p < npieces; ++p) {
-#pragma unroll
         for (int i = 0; i < St::per_thread; ++i) {
             const int idx = i * kIirThreads + tid;
             const int row = idx / St::segs, seg = idx % St::segs;
-            *reinterpret_cast<float4 *>(stage + row * St::pitch + seg * St::elems) = pre[i];
+            const int64_t g = (row0 + row) * a.T + (int64_t)p * kPiece + (int64_t)seg * St::elems;
+            IO *dst = stage + row * St::pitch + seg * St::elems;
+#pragma unroll
+            for (int e = 0; e < St::elems; ++e) dst[e] = (g + e < a.n) ? x[g + e] : IO(0);
+        }
+    };
+    if (interior) load_piece(0);
+#pragma unroll 1
+    for (int p = 0; p < npieces; ++p) {
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < St::per_thread; ++i) {
+                const int idx = i * kIirThreads + tid;
+                const int row = idx / St::segs, seg = idx % St::segs;
+                *reinterpret_cast<pre_t *>(stage + row * St::pitch + seg * St::elems) = pre[i];
+            }
+        } else {
+            stage_slow(p);
         }
         __syncthreads();
-        if (p + 1 < npieces) load_piece(p + 1);  // in flight while this piece is computed
+        if (interior && p + 1 < npieces) load_piece(p + 1);  // in flight while this piece is computed
         IO *myrow = stage + tid * St::pitch;
         auto run_piece = [&](auto capture) {
 #pragma unroll
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
                 const int row = idx / St::segs, seg = idx % St::segs;
                 const int64_t g = (row0 + row) * a.T + (int64_t)p * kPiece + (int64_t)seg * St::elems;
                 const float4 val = *reinterpret_cast<const float4 *>(stage + row * St::pitch + seg * St::elems);
-                if (g + St::elems <= a.n) {
+                if (interior || g + St::elems <= a.n) {
                     *reinterpret_cast<float4 *>(y + g) = val;
                 } else if (g < a.n) {
                     const IO *tmp = reinterpret_cast<const IO *>(&val);
@@ -370,23 +382,29 @@ __global__ __launch_bounds__(256) void iir_k1_mfma_kernel(const IO *__restrict__
     const int64_t chunk0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
     if (chunk0 >= J) return;
     const int npieces = (int)(T / kMmPiece);
-    float4 pre[kLoads];
+    // waves whose 16 chunks lie inside the signal prefetch with unguarded 16-byte loads; the last wave or two stage
+    // every piece synchronously by their own code (per-lane guards around the loads = a vmcnt(0) behind each of them)
+    const bool interior = (chunk0 + 16) * T <= n;
+    typedef float pre_t __attribute__((ext_vector_type(4)));
+    pre_t pre[kLoads];
     auto load_piece = [&](int p) {
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
             const int idx = i * 64 + lane;                    // 16-byte segment of the 16 x piece image
             const int row = idx / (kMmPiece / E), seg = idx % (kMmPiece / E);
             const int64_t g = (chunk0 + row) * T + (int64_t)p * kMmPiece + (int64_t)seg * E;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g + E <= n) {
-                val = *reinterpret_cast<const float4 *>(x + g);
-            } else if (g < n) {
-                IO tmp[E];
+            pre[i] = *reinterpret_cast<const pre_t *>(x + g);
+        }
+    };
+    auto stage_slow = [&](int p) {
+#pragma unroll 1
+        for (int i = 0; i < kLoads; ++i) {
+            const int idx = i * 64 + lane;
+            const int row = idx / (kMmPiece / E), seg = idx % (kMmPiece / E);
+            const int64_t g = (chunk0 + row) * T + (int64_t)p * kMmPiece + (int64_t)seg * E;
+            IO *dst = reinterpret_cast<IO *>(img) + row * kMmPitch + seg * E;
 #pragma unroll
-                for (int e = 0; e < E; ++e) tmp[e] = (g + e < n) ? x[g + e] : IO(0);
-                val = *reinterpret_cast<const float4 *>(tmp);
-            }
-            pre[i] = val;
+            for (int e = 0; e < E; ++e) dst[e] = (g + e < n) ? x[g + e] : IO(0);
         }
     };
     v4d_t acc0[NT], acc1[NT];
@@ -394,13 +412,17 @@ __global__ __launch_bounds__(256) void iir_k1_mfma_kernel(const IO *__restrict__
     for (int t = 0; t < NT; ++t) acc0[t] = acc1[t] = v4d_t{0.0, 0.0, 0.0, 0.0};
     const int c = lane & 15, j = lane >> 4;
     const size_t tstride = (size_t)(T / 4) * 64;  // doubles per row tile of the table
-    load_piece(0);
+    if (interior) load_piece(0);
     for (int p = 0; p < npieces; ++p) {
+        if (interior) {
 #pragma unroll
-        for (int i = 0; i < kLoads; ++i) {
-            const int idx = i * 64 + lane;
-            const int row = idx / (kMmPiece / E), seg = idx % (kMmPiece / E);
-            *reinterpret_cast<float4 *>(img + (row * kMmPitch + seg * E) * W) = pre[i];
+            for (int i = 0; i < kLoads; ++i) {
+                const int idx = i * 64 + lane;
+                const int row = idx / (kMmPiece / E), seg = idx % (kMmPiece / E);
+                *reinterpret_cast<pre_t *>(img + (row * kMmPitch + seg * E) * W) = pre[i];
+            }
+        } else {
+            stage_slow(p);
         }
         // The A operands stream from the L2-resident table inside the step loop; the HBM loads of the next
         // piece are requested only AFTER the loop: vmcnt retires in order, so table loads queued behind a
@@ -417,7 +439,7 @@ __global__ __launch_bounds__(256) void iir_k1_mfma_kernel(const IO *__restrict__
             }
         }
         asm volatile("" ::: "memory");
-        if (p + 1 < npieces) load_piece(p + 1);
+        if (interior && p + 1 < npieces) load_piece(p + 1);
     }
     const int64_t cj = chunk0 + c;
     if (cj < J) {
@@ -494,23 +516,27 @@ __global__ __launch_bounds__(256) void iir_k1c_mfma_kernel(const IO *__restrict_
     const int64_t chunk0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
     if (chunk0 >= J) return;
     const int npieces = (int)(T / PCX);
-    float4 pre[kLoads];
+    const bool interior = (chunk0 + 16) * T <= n;  // (see iir_k1_mfma_kernel)
+    typedef float pre_t __attribute__((ext_vector_type(4)));
+    pre_t pre[kLoads];
     auto load_piece = [&](int p) {
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
             const int idx = i * 64 + lane;
             const int row = idx / (PCX / E), seg = idx % (PCX / E);
             const int64_t g = (chunk0 + row) * T + (int64_t)p * PCX + (int64_t)seg * E;  // complex index
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g + E <= n) {
-                val = *reinterpret_cast<const float4 *>(x + 2 * g);
-            } else if (g < n) {
-                IO tmp[2 * E];
+            pre[i] = *reinterpret_cast<const pre_t *>(x + 2 * g);
+        }
+    };
+    auto stage_slow = [&](int p) {
+#pragma unroll 1
+        for (int i = 0; i < kLoads; ++i) {
+            const int idx = i * 64 + lane;
+            const int row = idx / (PCX / E), seg = idx % (PCX / E);
+            const int64_t g = (chunk0 + row) * T + (int64_t)p * PCX + (int64_t)seg * E;
+            IO *dst = img + (row * PITCH + seg * E) * 2;
 #pragma unroll
-                for (int e = 0; e < 2 * E; ++e) tmp[e] = (g + e / 2 < n) ? x[2 * g + e] : IO(0);
-                val = *reinterpret_cast<const float4 *>(tmp);
-            }
-            pre[i] = val;
+            for (int e = 0; e < 2 * E; ++e) dst[e] = (g + e / 2 < n) ? x[2 * g + e] : IO(0);
         }
     };
     v4d_t ar0[NT], ar1[NT], ai0[NT], ai1[NT];
@@ -518,13 +544,17 @@ __global__ __launch_bounds__(256) void iir_k1c_mfma_kernel(const IO *__restrict_
     for (int t = 0; t < NT; ++t) ar0[t] = ar1[t] = ai0[t] = ai1[t] = v4d_t{0.0, 0.0, 0.0, 0.0};
     const int c = lane & 15, j = lane >> 4;
     const size_t tstride = (size_t)(T / 4) * 64;
-    load_piece(0);
+    if (interior) load_piece(0);
     for (int p = 0; p < npieces; ++p) {
+        if (interior) {
 #pragma unroll
-        for (int i = 0; i < kLoads; ++i) {
-            const int idx = i * 64 + lane;
-            const int row = idx / (PCX / E), seg = idx % (PCX / E);
-            *reinterpret_cast<float4 *>(img + (row * PITCH + seg * E) * 2) = pre[i];
+            for (int i = 0; i < kLoads; ++i) {
+                const int idx = i * 64 + lane;
+                const int row = idx / (PCX / E), seg = idx % (PCX / E);
+                *reinterpret_cast<pre_t *>(img + (row * PITCH + seg * E) * 2) = pre[i];
+            }
+        } else {
+            stage_slow(p);
         }
         const double *gt = Gt + ((size_t)p * (PCX / 4)) * 64 + lane;
         const IO *xs = img + (c * PITCH + j) * 2;
@@ -542,7 +572,7 @@ __global__ __launch_bounds__(256) void iir_k1c_mfma_kernel(const IO *__restrict_
             }
         }
         asm volatile("" ::: "memory");
-        if (p + 1 < npieces) load_piece(p + 1);
+        if (interior && p + 1 < npieces) load_piece(p + 1);
     }
     const int64_t cj = chunk0 + c;
     if (cj < J) {
@@ -631,41 +661,51 @@ __global__ __launch_bounds__(kIirThreads) __attribute__((amdgpu_waves_per_eu(NSE
 
     const int64_t row0 = wg * kIirThreads;
     const int npieces = (int)(a.T / PC);
-    float4 pre[8];
+    const bool interior = (row0 + kIirThreads) * a.T <= a.n;  // (see iir_chunk_kernel)
+    typedef float pre_t __attribute__((ext_vector_type(4)));
+    pre_t pre[8];
     auto load_piece = [&](int p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = i * kIirThreads + tid;
             const int row = idx >> 3, seg = idx & 7;           // 8 x 16-byte segments per 128-byte row piece
             const int64_t g = (row0 + row) * a.T + (int64_t)p * PC + (int64_t)seg * (E / 2);  // complex index
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g + E / 2 <= a.n) {
-                val = *reinterpret_cast<const float4 *>(x + 2 * g);
-            } else if (g < a.n) {
-                IO tmp[E];
-#pragma unroll
-                for (int e = 0; e < E; ++e) tmp[e] = (g + e / 2 < a.n) ? x[2 * g + e] : IO(0);
-                val = *reinterpret_cast<const float4 *>(tmp);
-            }
-            pre[i] = val;
+            pre[i] = *reinterpret_cast<const pre_t *>(x + 2 * g);
         }
     };
-    load_piece(0);
-#pragma unroll 1
-    for (int p = 0; p < npieces; ++p) {
+    auto split_store = [&](const IO *e, int row, int seg) __attribute__((always_inline)) {
 #pragma unroll
+        for (int k = 0; k < E / 2; ++k) {
+            st_re[row * PITCH + seg * (E / 2) + k] = e[2 * k];
+            st_im[row * PITCH + seg * (E / 2) + k] = e[2 * k + 1];
+        }
+    };
+    auto stage_slow = [&](int p) {
+#pragma unroll 1
         for (int i = 0; i < 8; ++i) {
             const int idx = i * kIirThreads + tid;
             const int row = idx >> 3, seg = idx & 7;
-            const IO *e = reinterpret_cast<const IO *>(&pre[i]);
+            const int64_t g = (row0 + row) * a.T + (int64_t)p * PC + (int64_t)seg * (E / 2);
+            IO tmp[E];
 #pragma unroll
-            for (int k = 0; k < E / 2; ++k) {
-                st_re[row * PITCH + seg * (E / 2) + k] = e[2 * k];
-                st_im[row * PITCH + seg * (E / 2) + k] = e[2 * k + 1];
+            for (int e = 0; e < E; ++e) tmp[e] = (g + e / 2 < a.n) ? x[2 * g + e] : IO(0);
+            split_store(tmp, row, seg);
+        }
+    };
+    if (interior) load_piece(0);
+#pragma unroll 1
+    for (int p = 0; p < npieces; ++p) {
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = i * kIirThreads + tid;
+                split_store(reinterpret_cast<const IO *>(&pre[i]), idx >> 3, idx & 7);
             }
+        } else {
+            stage_slow(p);
         }
         __syncthreads();
-        if (p + 1 < npieces) load_piece(p + 1);
+        if (interior && p + 1 < npieces) load_piece(p + 1);
         IO *rr = st_re + tid * PITCH, *ri = st_im + tid * PITCH;
         auto run_plane = [&](auto capture, IO *r, double (&z)[D], double *zf) __attribute__((always_inline)) {
 #pragma unroll
@@ -702,7 +742,7 @@ __global__ __launch_bounds__(kIirThreads) __attribute__((amdgpu_waves_per_eu(NSE
                 out[2 * k] = st_re[row * PITCH + seg * (E / 2) + k];
                 out[2 * k + 1] = st_im[row * PITCH + seg * (E / 2) + k];
             }
-            if (g + E / 2 <= a.n) {
+            if (interior || g + E / 2 <= a.n) {
                 *reinterpret_cast<float4 *>(y + 2 * g) = *reinterpret_cast<const float4 *>(out);
             } else if (g < a.n) {
 #pragma unroll
