@@ -325,8 +325,8 @@ static bool bx_geometry(const FirHandle *h, int L, int M, FirHandle::BxTab *t)
 
 static int bx_columns(const FirHandle::BxTab *t, int comp, int64_t n_out)
 {
-    // columns per workgroup: what a window of kBxUnitsC / kBxUnitsR 8-sample units holds (complex64: 48 KiB of bf16 planes, 3 workgroups
-    // per CU by LDS, 2 by registers), multiples of 64 (16 for wide strides), at most 256
+    // columns per workgroup: what a window of kBxUnitsC / kBxUnitsR 8-sample units holds (48 KiB of bf16 planes: 3
+    // workgroups per CU by LDS, 2 by registers), multiples of 64 (16 for wide strides), at most 512
     auto win_of = [&](int NS) { return ((t->q * t->DS * (NS - 1) + 32 * t->KB) + 7) / 8 * 8; };
     const int cap = 8 * (comp == 2 ? kBxUnitsC : kBxUnitsR);
     int NS = 512;
