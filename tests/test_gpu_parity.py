@@ -1243,3 +1243,34 @@ def test_direct_fir_random_geometries(seed):
             assert_close(g, ref[:len(g)], TOL32, "%s P=%d L=%d M=%d n=%d hist=%d @%d" % (np.dtype(dt).name, P, L, M, n, hist, lo))
         xd.free()
         yd.free()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_bf16x3_path_is_scale_invariant(dt):
+    """The bf16x3 matrix-pipe path is a float32 computation with the full float32 exponent range (no block
+    scaling): scaling the signal by 2^+-80 scales the output by exactly that factor, bit for bit."""
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(96) / 10
+    n = 400_000
+    cplx = np.dtype(dt).kind == "c"
+    x = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dt)
+    x[1000] *= 1e4  # a loud sample next to quiet ones
+    x[2000:2100] *= 1e-6
+    k = _ffi.FirKernel(b, _ffi.code_of(dt))
+    k.set_algo(_ffi.FIR_DIRECT)
+    outs = []
+    for e in (0, 80, -80):
+        xd = _ffi.DeviceArray.from_host((x * np.float32(2.0) ** e).astype(dt))
+        yd = _ffi.DeviceArray(n * 4 // 3 - 1, dt)
+        k.updn_dev(xd, yd, 4, 3, n=n - n % 3)
+        _ffi.sync()
+        outs.append(yd.to_host())
+        xd.free()
+        yd.free()
+    assert np.array_equal(outs[1], outs[0] * np.float32(2.0) ** 80)
+    assert np.array_equal(outs[2], outs[0] * np.float32(2.0) ** -80)
+    # and the quiet stretch keeps its own relative accuracy (error measured against ITS level, not the loud sample's)
+    lo, hi = 2040 * 4 // 3, 2090 * 4 // 3
+    ref = orc.downsample(orc.fir_up(b, x[:2200], 4), 3)
+    err = np.max(np.abs(outs[0][lo:hi] - ref[lo:hi])) / np.max(np.abs(ref[lo:hi]))
+    assert err < 2e-6, err
