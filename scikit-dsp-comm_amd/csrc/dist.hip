@@ -282,7 +282,11 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
             int r1 = halo_exchange_locked(x_dev, n_local, halo, h->dtype, c.comm_stream, false);
             if (r1) return r1;
             SK_HIP(hipEventRecord(c.ev_halo, c.comm_stream));
-            r1 = fir_ols_launch(h, (char *)x_dev + (size_t)V * esz, n_local - V, V, (char *)y_dev + (size_t)V * esz, c.stream);
+            // The interior tiles are one persistent launch that fills every CU (2 x 76 KiB of LDS) for the whole
+            // step: with more than one rank a few workgroup slots stay free, so that the send/recv kernel of the
+            // halo can start beside it instead of behind it (8 of 512 workgroups = 1.6 % of the tile walkers).
+            const int reserve = getenv("SKDSP_SHARD_RESERVE") ? atoi(getenv("SKDSP_SHARD_RESERVE")) : (rc().world > 1 ? 8 : 0);
+            r1 = fir_ols_launch(h, (char *)x_dev + (size_t)V * esz, n_local - V, V, (char *)y_dev + (size_t)V * esz, c.stream, 1, reserve);
             if (r1) return r1;
             SK_HIP(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
             return fir_ols_launch(h, x_dev, V, first ? 0 : halo, y_dev, c.stream);

@@ -616,7 +616,7 @@ int fir_ols_tile_outputs(FirHandle *h, int *V)
     return SKDSP_OK;
 }
 
-int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s, int dec)
+int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s, int dec, int reserve_wgs)
 {
     if (n <= 0) return SKDSP_OK;
     if (dec > 1) n = (n / dec) * dec;  // the dropped tail is never computed
@@ -643,6 +643,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.dec = dec > 1 ? dec : 1;
     A.n_keep = n;
     int64_t grid = 2 * (int64_t)ctx().num_cus;  // 2 resident workgroups per CU (76 KiB LDS each)
+    if (reserve_wgs > 0 && grid > 8 * (int64_t)reserve_wgs) grid -= reserve_wgs;  // leave slots for a concurrent (RCCL) kernel
     if (grid > ntiles) grid = ntiles;
     A.trace = nullptr;
     if (const char *tp = getenv("SKDSP_OLS_TRACE")) {  // developer diagnostics: dump phase stamps of one launch
