@@ -283,9 +283,9 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
             if (r1) return r1;
             SK_HIP(hipEventRecord(c.ev_halo, c.comm_stream));
             // The interior tiles are one persistent launch that fills every CU (2 x 76 KiB of LDS) for the whole
-            // step: with more than one rank a few workgroup slots stay free, so that the send/recv kernel of the
-            // halo can start beside it instead of behind it (8 of 512 workgroups = 1.6 % of the tile walkers).
-            const int reserve = getenv("SKDSP_SHARD_RESERVE") ? atoi(getenv("SKDSP_SHARD_RESERVE")) : (rc().world > 1 ? 8 : 0);
+            // step: a few workgroup slots stay free, so that the send/recv kernel of the halo can start beside it
+            // instead of behind it (8 of 512 workgroups; fir_ols_launch leaves them free by default anyway).
+            const int reserve = getenv("SKDSP_SHARD_RESERVE") ? atoi(getenv("SKDSP_SHARD_RESERVE")) : 8;
             r1 = fir_ols_launch(h, (char *)x_dev + (size_t)V * esz, n_local - V, V, (char *)y_dev + (size_t)V * esz, c.stream, 1, reserve);
             if (r1) return r1;
             SK_HIP(hipStreamWaitEvent(c.stream, c.ev_halo, 0));

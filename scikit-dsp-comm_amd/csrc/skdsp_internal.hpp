@@ -108,7 +108,7 @@ int fir_ols_tile_outputs(FirHandle *h, int *V);  // outputs per overlap-save til
 int fir_algo_for(const FirHandle *h, int64_t n);  // SKDSP_FIR_OLS / SKDSP_FIR_DIRECT as skdsp_fir_filter_dev would pick
 int fir_ols_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, hipStream_t s,
                    int dec = 1,           // dec > 1: decimating store, y holds n / dec samples
-                   int reserve_wgs = 0);  // persistent grid smaller by this many workgroups (multiple of 8)
+                   int reserve_wgs = -1);  // persistent grid smaller by this many workgroups (multiple of 8; -1: default 8)
 void fir_ols_free(OlsPlan *p);
 
 // ---- IIR -----------------------------------------------------------------
