@@ -96,8 +96,8 @@ def main():
         yd = _ffi.DeviceArray(n, dtype)
         step = lambda: k.filter_dev(xd, yd)                      # noqa: E731
         units, alg_bytes = n, 8.0 * n
-        kern = "ols_tile_kernel (two real tiles per complex tile)"
-        wl = "multirate_FIR.filter: 127-tap lowpass, float32, 2^%d samples, FFT overlap-save" % args.log2n
+        kern = "fir_bx_kernel"
+        wl = "multirate_FIR.filter: 127-tap lowpass, float32, 2^%d samples, direct form on the BF16 matrix pipe (3-way bf16 split = float32 precision)" % args.log2n
         metric = "float32 MSamples/s (FIR-127 tap)"
     elif args.workload == "updn43":
         b = firwin_lowpass(512, 0.225)

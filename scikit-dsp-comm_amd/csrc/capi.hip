@@ -110,9 +110,10 @@ static int pick_fir_algo(const FirHandle *h, int64_t n)
     }
     if (algo == SKDSP_FIR_OLS && !fir_ols_supported(h)) algo = SKDSP_FIR_DIRECT;
     if (algo != SKDSP_FIR_AUTO) return algo;
-    // measured crossover at 2^26 samples: the bf16x3 matrix-pipe kernel (real taps) stays ahead of overlap-save up
-    // to 3 lag blocks for complex64 (0.21 vs 0.23 ms at 81 taps) and 4 for float32 (0.130 vs 0.143 ms at 113 taps)
-    const int ols_from = h->taps_complex ? 48 : (h->dtype == SKDSP_C64 ? 82 : 114);
+    // measured crossover at 2^26 samples (same box, alternating runs): the bf16x3 matrix-pipe kernel (real taps) stays
+    // ahead of overlap-save up to 3 lag blocks for complex64 (0.21 vs 0.23 ms at 81 taps; 0.234 vs 0.227 at 96) and
+    // 5 for float32 (0.135 vs 0.138 ms at 145 taps)
+    const int ols_from = h->taps_complex ? 48 : (h->dtype == SKDSP_C64 ? 82 : 146);
     if (fir_ols_supported(h) && h->ntaps >= ols_from && n >= 4096) return SKDSP_FIR_OLS;
     return SKDSP_FIR_DIRECT;
 }

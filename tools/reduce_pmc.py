@@ -18,7 +18,7 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 WORK = {  # workload -> (substring of every kernel of a step, substring of the kernel that runs once per step, algorithmic bytes)
     "fir1024": ("ols_tile_kernel", "ols_tile_kernel", 16 * 2 ** 26),
-    "fir127": ("ols_tile_kernel", "ols_tile_kernel", 8 * 2 ** 26),
+    "fir127": ("skdsp::fir_", "skdsp::fir_", 8 * 2 ** 26),
     "updn43": ("skdsp::fir_", "skdsp::fir_", 8 * 2 ** 26 + 8 * ((2 ** 26 * 4) // 3)),
     "iir8": ("skdsp::iir_", "float, true>", 8 * 2 ** 26),  # K1 (matrix pipe or recurrence) + carries/K2 + K3
 }
