@@ -1274,3 +1274,38 @@ def test_bf16x3_path_is_scale_invariant(dt):
     ref = orc.downsample(orc.fir_up(b, x[:2200], 4), 3)
     err = np.max(np.abs(outs[0][lo:hi] - ref[lo:hi])) / np.max(np.abs(ref[lo:hi]))
     assert err < 2e-6, err
+
+
+@pytest.mark.parametrize("case", ["f32_direct_2p30", "c64_ols_2p29", "c64_updn43_2p29", "f32_ols_2p30"])
+def test_large_index_ranges(case):
+    """4-8 GiB signals (sample and byte offsets beyond 2^31/2^32): windows at the head, the middle and the tail of
+    every FIR engine against the oracle."""
+    import bench
+    rng = np.random.default_rng(5)
+    dt, n, b, L, M, algo = {
+        "f32_direct_2p30": (np.float32, 1 << 30, rng.standard_normal(40) / 6, 1, 1, _ffi.FIR_DIRECT),
+        "c64_ols_2p29": (np.complex64, 1 << 29, bench.firwin_lowpass(1024, 0.2), 1, 1, _ffi.FIR_OLS),
+        "c64_updn43_2p29": (np.complex64, (1 << 29) - ((1 << 29) % 3), bench.firwin_lowpass(512, 0.225), 4, 3, _ffi.FIR_DIRECT),
+        "f32_ols_2p30": (np.float32, 1 << 30, rng.standard_normal(300) / 17, 1, 1, _ffi.FIR_OLS),
+    }[case]
+    k = _ffi.FirKernel(b, _ffi.code_of(dt))
+    k.set_algo(algo)
+    xd = _ffi.DeviceArray(n, dt).fill_noise(9)
+    n_out = n * L // M
+    yd = _ffi.DeviceArray(n_out, dt)
+    try:
+        if L == 1 and M == 1:
+            k.filter_dev(xd, yd)
+        else:
+            k.updn_dev(xd, yd, L, M)
+        _ffi.sync()
+        pad = -(-len(b) // L) + 2
+        for lo in (0, (n // 2) - ((n // 2) % M), n - 30000 - ((n - 30000) % M)):
+            hi = min(n, lo + 30000)
+            lo2 = max(lo - pad, 0)
+            ref = orc.fir_up(b, xd.to_host(lo2, hi - lo2), L)[(lo - lo2) * L::M]
+            got = yd.to_host(lo * L // M, min(len(ref), n_out - lo * L // M))
+            assert_close(got, ref[:len(got)], TOL32, "%s @%d" % (case, lo))
+    finally:
+        xd.free()
+        yd.free()
