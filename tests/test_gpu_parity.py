@@ -1309,3 +1309,26 @@ def test_large_index_ranges(case):
     finally:
         xd.free()
         yd.free()
+
+
+@pytest.mark.parametrize("dt,lg", [(np.float32, 30), (np.complex64, 29), (np.float64, 29)])
+def test_iir_large_index_ranges(dt, lg):
+    """4 GiB signals through the IIR scan (8192-sample chunks, interleaved complex kernels): head, middle and tail
+    windows against the oracle (the filter forgets after ~8k samples, so a window restarts 20000 samples early)."""
+    import bench
+    sos = bench.elliptic_bpf_sos()
+    n = 1 << lg
+    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+    xd = _ffi.DeviceArray(n, dt).fill_noise(3)
+    yd = _ffi.DeviceArray(n, dt)
+    try:
+        k.filter_dev(xd, yd)
+        _ffi.sync()
+        tol = TOL32 if np.dtype(dt).name in ("float32", "complex64") else 1e-9
+        for lo in (0, n // 2, n - 60000):
+            lo2 = max(lo - 20000, 0)
+            ref = orc.sos_filter(sos, xd.to_host(lo2, lo + 40000 - lo2))[lo - lo2:]
+            assert_close(yd.to_host(lo, 40000), ref, tol, "%s @%d" % (np.dtype(dt).name, lo))
+    finally:
+        xd.free()
+        yd.free()
