@@ -701,6 +701,35 @@ static int iir_create_common(int nsec, int order, const std::vector<double> &coe
     h->nsec = nsec;
     h->order = order;
     h->coef = coef;
+    if (order == 2 && nsec >= 2 && !getenv("SKDSP_IIR_NO_UNIT")) {
+        // unit-tail re-factorisation (see IirHandle): H_0' = H_0 * prod_{j>=1} b0_j,  H_k' = H_k / b0_k
+        bool ok = true;
+        for (int s = 0; s < nsec && ok; ++s) {
+            const double *c = coef.data() + 5 * s;
+            ok = c[0] != 0.0 && std::isfinite(c[0]) && (s == 0 || std::fabs(c[2] / c[0] - 1.0) <= 1e-13);
+        }
+        if (ok) {
+            std::vector<long double> tail((size_t)nsec + 1, 1.0L);  // tail[k] = prod_{j>=k} b0_j
+            for (int s = nsec - 1; s >= 0; --s) tail[s] = tail[s + 1] * (long double)coef[5 * s];
+            for (int s = 0; s < nsec && ok; ++s) ok = std::isfinite((double)tail[s]) && tail[s] != 0.0L;
+            if (ok) {
+                h->state_scale.resize((size_t)2 * nsec);
+                for (int s = 0; s < nsec; ++s) {
+                    double *c = h->coef.data() + 5 * s;
+                    if (s == 0) {
+                        for (int k = 0; k < 3; ++k) c[k] = (double)((long double)c[k] * tail[1]);
+                    } else {
+                        const long double b0 = c[0];
+                        c[1] = (double)((long double)c[1] / b0);
+                        c[0] = 1.0;
+                        c[2] = 1.0;
+                    }
+                    h->state_scale[2 * s] = h->state_scale[2 * s + 1] = (double)tail[s + 1];
+                }
+                h->unit_tail = true;
+            }
+        }
+    }
     *out = h.release();
     return SKDSP_OK;
 }

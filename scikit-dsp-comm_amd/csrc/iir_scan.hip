@@ -68,13 +68,24 @@ struct IirPlan {
 template <int NSEC, int ORD> struct Coef { double c[NSEC * (2 * ORD + 1)]; };
 
 // one sample through the cascade; z = DF2T delay lines of every section
-template <int NSEC, int ORD>
+// UNIT (biquads): sections 1.. have b0 = b2 = 1 (IirHandle::unit_tail): y = x + z0, z0 = b1 x - a1 y + z1,
+// z1 = x - a2 y -- 4 flops and 3 coefficients instead of 5 and 5.  The coefficients live in SGPRs; the general
+// form of an 8-biquad cascade needs 80 of them, more than a wave has, and hipcc then re-reads ~9 spilled
+// coefficients per sample from VGPR lanes (1100 v_readlane next to 3100 FP64 instructions in K3).
+template <int NSEC, int ORD, bool UNIT = false>
 __device__ __forceinline__ double cascade_step(const Coef<NSEC, ORD> &cf, double (&z)[NSEC * ORD], double x)
 {
 #pragma unroll
     for (int s = 0; s < NSEC; ++s) {
         const double *c = cf.c + s * (2 * ORD + 1);
         const double xn = x;
+        if (UNIT && ORD == 2 && s >= 1) {
+            const double yu = xn + z[2 * s];
+            z[2 * s] = fma(c[1], xn, fma(-c[3], yu, z[2 * s + 1]));
+            z[2 * s + 1] = fma(-c[4], yu, xn);
+            x = yu;
+            continue;
+        }
         const double yv = fma(c[0], xn, z[s * ORD]);
 #pragma unroll
         for (int k = 1; k < ORD; ++k) z[s * ORD + k - 1] = fma(c[k], xn, fma(-c[ORD + k], yv, z[s * ORD + k]));
@@ -134,7 +145,7 @@ struct IirArgs {
 };
 
 // Kernel body shared by K1 (WRITE=false) and K3 (WRITE=true).
-template <int NSEC, int ORD, typename IO, bool WRITE>
+template <int NSEC, int ORD, typename IO, bool WRITE, bool UNIT = false>
 __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<NSEC, ORD> cf)
 {
     constexpr int D = NSEC * ORD;
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
                 IO *e4 = reinterpret_cast<IO *>(&raw);
 #pragma unroll
                 for (int e = 0; e < St::elems; ++e) {
-                    const double yv = cascade_step<NSEC, ORD>(cf, z, (double)e4[e]);
+                    const double yv = cascade_step<NSEC, ORD, UNIT>(cf, z, (double)e4[e]);
                     if (WRITE) e4[e] = (IO)yv;
                     if (decltype(capture)::value && zf_owner && sgi * St::elems + e == zf_off % kPiece) {
 #pragma unroll
@@ -589,7 +600,7 @@ __global__ __launch_bounds__(256) void iir_k1c_mfma_kernel(const IO *__restrict_
     }
 }
 
-template <int NSEC, int ORD, typename IO>
+template <int NSEC, int ORD, typename IO, bool UNIT = false>
 __global__ __launch_bounds__(kIirThreads) __attribute__((amdgpu_waves_per_eu(NSEC <= 8 ? 2 : 1, NSEC <= 8 ? 2 : 1))) void iir_k3c_kernel(IirArgs a, Coef<NSEC, ORD> cf)
 {
     constexpr int D = NSEC * ORD;
@@ -714,7 +725,7 @@ __global__ __launch_bounds__(kIirThreads) __attribute__((amdgpu_waves_per_eu(NSE
                 IO *e4 = reinterpret_cast<IO *>(&raw);
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    e4[e] = (IO)cascade_step<NSEC, ORD>(cf, z, (double)e4[e]);
+                    e4[e] = (IO)cascade_step<NSEC, ORD, UNIT>(cf, z, (double)e4[e]);
                     if (decltype(capture)::value && zf_owner && c4 * E + e == zf_off % PC) {
 #pragma unroll
                         for (int d = 0; d < D; ++d) zf[d] = z[d];
@@ -998,7 +1009,8 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
         hipLaunchKernelGGL((iir_carry_kernel<D, ORD>), dim3(W, 2), dim3(256), 0, s, (const double *)a.v, (const double *)p->lbk_dev, a.J,
                            a.zi, carry);
         a.n_lb = 0;
-        hipLaunchKernelGGL((iir_k3c_kernel<NSEC, ORD, IO>), dim3(W), dim3(kIirThreads), 0, s, a, cf);
+        if (NSEC >= 2 && h->unit_tail) hipLaunchKernelGGL((iir_k3c_kernel<NSEC, ORD, IO, (NSEC >= 2)>), dim3(W), dim3(kIirThreads), 0, s, a, cf);
+        else hipLaunchKernelGGL((iir_k3c_kernel<NSEC, ORD, IO>), dim3(W), dim3(kIirThreads), 0, s, a, cf);
         SK_HIP(hipGetLastError());
         return SKDSP_OK;
     }
@@ -1022,7 +1034,8 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
         hipLaunchKernelGGL((iir_wg_scan_kernel<D>), dim3(nbatch), dim3(1024), 0, s, (const double *)agg, (const double *)p->pw_dev, W, carry, a.zi);
         SK_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL((iir_chunk_kernel<NSEC, ORD, IO, true>), dim3(W, nbatch), dim3(kIirThreads), 0, s, a, cf);
+    if (NSEC >= 2 && h->unit_tail) hipLaunchKernelGGL((iir_chunk_kernel<NSEC, ORD, IO, true, (NSEC >= 2)>), dim3(W, nbatch), dim3(kIirThreads), 0, s, a, cf);
+    else hipLaunchKernelGGL((iir_chunk_kernel<NSEC, ORD, IO, true>), dim3(W, nbatch), dim3(kIirThreads), 0, s, a, cf);
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
 }
@@ -1079,8 +1092,16 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     a.il = interleaved ? 1 : 0;
     a.pw = p->pw_dev; a.v = p->v_dev; a.agg = nullptr; a.carry = nullptr; a.lbmat = nullptr; a.n_lb = 0; a.n_lv = 8;
     a.zi = nullptr; a.zf = nullptr;
+    std::vector<double> zi_int;  // the caller's DF2T states in the internal factorisation (IirHandle::state_scale)
     if (zi_host) {
+        if (!h->state_scale.empty()) {
+            zi_int.resize((size_t)nbatch * D);
+            for (int b = 0; b < nbatch; ++b)
+                for (int d = 0; d < D; ++d) zi_int[(size_t)b * D + d] = zi_host[(size_t)b * D + d] * h->state_scale[d];
+            zi_host = zi_int.data();
+        }
         SK_HIP(hipMemcpyAsync(p->state_dev, zi_host, (size_t)nbatch * D * 8, hipMemcpyHostToDevice, s));
+        if (!zi_int.empty()) SK_HIP(hipStreamSynchronize(s));  // zi_int is a local
         a.zi = p->state_dev;
     }
     if (zf_host) a.zf = p->state_dev + 2 * D;
@@ -1090,6 +1111,9 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     if (zf_host) {
         SK_HIP(hipMemcpyAsync(zf_host, p->state_dev + 2 * D, (size_t)nbatch * D * 8, hipMemcpyDeviceToHost, s));
         SK_HIP(hipStreamSynchronize(s));
+        if (!h->state_scale.empty())
+            for (int b = 0; b < nbatch; ++b)
+                for (int d = 0; d < D; ++d) zf_host[(size_t)b * D + d] /= h->state_scale[d];
     }
     return SKDSP_OK;
 }

@@ -20,7 +20,7 @@ WORK = {  # workload -> (substring of every kernel of a step, substring of the k
     "fir1024": ("ols_tile_kernel", "ols_tile_kernel", 16 * 2 ** 26),
     "fir127": ("skdsp::fir_", "skdsp::fir_", 8 * 2 ** 26),
     "updn43": ("skdsp::fir_", "skdsp::fir_", 8 * 2 ** 26 + 8 * ((2 ** 26 * 4) // 3)),
-    "iir8": ("skdsp::iir_", "float, true>", 8 * 2 ** 26),  # K1 (matrix pipe or recurrence) + carries/K2 + K3
+    "iir8": ("skdsp::iir_", "float, true", 8 * 2 ** 26),  # K1 (matrix pipe or recurrence) + carries/K2 + K3 (the WRITE = true instantiation runs once per step)
 }
 for w, (pat, marker, alg) in WORK.items():
     out = {}
