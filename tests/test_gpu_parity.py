@@ -1332,3 +1332,41 @@ def test_iir_large_index_ranges(dt, lg):
     finally:
         xd.free()
         yd.free()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex128])
+def test_iir_unit_tail_factorisation_states(dt):
+    """Cascades with b2 = b0 in every section run re-factored (all gain in section 0, b0 = b2 = 1 elsewhere); the
+    states still cross the API in the caller's factorisation: wildly different per-section gains, zi in, zf out,
+    block-wise == one shot, all against scipy.  A cascade that does not qualify (b2 != b0) takes the general form."""
+    from scipy import signal
+    import sk_dsp_comm_amd.multirate_helper as mrh
+    rng = np.random.default_rng(17)
+    sos = signal.ellip(10, 0.4, 70, 0.27, output="sos")
+    g = np.array([3e3, 2e-4, -7.0, 1.0, 5e2])  # redistribute the gain between the sections (product kept)
+    g[-1] = 1.0 / np.prod(g[:-1])
+    sos[:, :3] *= g[:, None]
+    assert np.allclose(sos[:, 2], sos[:, 0], rtol=1e-14)
+    cplx = np.dtype(dt).kind == "c"
+    n = 500_000
+    x = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dt)
+    zi = (rng.standard_normal((5, 2)) + (1j * rng.standard_normal((5, 2)) if cplx else 0)) * np.abs(g)[:, None]
+    wide = np.complex128 if cplx else np.float64
+    y_ref, zf_ref = signal.sosfilt(sos, x.astype(wide), zi=zi)
+    f = mrh.multirate_IIR(sos)
+    y, zf = f.filter_stream(x, zi)
+    tol = 2e-6 if dt == np.float32 else 1e-10
+    assert max(rel_err(y, y_ref)) <= tol
+    assert np.max(np.abs(zf - zf_ref) / (np.abs(zf_ref).max(axis=1, keepdims=True) + 1e-300)) <= tol
+    zs, outs = zi, []
+    for lo, hi in ((0, 1000), (1000, 200_001), (200_001, n)):
+        yb, zs = f.filter_stream(x[lo:hi], zs)
+        outs.append(yb)
+    assert max(rel_err(np.concatenate(outs), y_ref)) <= tol
+    assert np.max(np.abs(zs - zf_ref) / (np.abs(zf_ref).max(axis=1, keepdims=True) + 1e-300)) <= tol
+    sos2 = sos.copy()
+    sos2[2, 2] *= 0.9  # no longer b2 == b0: general form
+    y2, zf2 = mrh.multirate_IIR(sos2).filter_stream(x, zi)
+    y2_ref, zf2_ref = signal.sosfilt(sos2, x.astype(wide), zi=zi)
+    assert max(rel_err(y2, y2_ref)) <= tol
+    assert np.max(np.abs(zf2 - zf2_ref) / (np.abs(zf2_ref).max(axis=1, keepdims=True) + 1e-300)) <= tol
