@@ -117,8 +117,8 @@ struct IirHandle : HandleBase {
     int nsec = 0;   // number of cascaded sections
     int order = 0;  // order of each section (2 for SOS, K-1 for a transfer function)
     std::vector<double> coef;  // per section: b[0..order], a[1..order]  (a0-normalised)
-    // Biquad cascades whose sections all have b2 == b0 (zeros on the unit circle: Butterworth / Chebyshev-II /
-    // elliptic low-, high-pass and band-stop designs) are re-factored at creation -- the same transfer function with
+    // Biquad cascades whose sections all have b2 == b0 (zeros on the unit circle: every Butterworth / Chebyshev /
+    // elliptic design of scipy.signal, all band types) are re-factored at creation -- the same transfer function with
     // all gain in section 0 and b0 = b2 = 1 in the others -- so that K3 needs 3 coefficients and 4 flops per such
     // section (iir_scan.hip).  state_scale[d] converts a DF2T state of the caller's factorisation into the internal
     // one (z_int = scale * z); empty = identity.
