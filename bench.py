@@ -127,7 +127,7 @@ def main():
             step = lambda: iir.filter_local_dev(xd, yd, n)       # noqa: E731
         units, alg_bytes = n, 8.0 * n
         compute = ("FP64 vector (v_fma_f64)", 78.6, 72.0 * n)     # 9 flop per biquad per sample
-        kern = "iir_k1_mfma_kernel + iir_carry_kernel + iir_chunk_kernel"
+        kern = "iir_k1r_kernel + iir_carry_kernel + iir_chunk_kernel"
         wl = "multirate_IIR.filter: 8-biquad elliptic bandpass, float32, 2^%d samples, affine scan" % args.log2n
         metric = "float32 MSamples/s (8-biquad SOS IIR)"
 

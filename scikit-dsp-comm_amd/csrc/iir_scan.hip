@@ -506,6 +506,114 @@ __global__ __launch_bounds__(256) void iir_carry_kernel(const double *__restrict
     }
 }
 
+// K1 with the end-state map G in REGISTERS (chunks of 128, 256 or 512 samples, <= 16 states): wave w keeps the 32
+// A operands of piece w % NP for the whole launch and walks groups of 16 chunks; the partial products of the NP
+// pieces of a chunk group are summed through LDS.  Without table loads in the step loop the prefetch of the next
+// group's samples can be issued BEFORE the MFMAs (vmcnt retires in order: table loads queued behind a prefetch
+// would wait for HBM at every step, which is why iir_k1_mfma_kernel requests its samples only after the loop).
+template <typename IO, int NP>
+__global__ __launch_bounds__(256) void iir_k1r_kernel(const IO *__restrict__ xin, int64_t n, int64_t J, int64_t batch_stride,
+                                                      const double *__restrict__ Gt, double *__restrict__ vout, int D)
+{
+    constexpr int T = kMmPiece * NP;
+    constexpr int E = 16 / (int)sizeof(IO);
+    constexpr int W = (int)sizeof(IO) / 4;
+    constexpr int kLoads = 16 * kMmPiece / E / 64;
+    constexpr int GPW = 4 / NP;  // chunk groups a workgroup works on at a time
+    __shared__ __attribute__((aligned(16))) float lds[4 * 16 * kMmPitch * W];
+    __shared__ double part[2][4][64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int piece = wave % NP, sub = wave / NP;
+    const int bat = blockIdx.y;
+    const IO *x = xin + (size_t)bat * batch_stride;
+    double *vbase = vout + (size_t)bat * D * J;
+    float *img = lds + wave * (16 * kMmPitch * W);
+    const int64_t ngroups = (J + 15) / 16;
+    const int64_t niter = (ngroups + (int64_t)gridDim.x * GPW - 1) / ((int64_t)gridDim.x * GPW);
+
+    double areg[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) areg[s] = Gt[((size_t)piece * 32 + s) * 64 + lane];
+
+    typedef float pre_t __attribute__((ext_vector_type(4)));
+    pre_t pre[kLoads];
+    auto group_of = [&](int64_t it) { return (it * gridDim.x + blockIdx.x) * GPW + sub; };
+    auto interior = [&](int64_t g) { return g < ngroups && (16 * g + 16) * (int64_t)T <= n; };
+    auto load_piece = [&](int64_t g) {  // interior groups only
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int idx = i * 64 + lane;
+            const int row = idx / (kMmPiece / E), seg = idx % (kMmPiece / E);
+            const int64_t e = (16 * g + row) * T + (int64_t)piece * kMmPiece + (int64_t)seg * E;
+            pre[i] = *reinterpret_cast<const pre_t *>(x + e);
+        }
+    };
+    auto stage_slow = [&](int64_t g) {
+#pragma unroll 1
+        for (int i = 0; i < kLoads; ++i) {
+            const int idx = i * 64 + lane;
+            const int row = idx / (kMmPiece / E), seg = idx % (kMmPiece / E);
+            const int64_t e = (16 * g + row) * T + (int64_t)piece * kMmPiece + (int64_t)seg * E;
+            IO *dst = reinterpret_cast<IO *>(img) + row * kMmPitch + seg * E;
+#pragma unroll
+            for (int k = 0; k < E; ++k) dst[k] = (e + k < n) ? x[e + k] : IO(0);
+        }
+    };
+    const int c = lane & 15, j = lane >> 4;
+    bool fast = interior(group_of(0));
+    if (fast) load_piece(group_of(0));
+#pragma unroll 1
+    for (int64_t it = 0; it < niter; ++it) {
+        const int64_t g = group_of(it);
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < kLoads; ++i) {
+                const int idx = i * 64 + lane;
+                const int row = idx / (kMmPiece / E), seg = idx % (kMmPiece / E);
+                *reinterpret_cast<pre_t *>(img + (row * kMmPitch + seg * E) * W) = pre[i];
+            }
+        } else if (g < ngroups) {
+            stage_slow(g);
+        }
+        const int64_t gn = group_of(it + 1);
+        fast = it + 1 < niter && interior(gn);
+        if (fast) load_piece(gn);  // in flight during the MFMAs below
+        v4d_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        if (g < ngroups) {
+            const IO *xs = reinterpret_cast<const IO *>(img) + c * kMmPitch + j;
+#pragma unroll
+            for (int s = 0; s < 32; s += 2) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[s], (double)xs[4 * s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[s + 1], (double)xs[4 * s + 4], acc1, 0, 0, 0);
+            }
+        }
+        const v4d_t acc = acc0 + acc1;
+        double *mine = part[it & 1][wave] + lane * 4;
+        if (NP > 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[r] = acc[r];
+            __syncthreads();  // (one barrier per iteration: the partial buffers alternate)
+        }
+        if (piece == 0 && g < ngroups) {
+            double sum[4] = {acc[0], acc[1], acc[2], acc[3]};
+#pragma unroll
+            for (int q = 1; q < NP; ++q) {
+                const double *other = part[it & 1][wave + q] + lane * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] += other[r];
+            }
+            const int64_t cj = 16 * g + c;
+            if (cj < J) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = j + 4 * r;
+                    if (d < D) vbase[(size_t)d * J + cj] = sum[r];
+                }
+            }
+        }
+    }
+}
+
 // ---- interleaved complex signals, aggregate-free mode: no planes ---------------------------------
 // A complex signal through a real-coefficient cascade is two independent real recurrences.  The
 // planar detour (deinterleave -> 2 planes -> interleave) costs two extra passes over the signal
@@ -1016,7 +1124,19 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
     }
     if (fast) {
         const int64_t waves = (a.J + 15) / 16;
-        if (D <= 16)
+        static const bool no_k1r = getenv("SKDSP_IIR_NO_K1R") != nullptr;  // developer A/B switch
+        const int np = (int)(a.T / kMmPiece);
+        if (D <= 16 && !no_k1r && (np == 1 || np == 2 || np == 4) && a.T == (int64_t)np * kMmPiece) {
+            // G in registers: persistent workgroups (3 per CU), each iteration 4 / np groups of 16 chunks
+            const int64_t ngroups = waves, per_wg = 4 / np;
+            static const int wgs_per_cu = getenv("SKDSP_K1R_WGS") ? atoi(getenv("SKDSP_K1R_WGS")) : 2;
+            const unsigned grid = (unsigned)std::min<int64_t>((ngroups + per_wg - 1) / per_wg, (int64_t)wgs_per_cu * ctx().num_cus);
+#define SK_K1R(NP) hipLaunchKernelGGL((iir_k1r_kernel<IO, NP>), dim3(grid, nbatch), dim3(256), 0, s, (const IO *)a.x, a.n, a.J, a.batch_stride, (const double *)p->gt_dev, a.v, D)
+            if (np == 1) SK_K1R(1);
+            else if (np == 2) SK_K1R(2);
+            else SK_K1R(4);
+#undef SK_K1R
+        } else if (D <= 16)
             hipLaunchKernelGGL((iir_k1_mfma_kernel<IO, 1>), dim3((unsigned)((waves + 3) / 4), nbatch), dim3(256), 0, s, (const IO *)a.x,
                                a.n, a.T, a.J, a.batch_stride, (const double *)p->gt_dev, a.v, D);
         else
