@@ -1370,3 +1370,26 @@ def test_iir_unit_tail_factorisation_states(dt):
     y2_ref, zf2_ref = signal.sosfilt(sos2, x.astype(wide), zi=zi)
     assert max(rel_err(y2, y2_ref)) <= tol
     assert np.max(np.abs(zf2 - zf2_ref) / (np.abs(zf2_ref).max(axis=1, keepdims=True) + 1e-300)) <= tol
+
+
+@pytest.mark.parametrize("dt,n", [(np.float32, 2 ** 24), (np.float32, 2 ** 25 - 12345), (np.float32, 3 * 2 ** 24), (np.float32, 2 ** 26),
+                                  (np.float64, 2 ** 25), (np.float32, 2 ** 26 + 2 ** 22)])
+def test_iir_chunk_state_kernels_by_chunk_length(dt, n):
+    """Chunk lengths 128 / 256 / 512 run the register-resident K1 (iir_k1r_kernel, 1 / 2 / 4 pieces per chunk, ragged
+    last group), 384 and 640 the L2-streamed one: head, middle and tail windows against the oracle."""
+    import bench
+    sos = bench.elliptic_bpf_sos()
+    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+    xd = _ffi.DeviceArray(n, dt).fill_noise(5)
+    yd = _ffi.DeviceArray(n, dt)
+    try:
+        k.filter_dev(xd, yd)
+        _ffi.sync()
+        tol = TOL32 if dt == np.float32 else 1e-9
+        for lo in (0, n // 2 + 777, n - 50000):
+            lo2 = max(lo - 20000, 0)
+            ref = orc.sos_filter(sos, xd.to_host(lo2, lo + 40000 - lo2))[lo - lo2:]
+            assert_close(yd.to_host(lo, 40000), ref, tol, "n=%d @%d" % (n, lo))
+    finally:
+        xd.free()
+        yd.free()
