@@ -142,6 +142,9 @@ struct IirArgs {
     int n_lv;             // chunk-level scan levels whose power M^(2^l) is not yet negligible (<= 8)
     const double *zi;     // [batch][D] initial state (streaming; null = rest, what the reference uses)
     double *zf;           // [batch][D] state after sample n-1 (null = not wanted)
+    int dec;              // > 1: K3 stores only y[k * dec] (at y[k]), k < n_keep / dec  (.dn: no full-rate result in HBM)
+    int dec_dq, dec_dr;   // (32 T) div / mod dec: index step between a thread's staged segments
+    int64_t n_keep;       // (n / dec) * dec
 };
 
 // Kernel body shared by K1 (WRITE=false) and K3 (WRITE=true).
@@ -312,13 +315,42 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
         else run_piece(std::false_type{});
         if (WRITE) {
             __syncthreads();
+            int64_t dq_run = 0;
+            int dr_run = 0;
 #pragma unroll
             for (int i = 0; i < St::per_thread; ++i) {
                 const int idx = i * kIirThreads + tid;
                 const int row = idx / St::segs, seg = idx % St::segs;
                 const int64_t g = (row0 + row) * a.T + (int64_t)p * kPiece + (int64_t)seg * St::elems;
                 const float4 val = *reinterpret_cast<const float4 *>(stage + row * St::pitch + seg * St::elems);
-                if (interior || g + St::elems <= a.n) {
+                if (a.dec > 1) {
+                    // decimating store: segment i of this thread starts 32 T samples after segment i - 1, so its
+                    // (quotient, remainder) by dec follow from the first one by adding (dec_dq, dec_dr)
+                    if (i == 0) {
+                        dq_run = g / a.dec;
+                        dr_run = (int)(g - dq_run * a.dec);
+                    }
+                    const IO *tmp = reinterpret_cast<const IO *>(&val);
+                    if (a.dec >= St::elems) {  // at most one kept sample per 16-byte segment: one store
+                        const int e0 = dr_run == 0 ? 0 : a.dec - dr_run;
+                        if (e0 < St::elems && g + e0 < a.n_keep) {
+                            IO pick = tmp[0];
+#pragma unroll
+                            for (int e = 1; e < St::elems; ++e) pick = (e0 == e) ? tmp[e] : pick;
+                            y[dq_run + (dr_run != 0)] = pick;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < St::elems; ++e) {
+                            const int t = dr_run + e;  // < dec + elems
+                            const int m = (t >= a.dec) + (t >= 2 * a.dec) + (t >= 3 * a.dec) + (t >= 4 * a.dec);
+                            if (t == m * a.dec && g + e < a.n_keep) y[dq_run + m] = tmp[e];
+                        }
+                    }
+                    dq_run += a.dec_dq;
+                    dr_run += a.dec_dr;
+                    if (dr_run >= a.dec) { dr_run -= a.dec; ++dq_run; }
+                } else if (interior || g + St::elems <= a.n) {
                     *reinterpret_cast<float4 *>(y + g) = val;
                 } else if (g < a.n) {
                     const IO *tmp = reinterpret_cast<const IO *>(&val);
@@ -1176,7 +1208,7 @@ static int dispatch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream
 // x_dev/y_dev: real planar arrays (float or double per h->dtype's precision); complex
 // callers deinterleave first (capi) and pass nbatch = 2 with batch_stride.
 int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, hipStream_t s,
-                      const double *zi_host, double *zf_host, int interleaved)
+                      const double *zi_host, double *zf_host, int interleaved, int dec)
 {
     if (n <= 0) {
         if (zf_host) {
@@ -1212,6 +1244,14 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     a.il = interleaved ? 1 : 0;
     a.pw = p->pw_dev; a.v = p->v_dev; a.agg = nullptr; a.carry = nullptr; a.lbmat = nullptr; a.n_lb = 0; a.n_lv = 8;
     a.zi = nullptr; a.zf = nullptr;
+    a.dec = dec > 1 ? dec : 1;
+    a.n_keep = (n / a.dec) * a.dec;
+    {
+        const int64_t step = (int64_t)(kIirThreads / (kPiece / (16 / (dtype_double(h->dtype) ? 8 : 4)))) * T;  // rows between a thread's segments x T
+        a.dec_dq = (int)(step / a.dec);
+        a.dec_dr = (int)(step % a.dec);
+    }
+    SK_CHECK(a.dec == 1 || (!interleaved && zf_host == nullptr), SKDSP_ERR_UNSUPPORTED, "iir: decimating store needs a real signal and no state output");
     std::vector<double> zi_int;  // the caller's DF2T states in the internal factorisation (IirHandle::state_scale)
     if (zi_host) {
         if (!h->state_scale.empty()) {

@@ -131,7 +131,8 @@ struct IirHandle : HandleBase {
 // (re, im) batch_stride elements apart.  In-place (y == x) is allowed.
 int iir_launch_planar(IirHandle *h, const void *x_dev, int64_t n, int nbatch, int64_t batch_stride, void *y_dev, hipStream_t s,
                       const double *zi_host = nullptr, double *zf_host = nullptr,  // [nbatch][D] states (streaming)
-                      int interleaved = 0);  // 1: x / y interleaved complex, nbatch = 2; returns 1 if not applicable
+                      int interleaved = 0,   // 1: x / y interleaved complex, nbatch = 2; returns 1 if not applicable
+                      int dec = 1);          // > 1 (real signals): y receives only every dec-th output (n / dec samples)
 void iir_free(IirPlan *p);
 bool iir_shape_supported(int nsec, int order);
 
