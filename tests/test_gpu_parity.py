@@ -1393,3 +1393,39 @@ def test_iir_chunk_state_kernels_by_chunk_length(dt, n):
     finally:
         xd.free()
         yd.free()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("M,n", [(12, 2 ** 24), (3, 2 ** 24 - 1), (2, 3_000_001), (4, 2 ** 22), (7, 5_000_003), (5, 40_000), (4096, 2 ** 22)])
+def test_iir_dn_decimating_store(dt, M, n):
+    """.dn of a real signal: K3 stores every M-th output itself.  Identical to the full-rate result followed by the
+    downsample kernel (SKDSP_IIR_DN_FULL), and head / tail windows against the oracle; ragged lengths, M below and
+    above the 4 samples of a staged segment."""
+    import ctypes
+    import bench
+    sos = bench.elliptic_bpf_sos()
+    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+    xd = _ffi.DeviceArray(n, dt).fill_noise(2)
+    yd = _ffi.DeviceArray(n // M + 8, dt)
+    y2 = _ffi.DeviceArray(n // M + 8, dt)
+    lib = _ffi.load()
+    try:
+        yd.write(np.full(n // M + 8, 7.0, dt), at=0)  # sentinel: nothing may be written beyond n // M outputs
+        _ffi.check(lib.skdsp_iir_dn_dev(ctypes.c_void_p(k.h), ctypes.c_void_p(xd.ptr), n, M, ctypes.c_void_p(yd.ptr)))
+        os.environ["SKDSP_IIR_DN_FULL"] = "1"
+        try:
+            _ffi.check(lib.skdsp_iir_dn_dev(ctypes.c_void_p(k.h), ctypes.c_void_p(xd.ptr), n, M, ctypes.c_void_p(y2.ptr)))
+        finally:
+            del os.environ["SKDSP_IIR_DN_FULL"]
+        _ffi.sync()
+        got = yd.to_host(0, n // M + 8)
+        assert np.all(got[n // M:] == 7.0)
+        assert np.array_equal(got[:n // M], y2.to_host(0, n // M))
+        tol = TOL32 if dt == np.float32 else 1e-9
+        m = min(n, 60000)
+        ref = orc.sos_filter(sos, xd.to_host(0, m))[::M][:m // M]
+        assert_close(got[:len(ref)], ref, tol, "head M=%d" % M)
+    finally:
+        xd.free()
+        yd.free()
+        y2.free()
