@@ -824,9 +824,14 @@ int skdsp_iir_dn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int M, void 
     SK_CHECK(M >= 1, SKDSP_ERR_BADARG, "iir_dn: M must be >= 1");
     std::lock_guard<std::mutex> lk(h->mu);
     if (n <= 0) return SKDSP_OK;
-    // real signals: K3 stores every M-th output itself -- the full-rate result never reaches HBM
-    if (M > 1 && M <= 4096 && !dtype_complex(h->dtype) && !getenv("SKDSP_IIR_DN_FULL"))
-        return iir_launch_planar(h, x_dev, n, 1, 0, y_dev, ctx().stream, nullptr, nullptr, 0, M);
+    // K3 stores every M-th output itself -- the full-rate result never reaches HBM
+    if (M > 1 && M <= 4096 && !getenv("SKDSP_IIR_DN_FULL")) {
+        if (!dtype_complex(h->dtype)) return iir_launch_planar(h, x_dev, n, 1, 0, y_dev, ctx().stream, nullptr, nullptr, 0, M);
+        if (!getenv("SKDSP_IIR_PLANAR")) {  // interleaved complex kernels (decaying filters); 1 = not applicable
+            const int r1 = iir_launch_planar(h, x_dev, n, 2, 0, y_dev, ctx().stream, nullptr, nullptr, 1, M);
+            if (r1 != 1) return r1;
+        }
+    }
     void *full = nullptr;
     int rc = ws_reserve(2, (size_t)n * dtype_size(h->dtype) + 256, &full);
     if (rc) return rc;

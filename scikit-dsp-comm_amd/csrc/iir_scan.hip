@@ -882,6 +882,8 @@ __global__ __launch_bounds__(kIirThreads) __attribute__((amdgpu_waves_per_eu(NSE
         if (p == zf_piece) run_piece(std::true_type{});
         else run_piece(std::false_type{});
         __syncthreads();
+        int64_t dq_run = 0;
+        int dr_run = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = i * kIirThreads + tid;
@@ -893,7 +895,29 @@ __global__ __launch_bounds__(kIirThreads) __attribute__((amdgpu_waves_per_eu(NSE
                 out[2 * k] = st_re[row * PITCH + seg * (E / 2) + k];
                 out[2 * k + 1] = st_im[row * PITCH + seg * (E / 2) + k];
             }
-            if (interior || g + E / 2 <= a.n) {
+            if (a.dec > 1) {
+                // decimating store (see iir_chunk_kernel): a segment holds E / 2 <= 2 <= dec complex samples, so at most
+                // one of them is kept
+                if (i == 0) {
+                    dq_run = g / a.dec;
+                    dr_run = (int)(g - dq_run * a.dec);
+                }
+                const int e0 = dr_run == 0 ? 0 : a.dec - dr_run;
+                if (e0 < E / 2 && g + e0 < a.n_keep) {
+                    IO re = out[0], im = out[1];
+#pragma unroll
+                    for (int k = 1; k < E / 2; ++k) {
+                        re = (e0 == k) ? out[2 * k] : re;
+                        im = (e0 == k) ? out[2 * k + 1] : im;
+                    }
+                    IO *dst = y + 2 * (dq_run + (dr_run != 0));
+                    dst[0] = re;
+                    dst[1] = im;
+                }
+                dq_run += a.dec_dq;
+                dr_run += a.dec_dr;
+                if (dr_run >= a.dec) { dr_run -= a.dec; ++dq_run; }
+            } else if (interior || g + E / 2 <= a.n) {
                 *reinterpret_cast<float4 *>(y + 2 * g) = *reinterpret_cast<const float4 *>(out);
             } else if (g < a.n) {
 #pragma unroll
@@ -1247,11 +1271,13 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     a.dec = dec > 1 ? dec : 1;
     a.n_keep = (n / a.dec) * a.dec;
     {
-        const int64_t step = (int64_t)(kIirThreads / (kPiece / (16 / (dtype_double(h->dtype) ? 8 : 4)))) * T;  // rows between a thread's segments x T
+        // rows between a thread's staged segments x T (the interleaved complex kernel stages 8 segments per row piece)
+        const int64_t step = (interleaved ? kIirThreads / 8 : kIirThreads / (kPiece / (16 / (dtype_double(h->dtype) ? 8 : 4)))) * T;
         a.dec_dq = (int)(step / a.dec);
         a.dec_dr = (int)(step % a.dec);
     }
-    SK_CHECK(a.dec == 1 || (!interleaved && zf_host == nullptr), SKDSP_ERR_UNSUPPORTED, "iir: decimating store needs a real signal and no state output");
+    SK_CHECK(a.dec == 1 || (zf_host == nullptr && (interleaved || nbatch == 1)), SKDSP_ERR_UNSUPPORTED,
+             "iir: decimating store needs a real or interleaved complex signal and no state output");
     std::vector<double> zi_int;  // the caller's DF2T states in the internal factorisation (IirHandle::state_scale)
     if (zi_host) {
         if (!h->state_scale.empty()) {

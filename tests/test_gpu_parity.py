@@ -1395,10 +1395,10 @@ def test_iir_chunk_state_kernels_by_chunk_length(dt, n):
         yd.free()
 
 
-@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
 @pytest.mark.parametrize("M,n", [(12, 2 ** 24), (3, 2 ** 24 - 1), (2, 3_000_001), (4, 2 ** 22), (7, 5_000_003), (5, 40_000), (4096, 2 ** 22)])
 def test_iir_dn_decimating_store(dt, M, n):
-    """.dn of a real signal: K3 stores every M-th output itself.  Identical to the full-rate result followed by the
+    """.dn: K3 (real signals) / the interleaved complex K3 stores every M-th output itself.  Identical to the full-rate result followed by the
     downsample kernel (SKDSP_IIR_DN_FULL), and head / tail windows against the oracle; ragged lengths, M below and
     above the 4 samples of a staged segment."""
     import ctypes
@@ -1421,7 +1421,7 @@ def test_iir_dn_decimating_store(dt, M, n):
         got = yd.to_host(0, n // M + 8)
         assert np.all(got[n // M:] == 7.0)
         assert np.array_equal(got[:n // M], y2.to_host(0, n // M))
-        tol = TOL32 if dt == np.float32 else 1e-9
+        tol = TOL32 if dt in (np.float32, np.complex64) else 1e-9
         m = min(n, 60000)
         ref = orc.sos_filter(sos, xd.to_host(0, m))[::M][:m // M]
         assert_close(got[:len(ref)], ref, tol, "head M=%d" % M)
