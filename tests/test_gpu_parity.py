@@ -1429,38 +1429,3 @@ def test_iir_dn_decimating_store(dt, M, n):
         xd.free()
         yd.free()
         y2.free()
-
-
-@pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("L,n", [(12, 1_398_101), (3, 2 ** 22 + 5), (2, 3_000_001), (4, 2 ** 20), (7, 700_001), (5, 8_000), (64, 2 ** 16), (12, 2 ** 22)])
-def test_iir_up_without_the_zero_stuffed_copy(dt, L, n):
-    """.up of a real signal: the scan kernels read x itself and treat the gaps as zeros (chunks of 128 / 256 / 512
-    outputs on the matrix-pipe K1, short signals on the recurrence K1).  Identical to zero-stuffing first
-    (SKDSP_IIR_UP_STUFF), and the head against scipy."""
-    import ctypes
-    from scipy import signal
-    sos = signal.butter(8, 0.9 / L, output="sos")
-    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
-    xd = _ffi.DeviceArray(n, dt).fill_noise(4)
-    yd = _ffi.DeviceArray(n * L, dt)
-    y2 = _ffi.DeviceArray(n * L, dt)
-    lib = _ffi.load()
-    try:
-        _ffi.check(lib.skdsp_iir_up_dev(ctypes.c_void_p(k.h), ctypes.c_void_p(xd.ptr), n, L, ctypes.c_void_p(yd.ptr)))
-        os.environ["SKDSP_IIR_UP_STUFF"] = "1"
-        try:
-            _ffi.check(lib.skdsp_iir_up_dev(ctypes.c_void_p(k.h), ctypes.c_void_p(xd.ptr), n, L, ctypes.c_void_p(y2.ptr)))
-        finally:
-            del os.environ["SKDSP_IIR_UP_STUFF"]
-        _ffi.sync()
-        got = yd.to_host()
-        assert_close(got, y2.to_host(), 2e-7 if dt == np.float32 else 1e-13, "fused vs stuffed L=%d" % L)
-        m = min(n, 30000)
-        xu = np.zeros(m * L)
-        xu[::L] = L * xd.to_host(0, m).astype(np.float64)
-        ref = signal.sosfilt(sos, xu)
-        assert_close(got[:m * L], ref, TOL32 if dt == np.float32 else 1e-9, "head L=%d" % L)
-    finally:
-        xd.free()
-        yd.free()
-        y2.free()
