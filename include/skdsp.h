@@ -61,6 +61,11 @@ int skdsp_device_count(void);
 int skdsp_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes, int *clock_khz);
 const char *skdsp_last_error(void);
 const char *skdsp_version(void);
+/* Run-time switches (algorithm A/B selectors, pipeline chunk size, ...).  Each option NAME is read once from the
+ * environment variable SKDSP_<NAME> when the library first needs it; afterwards only these calls change it, so no
+ * launch path calls getenv().  Names: see struct Options in csrc/skdsp_internal.hpp.  Unknown name -> BADARG. */
+int skdsp_set_option(const char *name, int value);
+int skdsp_get_option(const char *name, int *value);
 
 int skdsp_malloc(void **dptr, int64_t bytes);
 int skdsp_free(void *dptr);

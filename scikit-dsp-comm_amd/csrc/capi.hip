@@ -39,6 +39,49 @@ Context &ctx()
     return c;
 }
 
+// ---- options: environment read once, skdsp_set_option afterwards ----------------------------
+namespace {
+struct OptEntry { const char *name; int Options::*field; };
+const OptEntry kOptTable[] = {
+    {"device", &Options::device}, {"fir_algo", &Options::fir_algo}, {"dn_no_ols", &Options::dn_no_ols},
+    {"fir_mm", &Options::fir_mm}, {"fir_bx", &Options::fir_bx}, {"fir_no_sw", &Options::fir_no_sw},
+    {"sw_no_tile", &Options::sw_no_tile}, {"sw_no_lpt", &Options::sw_no_lpt}, {"mm_ns", &Options::mm_ns},
+    {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
+    {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
+    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"shard_no_overlap", &Options::shard_no_overlap},
+    {"shard_reserve", &Options::shard_reserve}, {"dist_force_comm", &Options::dist_force_comm},
+    {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline},
+};
+int parse_opt(const char *name, const char *v)
+{
+    if (!strcmp(name, "fir_algo")) {
+        if (!strcmp(v, "direct")) return SKDSP_FIR_DIRECT;
+        if (!strcmp(v, "ols")) return SKDSP_FIR_OLS;
+        if (!strcmp(v, "auto")) return SKDSP_FIR_AUTO;
+    }
+    if (!*v) return 1;  // SKDSP_X= (set, empty) switches X on
+    return atoi(v);
+}
+Options options_from_env()
+{
+    Options o;
+    for (const OptEntry &e : kOptTable) {
+        char key[64] = "SKDSP_";
+        size_t k = 6;
+        for (const char *p = e.name; *p && k + 1 < sizeof(key); ++p) key[k++] = (char)toupper((unsigned char)*p);
+        key[k] = 0;
+        if (const char *v = getenv(key)) o.*(e.field) = parse_opt(e.name, v);
+    }
+    return o;
+}
+}  // namespace
+
+Options &opt()
+{
+    static Options o = options_from_env();
+    return o;
+}
+
 static int init_locked(int device)
 {
     Context &c = ctx();
@@ -74,9 +117,7 @@ int ensure_init()
     Context &c = ctx();
     if (c.ready) return SKDSP_OK;
     std::lock_guard<std::mutex> lk(c.mu);
-    int dev = -1;
-    if (const char *env = getenv("SKDSP_DEVICE")) dev = atoi(env);
-    return init_locked(dev);
+    return init_locked(opt().device);
 }
 
 int ws_reserve(int slot, size_t bytes, void **out)
@@ -103,11 +144,7 @@ static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // being HBM-bound (2*P FMA per c64 sample on the VALU vs ~120 flop in the FFT domain).
 static int pick_fir_algo(const FirHandle *h, int64_t n)
 {
-    int algo = h->algo;
-    if (const char *env = getenv("SKDSP_FIR_ALGO")) {
-        if (!strcmp(env, "direct")) algo = SKDSP_FIR_DIRECT;
-        else if (!strcmp(env, "ols")) algo = SKDSP_FIR_OLS;
-    }
+    int algo = opt().fir_algo != SKDSP_FIR_AUTO ? opt().fir_algo : h->algo;
     if (algo == SKDSP_FIR_OLS && !fir_ols_supported(h)) algo = SKDSP_FIR_DIRECT;
     if (algo != SKDSP_FIR_AUTO) return algo;
     // measured crossover at 2^26 samples (same box, alternating runs): the bf16x3 matrix-pipe kernel (real taps) stays
@@ -126,7 +163,7 @@ int fir_algo_for(const FirHandle *h, int64_t n) { return pick_fir_algo(h, n); }
 // (2^26: 0.14-0.20 ms against a flat 0.24) and always for float32 (0.07-0.15 against 0.26).
 static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev)
 {
-    bool ols = M > 1 && fir_ols_supported(h) && pick_fir_algo(h, n) == SKDSP_FIR_OLS && !getenv("SKDSP_DN_NO_OLS");
+    bool ols = M > 1 && fir_ols_supported(h) && pick_fir_algo(h, n) == SKDSP_FIR_OLS && !opt().dn_no_ols;
     if (ols) {
         const int kb = h->algo == SKDSP_FIR_OLS ? 0 : fir_bx_blocks(h, 1, M);
         if (kb > 0) ols = h->dtype == SKDSP_C64 && kb > 4 * M;
@@ -188,7 +225,7 @@ static int iir_any_dev(IirHandle *h, const void *x_dev, int64_t n, void *y_dev, 
         return SKDSP_OK;
     }
     if (!dtype_complex(h->dtype)) return iir_launch_planar(h, x_dev, n, 1, 0, y_dev, s, zi, zf);
-    const bool planar_only = getenv("SKDSP_IIR_PLANAR") != nullptr;  // developer A/B switch (and the tests)
+    const bool planar_only = opt().iir_planar != 0;  // developer A/B switch (and the tests)
     if (!planar_only) {
         // decaying filters: both components stay interleaved end to end (iir_k1c / iir_k3c kernels)
         const int r1 = iir_launch_planar(h, x_dev, n, 2, 0, y_dev, s, zi, zf, 1);
@@ -667,10 +704,10 @@ static int fir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M
     FirHandle *h = as_handle<FirHandle>(hh, H_FIR);
     SK_CHECK(h, SKDSP_ERR_BADARG, "fir: not a FIR handle");
     SK_CHECK(n >= 0 && L >= 1 && M >= 1, SKDSP_ERR_BADARG, "fir: bad arguments (n=%lld L=%d M=%d)", (long long)n, L, M);
-    SK_CHECK(n == 0 || (x && y), SKDSP_ERR_BADARG, "fir: null buffer");
     const size_t esz = dtype_size(h->dtype);
     const int64_t n_out = mode == 0 ? n : (n * L) / M;
     if (n_out == 0) return SKDSP_OK;
+    SK_CHECK(x && y, SKDSP_ERR_BADARG, "fir: null buffer");
     std::lock_guard<std::mutex> lk(h->mu);
     void *x_dev = nullptr, *y_dev = nullptr;
     int rc = stage_in(x, (size_t)n * esz, &x_dev);
@@ -701,7 +738,7 @@ static int iir_create_common(int nsec, int order, const std::vector<double> &coe
     h->nsec = nsec;
     h->order = order;
     h->coef = coef;
-    if (order == 2 && nsec >= 2 && !getenv("SKDSP_IIR_NO_UNIT")) {
+    if (order == 2 && nsec >= 2 && !opt().iir_no_unit) {
         // unit-tail re-factorisation (see IirHandle): H_0' = H_0 * prod_{j>=1} b0_j,  H_k' = H_k / b0_k
         bool ok = true;
         for (int s = 0; s < nsec && ok; ++s) {
@@ -816,18 +853,14 @@ int skdsp_iir_up_dev(skdsp_handle hh, const void *x_dev, int64_t n, int L, void 
     return iir_up_any(h, x_dev, n, L, y_dev);
 }
 
-int skdsp_iir_dn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int M, void *y_dev)
+// y = downsample(filter(x), M) on device vectors (both the _dev and the host-pointer entry use it)
+static int iir_dn_any(IirHandle *h, const void *x_dev, int64_t n, int M, void *y_dev)
 {
-    API_BEGIN;
-    IirHandle *h = as_handle<IirHandle>(hh, H_IIR);
-    SK_CHECK(h, SKDSP_ERR_BADARG, "iir_dn: not an IIR handle");
-    SK_CHECK(M >= 1, SKDSP_ERR_BADARG, "iir_dn: M must be >= 1");
-    std::lock_guard<std::mutex> lk(h->mu);
     if (n <= 0) return SKDSP_OK;
     // K3 stores every M-th output itself -- the full-rate result never reaches HBM
-    if (M > 1 && M <= 4096 && !getenv("SKDSP_IIR_DN_FULL")) {
+    if (M > 1 && M <= 4096 && !opt().iir_dn_full) {
         if (!dtype_complex(h->dtype)) return iir_launch_planar(h, x_dev, n, 1, 0, y_dev, ctx().stream, nullptr, nullptr, 0, M);
-        if (!getenv("SKDSP_IIR_PLANAR")) {  // interleaved complex kernels (decaying filters); 1 = not applicable
+        if (!opt().iir_planar) {  // interleaved complex kernels (decaying filters); 1 = not applicable
             const int r1 = iir_launch_planar(h, x_dev, n, 2, 0, y_dev, ctx().stream, nullptr, nullptr, 1, M);
             if (r1 != 1) return r1;
         }
@@ -839,30 +872,36 @@ int skdsp_iir_dn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int M, void 
     return downsample_launch(full, n, M, 0, h->dtype, y_dev, ctx().stream);
 }
 
+int skdsp_iir_dn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int M, void *y_dev)
+{
+    API_BEGIN;
+    IirHandle *h = as_handle<IirHandle>(hh, H_IIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "iir_dn: not an IIR handle");
+    SK_CHECK(M >= 1, SKDSP_ERR_BADARG, "iir_dn: M must be >= 1");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return iir_dn_any(h, x_dev, n, M, y_dev);
+}
+
 static int iir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M, void *y)
 {
     API_BEGIN;
     IirHandle *h = as_handle<IirHandle>(hh, H_IIR);
     SK_CHECK(h, SKDSP_ERR_BADARG, "iir: not an IIR handle");
     SK_CHECK(n >= 0 && L >= 1 && M >= 1, SKDSP_ERR_BADARG, "iir: bad arguments");
-    SK_CHECK(n == 0 || (x && y), SKDSP_ERR_BADARG, "iir: null buffer");
     const size_t esz = dtype_size(h->dtype);
     const int64_t n_out = (n * L) / M;
-    if (n_out == 0) return SKDSP_OK;
+    if (n_out == 0) return SKDSP_OK;  // fewer than M samples: nothing to deliver (y may be NULL)
+    SK_CHECK(x && y, SKDSP_ERR_BADARG, "iir: null buffer");
     std::lock_guard<std::mutex> lk(h->mu);
     void *x_dev = nullptr, *y_dev = nullptr;
     int rc = stage_in(x, (size_t)n * esz, &x_dev);
     if (rc) return rc;
-    hipStream_t s = ctx().stream;
     if (L > 1) {
         if ((rc = ws_reserve(1, (size_t)n * L * esz + 256, &y_dev))) return rc;
         if ((rc = iir_up_any(h, x_dev, n, L, y_dev))) return rc;
     } else if (M > 1) {
-        void *full = nullptr;
-        if ((rc = ws_reserve(2, (size_t)n * esz + 256, &full))) return rc;
         if ((rc = ws_reserve(1, (size_t)n_out * esz + 256, &y_dev))) return rc;
-        if ((rc = iir_any_dev(h, x_dev, n, full))) return rc;
-        if ((rc = downsample_launch(full, n, M, 0, h->dtype, y_dev, s))) return rc;
+        if ((rc = iir_dn_any(h, x_dev, n, M, y_dev))) return rc;  // K3 stores every M-th output itself
     } else {
         if ((rc = ws_reserve(1, (size_t)n * esz + 256, &y_dev))) return rc;
         if ((rc = iir_any_dev(h, x_dev, n, y_dev))) return rc;
@@ -917,6 +956,28 @@ int skdsp_downsample(const void *x, int64_t n, int M, int p, int dtype, void *y)
     if ((rc = ws_reserve(1, (size_t)n_out * esz + 256, &y_dev))) return rc;
     if ((rc = downsample_launch(x_dev, n, M, p, dtype, y_dev, ctx().stream))) return rc;
     return stage_out(y, y_dev, (size_t)n_out * esz);
+}
+
+int skdsp_set_option(const char *name, int value)
+{
+    SK_CHECK(name, SKDSP_ERR_BADARG, "set_option: null name");
+    for (const OptEntry &e : kOptTable)
+        if (!strcmp(e.name, name)) {
+            opt().*(e.field) = value;
+            return SKDSP_OK;
+        }
+    SK_CHECK(false, SKDSP_ERR_BADARG, "set_option: unknown option '%s'", name);
+}
+
+int skdsp_get_option(const char *name, int *value)
+{
+    SK_CHECK(name && value, SKDSP_ERR_BADARG, "get_option: null argument");
+    for (const OptEntry &e : kOptTable)
+        if (!strcmp(e.name, name)) {
+            *value = opt().*(e.field);
+            return SKDSP_OK;
+        }
+    SK_CHECK(false, SKDSP_ERR_BADARG, "get_option: unknown option '%s'", name);
 }
 
 int skdsp_set_wide_output(skdsp_handle hh, int on)

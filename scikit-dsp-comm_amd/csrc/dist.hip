@@ -160,7 +160,7 @@ int skdsp_dist_init(int rank, int world, const void *id128)
     r.world = world;
     // a 1-rank job needs no communicator; SKDSP_DIST_FORCE_COMM=1 builds one anyway so the
     // RCCL plumbing (dlopen, id, init, p2p to self, all-reduce) can be exercised on one GPU
-    if (world == 1 && !(getenv("SKDSP_DIST_FORCE_COMM") && id128)) return SKDSP_OK;
+    if (world == 1 && !(opt().dist_force_comm && id128)) return SKDSP_OK;
     SK_CHECK(id128, SKDSP_ERR_BADARG, "dist_init: null unique id");
     int rr = rccl_load();
     if (rr) return rr;
@@ -264,7 +264,7 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
         // 8 KB halo crosses xGMI on a second stream; tile 0 follows once it has landed.
         int V = 0;
         if (h->dtype == SKDSP_C64 && rc().comm && fir_algo_for(h, n_local) == SKDSP_FIR_OLS &&
-            !getenv("SKDSP_SHARD_NO_OVERLAP")) {
+            !opt().shard_no_overlap) {
             int r0 = fir_ols_tile_outputs(h, &V);
             if (r0) return r0;
         }
@@ -285,7 +285,7 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
             // The interior tiles are one persistent launch that fills every CU (2 x 76 KiB of LDS) for the whole
             // step: a few workgroup slots stay free, so that the send/recv kernel of the halo can start beside it
             // instead of behind it (8 of 512 workgroups; fir_ols_launch leaves them free by default anyway).
-            const int reserve = getenv("SKDSP_SHARD_RESERVE") ? atoi(getenv("SKDSP_SHARD_RESERVE")) : 8;
+            const int reserve = opt().shard_reserve;
             r1 = fir_ols_launch(h, (char *)x_dev + (size_t)V * esz, n_local - V, V, (char *)y_dev + (size_t)V * esz, c.stream, 1, reserve);
             if (r1) return r1;
             SK_HIP(hipStreamWaitEvent(c.stream, c.ev_halo, 0));

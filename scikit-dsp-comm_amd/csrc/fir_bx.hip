@@ -351,8 +351,7 @@ bool fir_bx_supported(const FirHandle *h, int L, int M, int64_t n_out)
 int fir_bx_blocks(const FirHandle *h, int L, int M)
 {
     if (h->taps_complex || dtype_double(h->dtype)) return 0;
-    static const bool off = (getenv("SKDSP_FIR_BX") && atoi(getenv("SKDSP_FIR_BX")) == 0) || (getenv("SKDSP_FIR_MM") && atoi(getenv("SKDSP_FIR_MM")) == 0);
-    if (off) return 0;
+    if (!opt().fir_bx || !opt().fir_mm) return 0;
     FirHandle::BxTab t;
     return bx_geometry(h, L, M, &t) ? t.KB : 0;
 }

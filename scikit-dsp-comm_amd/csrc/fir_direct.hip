@@ -661,8 +661,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     if (n_out <= 0) return SKDSP_OK;
     SK_CHECK(!(h->taps_complex && !dtype_complex(h->dtype)), SKDSP_ERR_BADARG,
              "fir: complex taps need a complex signal dtype (promote x first)");
-    static const int mm_mode = getenv("SKDSP_FIR_MM") ? atoi(getenv("SKDSP_FIR_MM")) : 1;  // 0: never (developer A/B)
-    static const int bx_mode = getenv("SKDSP_FIR_BX") ? atoi(getenv("SKDSP_FIR_BX")) : 1;  // 0: never (developer A/B)
+    const int mm_mode = opt().fir_mm, bx_mode = opt().fir_bx;  // 0: never (developer A/B)
     if (mm_mode && bx_mode && fir_bx_supported(h, L, M, n_out)) return fir_bx_launch(h, x, n, n_hist, L, M, n_out, y, s);
     if (mm_mode && fir_mm_supported(h, L, M, n_out)) return fir_mm_launch(h, x, n, n_hist, L, M, n_out, y, s);
     void *bank = nullptr;
@@ -680,7 +679,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     const size_t lds_cap = 80 * 1024;  // <= 2 workgroups per CU of the 160 KiB LDS
 
     // ---- preferred: register sliding window (R consecutive outputs per thread) ----
-    static const bool no_sw = getenv("SKDSP_FIR_NO_SW") != nullptr;  // developer A/B switch
+    const bool no_sw = opt().fir_no_sw != 0;  // developer A/B switch
     if (!no_sw) {
         const int Rmax = dtype_double(h->dtype) && dtype_complex(h->dtype) ? 4 : 8;
         for (int R = Rmax; R >= 2; R >>= 1) {
@@ -696,7 +695,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
             // interpolation by more than 4 classes: the whole output run of the workgroup is staged
             // in LDS (needs 256*R*Lp elements next to the window) -- prefer a smaller R that fits
             const size_t tile_bytes = (size_t)256 * R * a.Lp * esz;
-            const bool want_tile = a.Lp > 4 && !getenv("SKDSP_SW_NO_TILE");  // up to 4 classes the per-class row transposition measured faster
+            const bool want_tile = a.Lp > 4 && !opt().sw_no_tile;  // up to 4 classes the per-class row transposition measured faster
             const bool tile_fits = (size_t)phys * esz + 4096 + tile_bytes <= lds_cap;
             if (want_tile && !tile_fits && R > 2) continue;
             const FirHandle::SwTab *tab = nullptr;
@@ -716,7 +715,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
             w.out_off = -1;
             w.out_tile = 0;
             const bool lpt_ok = h->dtype == SKDSP_C64 && !h->taps_complex && R == 8 && w.tap_off >= 0 && a.Lp >= 2 && a.Lp <= 4 &&
-                                !getenv("SKDSP_SW_NO_LPT");
+                                !opt().sw_no_lpt;
             if (lpt_ok) {
                 w.out_off = 0;  // unrolled-class kernel: its output tiles alias the (finished) window image
             } else if (want_tile && tile_fits) {

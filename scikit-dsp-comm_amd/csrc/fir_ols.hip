@@ -23,9 +23,6 @@
 #include <cstdlib>
 #include <cstdio>
 
-#ifndef SKDSP_OLS_DEFAULT_THREADS
-#define SKDSP_OLS_DEFAULT_THREADS 256
-#endif
 #ifndef SKDSP_OLS_NOMEM
 #define SKDSP_OLS_NOMEM 0  // diagnostic: FFT/LDS work only, no x/y traffic (wrong results)
 #endif
@@ -46,8 +43,6 @@ struct OlsPlan {
     int ov = 0;  // overlap (discarded head) in samples, multiple of 512
     int V = 0;   // valid outputs per tile
     float4 *T1 = nullptr, *T2 = nullptr, *Hp = nullptr;
-    float2 *T1h = nullptr;
-    float4 *Hh = nullptr;
 };
 
 struct OlsArgs {
@@ -55,8 +50,6 @@ struct OlsArgs {
     cf *y;
     int64_t n, n_hist;
     const float4 *T1, *T2, *Hp;
-    const float2 *T1h;  // 512-thread kernel tables
-    const float4 *Hh;
     unsigned long long *trace;  // developer phase timing (SKDSP_OLS_TRACE), else null
     int ov, V, a0;  // a0 = ov / 512: first stored 512-block
     int aligned;    // x and y element-aligned (8 bytes complex64, 4 bytes float32)
@@ -412,147 +405,6 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 #undef SK_STAMP
 }
 
-// ---------------------------------------------------------------------------------------
-// 512-thread tile kernel (ols_core.hpp, second half): lane pair T = 2 t + e shares what one
-// thread of the kernel above does.  16 waves per CU (2 workgroups) instead of 8, <= 128 VGPRs.
-// ---------------------------------------------------------------------------------------
-// value held by the lane neighbour (lane ^ 1): one DPP move per dword
-__device__ __forceinline__ cf pair_xchg(cf a) { return make_float2(__shfl_xor(a.x, 1), __shfl_xor(a.y, 1)); }
-
-template <bool REAL>
-__device__ __forceinline__ void h_load_tile(const OlsArgs &A, int64_t tile, int T, cf *v)
-{
-    if (REAL) {
-        const float *xr = reinterpret_cast<const float *>(A.x);
-        const int64_t inA = (2 * tile) * A.V - A.ov, inB = inA + A.V;
-        const bool interior = inA >= -A.n_hist && inB + kN <= A.n;
-        if (interior) {
-            int tt = T;
-            asm volatile("" : "+v"(tt));
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                const float ra = __builtin_nontemporal_load(xr + inA + (unsigned)(a * 512 + tt));
-                const float rb = __builtin_nontemporal_load(xr + inB + (unsigned)(a * 512 + tt));
-                v[a] = make_float2(ra, rb);
-            }
-        } else {
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                const int64_t ga = inA + 512 * a + T, gb = ga + A.V;
-                float re = 0.f, im = 0.f;
-                if (ga >= -A.n_hist && ga < A.n) re = xr[ga];
-                if (gb >= -A.n_hist && gb < A.n) im = xr[gb];
-                v[a] = make_float2(re, im);
-            }
-        }
-    } else {
-        const int64_t in0 = tile * A.V - A.ov;
-        const bool interior = in0 >= -A.n_hist && in0 + kN <= A.n;
-        if (interior) {
-            int tt = T;
-            asm volatile("" : "+v"(tt));
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                const v2f_t nv = __builtin_nontemporal_load(reinterpret_cast<const v2f_t *>(A.x + in0) + (unsigned)(a * 512 + tt));
-                v[a] = make_float2(nv.x, nv.y);
-            }
-        } else {
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                const int64_t g = in0 + 512 * a + T;
-                cf val = make_float2(0.f, 0.f);
-                if (g >= -A.n_hist && g < A.n) val = A.x[g];
-                v[a] = val;
-            }
-        }
-    }
-}
-
-template <bool REAL>
-__device__ __forceinline__ void h_store_tile(const OlsArgs &A, int64_t tile, int T, const cf *v)
-{
-    if (REAL) {
-        float *yr = reinterpret_cast<float *>(A.y);
-        const int64_t outA = (2 * tile) * A.V, outB = outA + A.V;
-        const bool full = outB + A.V <= A.n;
-#pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            if (a < A.a0) continue;
-            const int64_t ga = outA + 512 * (a - A.a0) + T, gb = ga + A.V;
-            if (full) {
-                __builtin_nontemporal_store(v[a].x, yr + ga);
-                __builtin_nontemporal_store(v[a].y, yr + gb);
-            } else {
-                if (ga < A.n) yr[ga] = v[a].x;
-                if (gb < A.n) yr[gb] = v[a].y;
-            }
-        }
-    } else {
-        const int64_t out0 = tile * A.V;
-        const bool full = out0 + A.V <= A.n;
-#pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            if (a < A.a0) continue;
-            const int64_t g = out0 + 512 * (a - A.a0) + T;
-            if (full) {
-                v2f_t nv;
-                nv.x = v[a].x; nv.y = v[a].y;
-                __builtin_nontemporal_store(nv, reinterpret_cast<v2f_t *>(A.y) + g);
-            } else if (g < A.n) {
-                A.y[g] = v[a];
-            }
-        }
-    }
-}
-
-template <bool REAL>
-__global__ __launch_bounds__(512, 4) void ols_tile_kernel512(OlsArgs A)
-{
-    __shared__ float4 lds[kLdsUnits + 2 * kT2Units];
-    float4 *T2f = lds + kLdsUnits;
-    float4 *T2t = lds + kLdsUnits + kT2Units;
-    const int T = threadIdx.x;
-    if (T < 256) {
-        const float4 w = A.T2[T];
-        T2f[T] = w;
-        T2t[(T & 15) * 16 + (T >> 4)] = w;
-    }
-    cf tw[16];
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) tw[k1] = A.T1h[k1 * 512 + T];
-    tw[0] = make_float2(1.f, 0.f);
-    const float ef_ = (float)(T & 1);
-    const cf ef = make_float2(ef_, ef_);
-    const cf sg = make_float2(1.f - 2.f * ef_, 1.f - 2.f * ef_);
-    __syncthreads();
-
-    for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
-        cf v[16];
-        h_load_tile<REAL>(A, tile, T, v);
-        h_fwd_pass1(T, v, tw, lds);
-        __syncthreads();
-        cf S[16], Z[16];
-        h_fwd_pass23(T, T2f, lds, ef, S);
-        float4 hh[8];
-        {
-            int tt = T;
-            asm volatile("" : "+v"(tt));
-#pragma unroll
-            for (int j = 0; j < 8; ++j) hh[j] = A.Hh[(unsigned)(j * 512 + tt)];
-        }
-#pragma unroll
-        for (int m = 0; m < 16; ++m) Z[m] = pm_combine(pair_xchg(S[m]), S[m], sg);
-        h_mul_H(hh, Z);
-#pragma unroll
-        for (int m = 0; m < 16; ++m) S[m] = pm_combine(pair_xchg(Z[m]), Z[m], sg);  // U[m] = X[m] +- X[m+16]
-        h_inv_pass32(T, T2t, lds, ef, S);
-        __syncthreads();
-        h_inv_pass1(T, tw, lds, v);
-        h_store_tile<REAL>(A, tile, T, v);
-        __syncthreads();
-    }
-}
-
 bool fir_ols_supported(const FirHandle *h)
 {
     // complex64 signal; overlap must leave at least half the tile as useful output
@@ -569,27 +421,20 @@ static int ensure_plan(FirHandle *h)
     p->ov = ((h->ntaps - 1 + 511) / 512) * 512;
     if (p->ov == 0) p->ov = 512;
     p->V = kN - p->ov;
-    std::vector<float4> T1, T2, Hp, Hh;
-    std::vector<float2> T1h;
+    std::vector<float4> T1, T2, Hp;
     make_T1(T1);
     make_T2(T2);
     make_Hp(h->taps_host.data(), h->ntaps, h->taps_complex ? 2 : 1, Hp);
-    make_T1h(T1h);
-    make_Hh(h->taps_host.data(), h->ntaps, h->taps_complex ? 2 : 1, Hh);
     hipError_t e;
     if ((e = hipMalloc((void **)&p->T1, T1.size() * sizeof(float4))) != hipSuccess ||
         (e = hipMalloc((void **)&p->T2, T2.size() * sizeof(float4))) != hipSuccess ||
-        (e = hipMalloc((void **)&p->Hp, Hp.size() * sizeof(float4))) != hipSuccess ||
-        (e = hipMalloc((void **)&p->T1h, T1h.size() * sizeof(float2))) != hipSuccess ||
-        (e = hipMalloc((void **)&p->Hh, Hh.size() * sizeof(float4))) != hipSuccess) {
+        (e = hipMalloc((void **)&p->Hp, Hp.size() * sizeof(float4))) != hipSuccess) {
         fir_ols_free(p);
         return hip_fail(e, "hipMalloc(ols tables)", __FILE__, __LINE__);
     }
     if ((e = hipMemcpy(p->T1, T1.data(), T1.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(p->T2, T2.data(), T2.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(p->Hp, Hp.data(), Hp.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(p->T1h, T1h.data(), T1h.size() * sizeof(float2), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(p->Hh, Hh.data(), Hh.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess) {
+        (e = hipMemcpy(p->Hp, Hp.data(), Hp.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess) {
         fir_ols_free(p);
         return hip_fail(e, "hipMemcpy(ols tables)", __FILE__, __LINE__);
     }
@@ -603,8 +448,6 @@ void fir_ols_free(OlsPlan *p)
     if (p->T1) (void)hipFree(p->T1);
     if (p->T2) (void)hipFree(p->T2);
     if (p->Hp) (void)hipFree(p->Hp);
-    if (p->T1h) (void)hipFree(p->T1h);
-    if (p->Hh) (void)hipFree(p->Hh);
     delete p;
 }
 
@@ -630,7 +473,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.y = (cf *)y;
     A.n = n;
     A.n_hist = n_hist;
-    A.T1 = p->T1; A.T2 = p->T2; A.Hp = p->Hp; A.T1h = p->T1h; A.Hh = p->Hh;
+    A.T1 = p->T1; A.T2 = p->T2; A.Hp = p->Hp;
     A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512;
     const bool real = h->dtype == SKDSP_F32;
     // element alignment is all the vector accesses need: tile starts are odd multiples of the
@@ -645,10 +488,11 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     int64_t grid = 2 * (int64_t)ctx().num_cus;  // 2 resident workgroups per CU (76 KiB LDS each)
     // 8 slots stay free: room for a concurrent kernel (the RCCL send/recv of a halo, another stream of the caller) at
     // no measurable cost (0.2375 vs 0.2375 ms at 2^26, alternating runs on one box)
-    if (reserve_wgs < 0) reserve_wgs = getenv("SKDSP_OLS_RESERVE") ? atoi(getenv("SKDSP_OLS_RESERVE")) : 8;
+    if (reserve_wgs < 0) reserve_wgs = opt().ols_reserve;
     if (reserve_wgs > 0 && grid > 8 * (int64_t)reserve_wgs) grid -= reserve_wgs;
     if (grid > ntiles) grid = ntiles;
     A.trace = nullptr;
+#ifdef SKDSP_OLS_TRACE_BUILD  // developer build only (-DSKDSP_OLS_TRACE_BUILD): not part of the product launch path
     if (const char *tp = getenv("SKDSP_OLS_TRACE")) {  // developer diagnostics: dump phase stamps of one launch
         const size_t nw = 16 * 8 * 16;
         unsigned long long *d = nullptr;
@@ -668,13 +512,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
         }
         return SKDSP_OK;
     }
-    static const int nthreads = getenv("SKDSP_OLS_THREADS") ? atoi(getenv("SKDSP_OLS_THREADS")) : SKDSP_OLS_DEFAULT_THREADS;
-    if (nthreads == 512) {
-        if (real) hipLaunchKernelGGL((ols_tile_kernel512<true>), dim3((unsigned)grid), dim3(512), 0, s, A);
-        else hipLaunchKernelGGL((ols_tile_kernel512<false>), dim3((unsigned)grid), dim3(512), 0, s, A);
-        SK_HIP(hipGetLastError());
-        return SKDSP_OK;
-    }
+#endif
     if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
     else hipLaunchKernelGGL((ols_tile_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
     SK_HIP(hipGetLastError());

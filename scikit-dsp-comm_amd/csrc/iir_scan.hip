@@ -1159,7 +1159,7 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
     a.n_lb = p->n_lb;
     a.n_lv = p->n_lv < 8 ? p->n_lv : 8;
     // aggregate-free mode: matrix-pipe K1, carries from the chunk states themselves, unchanged K3
-    const bool fast = p->n_lv <= 5 && D <= 32 && ORD == 2 && a.T % kMmPiece == 0 && p->gt_dev && !getenv("SKDSP_IIR_NO_MFMA");
+    const bool fast = p->n_lv <= 5 && D <= 32 && ORD == 2 && a.T % kMmPiece == 0 && p->gt_dev && !opt().iir_no_mfma;
     if (a.il) {
         if (!fast || a.T % 64 != 0) return 1;  // not applicable (error codes are negative): the caller takes the planar detour
         const int64_t waves = (a.J + 15) / 16;
@@ -1180,12 +1180,12 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
     }
     if (fast) {
         const int64_t waves = (a.J + 15) / 16;
-        static const bool no_k1r = getenv("SKDSP_IIR_NO_K1R") != nullptr;  // developer A/B switch
+        const bool no_k1r = opt().iir_no_k1r != 0;  // developer A/B switch
         const int np = (int)(a.T / kMmPiece);
         if (D <= 16 && !no_k1r && (np == 1 || np == 2 || np == 4) && a.T == (int64_t)np * kMmPiece) {
             // G in registers: persistent workgroups (3 per CU), each iteration 4 / np groups of 16 chunks
             const int64_t ngroups = waves, per_wg = 4 / np;
-            static const int wgs_per_cu = getenv("SKDSP_K1R_WGS") ? atoi(getenv("SKDSP_K1R_WGS")) : 2;
+            const int wgs_per_cu = opt().k1r_wgs > 0 ? opt().k1r_wgs : 2;
             const unsigned grid = (unsigned)std::min<int64_t>((ngroups + per_wg - 1) / per_wg, (int64_t)wgs_per_cu * ctx().num_cus);
 #define SK_K1R(NP) hipLaunchKernelGGL((iir_k1r_kernel<IO, NP>), dim3(grid, nbatch), dim3(256), 0, s, (const IO *)a.x, a.n, a.J, a.batch_stride, (const double *)p->gt_dev, a.v, D)
             if (np == 1) SK_K1R(1);

@@ -377,150 +377,5 @@ SK_HD void inv_pass1(int t, const cf *tw, const float4 *lds, cf *v)
     }
 }
 
-
-// ============================================================================
-// 512-thread variant: the two columns (e = 0, 1) of a 256-thread tile are split over a
-// lane pair T = 2 t + e, so a tile is worked on by 8 waves instead of 4 (twice the waves
-// to cover LDS / barrier latency, 32 instead of 64 data registers per thread).  Passes 1
-// and 2 split trivially (one DFT16 per thread instead of two).  The 32-point pass 3 is
-// split by the parity of c = 2 q + e (decimation in time): thread e does the DFT16 of its
-// own-parity samples, the odd thread twiddles by W32^m, and ONE exchange between lane
-// neighbours (DPP) gives X[m] = E[m] + O'[m] to the even and X[m+16] = E[m] - O'[m] to the
-// odd thread.  The inverse is the exact mirror.  LDS image, T2 tables and bank behaviour
-// are those of the 256-thread kernel (each thread touches one half of a float4 unit).
-// ============================================================================
-#if defined(__HIP_DEVICE_COMPILE__)
-// p + sg * s,  sg = (+-1, +-1)
-SK_HD cf pm_combine(cf p, cf s_, cf sg)
-{
-    v2f r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(V(s_)), "v"(V(sg)), "v"(V(p)));
-    return C(r);
-}
-// a + ef * (a * (W - 1)),  W = c - i s (forward) / c + i s (inverse), ef = (e, e) as floats:
-// multiplies by W on odd lanes and by 1 on even lanes without a branch
-template <bool INV> SK_HD cf mul_w_if(cf a, float cm1, float s, cf ef)
-{
-    const cf d = cmul_k<INV>(a, cm1, s);
-    v2f r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(V(d)), "v"(V(ef)), "v"(V(a)));
-    return C(r);
-}
-#else
-// host emulation supplies the neighbour's value explicitly (see tests/host/ols_emul.cpp)
-SK_HD cf pm_combine(cf p, cf s_, cf sg) { return make_float2(p.x + sg.x * s_.x, p.y + sg.y * s_.y); }
-template <bool INV> SK_HD cf mul_w_if(cf a, float cm1, float s, cf ef)
-{
-    const cf d = cmul_k<INV>(a, cm1, s);
-    return make_float2(a.x + ef.x * d.x, a.y + ef.y * d.y);
-}
-#endif
-
-// (cos - 1, sin)(2 pi m / 32), m = 0..15, rounded from float64
-#define SK_CM1_32                                                                                         \
-    {0.0f, -0.019214719596769569f, -0.076120467488713262f, -0.16853038769745476f, -0.29289321881345243f,  \
-     -0.44442976698039771f, -0.61731656763491016f, -0.80490967798387167f, -1.0f, -1.1950903220161282f,    \
-     -1.3826834323650898f, -1.555570233019602f, -1.7071067811865475f, -1.8314696123025453f,                \
-     -1.9238795325112867f, -1.9807852804032304f}
-
-SK_HD cf *lds2_at(float4 *lds, int unit, int e) { return reinterpret_cast<cf *>(lds + unit) + e; }
-SK_HD const cf *lds2_at(const float4 *lds, int unit, int e) { return reinterpret_cast<const cf *>(lds + unit) + e; }
-
-// pass 1: v[a] = x[512 a + T];  tw[k1] = W_8192^(T k1).  thread T = 2 (16 b + q) + e.
-SK_HD void h_fwd_pass1(int T, const cf *v, const cf *tw, float4 *lds)
-{
-    const int t = T >> 1, e = T & 1, b = t >> 4, q = t & 15;
-    cf o[16];
-    Dft<16, 1, false>::run(v, o);
-    *lds2_at(lds, lds_unit(0, b, q), e) = o[0];
-    static_for<1, 16>([&](auto kc) {
-        constexpr int k1 = decltype(kc)::value;
-        *lds2_at(lds, lds_unit(k1, b, q), e) = cmul(o[k1], tw[k1]);
-    });
-}
-
-// exchange-1 read + pass 2 + exchange 2 + this thread's half of pass 3 (no neighbour yet).
-// thread T = 2 (16 k1 + q) + e, then (k1, k2 = q, e).  S out (16): E[m] (e = 0) or W32^m O[m] (e = 1).
-SK_HD void h_fwd_pass23(int T, const float4 *T2 /* LDS [k2][q] */, float4 *lds, cf ef, cf *S)
-{
-    const int t = T >> 1, e = T & 1, k1 = t >> 4, q = t & 15;
-    cf in[16], o[16];
-    SK_UNROLL
-    for (int b = 0; b < 16; ++b) in[b] = *lds2_at(lds, lds_unit(k1, b, q), e);
-    Dft<16, 1, false>::run(in, o);
-    *lds2_at(lds, lds_unit(k1, 0, q), e) = o[0];
-    SK_UNROLL
-    for (int k2 = 1; k2 < 16; ++k2) *lds2_at(lds, lds_unit(k1, k2, q), e) = cmul(o[k2], *lds2_at(T2, k2 * 16 + q, e));
-    cf z[16];
-    SK_UNROLL
-    for (int qq = 0; qq < 16; ++qq) z[qq] = *lds2_at(lds, lds_unit(k1, q, qq), e);  // q doubles as k2
-    Dft<16, 1, false>::run(z, S);
-    constexpr float Cm1[16] = SK_CM1_32;
-    constexpr float St[32] = SK_S32;
-    static_for<1, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        S[m] = mul_w_if<false>(S[m], Cm1[m], St[m], ef);
-    });
-}
-
-// neighbour combine: Z[m] = P[m] + sg S[m]  (even lane: E + O' -> k3 = m; odd lane: E - O' -> k3 = m + 16)
-SK_HD void h_combine(const cf *S, const cf *P, cf sg, cf *Z)
-{
-    SK_UNROLL
-    for (int m = 0; m < 16; ++m) Z[m] = pm_combine(P[m], S[m], sg);
-}
-
-// H: Hh[j*512 + T] = (H[k(m=2j)], H[k(m=2j+1)]), k = k1 + 16 k2 + 256 (m + 16 e)
-SK_HD void h_load_H(int T, const float4 *Hh, float4 *hh)
-{
-    SK_UNROLL
-    for (int j = 0; j < 8; ++j) hh[j] = Hh[j * 512 + T];
-}
-SK_HD void h_mul_H(const float4 *hh, cf *Z)
-{
-    SK_UNROLL
-    for (int j = 0; j < 8; ++j) {
-        Z[2 * j] = cmul(Z[2 * j], lo(hh[j]));
-        Z[2 * j + 1] = cmul(Z[2 * j + 1], hi(hh[j]));
-    }
-}
-
-// inverse half of pass 3 after the neighbour combine U[m] = X[m] +- X[m+16] (done by the caller
-// with h_combine): conj W32^m on odd lanes, IDFT16 -> z[2 qq + e], conj T2, exchange 2',
-// inverse pass 2, exchange-1' write (own rows).  thread (k1, k2, e) -> (k1, q, e).
-SK_HD void h_inv_pass32(int T, const float4 *T2t /* LDS [qq][k2] */, float4 *lds, cf ef, cf *U)
-{
-    const int t = T >> 1, e = T & 1, k1 = t >> 4, k2 = t & 15;
-    constexpr float Cm1[16] = SK_CM1_32;
-    constexpr float St[32] = SK_S32;
-    static_for<1, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        U[m] = mul_w_if<true>(U[m], Cm1[m], St[m], ef);
-    });
-    cf z[16];
-    Dft<16, 1, true>::run(U, z);
-    SK_UNROLL
-    for (int qq = 0; qq < 16; ++qq) *lds2_at(lds, lds_unit(k1, k2, qq), e) = cmulc(z[qq], *lds2_at(T2t, qq * 16 + k2, e));
-    cf in[16], o[16];
-    SK_UNROLL
-    for (int kk = 0; kk < 16; ++kk) in[kk] = *lds2_at(lds, lds_unit(k1, kk, k2), e);  // k2 doubles as q
-    Dft<16, 1, true>::run(in, o);
-    SK_UNROLL
-    for (int b = 0; b < 16; ++b) *lds2_at(lds, lds_unit(k1, b, k2), e) = o[b];
-}
-
-// exchange-1' read + conj twiddle + inverse pass 1: v[a] = y[512 a + T]
-SK_HD void h_inv_pass1(int T, const cf *tw, const float4 *lds, cf *v)
-{
-    const int t = T >> 1, e = T & 1, b = t >> 4, q = t & 15;
-    cf in[16];
-    in[0] = *lds2_at(lds, lds_unit(0, b, q), e);
-    static_for<1, 16>([&](auto kc) {
-        constexpr int k1 = decltype(kc)::value;
-        in[k1] = cmulc(*lds2_at(lds, lds_unit(k1, b, q), e), tw[k1]);
-    });
-    Dft<16, 1, true>::run(in, v);
-}
-
 }  // namespace ols
 }  // namespace skdsp

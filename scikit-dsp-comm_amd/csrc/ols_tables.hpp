@@ -86,33 +86,5 @@ inline void make_Hp(const double *taps, int ntaps, int comp, std::vector<float4>
         }
 }
 
-// ---- tables of the 512-thread kernel ----
-// T1h[k1*512 + T] = W_8192^(T k1)   (T = 2 t + e is the column index rho itself)
-inline void make_T1h(std::vector<float2> &T1h)
-{
-    T1h.resize(16 * 512);
-    for (int k1 = 0; k1 < 16; ++k1)
-        for (int T = 0; T < 512; ++T) {
-            const cd w = wexp((long long)T * k1, kN);
-            T1h[k1 * 512 + T] = make_float2((float)w.real(), (float)w.imag());
-        }
-}
-
-// Hh[j*512 + T] = (H[k(2j)], H[k(2j+1)]) / N,  k(m) = k1 + 16 k2 + 256 (m + 16 e),  T = 2 (16 k1 + k2) + e
-inline void make_Hh(const double *taps, int ntaps, int comp, std::vector<float4> &Hh)
-{
-    std::vector<cd> h(kN, cd(0, 0));
-    for (int k = 0; k < ntaps; ++k) h[k] = comp == 2 ? cd(taps[2 * k], taps[2 * k + 1]) : cd(taps[k], 0.0);
-    fft_host(h);
-    Hh.resize(8 * 512);
-    const double sc = 1.0 / (double)kN;
-    for (int j = 0; j < 8; ++j)
-        for (int T = 0; T < 512; ++T) {
-            const int t = T >> 1, e = T & 1, k1 = t >> 4, k2 = t & 15;
-            const cd a = h[k1 + 16 * k2 + 256 * (2 * j + 16 * e)] * sc, b = h[k1 + 16 * k2 + 256 * (2 * j + 1 + 16 * e)] * sc;
-            Hh[j * 512 + T] = make_float4((float)a.real(), (float)a.imag(), (float)b.real(), (float)b.imag());
-        }
-}
-
 }  // namespace ols
 }  // namespace skdsp

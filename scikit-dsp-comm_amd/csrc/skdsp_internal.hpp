@@ -28,6 +28,34 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         }                                    \
     } while (0)
 
+// ------------------------------------------------------------------ options
+// Run-time switches.  Read from the environment ONCE (first use: SKDSP_<NAME>), changed afterwards only through
+// skdsp_set_option(): no getenv() on any launch path.  Most are developer A/B switches of measured alternatives.
+struct Options {
+    int device = -1;          // SKDSP_DEVICE: GPU to bind when skdsp_init() was not called explicitly
+    int fir_algo = 0;         // SKDSP_FIR_ALGO = auto|direct|ols (0|1|2): override of every handle's choice
+    int dn_no_ols = 0;        // .dn never through the overlap-save decimating store
+    int fir_mm = 1;           // 0: no matrix-pipe FIR kernels at all (register sliding-window kernels instead)
+    int fir_bx = 1;           // 0: no bf16x3 matrix-pipe kernel (FP32 matrix pipe instead)
+    int fir_no_sw = 0;        // skip the register sliding-window kernel (generic polyphase fallback)
+    int sw_no_tile = 0, sw_no_lpt = 0;
+    int mm_ns = 256;          // column blocks per workgroup of fir_mm_kernel
+    int ols_reserve = 8;      // workgroup slots a persistent overlap-save launch leaves free
+    int iir_planar = 0;       // complex IIR through two real planes (tests compare it with the interleaved kernels)
+    int iir_no_unit = 0;      // keep general biquads (no unit-tail re-factorisation)
+    int iir_dn_full = 0;      // .dn as full-rate scan + downsample kernel
+    int iir_no_mfma = 0;      // recurrence K1 instead of the matrix-pipe K1
+    int iir_no_k1r = 0;
+    int k1r_wgs = 2;
+    int iir_two_pass = 0;     // K1 + carries + K3 even where the single-pass scan applies
+    int shard_no_overlap = 0; // sharded FIR: halo exchange in front of the whole filter instead of beside the interior tiles
+    int shard_reserve = 8;
+    int dist_force_comm = 0;  // build an RCCL communicator for a 1-rank job too (exercises the plumbing on one GPU)
+    int host_chunk_log2 = 24; // host-pointer entry points: samples per pipelined chunk (pinned double buffers)
+    int host_pipeline = 1;    // 0: single staged copy in / kernel / copy out
+};
+Options &opt();
+
 // ------------------------------------------------------------------ context
 struct Context {
     bool ready = false;

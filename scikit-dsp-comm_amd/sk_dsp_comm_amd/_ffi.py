@@ -23,6 +23,7 @@ _CODE_OF = {np.dtype(np.float32): F32, np.dtype(np.complex64): C64, np.dtype(np.
 # every symbol include/skdsp.h declares (tests check the built library exports all of them)
 SYMBOLS = [
     "skdsp_init", "skdsp_shutdown", "skdsp_device_count", "skdsp_device_info", "skdsp_last_error", "skdsp_version",
+    "skdsp_set_option", "skdsp_get_option",
     "skdsp_malloc", "skdsp_free", "skdsp_memcpy_h2d", "skdsp_memcpy_d2h", "skdsp_memcpy_d2d", "skdsp_memset",
     "skdsp_sync", "skdsp_timer_start", "skdsp_timer_stop", "skdsp_fill_noise_dev",
     "skdsp_fir_create", "skdsp_fir_set_algo", "skdsp_fir_get_algo", "skdsp_fir_filter", "skdsp_fir_filter_dev",
@@ -64,6 +65,8 @@ def load():
         L.skdsp_last_error.restype = ctypes.c_char_p
         L.skdsp_version.restype = ctypes.c_char_p
         L.skdsp_init.argtypes = [ci]
+        L.skdsp_set_option.argtypes = [ctypes.c_char_p, ci]
+        L.skdsp_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ci)]
         L.skdsp_device_info.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(ci), ctypes.POINTER(i64), ctypes.POINTER(ci)]
         L.skdsp_malloc.argtypes = [pvp, i64]
         L.skdsp_free.argtypes = [vp]
@@ -127,6 +130,36 @@ def init(device=None):
     if device is None:
         device = int(os.environ.get("SKDSP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     check(L.skdsp_init(int(device)))
+
+
+def set_option(name, value):
+    """Run-time switch of the library (struct Options in csrc/skdsp_internal.hpp); returns the previous value."""
+    L = load()
+    old = ctypes.c_int(0)
+    check(L.skdsp_get_option(name.encode(), ctypes.byref(old)))
+    check(L.skdsp_set_option(name.encode(), int(value)))
+    return old.value
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    check(load().skdsp_get_option(name.encode(), ctypes.byref(v)))
+    return v.value
+
+
+class option:
+    """with _ffi.option("iir_planar", 1): ...  -- temporary switch (tests, A/B timing)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
 
 
 def device_info():
@@ -358,6 +391,14 @@ class IirKernel(_HostCalls):
     def filter_dev(self, xd, yd, n=None):
         n = xd.n if n is None else n
         check(load().skdsp_iir_filter_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, ctypes.c_void_p(yd.ptr)))
+
+    def up_dev(self, xd, yd, L, n=None):
+        n = xd.n if n is None else n
+        check(load().skdsp_iir_up_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, int(L), ctypes.c_void_p(yd.ptr)))
+
+    def dn_dev(self, xd, yd, M, n=None):
+        n = xd.n if n is None else n
+        check(load().skdsp_iir_dn_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, int(M), ctypes.c_void_p(yd.ptr)))
 
     def state_len(self):
         k = ctypes.c_int(0)

@@ -59,14 +59,30 @@ def _rows(fn, xg):
     return np.stack(out).reshape(xg.shape[:-1] + (out[0].shape[-1],))
 
 
-class _KernelCache:
-    """One device handle per signal dtype, created lazily."""
+def _fingerprint(*arrays):
+    """Cheap identity of the coefficient arrays an object currently holds (the reference reads its public
+    attributes on every call, so obj.b = new_taps must take effect on the next call)."""
+    out = []
+    for a in arrays:
+        a = np.asarray(a)
+        out.append((a.dtype.str, a.shape, hash(a.tobytes())))
+    return tuple(out)
 
-    def __init__(self, make):
+
+class _KernelCache:
+    """One device handle per signal dtype, created lazily and dropped when the coefficients change."""
+
+    def __init__(self, make, coeffs):
         self._make = make
+        self._coeffs = coeffs     # () -> tuple of the arrays the handles were built from
         self._k = {}
+        self._fp = None
 
     def get(self, np_dtype):
+        fp = _fingerprint(*self._coeffs())
+        if fp != self._fp:
+            self._k = {}
+            self._fp = fp
         code = _ffi.code_of(np_dtype)
         k = self._k.get(code)
         if k is None:
@@ -81,8 +97,11 @@ class multirate_FIR(object):
         self.N_forder = len(b)
         self.b = b
         log.info('FIR filter taps = %d' % self.N_forder)
-        self._bc = bool(np.iscomplexobj(np.asarray(b)))
-        self._kern = _KernelCache(lambda code: _ffi.FirKernel(np.asarray(self.b), code))
+        self._kern = _KernelCache(lambda code: _ffi.FirKernel(np.asarray(self.b), code), lambda: (self.b,))
+
+    @property
+    def _bc(self):
+        return bool(np.iscomplexobj(np.asarray(self.b)))
 
     # --- reference surface --------------------------------------------------
     def filter(self, x):
@@ -128,6 +147,8 @@ class multirate_FIR(object):
             raise TypeError("M must be an int")
         Li, gain_fix = _stuff_factor(x, L_change)
         xg, ref_dt = _signal(x, self._bc)
+        if (xg.size * Li) // M_change == 0:  # ZeroDivisionError for M = 0, like downsample()
+            return np.zeros(0, dtype=ref_dt if config.strict_dtype else xg.dtype)
         k = self._kern.get(xg.dtype)
         y = k.updn(xg, Li, M_change, wide=_wide())
         if gain_fix != 1.0:
@@ -181,7 +202,7 @@ class multirate_IIR(object):
                       + np.sum(np.sign(np.abs(sos[:, 1])))
         self.sos = sos
         log.info('IIR filter order = %d' % self.N_forder)
-        self._kern = _KernelCache(self._make)
+        self._kern = _KernelCache(self._make, lambda: (self.sos,))
 
     def _validated(self):
         sos = np.atleast_2d(np.asarray(self.sos))
@@ -269,6 +290,8 @@ class multirate_IIR(object):
         if xg.ndim != 1:
             raise ValueError("cannot reshape array of size %d into shape (%d,%d)"
                              % (xg.size, int(np.floor(len(xg) / M_change)), M_change))
+        if len(xg) // M_change == 0:  # fewer than M samples: the reference returns an empty view
+            return np.zeros(0, dtype=ref_dt if config.strict_dtype else xg.dtype)
         ks = self._kern.get(xg.dtype)
         y = xg
         for k in ks[:-1]:
@@ -291,17 +314,17 @@ class rate_change(object):
 
     def __init__(self, M_change=12, fcutoff=0.9, N_filt_order=8, ftype='butter'):
         import scipy.signal as signal
-        self.M = M_change  # Rate change factor M or L
-        self.fc = fcutoff * .5  # must be fs/(2*M), but scale by fcutoff
+        self.M = M_change            # interpolation (.up) / decimation (.dn) factor
+        self.fc = fcutoff * .5       # fraction of the post-change Nyquist band kept, in cycles/sample of the low rate
         self.N_forder = N_filt_order
+        wn = 2 / self.M * self.fc    # scipy's normalised cutoff: fcutoff / M of the high-rate Nyquist frequency
         if ftype.lower() == 'butter':
-            self.b, self.a = signal.butter(self.N_forder, 2 / self.M * self.fc)
+            self.b, self.a = signal.butter(self.N_forder, wn)
         elif ftype.lower() == 'cheby1':
-            # Set the ripple to 0.05 dB
-            self.b, self.a = signal.cheby1(self.N_forder, 0.05, 2 / self.M * self.fc)
+            self.b, self.a = signal.cheby1(self.N_forder, 0.05, wn)  # 0.05 dB passband ripple, as the reference fixes it
         else:
             warnings.warn('ftype must be "butter" or "cheby1"')
-        self._kern = _KernelCache(lambda code: _ffi.IirKernel(code, b=self.b, a=self.a))
+        self._kern = _KernelCache(lambda code: _ffi.IirKernel(code, b=self.b, a=self.a), lambda: (self.b, self.a))
 
     def up(self, x):
         """y = lfilter(b, a, M*upsample(x, M))  (multirate_helper.py:69-75)"""

@@ -43,14 +43,11 @@ def _gpu_dtype(x):
 
 def cic(m, k):
     """FIR taps of k cascaded length-m boxcars with unit DC gain (sigsys.py:62-93)."""
-    if k == 1:
-        b = np.ones(m)
-    else:
-        h = np.ones(m)
-        b = h
-        for _ in range(1, k):
-            b = np.convolve(b, h)  # cascade by convolving impulse responses
-    return b / np.sum(b)
+    box = np.ones(m)
+    taps = box
+    for _ in range(1, k):                 # k <= 1 (0 included) leaves a single boxcar, as in the reference
+        taps = np.convolve(taps, box)     # exact: the entries are integer path counts far below 2^53
+    return taps / np.sum(taps)
 
 
 def upsample(x, L):

@@ -151,103 +151,6 @@ int main()
     }
     printf("tile FIR (1024 complex taps) rel err %.3g\n", worst / peak);
     fails += worst / peak > 2e-6;
-    // ================= 512-thread variant (lane pairs T = 2 t + e) =================
-    {
-        std::vector<float2> T1h;
-        std::vector<float4> Hh;
-        make_T1h(T1h);
-        make_Hh(taps.data(), P, 2, Hh);
-        std::vector<float4> ldsh(kLdsUnits), T2t(256);
-        for (int i = 0; i < 256; ++i) T2t[(i & 15) * 16 + (i >> 4)] = T2[i];
-        std::vector<cf> r(512 * 16), S(512 * 16), Zh(512 * 16), tw(512 * 16);
-        for (int T = 0; T < 512; ++T) {
-            tw[T * 16] = make_float2(1.f, 0.f);
-            for (int k1 = 1; k1 < 16; ++k1) tw[T * 16 + k1] = T1h[k1 * 512 + T];
-            for (int a = 0; a < 16; ++a) r[T * 16 + a] = x[512 * a + T];
-        }
-        auto EF = [](int T) { const float e = (float)(T & 1); return make_float2(e, e); };
-        auto SG = [](int T) { const float g = (T & 1) ? -1.f : 1.f; return make_float2(g, g); };
-        for (int T = 0; T < 512; ++T) h_fwd_pass1(T, &r[T * 16], &tw[T * 16], ldsh.data());
-        // h_fwd_pass23 is wave-local (32-lane groups share k1): replay it group by group in
-        // lock-step -- exchange-1 reads + DFT, then ALL exchange-2 writes, then the reads.
-        {
-            std::vector<cf> o(512 * 16);
-            for (int T = 0; T < 512; ++T) {
-                const int t = T >> 1, e = T & 1, k1 = t >> 4, q = t & 15;
-                cf in[16];
-                for (int b = 0; b < 16; ++b) in[b] = *lds2_at(ldsh.data(), lds_unit(k1, b, q), e);
-                Dft<16, 1, false>::run(in, &o[T * 16]);
-            }
-            for (int T = 0; T < 512; ++T) {
-                const int t = T >> 1, e = T & 1, k1 = t >> 4, q = t & 15;
-                for (int k2 = 0; k2 < 16; ++k2)
-                    *lds2_at(ldsh.data(), lds_unit(k1, k2, q), e) = cmul(o[T * 16 + k2], *lds2_at(T2.data(), k2 * 16 + q, e));
-            }
-            constexpr float Cm1[16] = SK_CM1_32;
-            constexpr float St[32] = SK_S32;
-            for (int T = 0; T < 512; ++T) {
-                const int t = T >> 1, e = T & 1, k1 = t >> 4, k2 = t & 15;
-                cf z[16];
-                for (int qq = 0; qq < 16; ++qq) z[qq] = *lds2_at(ldsh.data(), lds_unit(k1, k2, qq), e);
-                Dft<16, 1, false>::run(z, &S[T * 16]);
-                for (int m = 1; m < 16; ++m) S[T * 16 + m] = mul_w_if<false>(S[T * 16 + m], Cm1[m], St[m], EF(T));
-            }
-        }
-        for (int T = 0; T < 512; ++T) h_combine(&S[T * 16], &S[(T ^ 1) * 16], SG(T), &Zh[T * 16]);
-        {   // spectrum placement: Zh[T][m] == X[k1 + 16 k2 + 256 (m + 16 e)]
-            std::vector<cd> X(kN);
-            for (int i = 0; i < kN; ++i) X[i] = cd(x[i].x, x[i].y);
-            fft_host(X);
-            double worst = 0, peak = 0;
-            for (int T = 0; T < 512; ++T)
-                for (int m = 0; m < 16; ++m) {
-                    const int t = T >> 1, e = T & 1;
-                    const int k = (t >> 4) + 16 * (t & 15) + 256 * (m + 16 * e);
-                    worst = std::max(worst, std::abs(X[k] - cd(Zh[T * 16 + m].x, Zh[T * 16 + m].y)));
-                    peak = std::max(peak, std::abs(X[k]));
-                }
-            printf("512-thread forward spectrum rel err %.3g\n", worst / peak);
-            fails += worst / peak > 5e-6;
-        }
-        for (int T = 0; T < 512; ++T) { float4 hh[8]; h_load_H(T, Hh.data(), hh); h_mul_H(hh, &Zh[T * 16]); }
-        std::vector<cf> U(512 * 16);
-        for (int T = 0; T < 512; ++T) h_combine(&Zh[T * 16], &Zh[(T ^ 1) * 16], SG(T), &U[T * 16]);
-        {   // h_inv_pass32 replayed in lock-step
-            constexpr float Cm1[16] = SK_CM1_32;
-            constexpr float St[32] = SK_S32;
-            std::vector<cf> z(512 * 16), o(512 * 16);
-            for (int T = 0; T < 512; ++T) {
-                for (int m = 1; m < 16; ++m) U[T * 16 + m] = mul_w_if<true>(U[T * 16 + m], Cm1[m], St[m], EF(T));
-                Dft<16, 1, true>::run(&U[T * 16], &z[T * 16]);
-            }
-            for (int T = 0; T < 512; ++T) {
-                const int t = T >> 1, e = T & 1, k1 = t >> 4, k2 = t & 15;
-                for (int qq = 0; qq < 16; ++qq)
-                    *lds2_at(ldsh.data(), lds_unit(k1, k2, qq), e) = cmulc(z[T * 16 + qq], *lds2_at(T2t.data(), qq * 16 + k2, e));
-            }
-            for (int T = 0; T < 512; ++T) {
-                const int t = T >> 1, e = T & 1, k1 = t >> 4, q = t & 15;
-                cf in[16];
-                for (int kk = 0; kk < 16; ++kk) in[kk] = *lds2_at(ldsh.data(), lds_unit(k1, kk, q), e);
-                Dft<16, 1, true>::run(in, &o[T * 16]);
-            }
-            for (int T = 0; T < 512; ++T) {
-                const int t = T >> 1, e = T & 1, k1 = t >> 4, q = t & 15;
-                for (int b = 0; b < 16; ++b) *lds2_at(ldsh.data(), lds_unit(k1, b, q), e) = o[T * 16 + b];
-            }
-        }
-        for (int T = 0; T < 512; ++T) h_inv_pass1(T, &tw[T * 16], ldsh.data(), &r[T * 16]);
-        double worst = 0, peak = 0;
-        for (int n = P - 1; n < kN; n += 7) {
-            cd acc(0, 0);
-            for (int k = 0; k < P; ++k) acc += cd(taps[2 * k], taps[2 * k + 1]) * cd(x[n - k].x, x[n - k].y);
-            const cf y = r[(n % 512) * 16 + n / 512];
-            worst = std::max(worst, std::abs(acc - cd(y.x, y.y)));
-            peak = std::max(peak, std::abs(acc));
-        }
-        printf("512-thread tile FIR rel err %.3g\n", worst / peak);
-        fails += worst / peak > 2e-6;
-    }
     printf(fails ? "FAIL\n" : "OK\n");
     return fails ? 1 : 0;
 }

@@ -429,7 +429,7 @@ import os, sys, ctypes
 import numpy as np
 sys.path.insert(0, os.path.join(%r, 'scikit-dsp-comm_amd'))
 sys.path.insert(0, %r)
-os.environ['SKDSP_DIST_FORCE_COMM'] = '1'
+os.environ['SKDSP_DIST_FORCE_COMM'] = '1'  # read once, when the library first needs its options
 from sk_dsp_comm_amd import _ffi
 _ffi.init(0)
 L = _ffi.load()
@@ -524,33 +524,6 @@ def test_sharded_fir_eight_shards_emulated_on_one_gpu():
         xs = xd.to_host(s0 - 3000, 6000)
         ref = orc.fir_filter(b, xs)[P - 1:]
         assert_close(y_sh[s0 - 3000 + P - 1:s0 + 3000], ref, TOL32, "boundary of shard %d" % r)
-
-
-def test_ols_512_thread_variant_in_subprocess():
-    """The alternative 16-points-per-thread tile (SKDSP_OLS_THREADS=512, kept selectable
-    because it was measured) must stay parity-correct."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r"""
-import os, sys
-import numpy as np
-sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'scikit-dsp-comm_amd'))
-from sk_dsp_comm_amd import _ffi
-from oracle import oracle as orc
-rng = np.random.default_rng(12)
-for n, P, dt in ((30001, 1024, np.complex64), (7168 * 3, 300, np.complex64), (50000, 127, np.float32)):
-    x = rng.standard_normal(n).astype(np.float32) if dt == np.float32 else ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2)).astype(dt)
-    b = rng.standard_normal(P) / np.sqrt(P)
-    k = _ffi.FirKernel(b, _ffi.code_of(dt)); k.set_algo(_ffi.FIR_OLS)
-    y = k.filter(x); ref = orc.fir_filter(b, x)
-    e = float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))
-    assert e < 1e-6, (n, P, e)
-print('OLS512_OK')
-""" % (root, root)
-    env = dict(os.environ, SKDSP_OLS_THREADS="512")
-    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, env=env)
-    assert b"OLS512_OK" in out.stdout, out.stdout.decode()[-3000:]
 
 
 class _CopyTransport:
@@ -986,13 +959,10 @@ def test_fir_dn_overlap_save_decimating_store(M, ntaps, dt):
     yd = _ffi.DeviceArray(n // M, dt)
     k.dn_dev(xd, yd, M, n_hist=ntaps - 1)
     y = yd.to_host()
-    os.environ["SKDSP_DN_NO_OLS"] = "1"
-    try:
+    with _ffi.option("dn_no_ols", 1):
         y2 = _ffi.DeviceArray(n // M, dt)
         k.dn_dev(xd, y2, M, n_hist=ntaps - 1)
         y_direct = y2.to_host()
-    finally:
-        del os.environ["SKDSP_DN_NO_OLS"]
     assert_close(y, y_direct, 2e-6, "ols-dn vs direct M=%d" % M)
     # and against the oracle on windows (incl. the history at the start and the ragged end)
     hist = np.empty(ntaps - 1, dt)
@@ -1139,13 +1109,10 @@ def test_iir_matrix_pipe_chunk_states_large(dt):
     s0 = n - 2 * m
     ref = orc.sos_filter(sos, xd.to_host(s0 - 20000, m + 20000))[20000:]
     assert_close(yd.to_host(s0, m), ref, tol, "deep window")
-    os.environ["SKDSP_IIR_NO_MFMA"] = "1"
-    try:
+    with _ffi.option("iir_no_mfma", 1):
         y2 = _ffi.DeviceArray(n, dt)
         k.filter_dev(xd, y2)
         _ffi.sync()
-    finally:
-        del os.environ["SKDSP_IIR_NO_MFMA"]
     assert_close(yd.to_host(s0, m), y2.to_host(s0, m), 1e-6 if dt == np.float32 else 1e-11, "matrix-pipe vs recurrence K1")
 
 
@@ -1193,14 +1160,11 @@ def test_iir_complex_interleaved_kernels(dt, nsec):
     ref, zf_ref = signal.sosfilt(sos, xd.to_host(n - m - w, m + w).astype(np.complex128), zi=np.zeros((nsec, 2), complex))
     assert_close(yd.to_host(n - m, m), ref[w:], tol, "tail window")
     assert_close(zf, zf_ref, tol, "final state")
-    os.environ["SKDSP_IIR_PLANAR"] = "1"
-    try:
+    with _ffi.option("iir_planar", 1):
         y2 = _ffi.DeviceArray(n, dt)
         zf2 = k.filter_state_dev(xd, y2, zi=flat)
         _ffi.sync()
         zf2 = (zf2[:D] + 1j * zf2[D:]).reshape(nsec, 2)
-    finally:
-        del os.environ["SKDSP_IIR_PLANAR"]
     assert_close(yd.to_host(0, n), y2.to_host(0, n), 1e-6 if dt == np.complex64 else 1e-12, "interleaved vs planar")
     assert_close(zf, zf2, 1e-9, "state: interleaved vs planar")
 
@@ -1412,11 +1376,8 @@ def test_iir_dn_decimating_store(dt, M, n):
     try:
         yd.write(np.full(n // M + 8, 7.0, dt), at=0)  # sentinel: nothing may be written beyond n // M outputs
         _ffi.check(lib.skdsp_iir_dn_dev(ctypes.c_void_p(k.h), ctypes.c_void_p(xd.ptr), n, M, ctypes.c_void_p(yd.ptr)))
-        os.environ["SKDSP_IIR_DN_FULL"] = "1"
-        try:
+        with _ffi.option("iir_dn_full", 1):
             _ffi.check(lib.skdsp_iir_dn_dev(ctypes.c_void_p(k.h), ctypes.c_void_p(xd.ptr), n, M, ctypes.c_void_p(y2.ptr)))
-        finally:
-            del os.environ["SKDSP_IIR_DN_FULL"]
         _ffi.sync()
         got = yd.to_host(0, n // M + 8)
         assert np.all(got[n // M:] == 7.0)
