@@ -1,25 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X streaming-filter path.
 
-    python bench.py --gpus N --steps K --warmup W           (N=1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W    (N>1, one rank per GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" = one pass of multirate_FIR.filter (1024-tap lowpass, complex64) over each
-rank's contiguous sample block of 2^26 samples, inputs already resident in HBM:
-halo exchange of the Ntaps-1 = 1023 preceding samples over RCCL (N>1), then the
-overlap-save kernel.  value = total samples all ranks filtered / max-over-ranks time.
+N = 1: one process, one GPU.  N > 1: one rank per GPU over RCCL; either launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the ranks read
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or, when no launcher set
+WORLD_SIZE, bench.py spawns its own N ranks (same environment contract, 127.0.0.1
+rendezvous) and forwards rank 0's line and the first non-zero exit code.
 
-The product path uses no PyTorch; with N>1 the ranks rendezvous through a file
+A "step" = one pass of multirate_FIR.filter (1024-tap lowpass, complex64) over each rank's
+contiguous sample block, inputs already resident in HBM: halo exchange of the Ntaps-1 = 1023
+preceding samples over RCCL (N > 1) beside the overlap-save kernel.  value = total samples all
+ranks filtered / max-over-ranks time.
+
+  default            weak scaling, 2^26 samples per GPU (the size the metric is quoted on)
+  --scaling strong --total-log2n 30
+                     BASELINE.json config 5 as written: 2^30 samples in total, 2^30 / N per GPU
+                     (N = 1 runs all 2^30 on one GPU: 8 GiB in + 8 GiB out of its 288 GB)
+
+The product path uses no PyTorch; the ranks rendezvous through a file
 (sk_dsp_comm_amd.sharding.FileRendezvous) and barrier / max-reduce through RCCL.
 
-Prints ONE JSON line on rank 0 (fields per the driver contract + "roofline" and
-"cpu_baseline").  Other workloads (--workload updn43|iir8|fir127) are measurement aids
-for the remaining BASELINE.json configs and print the same shape.
+Rank 0 prints ONE JSON line: the driver contract's fields + "roofline" and "cpu_baseline"
+(the C port of the reference's arithmetic) + "cpu_baseline_scipy" (literally the reference's
+scipy.signal call) + "other_configs" (BASELINE.json configs 3, 4 and the 127-tap shape, timed
+in the same process after the headline) + per-rank kernel / step times for N > 1.
+--workload updn43|iir8|fir127 runs one of the other configs as the main line instead.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -49,191 +62,313 @@ def elliptic_bpf_sos():
     return np.load(os.path.join(ROOT, "tests", "golden", "g7_iir_sos.npz"))["sos8"]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--settle-seconds", type=float, default=0.15,
-                    help="untimed passes before the warm-up steps until the GPU clock has left its idle state")
-    ap.add_argument("--workload", default="fir1024", choices=["fir1024", "updn43", "iir8", "fir127"])
-    ap.add_argument("--log2n", type=int, default=26, help="samples per GPU = 2^log2n")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------ launcher
+def self_launch(args):
+    """No launcher set WORLD_SIZE: spawn one rank per GPU ourselves (torchrun's environment contract)."""
+    n = args.gpus
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, deadline = 0, time.time() + args.launch_timeout
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:          # one rank failed: the others would wait for it forever
+                    q.terminate()
+        if time.time() > deadline:
+            rc = rc or 124
+            for q in live:
+                q.kill()
+            break
+        time.sleep(0.05)
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
 
-    from sk_dsp_comm_amd import _ffi, sharding
 
-    rank, world, local = sharding.env_rank_world()
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with one process per GPU "
-                     "(python -m torch.distributed.run --nproc-per-node %d ...)" % (args.gpus, args.gpus))
-        args.gpus = world
-    tr = sharding.RcclTransport(rank, world, local)  # binds this process to GPU LOCAL_RANK
-    info = _ffi.device_info()
+# ------------------------------------------------------------------------------ workloads
+class Workload:
+    """step() = one pass; units = input samples per rank per pass."""
 
-    n = 1 << args.log2n
-    K, W = args.steps, args.warmup
 
-    # ------------------------------------------------------------- workload
-    if args.workload == "fir1024":
+def make_workload(name, n, rank, world, tr, _ffi, sharding):
+    w = Workload()
+    w.name, w.n, w.units, w.compute, w.check, w.taps = name, n, n, None, None, None
+    lg = "2^%d" % (n.bit_length() - 1) if n & (n - 1) == 0 else str(n)
+    if name == "fir1024":
         b = firwin_lowpass(1024, 0.2)
-        dtype, arith = np.complex64, "c64"
-        fir = sharding.ShardedFIR(b, tr, dtype=dtype)
-        xd = fir.new_shard_buffer(n).fill_noise(2026, first_index=rank * n)
-        yd = _ffi.DeviceArray(n, dtype)
-        step = lambda: fir.filter_local_dev(xd, yd, n)           # noqa: E731
-        units, alg_bytes = n, 16.0 * n                           # 8 B in + 8 B out per sample
-        kern = "ols_tile_kernel"
-        wl = "multirate_FIR.filter: 1024-tap lowpass, complex64, 2^%d samples per GPU, FFT overlap-save" % args.log2n
-        metric = "complex64 MSamples/s (FIR-1024 tap, 2^26 samples)"
-    elif args.workload == "fir127":
+        w.taps, w.dtype, w.arith = b, np.complex64, "c64"
+        fir = sharding.ShardedFIR(b, tr, dtype=w.dtype)
+        w.xd = fir.new_shard_buffer(n).fill_noise(2026, first_index=rank * n)
+        w.yd = _ffi.DeviceArray(n, w.dtype)
+        w.step = lambda: fir.filter_local_dev(w.xd, w.yd, n)
+        w.alg_bytes = 16.0 * n                                   # 8 B in + 8 B out per sample
+        w.kern = "ols_tile_kernel"
+        w.wl = "multirate_FIR.filter: 1024-tap lowpass, complex64, %s samples per GPU, FFT overlap-save" % lg
+        w.metric = "complex64 MSamples/s (FIR-1024 tap, %s samples%s)" % (lg, " per GPU" if world > 1 else "")
+
+        def check():
+            from oracle import oracle as orc
+            s0, wn = 3 * 7168 - 100, 2048
+            ref = orc.fir_filter(b, w.xd.to_host(s0 - 1023, wn + 1023))[1023:]
+            got = w.yd.to_host(s0, wn)
+            return float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+        w.check = check
+    elif name == "fir127":
         b = firwin_lowpass(127, 0.2)
-        dtype, arith = np.float32, "f32"
+        w.taps, w.dtype, w.arith = b, np.float32, "f32"
         k = _ffi.FirKernel(b, _ffi.F32)
-        xd = _ffi.DeviceArray(n, dtype).fill_noise(2026)
-        yd = _ffi.DeviceArray(n, dtype)
-        step = lambda: k.filter_dev(xd, yd)                      # noqa: E731
-        units, alg_bytes = n, 8.0 * n
-        kern = "fir_bx_kernel"
-        wl = "multirate_FIR.filter: 127-tap lowpass, float32, 2^%d samples, direct form on the BF16 matrix pipe (3-way bf16 split = float32 precision)" % args.log2n
-        metric = "float32 MSamples/s (FIR-127 tap)"
-    elif args.workload == "updn43":
+        w.xd = _ffi.DeviceArray(n, w.dtype).fill_noise(2026)
+        w.yd = _ffi.DeviceArray(n, w.dtype)
+        w.step = lambda: k.filter_dev(w.xd, w.yd)
+        w.alg_bytes = 8.0 * n
+        w.kern = "fir_bx_kernel"
+        w.wl = ("multirate_FIR.filter: 127-tap lowpass, float32, %s samples, direct form on the BF16 matrix pipe "
+                "(3-way bf16 split = float32 precision)" % lg)
+        w.metric = "float32 MSamples/s (FIR-127 tap, %s samples)" % lg
+    elif name == "updn43":
         b = firwin_lowpass(512, 0.225)
-        dtype, arith = np.complex64, "c64"
+        w.taps, w.dtype, w.arith = b, np.complex64, "c64"
         k = _ffi.FirKernel(b, _ffi.C64)
-        xd = _ffi.DeviceArray(n, dtype).fill_noise(2026)
+        w.xd = _ffi.DeviceArray(n, w.dtype).fill_noise(2026)
         n_out = (n * 4) // 3
-        yd = _ffi.DeviceArray(n_out, dtype)
-        step = lambda: k.updn_dev(xd, yd, 4, 3)                  # noqa: E731
-        units, alg_bytes = n, 8.0 * n + 8.0 * n_out              # 18.67 B per input sample
+        w.yd = _ffi.DeviceArray(n_out, w.dtype)
+        w.step = lambda: k.updn_dev(w.xd, w.yd, 4, 3)
+        w.alg_bytes = 8.0 * n + 8.0 * n_out                      # 18.67 B per input sample
         # float32 arithmetic carried by 6 bf16 products per multiply: against the FP32 matrix / vector peak the useful
         # flops may exceed 100 % -- that is the point of the split
-        compute = ("useful f32 flops vs the FP32 matrix-pipe peak (computed as 6 bf16 MFMA products per multiply)", 157.3, 4.0 * 512 / 4 * n_out)  # 4*Ntaps/L flop per c64 output
-        kern = "fir_bx_kernel"
-        wl = "downsample(multirate_FIR.up(x,4),3): 512-tap prototype, complex64, 2^%d input samples, fused polyphase (Toeplitz product on the BF16 matrix pipe, 3-way bf16 split = float32 precision)" % args.log2n
-        metric = "complex64 input MSamples/s (polyphase L=4/M=3, 512 taps)"
-    else:
+        w.compute = ("useful f32 flops vs the FP32 matrix-pipe peak (computed as 6 bf16 MFMA products per multiply)",
+                     157.3, 4.0 * 512 / 4 * n_out)               # 4*Ntaps/L flop per c64 output
+        w.kern = "fir_bx_kernel"
+        w.wl = ("downsample(multirate_FIR.up(x,4),3): 512-tap prototype, complex64, %s input samples, fused polyphase "
+                "(Toeplitz product on the BF16 matrix pipe, 3-way bf16 split = float32 precision)" % lg)
+        w.metric = "complex64 input MSamples/s (polyphase L=4/M=3, 512 taps, %s samples)" % lg
+    elif name == "iir8":
         sos = elliptic_bpf_sos()
-        dtype, arith = np.float32, "f32 I/O, f64 state"
-        xd = _ffi.DeviceArray(n, dtype).fill_noise(2026, first_index=rank * n)
-        yd = _ffi.DeviceArray(n, dtype)
+        w.sos, w.dtype, w.arith = sos, np.float32, "f32 I/O, f64 state"
+        w.xd = _ffi.DeviceArray(n, w.dtype).fill_noise(2026, first_index=rank * n)
+        w.yd = _ffi.DeviceArray(n, w.dtype)
         if world == 1:
             k = _ffi.IirKernel(_ffi.F32, sos=sos)
-            step = lambda: k.filter_dev(xd, yd)                  # noqa: E731
+            w.step = lambda: k.filter_dev(w.xd, w.yd)
         else:  # contiguous sample blocks, exact state hand-off rank r -> r+1 (16 doubles per hop)
-            iir = sharding.ShardedIIR(sos, tr, dtype=dtype)
-            step = lambda: iir.filter_local_dev(xd, yd, n)       # noqa: E731
-        units, alg_bytes = n, 8.0 * n
-        compute = ("FP64 vector (v_fma_f64)", 78.6, 72.0 * n)     # 9 flop per biquad per sample
-        kern = "iir_k1r_kernel + iir_carry_kernel + iir_chunk_kernel"
-        wl = "multirate_IIR.filter: 8-biquad elliptic bandpass, float32, 2^%d samples, affine scan" % args.log2n
-        metric = "float32 MSamples/s (8-biquad SOS IIR)"
+            iir = sharding.ShardedIIR(sos, tr, dtype=w.dtype)
+            w.step = lambda: iir.filter_local_dev(w.xd, w.yd, n)
+        w.alg_bytes = 8.0 * n
+        w.compute = ("FP64 vector (v_fma_f64)", 78.6, 72.0 * n)   # 9 flop per biquad per sample (SURVEY 8d)
+        w.kern = "iir_scan kernels"
+        w.wl = "multirate_IIR.filter: 8-biquad elliptic bandpass, float32, %s samples, exact affine scan" % lg
+        w.metric = "float32 MSamples/s (8-biquad SOS IIR, %s samples)" % lg
+    else:
+        raise ValueError(name)
+    return w
 
-    if args.workload in ("fir1024", "fir127"):
-        compute = None
-    # --------------------------------------------------------------- timing
-    # The chip idles at ~160 MHz; the first ~50 launches after idle run on a ramping clock (0.28 ms
-    # for the first 50-launch window of the headline kernel, 0.236 ms from the second window on,
-    # flat for as long as the launches continue: profiles/r01/README.md).  Steady state is what a
-    # streaming job sees, so the clock is settled first, untimed, whatever W is.
-    # (the number of settle passes is agreed between the ranks: every pass of a sharded workload
-    # contains a send/recv pair, so a per-rank time-based loop would deadlock)
+
+def free_workload(w):
+    for a in ("xd", "yd"):
+        d = getattr(w, a, None)
+        if d is not None:
+            d.free()
+
+
+def timed_steps(w, K, W, settle_s, tr, _ffi):
+    """Settle the clock, W warm-up passes, then K timed passes bracketed by barrier + sync.
+    -> (wall seconds max over ranks, HIP-event ms max over ranks, this rank's (wall, event ms))."""
+    # The chip idles at ~160 MHz; the first ~50 launches after idle run on a ramping clock (0.28 ms for the first
+    # 50-launch window of the headline kernel, 0.236 ms from the second window on, flat for as long as the launches
+    # continue: profiles/r01/README.md).  Steady state is what a streaming job sees, so the clock is settled first,
+    # untimed, whatever W is.  (The number of settle passes is agreed between the ranks: every pass of a sharded
+    # workload contains a send/recv pair, so a per-rank time-based loop would deadlock.)
     t_settle = time.perf_counter()
     for _ in range(10):
-        step()
+        w.step()
     _ffi.sync()
     per_pass = max((time.perf_counter() - t_settle) / 10, 1e-6)
-    n_settle = int(tr.allreduce_max(float(min(20000, int(args.settle_seconds / per_pass) + 1)))) if args.settle_seconds > 0 else 0
+    n_settle = int(tr.allreduce_max(float(min(20000, int(settle_s / per_pass) + 1)))) if settle_s > 0 else 0
     for _ in range(n_settle):
-        step()
+        w.step()
     _ffi.sync()
     for _ in range(W):
-        step()
+        w.step()
     _ffi.sync()
     tr.barrier()
     _ffi.timer_start()
     t0 = time.perf_counter()
     for _ in range(K):
-        step()
+        w.step()
     ev_ms = _ffi.timer_stop()  # HIP events on the stream the kernels run on (synchronises)
     _ffi.sync()
     tr.barrier()
     t1 = time.perf_counter()
-    elapsed = tr.allreduce_max(t1 - t0)
-    ev_ms = tr.allreduce_max(ev_ms)
+    return tr.allreduce_max(t1 - t0), tr.allreduce_max(ev_ms), (t1 - t0, ev_ms)
+
+
+def roofline_of(w, ev_ms, K, log2n_for_traffic):
+    t_kernel = ev_ms * 1e-3 / K  # average launch (+ halo) duration from HIP events
+    achieved = w.alg_bytes / t_kernel / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": measured_traffic(w.name, log2n_for_traffic), "kernel": w.kern, "kernel_ms": t_kernel * 1e3,
+            "algorithmic_bytes_per_launch": w.alg_bytes}
+
+
+def compute_of(w, ev_ms, K):
+    if w.compute is None:
+        return None
+    # these workloads are also priced against arithmetic (DESIGN.md 4.2 / 4.3): useful flops of the reference
+    # formulation against the peak of the unit that executes them
+    tf = w.compute[2] / (ev_ms * 1e-3 / K) / 1e12
+    return {"unit": "TFLOP/s", "what": w.compute[0], "useful_flop_per_step": w.compute[2], "achieved": tf,
+            "peak": w.compute[1], "frac": tf / w.compute[1]}
+
+
+# ------------------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--settle-seconds", type=float, default=0.5,
+                    help="untimed passes before the warm-up steps until the GPU clock has left its idle state")
+    ap.add_argument("--workload", default="fir1024", choices=["fir1024", "updn43", "iir8", "fir127"])
+    ap.add_argument("--log2n", type=int, default=26, help="weak scaling: samples per GPU = 2^log2n")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--total-log2n", type=int, default=30, help="strong scaling: 2^total samples shared by all GPUs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--other-steps", type=int, default=100)
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="target CPU time of each baseline sample")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0)
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    from sk_dsp_comm_amd import _ffi, sharding
+
+    rank, world, local = sharding.env_rank_world()
+    args.gpus = world
+    tr = sharding.RcclTransport(rank, world, local)  # binds this process to GPU LOCAL_RANK
+    info = _ffi.device_info()
+
+    if args.scaling == "strong":
+        total = 1 << args.total_log2n
+        if total % world:
+            sys.exit("--scaling strong: %d GPUs do not divide 2^%d samples" % (world, args.total_log2n))
+        n = total // world
+    else:
+        n = 1 << args.log2n
+    K, W = args.steps, args.warmup
+
+    w = make_workload(args.workload, n, rank, world, tr, _ffi, sharding)
+    elapsed, ev_ms, mine = timed_steps(w, K, W, args.settle_seconds, tr, _ffi)
+
+    per_rank = None
+    if world > 1:
+        tab = tr.allgather_state(np.array([mine[0] * 1e3 / K, mine[1] / K]))
+        per_rank = {"step_ms": [float(v) for v in tab[:, 0]], "kernel_ms": [float(v) for v in tab[:, 1]]}
+    n_comm = tr.comm_count()
 
     # quick parity spot check of what was just computed (oracle = checker only)
-    check = None
-    if rank == 0 and args.workload == "fir1024":
-        from oracle import oracle as orc
-        s0, w = 3 * 7168 - 100, 2048
-        xs = xd.to_host(s0 - 1023, w + 1023)
-        ref = orc.fir_filter(b, xs)[1023:]
-        got = yd.to_host(s0, w)
-        check = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+    check = w.check() if (rank == 0 and w.check is not None) else None
 
-    # --------------------------------------------------------- cpu baseline
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, b if args.workload != "iir8" else None, xd)
-
+    out = None
     if rank == 0:
-        total_units = float(units) * world * K
-        ms_per_step = elapsed * 1e3 / K
-        t_kernel = ev_ms * 1e-3 / K  # average launch (+ halo) duration from HIP events
-        achieved = alg_bytes / t_kernel / 1e9
-        traffic = measured_traffic(args)
+        log2n = n.bit_length() - 1
         out = {
-            "metric": metric,
-            "value": total_units / elapsed / 1e6,
+            "metric": w.metric,
+            "value": float(w.units) * world * K / elapsed / 1e6,
             "unit": "MSamples/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": elapsed * 1e3 / K,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": arith,
+            "dtype": w.arith,
             "data": "synthetic",
-            "config": {"workload": wl, "samples_per_gpu": n, "total_samples": n * world, "clock_settle_s": args.settle_seconds,
+            "config": {"workload": w.wl, "samples_per_gpu": n, "total_samples": n * world,
+                       "clock_settle_s": args.settle_seconds,
                        "sharding": "single GPU" if world == 1 else
                                    ("contiguous sample blocks, RCCL state hand-off (2 x sections doubles per hop)"
                                     if args.workload == "iir8" else
-                                    "contiguous sample blocks, %d-sample RCCL halo" % (len(b) - 1)
+                                    "contiguous sample blocks, %d-sample RCCL halo beside the interior tiles" % (len(w.taps) - 1)
                                     if args.workload == "fir1024" else "independent replicas"),
+                       "n_ranks_rccl": n_comm,
                        "device": info["name"], "compute_units": info["compute_units"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kern,
-                         "kernel_ms": t_kernel * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
-            "cpu_baseline": cpu,
+            "roofline": roofline_of(w, ev_ms, K, log2n),
         }
-        if compute is not None:
-            # these two workloads are bound by vector arithmetic, not by HBM: useful
-            # flops of the reference formulation against the vector peak (the IIR scan executes 2.2x them)
-            tf = compute[2] / t_kernel / 1e12
-            out["compute"] = {"unit": "TFLOP/s", "what": compute[0], "useful_flop_per_step": compute[2], "achieved": tf,
-                              "peak": compute[1], "frac": tf / compute[1]}
+        c = compute_of(w, ev_ms, K)
+        if c is not None:
+            out["compute"] = c
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if check is not None:
             out["parity_spot_check_max_err"] = check
-        print(json.dumps(out))
+
+    # ------------------------------------------- CPU baselines (rank 0 of a 1-GPU run only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_port(args, w)
+        out["cpu_baseline_scipy"] = cpu_baseline_scipy(args, w)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    # ------------------------------------------- the other BASELINE.json configs, same process
+    if world == 1 and args.workload == "fir1024" and not args.no_other_configs and args.scaling == "weak":
+        free_workload(w)
+        others = {}
+        for name in ("updn43", "iir8", "fir127"):
+            try:
+                o = make_workload(name, 1 << 26, 0, 1, tr, _ffi, sharding)
+                Ko = args.other_steps
+                el, ev, _ = timed_steps(o, Ko, max(10, Ko // 5), 0.1, tr, _ffi)
+                r = roofline_of(o, ev, Ko, 26)
+                others[name] = {"workload": o.wl, "value": float(o.units) * Ko / el / 1e6, "unit": "MSamples/s (input)",
+                                "steps": Ko, "ms": el * 1e3 / Ko, "kernel_ms": r["kernel_ms"], "achieved_GBps": r["achieved"],
+                                "frac": r["frac"], "traffic": r["traffic"],
+                                "algorithmic_bytes_per_launch": o.alg_bytes}
+                c = compute_of(o, ev, Ko)
+                if c is not None:
+                    others[name]["compute"] = c
+                free_workload(o)
+            except Exception as e:  # a broken side config must not take the headline line with it
+                others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["other_configs"] = others
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     tr.close()
 
 
-def measured_traffic(args):
+def measured_traffic(workload, log2n):
     """HBM bytes per step from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE,
     WRITE_SIZE; separate --pmc runs, read side doubled per the gfx950 correction of
     MI355X_MICROARCH.md; tools/collect_profiles.sh + tools/reduce_pmc.py).  PMC counters cannot be
     read inside an un-profiled run, so this is the committed measurement of the same workload at
-    the same size, or null when none applies."""
-    if args.log2n != 26:
+    the same size (the newest profiles/rNN that has one), or null when none applies."""
+    if log2n != 26:
         return None
     prof = os.path.join(ROOT, "profiles")
     best = None
     for d in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
-        f = os.path.join(prof, d, "pmc_%s.json" % args.workload)
+        f = os.path.join(prof, d, "pmc_%s.json" % workload)
         if os.path.exists(f):
             best = f
     if best is None:
@@ -244,45 +379,74 @@ def measured_traffic(args):
         return None
 
 
-def cpu_baseline(args, b, xd):
-    """The oracle (C port of the reference's arithmetic: float64 accumulation of a
-    complex64/float32 input, i.e. what scipy.signal.lfilter/sosfilt do for the reference)
-    timed on this box's host cores on a bounded sample of the same workload."""
+def _sized_sample(run, first, n_max, seconds):
+    """Time run(m) on m = first samples, then once more on the m that should take `seconds`."""
+    t0 = time.perf_counter()
+    run(first)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    m = int(min(n_max, max(first, first * seconds / dt)))
+    t0 = time.perf_counter()
+    run(m)
+    return m, time.perf_counter() - t0
+
+
+def cpu_baseline_port(args, w):
+    """The oracle (C port of the reference's arithmetic: float64 accumulation of a complex64 / float32 input,
+    i.e. what scipy.signal.lfilter / sosfilt do for the reference) timed on this box's host cores on a bounded
+    sample of the same workload."""
     from oracle import oracle as orc
     cores_avail = os.cpu_count()
-    if args.workload == "iir8":
-        sos = elliptic_bpf_sos()
-        m = 1 << 22
-        x = xd.to_host(0, m)
-        t0 = time.perf_counter(); orc.sos_filter_f32in_timed(sos, x[:1 << 18]); dt = time.perf_counter() - t0
-        m = int(min(1 << 26, max(1 << 18, (1 << 18) * args.cpu_seconds / max(dt, 1e-6))))
-        m = min(m, xd.n)
-        x = xd.to_host(0, m)
-        best = min(_timed(lambda: orc.sos_filter_f32in_timed(sos, x)) for _ in range(2))
-        return {"value": m / best / 1e6, "unit": "MSamples/s", "cores": 1, "kind": "port",
-                "sample": "first %d of the 2^%d float32 samples, sequential DF2T in float64 (sosfilt restated in C)" % (m, args.log2n),
-                "cores_available": cores_avail}
-    if args.workload == "updn43":
-        m = 1 << 16
-        x = xd.to_host(0, m)
-        best = min(_timed(lambda: orc.downsample(orc.fir_up(b, x, 4), 3)) for _ in range(2))
-        return {"value": m / best / 1e6, "unit": "MSamples/s", "cores": 1, "kind": "port",
-                "sample": "first %d input samples through upsample -> 512-tap FIR at the 4x rate -> downsample" % m,
-                "cores_available": cores_avail}
-    x = xd.to_host(0, 1 << 16)
-    t0 = time.perf_counter(); orc.fir_filter_f32in_timed(b, x); dt = time.perf_counter() - t0
-    m = int(min(xd.n, max(1 << 16, (1 << 16) * args.cpu_seconds / max(dt, 1e-6))))
-    x = xd.to_host(0, m)
-    best = min(_timed(lambda: orc.fir_filter_f32in_timed(b, x)) for _ in range(2))
-    return {"value": m / best / 1e6, "unit": "MSamples/s", "cores": 1, "kind": "port",
-            "sample": "first %d of the 2^%d samples, direct-form float64 accumulation (lfilter FIR branch restated in C, 1 thread like the reference)" % (m, args.log2n),
-            "cores_available": cores_avail}
+    if w.name == "iir8":
+        x = w.xd.to_host(0, min(w.n, 1 << 26))
+        m, dt = _sized_sample(lambda k: orc.sos_filter_f32in_timed(w.sos, x[:k]), 1 << 18, x.size, args.cpu_seconds)
+        what = "sequential DF2T in float64 (sosfilt restated in C)"
+    elif w.name == "updn43":
+        x = w.xd.to_host(0, 1 << 20)
+        m, dt = _sized_sample(lambda k: orc.downsample(orc.fir_up(w.taps, x[:k], 4), 3), 1 << 14, x.size, args.cpu_seconds)
+        what = "upsample -> 512-tap FIR at the 4x rate -> downsample (the reference's three passes, restated in C)"
+    else:
+        x = w.xd.to_host(0, min(w.n, 1 << 26))
+        m, dt = _sized_sample(lambda k: orc.fir_filter_f32in_timed(w.taps, x[:k]), 1 << 16, x.size, args.cpu_seconds)
+        what = "direct-form float64 accumulation (lfilter FIR branch restated in C, 1 thread like the reference)"
+    return {"value": m / dt / 1e6, "unit": "MSamples/s", "cores": 1, "kind": "port",
+            "sample": "first %d samples of the workload: %s" % (m, what), "cores_available": cores_avail}
 
 
-def _timed(fn):
-    t0 = time.perf_counter()
-    fn()
-    return time.perf_counter() - t0
+def cpu_baseline_scipy(args, w):
+    """The reference's own CPU path: literally the scipy.signal / NumPy calls of multirate_helper.py:104-127,
+    169-192 and sigsys.py:3050-3053, 3078-3083, on a bounded sample, on this box's host cores."""
+    try:
+        from scipy import signal
+    except Exception as e:
+        return {"value": None, "kind": "scipy", "skipped": "scipy not importable on this box: %s" % e}
+    if w.name == "iir8":
+        x = w.xd.to_host(0, min(w.n, 1 << 24))
+        run = lambda k: signal.sosfilt(w.sos, x[:k])                                              # noqa: E731
+        first, what = 1 << 16, "scipy.signal.sosfilt(sos, x) (multirate_helper.py:173)"
+    elif w.name == "updn43":
+        x = w.xd.to_host(0, 1 << 18)
+
+        def run(k):
+            xs = x[:k]
+            up = np.hstack((xs.reshape(k, 1), np.zeros((k, 3)))).flatten()                        # sigsys.py:3050-3053
+            y = signal.lfilter(w.taps, [1], 4 * up)                                               # multirate_helper.py:116-117
+            return y[0::3]                                                                        # sigsys.py:3078-3083
+        first, what = 1 << 12, "upsample (hstack/flatten) -> scipy.signal.lfilter(b,[1],4*x_up) -> strided view"
+    else:
+        x = w.xd.to_host(0, min(w.n, 1 << 24))
+        run = lambda k: signal.lfilter(w.taps, [1], x[:k])                                        # noqa: E731
+        first, what = 1 << 14, "scipy.signal.lfilter(b, [1], x) (multirate_helper.py:108)"
+    m, dt = _sized_sample(run, first, x.size, args.cpu_seconds)
+    threads = None
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        pass
+    return {"value": m / dt / 1e6, "unit": "MSamples/s", "cores": 1, "kind": "scipy",
+            "sample": "first %d samples of the workload through %s; the call is effectively single-threaded "
+                      "(per-output dot / serial recursion)" % (m, what),
+            "blas_threads_configured": threads, "cores_available": os.cpu_count()}
 
 
 if __name__ == "__main__":

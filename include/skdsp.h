@@ -148,6 +148,7 @@ int skdsp_destroy(skdsp_handle h);
 int skdsp_dist_unique_id(void *id128);
 int skdsp_dist_init(int rank, int world, const void *id128);
 int skdsp_dist_shutdown(void);
+int skdsp_dist_comm_count(int *nranks);           /* ncclCommCount of the live communicator; 0 = none (1-rank job) */
 int skdsp_dist_barrier(void);                     /* 1-element RCCL all-reduce + stream sync */
 int skdsp_dist_allreduce_max(double *value);      /* in-place max over ranks */
 int skdsp_dist_allreduce_sum(double *value);

@@ -26,6 +26,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -56,6 +57,7 @@ static int rccl_load()
     SK_SYM(GetUniqueId, "ncclGetUniqueId");
     SK_SYM(CommInitRank, "ncclCommInitRank");
     SK_SYM(CommDestroy, "ncclCommDestroy");
+    SK_SYM(CommCount, "ncclCommCount");
     SK_SYM(Send, "ncclSend");
     SK_SYM(Recv, "ncclRecv");
     SK_SYM(GroupStart, "ncclGroupStart");
@@ -187,6 +189,16 @@ int skdsp_dist_shutdown(void)
     }
     r.rank = 0;
     r.world = 1;
+    return SKDSP_OK;
+}
+
+int skdsp_dist_comm_count(int *nranks)
+{
+    API_BEGIN;
+    SK_CHECK(nranks, SKDSP_ERR_BADARG, "dist_comm_count: null argument");
+    Rccl &r = rc();
+    *nranks = 0;  // no communicator: a 1-rank job (or dist_init not called)
+    if (r.comm) SK_NCCL(r.CommCount(r.comm, nranks));
     return SKDSP_OK;
 }
 

@@ -31,7 +31,7 @@ SYMBOLS = [
     "skdsp_sos_create", "skdsp_tf_create", "skdsp_tf2sos", "skdsp_iir_filter", "skdsp_iir_filter_dev", "skdsp_iir_up",
     "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev", "skdsp_iir_state_len", "skdsp_iir_filter_state_dev",
     "skdsp_upsample", "skdsp_upsample_dev", "skdsp_downsample", "skdsp_downsample_dev", "skdsp_set_wide_output", "skdsp_destroy",
-    "skdsp_dist_unique_id", "skdsp_dist_init", "skdsp_dist_shutdown", "skdsp_dist_barrier",
+    "skdsp_dist_unique_id", "skdsp_dist_init", "skdsp_dist_shutdown", "skdsp_dist_comm_count", "skdsp_dist_barrier",
     "skdsp_dist_allreduce_max", "skdsp_dist_allreduce_sum", "skdsp_dist_sendrecv", "skdsp_dist_allgather", "skdsp_dist_halo_exchange", "skdsp_fir_filter_shard_dev",
 ]
 
@@ -104,6 +104,7 @@ def load():
         L.skdsp_destroy.argtypes = [vp]
         L.skdsp_dist_unique_id.argtypes = [vp]
         L.skdsp_dist_init.argtypes = [ci, ci, vp]
+        L.skdsp_dist_comm_count.argtypes = [ctypes.POINTER(ci)]
         L.skdsp_dist_allreduce_max.argtypes = [ctypes.POINTER(ctypes.c_double)]
         L.skdsp_dist_allreduce_sum.argtypes = [ctypes.POINTER(ctypes.c_double)]
         L.skdsp_set_wide_output.argtypes = [vp, ci]

@@ -142,6 +142,13 @@ class RcclTransport:
             _ffi.check(L.skdsp_dist_init(0, 1, None))
             self._rdzv = None
 
+    def comm_count(self):
+        """Ranks in the live RCCL communicator (ncclCommCount); 0 when a 1-rank job built none."""
+        import ctypes
+        k = ctypes.c_int(0)
+        _ffi.check(_ffi.load().skdsp_dist_comm_count(ctypes.byref(k)))
+        return k.value
+
     def barrier(self):
         _ffi.check(_ffi.load().skdsp_dist_barrier())
 

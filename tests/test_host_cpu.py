@@ -237,3 +237,53 @@ def test_coefficient_headers_byte_exact_and_round_trip(tmp_path):
             assert open(fn).read() == c["text"], c["name"]
             back = c2h.read_sos_header(fn)
             assert back.shape == sos.shape and np.allclose(back, sos / sos[:, 3:4], rtol=1e-6, atol=1e-12)
+
+
+# ----------------------------------------------------------------- round-2 additions
+def test_kernel_cache_follows_reassigned_coefficients():
+    """The reference reads obj.b / obj.sos on every call: reassigning them must rebuild the device handles
+    (multirate_helper._KernelCache keys on a fingerprint of the coefficient arrays)."""
+    from sk_dsp_comm_amd import multirate_helper as mrh
+    made = []
+    holder = {"b": np.arange(4.0)}
+    cache = mrh._KernelCache(lambda code: made.append((code, holder["b"].copy())) or len(made), lambda: (holder["b"],))
+    k1 = cache.get(np.float32)
+    assert cache.get(np.float32) == k1 and len(made) == 1
+    assert cache.get(np.complex64) != k1 and len(made) == 2
+    holder["b"] = np.arange(4.0) + 1j            # real -> complex taps of the same length
+    k3 = cache.get(np.float32)
+    assert k3 != k1 and len(made) == 3 and np.iscomplexobj(made[-1][1])
+    holder["b"][0] = 5.0                         # in-place edit is seen too
+    assert cache.get(np.float32) != k3 and len(made) == 4
+    f = mrh.multirate_FIR(np.ones(3))
+    assert f._bc is False
+    f.b = np.ones(3) * 1j
+    assert f._bc is True
+
+
+def test_options_table_without_gpu():
+    """skdsp_set_option / skdsp_get_option work without a device; unknown names are BADARG -> ValueError."""
+    from sk_dsp_comm_amd import _ffi
+    assert _ffi.get_option("ols_reserve") == 8
+    with _ffi.option("iir_planar", 1):
+        assert _ffi.get_option("iir_planar") == 1
+    assert _ffi.get_option("iir_planar") == 0
+    with pytest.raises(ValueError):
+        _ffi.set_option("no_such_switch", 1)
+
+
+def test_bench_self_launch_reaches_the_device_layer():
+    """`python bench.py --gpus 2` with no launcher must spawn its own ranks and fail (here: no GPU) inside the
+    library's device binding, not in the launcher; the non-zero exit code of a rank is the exit code."""
+    import subprocess
+    import sys
+    from sk_dsp_comm_amd import _ffi
+    if _ffi.load().skdsp_device_count() > 0:
+        pytest.skip("a GPU is present: the launcher path is covered by the gpu tests")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = out.stdout.decode()
+    assert out.returncode != 0
+    assert "no HIP device available" in text and "must be launched" not in text, text[-2000:]
