@@ -173,7 +173,7 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
             w.step = lambda: iir.filter_local_dev(w.xd, w.yd, n)
         w.alg_bytes = 8.0 * n
         w.compute = ("FP64 vector (v_fma_f64)", 78.6, 72.0 * n)   # 9 flop per biquad per sample
-        w.kern = "iir_scan kernels"
+        w.kern = "iir_fused_kernel (single-pass scan)"
         w.wl = "multirate_IIR.filter: 8-biquad elliptic bandpass, float32, %s samples, exact affine scan" % lg
         w.metric = "float32 MSamples/s (8-biquad SOS IIR, %s samples)" % lg
     else:

@@ -1,0 +1,395 @@
+// iir_fused.hip -- single-pass exact IIR scan for gfx950 (MI355X): one launch, the signal is read once and written once.
+// Serves scipy.signal.sosfilt(sos, x) (multirate_helper.py:173) / lfilter(b, a, x) (:74, :81) for real signals and
+// decaying cascades of up to 8 biquads; everything else takes the K1 / carries / K3 path of iir_scan.hip.
+#include "iir_common.hpp"
+
+#ifndef SK_FUSED_DIAG
+#define SK_FUSED_DIAG 0  // developer builds: 1 no recurrence, 2 no scan / correction, 4 no MFMAs, 8 no look-back poll (wrong results)
+#endif
+
+namespace skdsp {
+
+// ------------------------------------------------------------------ single-pass scan
+// One launch, x read once, y written once (decaying cascades of <= 8 biquads, real signals).
+//
+// A workgroup owns one SEGMENT of 256 chunks x T samples (T = 128 float32 / 64 float64 samples: 32768 / 16384 samples)
+// and keeps every sample of it ON CHIP between the two sweeps an exact scan needs -- each thread holds its own chunk in
+// registers (128 VGPRs):
+//   A  the segment streams in through a [256 rows x 32 samples] LDS image (full-line 16-byte loads, next piece in
+//      flight); every thread copies its row into registers, and the same image feeds the FP64 matrix pipe with the B
+//      operands of  V = G x  (the from-rest end state of each chunk, as in iir_k1r_kernel; G from LDS)
+//   S  from-rest Hillis-Steele scan of the 256 chunk states -> p_j; p_255 is the segment's end state from rest
+//   L  decoupled look-back: the segment publishes p_255 as 8-byte {half, epoch} granules (relaxed agent-scope atomics:
+//      the data is its own flag, no fence) and reads its predecessor's.  For a filter whose transition over one
+//      segment is below 1e-30 (the applicability test) the predecessor's from-rest end state IS the exact state c at
+//      the start of this segment, so no workgroup ever waits for a chain.  Segments are handed out by a ticket
+//      counter, so a predecessor is always a workgroup that already runs; the poll is bounded and reports through
+//      a.err instead of hanging.
+//   C  exact initial state of chunk j:  z_j = p_(j-1) + M^j c, M^j c by binary powers (only chunks below 2^n_lv)
+//   B  the recurrence over the 128 register-resident samples, outputs written back through the LDS image as full lines
+// Per sample: 8 B of HBM traffic (the algorithmic bytes), ~40 FP64 VALU instructions of recurrence + ~12 of scan.
+struct FusedArgs {
+    const void *x;
+    void *y;
+    int64_t n;
+    int64_t batch_stride;
+    const double *pw;            // M^(2^l), M = A^T, row-major D x D each
+    const double *gt;            // G in MFMA A-operand order [T/4][64]
+    unsigned long long *lb;      // [batch][nseg][32] look-back granules
+    unsigned long long *ticket;  // [batch] segment dispenser (monotonic; ticket_base = its value before this launch)
+    unsigned long long ticket_base;
+    unsigned epoch;
+    int nseg;
+    int n_lv;
+    const double *zi;            // [batch][D] or null
+    double *zf;                  // [batch][D] or null
+    unsigned *err;               // set to 1 if a look-back poll gave up
+    int dec;                     // > 1: only y[k * dec] is stored (at y[k]), k < n_keep / dec  (.dn: no full-rate result in HBM)
+    int dec_dq, dec_dr;          // (rows between a thread's staged segments x T) div / mod dec
+    int64_t n_keep;              // (n / dec) * dec
+};
+
+template <int NSEC, typename IO, bool UNIT>
+__global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, Coef<NSEC, 2> cf, const double *__restrict__ pw,
+                                                                   const double *__restrict__ gtab)
+{
+    // (pw / gtab are separate __restrict__ parameters: the ticket atomic and the look-back stores precede the scan, and
+    // only loads through a noalias pointer stay scalar loads behind them -- as plain members of `a` every matrix
+    // entry of every scan level became a per-lane global load: 6.3 M vector loads per launch instead of 0.33 M)
+    constexpr int ORD = 2, D = NSEC * ORD;
+    constexpr int T = 512 / (int)sizeof(IO);
+    constexpr int NP = T / kPiece;
+    using St = Stage<IO>;
+    constexpr int kStageBytes = kIirThreads * St::pitch * (int)sizeof(IO);
+    constexpr int kScanBytes = kIirThreads * D * 8;
+    constexpr int kLdsBytes = kStageBytes > kScanBytes ? kStageBytes : kScanBytes;
+    __shared__ __attribute__((aligned(16))) char lds_raw[kLdsBytes];
+    __shared__ double gl[(T / 4) * 64];
+    __shared__ unsigned cw[32];
+    __shared__ int seg_sh;
+    IO *stage = reinterpret_cast<IO *>(lds_raw);
+    double *sc = reinterpret_cast<double *>(lds_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bat = blockIdx.y;
+    if (tid == 0) seg_sh = (int)(atomicAdd(a.ticket + bat, 1ull) - a.ticket_base);
+    for (int i = tid; i < (T / 4) * 64; i += kIirThreads) gl[i] = gtab[i];
+    __syncthreads();
+    const int seg = seg_sh;
+#ifdef SK_FUSED_STAGGER
+    // the two workgroups of a CU start together and would walk their phases in lock step (memory | matrix | LDS | VALU);
+    // delaying every second one of the first round by about half a segment's duration lets one's memory phases run
+    // under the other's arithmetic for the rest of the launch (workgroups b and b + 256 share a CU: 8 XCDs x 32 CUs)
+    if (seg < 2 * 256 && ((seg >> SK_FUSED_STAGGER_BIT) & 1))
+        for (int i = 0; i < SK_FUSED_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+    const IO *x = reinterpret_cast<const IO *>(a.x) + (size_t)bat * a.batch_stride;
+    IO *y = reinterpret_cast<IO *>(a.y) + (size_t)bat * a.batch_stride;
+    const int64_t row0 = (int64_t)seg * kIirThreads;   // first chunk of the segment
+    const bool interior = (row0 + kIirThreads) * T <= a.n;
+
+    typedef float pre_t __attribute__((ext_vector_type(4)));
+    pre_t pre[St::per_thread];
+    auto load_piece = [&](int p) {  // interior segments only
+#pragma unroll
+        for (int i = 0; i < St::per_thread; ++i) {
+            const int idx = i * kIirThreads + tid;
+            const int row = idx / St::segs, sg = idx % St::segs;
+            const int64_t g = (row0 + row) * T + (int64_t)p * kPiece + (int64_t)sg * St::elems;
+            pre[i] = __builtin_nontemporal_load(reinterpret_cast<const pre_t *>(x + g));
+        }
+    };
+    auto stage_slow = [&](int p) {  // zero beyond the signal
+#pragma unroll 1
+        for (int i = 0; i < St::per_thread; ++i) {
+            const int idx = i * kIirThreads + tid;
+            const int row = idx / St::segs, sg = idx % St::segs;
+            const int64_t g = (row0 + row) * T + (int64_t)p * kPiece + (int64_t)sg * St::elems;
+            IO *dst = stage + row * St::pitch + sg * St::elems;
+#pragma unroll
+            for (int e = 0; e < St::elems; ++e) dst[e] = (g + e < a.n) ? x[g + e] : IO(0);
+        }
+    };
+
+    // ---- A: stream the segment in; chunk rows to registers; V = G x on the matrix pipe --------------------------
+    IO xr[T];
+    v4d_t acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = v4d_t{0.0, 0.0, 0.0, 0.0};
+    const int c = lane & 15, j = lane >> 4;
+    IO *myrow = stage + tid * St::pitch;
+    if (interior) load_piece(0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < St::per_thread; ++i) {
+                const int idx = i * kIirThreads + tid;
+                const int row = idx / St::segs, sg = idx % St::segs;
+                *reinterpret_cast<pre_t *>(stage + row * St::pitch + sg * St::elems) = pre[i];
+            }
+        } else {
+            stage_slow(p);
+        }
+        __syncthreads();
+        if (interior && p + 1 < NP) load_piece(p + 1);  // in flight during the MFMAs
+#pragma unroll
+        for (int sgi = 0; sgi < St::segs; ++sgi) {
+            const float4 raw = *reinterpret_cast<const float4 *>(myrow + sgi * St::elems);
+            const IO *e4 = reinterpret_cast<const IO *>(&raw);
+#pragma unroll
+            for (int e = 0; e < St::elems; ++e) xr[p * kPiece + sgi * St::elems + e] = e4[e];
+        }
+        const IO *xs = stage + (wave * 64 + c) * St::pitch + j;
+#pragma unroll
+        for (int s = 0; s < kPiece / 4; ++s) {
+            const double ga = gl[(p * (kPiece / 4) + s) * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (!(SK_FUSED_DIAG & 4)) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, (double)xs[g * 16 * St::pitch + 4 * s], acc[g], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // chunk end states from the accumulator layout (col = lane & 15, row = (lane >> 4) + 4 reg) to one thread per chunk
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = j + 4 * r;
+            if (d < D) sc[d * kIirThreads + wave * 64 + g * 16 + c] = acc[g][r];
+        }
+    __syncthreads();
+    double v[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) v[d] = sc[d * kIirThreads + tid];
+    __syncthreads();
+
+    // ---- S: from-rest inclusive scan of the 256 chunk maps ---------------------------------------------------------
+    if (SK_FUSED_DIAG & 2) a.n_lv = 0;
+#pragma unroll 1
+    for (int l = 0; l < a.n_lv; ++l) {
+        const int s = 1 << l;
+#pragma unroll
+        for (int d = 0; d < D; ++d) sc[d * kIirThreads + tid] = v[d];
+        __syncthreads();
+        if (tid >= s) {
+            double left[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) left[d] = sc[d * kIirThreads + tid - s];
+            matvec_acc<D, ORD>(pw + (size_t)l * D * D, left, v);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) sc[d * kIirThreads + tid] = v[d];
+    __syncthreads();
+    double z[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) z[d] = tid ? sc[d * kIirThreads + tid - 1] : 0.0;
+
+    // ---- L: publish the segment's end state from rest, fetch the predecessor's ------------------------------------
+    if (tid < 2 * D) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(sc[(tid >> 1) * kIirThreads + kIirThreads - 1]);
+        const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+        unsigned long long *slot = a.lb + ((size_t)bat * a.nseg + seg) * 32 + tid;
+        __hip_atomic_store(slot, ((unsigned long long)a.epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned got = 0;
+        if (seg > 0 && !(SK_FUSED_DIAG & 8)) {
+            const unsigned long long *src = a.lb + ((size_t)bat * a.nseg + seg - 1) * 32 + tid;
+            unsigned long long g = 0;
+            int spins = 0;
+            for (;;) {
+                g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(g >> 32) == a.epoch) break;
+                if (++spins > (1 << 22)) {  // ~ seconds: never in a healthy run; fail loudly instead of hanging the GPU
+                    *a.err = 1u;
+                    g = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            got = (unsigned)g;
+        } else if (a.zi) {
+            const unsigned long long zb = (unsigned long long)__double_as_longlong(a.zi[(size_t)bat * D + (tid >> 1)]);
+            got = (tid & 1) ? (unsigned)(zb >> 32) : (unsigned)zb;
+        }
+        cw[tid] = got;
+    }
+    __syncthreads();
+
+    // ---- C: z_j = p_(j-1) + M^j c ------------------------------------------------------------------------------------
+    if ((wave << 6) < (1 << a.n_lv)) {  // (M^j c is below 1e-30 of c for j >= 2^n_lv)
+        double u[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) u[d] = __longlong_as_double((long long)(((unsigned long long)cw[2 * d + 1] << 32) | cw[2 * d]));
+#pragma unroll 1
+        for (int l = 0; l < a.n_lv; ++l) {
+            if ((tid >> l) & 1) {
+                double t2[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) t2[d] = 0.0;
+                matvec_acc<D, ORD>(pw + (size_t)l * D * D, u, t2);
+#pragma unroll
+                for (int d = 0; d < D; ++d) u[d] = t2[d];
+            }
+        }
+        if (tid < (1 << a.n_lv)) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) z[d] += u[d];
+        }
+    }
+
+    // ---- B: the recurrence over the register-resident chunk; outputs leave through the LDS image --------------------
+    const int64_t cj = row0 + tid;
+    const bool zf_owner = a.zf != nullptr && cj == (a.n - 1) / T;
+    const int zf_off = (int)((a.n - 1) % T);
+    // ONE copy of the 32-sample body (8 biquads: ~1300 FP64 instructions, 10 KiB of code; four copies would not stay in
+    // the instruction cache the two CUs share): the piece at hand always sits in xr[0 .. 31], the rest moves down behind it
+#pragma unroll 1
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int k = 0; k < kPiece; ++k) {
+            const double yv = (SK_FUSED_DIAG & 1) ? (double)xr[k] + z[0] : cascade_step<NSEC, ORD, UNIT>(cf, z, (double)xr[k]);
+            xr[k] = (IO)yv;
+            if (zf_owner && zf_off == p * kPiece + k) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) a.zf[(size_t)bat * D + d] = z[d];
+            }
+        }
+        __syncthreads();  // the image is free (phase A / the previous piece's stores have read it)
+#pragma unroll
+        for (int sgi = 0; sgi < St::segs; ++sgi) {
+            float4 raw;
+            IO *e4 = reinterpret_cast<IO *>(&raw);
+#pragma unroll
+            for (int e = 0; e < St::elems; ++e) e4[e] = xr[sgi * St::elems + e];
+            *reinterpret_cast<float4 *>(myrow + sgi * St::elems) = raw;
+        }
+#pragma unroll
+        for (int k = 0; k + kPiece < T; ++k) xr[k] = xr[k + kPiece];
+        __syncthreads();
+        int64_t dq_run = 0;
+        int dr_run = 0;
+#pragma unroll
+        for (int i = 0; i < St::per_thread; ++i) {
+            const int idx = i * kIirThreads + tid;
+            const int row = idx / St::segs, sg = idx % St::segs;
+            const int64_t g = (row0 + row) * T + (int64_t)p * kPiece + (int64_t)sg * St::elems;
+            const pre_t val = *reinterpret_cast<const pre_t *>(stage + row * St::pitch + sg * St::elems);
+            if (a.dec > 1) {
+                // decimating store (as in iir_chunk_kernel): segment i of this thread starts a fixed number of samples
+                // after segment i - 1, so its (quotient, remainder) by dec follow from the first by adding (dec_dq, dec_dr)
+                if (i == 0) {
+                    dq_run = g / a.dec;
+                    dr_run = (int)(g - dq_run * a.dec);
+                }
+                const IO *tmp = reinterpret_cast<const IO *>(&val);
+                if (a.dec >= St::elems) {  // at most one kept sample per 16-byte segment
+                    const int e0 = dr_run == 0 ? 0 : a.dec - dr_run;
+                    if (e0 < St::elems && g + e0 < a.n_keep) {
+                        IO pick = tmp[0];
+#pragma unroll
+                        for (int e = 1; e < St::elems; ++e) pick = (e0 == e) ? tmp[e] : pick;
+                        y[dq_run + (dr_run != 0)] = pick;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < St::elems; ++e) {
+                        const int t = dr_run + e;  // < dec + elems
+                        const int m = (t >= a.dec) + (t >= 2 * a.dec) + (t >= 3 * a.dec) + (t >= 4 * a.dec);
+                        if (t == m * a.dec && g + e < a.n_keep) y[dq_run + m] = tmp[e];
+                    }
+                }
+                dq_run += a.dec_dq;
+                dr_run += a.dec_dr;
+                if (dr_run >= a.dec) { dr_run -= a.dec; ++dq_run; }
+            } else if (interior) {
+                __builtin_nontemporal_store(val, reinterpret_cast<pre_t *>(y + g));
+            } else if (g < a.n) {
+                const IO *tmp = reinterpret_cast<const IO *>(&val);
+#pragma unroll
+                for (int e = 0; e < St::elems; ++e)
+                    if (g + e < a.n) y[g + e] = tmp[e];
+            }
+        }
+    }
+}
+
+// single-pass scan: one workgroup per segment of 256 chunks, segments handed out by ticket
+template <typename IO>
+static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, const double *zi_dev,
+                        double *zf_dev, hipStream_t s, int dec)
+{
+    IirPlan *p = h->plan;
+    constexpr int T = 512 / (int)sizeof(IO);
+    const int64_t S = (int64_t)kIirThreads * T;
+    const int64_t nseg = (n + S - 1) / S;
+    SK_CHECK(nseg < (1 << 30), SKDSP_ERR_BADARG, "iir: too many segments");
+    if (!p->ticket_dev) {
+        SK_HIP(hipMalloc((void **)&p->ticket_dev, 16));
+        SK_HIP(hipMemsetAsync(p->ticket_dev, 0, 16, s));
+        SK_HIP(hipHostMalloc((void **)&p->err_host, sizeof(unsigned), hipHostMallocMapped));
+        *p->err_host = 0;
+        p->ticket_count = 0;
+    }
+    SK_CHECK(*p->err_host == 0, SKDSP_ERR_HIP, "iir: a look-back poll of an earlier single-pass launch timed out (results of that call are invalid)");
+    const size_t need = (size_t)nbatch * nseg * 32 * 8;
+    if (need > p->lbg_cap) {
+        if (p->lbg_dev) {
+            SK_HIP(hipStreamSynchronize(s));
+            SK_HIP(hipFree(p->lbg_dev));
+        }
+        p->lbg_dev = nullptr; p->lbg_cap = 0;
+        SK_HIP(hipMalloc((void **)&p->lbg_dev, need));
+        SK_HIP(hipMemsetAsync(p->lbg_dev, 0, need, s));  // epoch 0 is never used as a tag
+        p->lbg_cap = need;
+    }
+    FusedArgs a;
+    a.x = x; a.y = y; a.n = n; a.batch_stride = batch_stride;
+    a.pw = p->pw_dev; a.gt = p->gt_dev;
+    a.lb = p->lbg_dev; a.ticket = p->ticket_dev; a.ticket_base = p->ticket_count;
+    a.epoch = ++p->epoch;
+    if (a.epoch == 0) a.epoch = ++p->epoch;
+    a.nseg = (int)nseg; a.n_lv = p->n_lv < 8 ? p->n_lv : 8;
+    a.zi = zi_dev; a.zf = zf_dev;
+    a.dec = dec > 1 ? dec : 1;
+    a.n_keep = (n / a.dec) * a.dec;
+    {
+        const int64_t step = (int64_t)(kIirThreads / Stage<IO>::segs) * T;  // samples between a thread's staged segments
+        a.dec_dq = (int)(step / a.dec);
+        a.dec_dr = (int)(step % a.dec);
+    }
+    unsigned *err_dev = nullptr;
+    SK_HIP(hipHostGetDevicePointer((void **)&err_dev, p->err_host, 0));
+    a.err = err_dev;
+    p->ticket_count += (unsigned long long)nseg;
+    const dim3 grid((unsigned)nseg, (unsigned)nbatch);
+#define SK_FUSED(N)                                                                                                  \
+    case N: {                                                                                                        \
+        Coef<N, 2> cf;                                                                                               \
+        std::memcpy(cf.c, h->coef.data(), sizeof(cf.c));                                                             \
+        if (N >= 2 && h->unit_tail) hipLaunchKernelGGL((iir_fused_kernel<N, IO, (N >= 2)>), grid, dim3(kIirThreads), 0, s, a, cf, a.pw, a.gt); \
+        else hipLaunchKernelGGL((iir_fused_kernel<N, IO, false>), grid, dim3(kIirThreads), 0, s, a, cf, a.pw, a.gt);  \
+        break;                                                                                                       \
+    }
+    switch (h->nsec) {
+#ifndef SK_FUSED_ONLY8  // (developer builds instantiate the 8-biquad kernels only)
+        SK_FUSED(1) SK_FUSED(2) SK_FUSED(3) SK_FUSED(4) SK_FUSED(5) SK_FUSED(6) SK_FUSED(7)
+#endif
+        SK_FUSED(8)
+        default: SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "iir: single-pass scan takes 1..8 biquads");
+    }
+#undef SK_FUSED
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+int iir_fused_launch(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, const double *zi_dev,
+                     double *zf_dev, hipStream_t s, int dec)
+{
+    return dtype_double(h->dtype) ? launch_fused<double>(h, x, n, nbatch, batch_stride, y, zi_dev, zf_dev, s, dec)
+                                  : launch_fused<float>(h, x, n, nbatch, batch_stride, y, zi_dev, zf_dev, s, dec);
+}
+
+}  // namespace skdsp

@@ -34,96 +34,9 @@
 // prefetches the next piece into registers while it computes the current one.
 // FP64 VALU is the busy unit (40 dependent-ish v_fma_f64 per sample for 8 biquads);
 // algorithmic bytes = 8 B per f32 sample (4 in + 4 out).
-#include "skdsp_internal.hpp"
-#include <type_traits>
-#include <cmath>
-#include <cstring>
+#include "iir_common.hpp"
 
 namespace skdsp {
-
-constexpr int kIirThreads = 256;
-constexpr int kPiece = 32;          // samples per thread per staged piece
-constexpr int kMaxPairs = 12288;    // K2 capacity: workgroups x state dimension (one 96 KiB LDS image)
-constexpr int kMaxW = 512;          // workgroups (of 256 chunks) per vector (1024 measured slower: more scan, same occupancy)
-constexpr int kPowers = 19;         // M^(2^l), l = 0..18
-
-struct IirPlan {
-    int nsec, order, D;
-    // per call geometry is recomputed; matrix powers are cached per chunk length T
-    int64_t cached_T = -1;
-    double *pw_dev = nullptr;    // kPowers matrices M^(2^l), each D x D row-major
-    double *lb_dev = nullptr;    // look-back matrices (M^256)^k, k = 1..7
-    double *lbk_dev = nullptr;   // chunk look-back powers M^k, k = 0..31, lane-contiguous (aggregate-free mode)
-    double *gt_dev = nullptr;    // G = [A^(T-1-k) b]_k in MFMA A-operand order: [T/4][64], grown on demand
-    size_t gt_cap = 0;
-    int n_lb = 0;                // terms of the in-kernel carry look-back (0 = use the K2 scan)
-    int n_lv = kPowers;          // first l with max|M^(2^l)| < 1e-30 (chunk-level scan depth that matters)
-    double *state_dev = nullptr; // [2][2][D]: zi and zf for up to two planes
-    double *v_dev = nullptr;     // [D][J] chunk end states (SoA), capacity below
-    double *agg_dev = nullptr;   // [2][kMaxW][D] workgroup aggregates / carries (ping-pong) + carry
-    size_t v_cap = 0;
-    std::vector<double> A_host;
-};
-
-template <int NSEC, int ORD> struct Coef { double c[NSEC * (2 * ORD + 1)]; };
-
-// one sample through the cascade; z = DF2T delay lines of every section
-// UNIT (biquads): sections 1.. have b0 = b2 = 1 (IirHandle::unit_tail): y = x + z0, z0 = b1 x - a1 y + z1,
-// z1 = x - a2 y -- 4 flops and 3 coefficients instead of 5 and 5.  The coefficients live in SGPRs; the general
-// form of an 8-biquad cascade needs 80 of them, more than a wave has, and hipcc then re-reads ~9 spilled
-// coefficients per sample from VGPR lanes (1100 v_readlane next to 3100 FP64 instructions in K3).
-template <int NSEC, int ORD, bool UNIT = false>
-__device__ __forceinline__ double cascade_step(const Coef<NSEC, ORD> &cf, double (&z)[NSEC * ORD], double x)
-{
-#pragma unroll
-    for (int s = 0; s < NSEC; ++s) {
-        const double *c = cf.c + s * (2 * ORD + 1);
-        const double xn = x;
-        if (UNIT && ORD == 2 && s >= 1) {
-            const double yu = xn + z[2 * s];
-            z[2 * s] = fma(c[1], xn, fma(-c[3], yu, z[2 * s + 1]));
-            z[2 * s + 1] = fma(-c[4], yu, xn);
-            x = yu;
-            continue;
-        }
-        const double yv = fma(c[0], xn, z[s * ORD]);
-#pragma unroll
-        for (int k = 1; k < ORD; ++k) z[s * ORD + k - 1] = fma(c[k], xn, fma(-c[ORD + k], yv, z[s * ORD + k]));
-        z[s * ORD + ORD - 1] = fma(c[ORD], xn, -c[2 * ORD] * yv);
-        x = yv;
-    }
-    return x;
-}
-
-// out += Mat * in   (Mat uniform, row-major D x D, read through the scalar cache).  Every power
-// of a cascade's transition matrix is block lower-triangular (section s never sees the state of a
-// later section), so row i stops at the end of its own ORD-wide block: 144 instead of 256 fma for
-// 8 biquads.
-template <int D, int ORD = D>
-__device__ __forceinline__ void matvec_acc(const double *__restrict__ Mat, const double (&in)[D], double (&out)[D])
-{
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        double acc = out[i];
-#pragma unroll
-        for (int j = 0; j < (i / ORD + 1) * ORD; ++j) acc = fma(Mat[i * D + j], in[j], acc);
-        out[i] = acc;
-    }
-}
-
-template <typename IO> struct Stage;
-template <> struct Stage<float> {
-    static constexpr int pitch = 36;       // floats per row (144 B)
-    static constexpr int segs = 8;         // 16-byte segments per 32-sample row piece
-    static constexpr int per_thread = 8;   // segments staged per thread per piece
-    static constexpr int elems = 4;        // samples per 16-byte segment
-};
-template <> struct Stage<double> {
-    static constexpr int pitch = 34;       // doubles per row (272 B)
-    static constexpr int segs = 16;
-    static constexpr int per_thread = 16;
-    static constexpr int elems = 2;
-};
 
 struct IirArgs {
     const void *x;
@@ -403,7 +316,6 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
 // x[chunk l & 15][k0 + (l >> 4)]; C: col = lane & 15, row = (lane >> 4) + 4 reg).  The samples of the
 // wave's 16 chunks are staged per 128-sample piece in a wave-private LDS image (row pitch 132 words:
 // the 64 B-operand reads of a step hit 64 distinct banks), so there is no workgroup barrier at all.
-typedef double v4d_t __attribute__((ext_vector_type(4)));
 constexpr int kMmPiece = 128;                 // samples of every chunk staged at a time
 constexpr int kMmPitch = kMmPiece + 4;        // in 4-byte words (float); doubles use 2 words per sample
 
@@ -998,6 +910,9 @@ void iir_free(IirPlan *p)
     if (p->state_dev) (void)hipFree(p->state_dev);
     if (p->v_dev) (void)hipFree(p->v_dev);
     if (p->agg_dev) (void)hipFree(p->agg_dev);
+    if (p->lbg_dev) (void)hipFree(p->lbg_dev);
+    if (p->ticket_dev) (void)hipFree(p->ticket_dev);
+    if (p->err_host) (void)hipHostFree(p->err_host);
     delete p;
 }
 
@@ -1082,7 +997,8 @@ static int ensure_powers(IirHandle *h, int64_t T, hipStream_t s)
         SK_HIP(hipMemcpyAsync(p->lbk_dev, lbk.data(), lbk.size() * 8, hipMemcpyHostToDevice, s));
         SK_HIP(hipStreamSynchronize(s));
     }
-    if (D <= 32 && T % kMmPiece == 0) {
+    p->gt_T = -1;
+    if (D <= 32 && (T % kMmPiece == 0 || T == 64)) {
         // G[:, k] = A^(T-1-k) b, b = the state one sample x = 1 leaves behind; stored as the MFMA A operand
         // of step s = k / 4: lane l holds row l & 15, column 4 s + (l >> 4)
         std::vector<long double> g(D, 0.0L);
@@ -1105,6 +1021,7 @@ static int ensure_powers(IirHandle *h, int64_t T, hipStream_t s)
         }
         SK_HIP(hipMemcpyAsync(p->gt_dev, gt.data(), gt.size() * 8, hipMemcpyHostToDevice, s));
         SK_HIP(hipStreamSynchronize(s));
+        p->gt_T = T;
     }
     std::vector<double> pw((size_t)kPowers * D * D);
     p->n_lv = kPowers;
@@ -1159,7 +1076,7 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
     a.n_lb = p->n_lb;
     a.n_lv = p->n_lv < 8 ? p->n_lv : 8;
     // aggregate-free mode: matrix-pipe K1, carries from the chunk states themselves, unchanged K3
-    const bool fast = p->n_lv <= 5 && D <= 32 && ORD == 2 && a.T % kMmPiece == 0 && p->gt_dev && !opt().iir_no_mfma;
+    const bool fast = p->n_lv <= 5 && D <= 32 && ORD == 2 && a.T % kMmPiece == 0 && p->gt_T == a.T && !opt().iir_no_mfma;
     if (a.il) {
         if (!fast || a.T % 64 != 0) return 1;  // not applicable (error codes are negative): the caller takes the planar detour
         const int64_t waves = (a.J + 15) / 16;
@@ -1245,6 +1162,20 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     if (rc) return rc;
     IirPlan *p = h->plan;
     const int D = p->D;
+    // Single-pass scan (one launch, x read once): real signals, <= 8 biquads whose transition over one 256-chunk segment
+    // is below 1e-30 (n_lb == 1 for the segment's chunk length), enough segments to fill the chip.
+    bool fused = false;
+    {
+        const int64_t Tf = dtype_double(h->dtype) ? 64 : 128;
+        if (!interleaved && h->order == 2 && D <= 16 && !opt().iir_two_pass && p->fused_state >= 0 &&
+            (dec <= 1 || (nbatch == 1 && zf_host == nullptr)) &&
+            n >= Tf * kIirThreads * (int64_t)ctx().num_cus) {
+            rc = ensure_powers(h, Tf, s);
+            if (rc) return rc;
+            p->fused_state = (p->n_lb == 1 && p->gt_T == Tf) ? 1 : -1;
+            fused = p->fused_state == 1;
+        }
+    }
     int maxW = kMaxPairs / D;
     if (maxW > kMaxW) maxW = kMaxW;
     const int64_t maxChunks = (int64_t)maxW * kIirThreads;
@@ -1254,9 +1185,11 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     if (T >= kMmPiece) T = ((T + kMmPiece - 1) / kMmPiece) * kMmPiece;  // whole 128-sample pieces for the matrix-pipe K1
     const int64_t J = (n + T - 1) / T;
     const int W = (int)((J + kIirThreads - 1) / kIirThreads);
-    rc = ensure_powers(h, T, s);
-    if (rc) return rc;
-    const size_t need = (size_t)nbatch * D * J * 8;
+    if (!fused) {
+        rc = ensure_powers(h, T, s);
+        if (rc) return rc;
+    }
+    const size_t need = fused ? 0 : (size_t)nbatch * D * J * 8;
     if (need > p->v_cap) {
         if (p->v_dev) SK_HIP(hipFree(p->v_dev));
         p->v_dev = nullptr; p->v_cap = 0;
@@ -1292,7 +1225,10 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     }
     if (zf_host) a.zf = p->state_dev + 2 * D;
     SK_CHECK(nbatch >= 1 && nbatch <= 2, SKDSP_ERR_BADARG, "iir: batch must be 1 or 2");
-    rc = dtype_double(h->dtype) ? dispatch_shape<double>(h, a, nbatch, W, s) : dispatch_shape<float>(h, a, nbatch, W, s);
+    if (fused)
+        rc = iir_fused_launch(h, x, n, nbatch, batch_stride, y, a.zi, a.zf, s, dec);
+    else
+        rc = dtype_double(h->dtype) ? dispatch_shape<double>(h, a, nbatch, W, s) : dispatch_shape<float>(h, a, nbatch, W, s);
     if (rc) return rc;  // (1 = interleaved path not applicable, nothing was launched)
     if (zf_host) {
         SK_HIP(hipMemcpyAsync(zf_host, p->state_dev + 2 * D, (size_t)nbatch * D * 8, hipMemcpyDeviceToHost, s));

@@ -1381,7 +1381,9 @@ def test_iir_dn_decimating_store(dt, M, n):
         _ffi.sync()
         got = yd.to_host(0, n // M + 8)
         assert np.all(got[n // M:] == 7.0)
-        assert np.array_equal(got[:n // M], y2.to_host(0, n // M))
+        # (the same kernel with and without the decimating store: identical; when the two calls take different scan
+        #  paths -- single-pass for the full-rate call -- they agree to float64 rounding instead)
+        assert_close(got[:n // M], y2.to_host(0, n // M), 0.0 if dt in (np.float32, np.complex64) else 1e-12, "dn vs full-rate + downsample")
         tol = TOL32 if dt in (np.float32, np.complex64) else 1e-9
         m = min(n, 60000)
         ref = orc.sos_filter(sos, xd.to_host(0, m))[::M][:m // M]
@@ -1390,3 +1392,63 @@ def test_iir_dn_decimating_store(dt, M, n):
         xd.free()
         yd.free()
         y2.free()
+
+
+# ----------------------------------------------------------------- single-pass IIR scan (iir_fused.hip)
+@pytest.mark.parametrize("dt,n", [(np.float32, 9_000_017), (np.float32, 2 ** 24), (np.float64, 4_400_003)])
+@pytest.mark.parametrize("filt", ["ellip8", "butter4", "biquad"])
+def test_iir_single_pass_scan_matches_two_pass_and_oracle(dt, n, filt):
+    """The single-pass scan (one launch, x read once: segments of 256 register-resident chunks, from-rest scan,
+    decoupled look-back, correction by binary powers) against the K1 / carries / K3 path (option iir_two_pass) and the
+    oracle: ragged lengths, initial state in, final state out, repeated launches (look-back epochs)."""
+    from scipy import signal
+    import bench
+    sos = {"ellip8": bench.elliptic_bpf_sos(), "butter4": signal.butter(4, 0.25, output="sos"),
+           "biquad": signal.tf2sos(*signal.iirpeak(0.1, 30))}[filt]
+    nsec = sos.shape[0]
+    rng = np.random.default_rng(5)
+    zi = rng.standard_normal((nsec, 2)) * 0.1
+    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+    xd = _ffi.DeviceArray(n, dt).fill_noise(77)
+    y1 = _ffi.DeviceArray(n, dt)
+    y2 = _ffi.DeviceArray(n, dt)
+    try:
+        zf1 = k.filter_state_dev(xd, y1, zi=zi.ravel())
+        with _ffi.option("iir_two_pass", 1):
+            zf2 = k.filter_state_dev(xd, y2, zi=zi.ravel())
+        tol = TOL32 if dt == np.float32 else 1e-12
+        w = 1 << 20
+        for s0 in (0, n // 2 - 12345, n - w):
+            assert_close(y1.to_host(s0, w), y2.to_host(s0, w), tol, "single-pass vs two-pass @%d" % s0)
+        assert_close(zf1, zf2, 1e-9, "final state")
+        m = 300_000
+        ref, _ = signal.sosfilt(sos, xd.to_host(0, m).astype(np.float64), zi=zi)
+        assert_close(y1.to_host(0, m), ref, TOL32 if dt == np.float32 else 1e-10, "head vs sosfilt(zi)")
+        lo = n - m - 60_000
+        ref2, zf_ref = signal.sosfilt(sos, xd.to_host(lo, n - lo).astype(np.float64), zi=np.zeros((nsec, 2)))
+        assert_close(y1.to_host(n - m, m), ref2[-m:], TOL32 if dt == np.float32 else 1e-10, "tail vs sosfilt")
+        assert_close(zf1, zf_ref.ravel(), 1e-9, "final state vs sosfilt")
+        # back-to-back launches reuse the look-back slots with a new epoch each: results must not change
+        first = y1.to_host(n - w, w)
+        for _ in range(5):
+            k.filter_dev(xd, y1)
+        _ffi.sync()
+        k.filter_state_dev(xd, y1, zi=zi.ravel(), want_zf=False)
+        assert np.array_equal(y1.to_host(n - w, w), first)
+    finally:
+        xd.free()
+        y1.free()
+        y2.free()
+
+
+def test_iir_single_pass_not_taken_for_slow_decay():
+    """A filter whose transition over one segment (32768 samples) does not vanish keeps the two-pass path (its
+    look-back would need a chain): r = 0.99999 resonator, exactness as in the slow-decay test."""
+    from scipy import signal
+    r, w0 = 0.99999, 0.3
+    sos = np.array([[1.0, 0.0, -1.0, 1.0, -2 * r * np.cos(w0), r * r]])
+    n = 9_000_000
+    x = np.random.default_rng(8).standard_normal(n).astype(np.float64)
+    y = mrh.multirate_IIR(sos).filter(x)
+    ref = signal.sosfilt(sos, x)
+    assert_close(y[-(1 << 20):], ref[-(1 << 20):], 1e-9, "slow decay")
