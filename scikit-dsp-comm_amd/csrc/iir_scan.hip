@@ -1023,12 +1023,17 @@ static int ensure_powers(IirHandle *h, int64_t T, hipStream_t s)
         SK_HIP(hipStreamSynchronize(s));
         p->gt_T = T;
     }
+    // A transition power counts as vanished when its largest entry is below `negl`: 1e-30 for float64 signals (nothing a
+    // float64 recurrence could resolve), 1e-18 for float32 signals (the dropped term is under a tenth of an ulp of the
+    // float64 STATE it would be added to, and eleven orders below the float32 rounding of the output) -- for the config-4
+    // cascade (pole radius 0.99465) that is 60 chunks of 128 samples instead of 101: one scan level less.
+    const long double negl = dtype_double(h->dtype) ? 1e-30L : 1e-18L;
     std::vector<double> pw((size_t)kPowers * D * D);
     p->n_lv = kPowers;
     for (int l = 0; l < kPowers; ++l) {
         long double mx = 0.0L;
         for (auto v : M) mx = fabsl(v) > mx ? fabsl(v) : mx;
-        if (std::isfinite((double)mx) && mx < 1e-30L && l < p->n_lv) p->n_lv = l;
+        if (std::isfinite((double)mx) && mx < negl && l < p->n_lv) p->n_lv = l;
         for (size_t i = 0; i < (size_t)D * D; ++i) {
             long double v = M[i];
             if (!std::isfinite((double)v)) v = 0.0L;  // unstable filter overflow: the reference overflows too
@@ -1047,7 +1052,7 @@ static int ensure_powers(IirHandle *h, int64_t T, hipStream_t s)
         for (int k = 1; k <= 8; ++k) {  // Pk = Mw^k
             long double mx = 0.0L;
             for (auto v : Pk) mx = fabsl(v) > mx ? fabsl(v) : mx;
-            if (!(mx >= 1e-30L)) { p->n_lb = k; break; }  // terms k.. are negligible: keep k terms (0..k-1)
+            if (!(mx >= negl)) { p->n_lb = k; break; }  // terms k.. are negligible: keep k terms (0..k-1)
             if (k == 8) break;
             for (size_t i = 0; i < (size_t)D * D; ++i) lb[(size_t)(k - 1) * D * D + i] = (double)Pk[i];
             matmul_ld(Pk, Mw, Pk, D);
@@ -1167,12 +1172,17 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     bool fused = false;
     {
         const int64_t Tf = dtype_double(h->dtype) ? 64 : 128;
-        if (!interleaved && h->order == 2 && D <= 16 && !opt().iir_two_pass && p->fused_state >= 0 &&
+        if (!interleaved && h->order == 2 && D <= 16 && opt().iir_two_pass <= 0 && p->fused_state >= 0 &&
             (dec <= 1 || (nbatch == 1 && zf_host == nullptr)) &&
             n >= Tf * kIirThreads * (int64_t)ctx().num_cus) {
             rc = ensure_powers(h, Tf, s);
             if (rc) return rc;
             p->fused_state = (p->n_lb == 1 && p->gt_T == Tf) ? 1 : -1;
+            // Measured crossover (2^26 float32, same box): the single pass costs one from-rest scan plus a correction per
+            // 128-sample chunk -- 7 + 3.25 levels of a 16 x 16 transition for the 8-biquad elliptic band-pass of BASELINE
+            // config 4 (0.206 ms) against 4 levels per 512-sample chunk in the two-pass scan (0.196 ms).  Up to 6 levels
+            // (every low-pass design tried: 0.12-0.13 vs 0.16-0.17 ms) and for float64 signals (0.35 vs 0.44 ms) it wins.
+            if (!dtype_double(h->dtype) && p->n_lv >= 7 && D >= 14 && opt().iir_two_pass >= 0) p->fused_state = -1;
             fused = p->fused_state == 1;
         }
     }

@@ -47,7 +47,7 @@ struct Options {
     int iir_no_mfma = 0;      // recurrence K1 instead of the matrix-pipe K1
     int iir_no_k1r = 0;
     int k1r_wgs = 2;
-    int iir_two_pass = 0;     // K1 + carries + K3 even where the single-pass scan applies
+    int iir_two_pass = 0;     // 1: K1 + carries + K3 even where the single-pass scan applies; -1: single pass wherever it applies
     int shard_no_overlap = 0; // sharded FIR: halo exchange in front of the whole filter instead of beside the interior tiles
     int shard_reserve = 8;
     int dist_force_comm = 0;  // build an RCCL communicator for a 1-rank job too (exercises the plumbing on one GPU)
