@@ -49,7 +49,8 @@ const OptEntry kOptTable[] = {
     {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
     {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"shard_no_overlap", &Options::shard_no_overlap},
-    {"shard_reserve", &Options::shard_reserve}, {"dist_force_comm", &Options::dist_force_comm},
+    {"shard_reserve", &Options::shard_reserve}, {"shard_two_launches", &Options::shard_two_launches},
+    {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
     {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline},
 };
 int parse_opt(const char *name, const char *v)
@@ -516,6 +517,9 @@ int skdsp_shutdown(void)
         (void)hipStreamSynchronize(c.comm_stream);
         (void)hipEventDestroy(c.ev_in);
         (void)hipEventDestroy(c.ev_halo);
+        if (c.halo_flag) (void)hipFree(c.halo_flag);
+        if (c.halo_err) (void)hipHostFree(c.halo_err);
+        c.halo_flag = nullptr; c.halo_err = nullptr;
         (void)hipStreamDestroy(c.comm_stream);
         c.comm_stream = nullptr;
         c.ev_in = c.ev_halo = nullptr;

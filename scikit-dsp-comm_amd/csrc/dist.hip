@@ -104,11 +104,13 @@ static int halo_exchange_locked(void *x_dev, int64_t n, int64_t n_halo, int dtyp
     if (n_halo == 0) return SKDSP_OK;
     char *x0 = (char *)x_dev;
     void *halo = x0 - (size_t)n_halo * esz;
-    if (r.world <= 1 || !r.comm) {
+    if ((r.world <= 1 && !opt().shard_self_halo) || !r.comm) {
         if (zero_first) SK_HIP(hipMemsetAsync(halo, 0, (size_t)n_halo * esz, s));
         return SKDSP_OK;
     }
     const size_t bytes = (size_t)n_halo * esz;
+    if (r.world == 1 && opt().shard_self_halo)  // test hook: the one rank is its own left neighbour
+        return sendrecv_locked(x0 + (size_t)(n - n_halo) * esz, 0, halo, 0, bytes, s);
     if (r.rank == 0 && zero_first) SK_HIP(hipMemsetAsync(halo, 0, bytes, s));  // zero initial state
     return sendrecv_locked(x0 + (size_t)(n - n_halo) * esz, r.rank + 1 < r.world ? r.rank + 1 : -1, halo,
                            r.rank > 0 ? r.rank - 1 : -1, bytes, s);
@@ -270,7 +272,8 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
         halo = h->ntaps - 1;
         // the first shard has no history: its kernels read zeros for x[-k] (n_hist = 0) instead of a halo that
         // would have to be cleared by two fill launches per call (~10 us of a 0.24 ms step)
-        const bool first = rc().world <= 1 || !rc().comm || rc().rank == 0;
+        const bool self = rc().world == 1 && rc().comm && opt().shard_self_halo;  // (test hook, see Options)
+        const bool first = !self && (rc().world <= 1 || !rc().comm || rc().rank == 0);
         // Overlap-save shards: only tile 0 reads the halo.  Tiles 1.. are the same problem started
         // V samples in (their history is local), so they run on the compute stream while the
         // 8 KB halo crosses xGMI on a second stream; tile 0 follows once it has landed.
@@ -286,22 +289,48 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
                 SK_HIP(hipStreamCreateWithFlags(&c.comm_stream, hipStreamNonBlocking));
                 SK_HIP(hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
                 SK_HIP(hipEventCreateWithFlags(&c.ev_halo, hipEventDisableTiming));
+                SK_HIP(hipMalloc((void **)&c.halo_flag, 256));
+                SK_HIP(hipMemsetAsync(c.halo_flag, 0, 256, c.stream));
+                SK_HIP(hipHostMalloc((void **)&c.halo_err, sizeof(unsigned), hipHostMallocMapped));
+                *c.halo_err = 0;
+                c.halo_seq = 0;
             }
+            SK_CHECK(*c.halo_err == 0, SKDSP_ERR_RCCL,
+                     "fir_filter_shard: an earlier sharded launch gave up waiting for its halo (RCCL receive never completed?)");
             std::lock_guard<std::mutex> lk(h->mu);
             const size_t esz = dtype_size(h->dtype);
             SK_HIP(hipEventRecord(c.ev_in, c.stream));            // x (and its tail, which is sent) is ready
             SK_HIP(hipStreamWaitEvent(c.comm_stream, c.ev_in, 0));
             int r1 = halo_exchange_locked(x_dev, n_local, halo, h->dtype, c.comm_stream, false);
             if (r1) return r1;
-            SK_HIP(hipEventRecord(c.ev_halo, c.comm_stream));
-            // The interior tiles are one persistent launch that fills every CU (2 x 76 KiB of LDS) for the whole
-            // step: a few workgroup slots stay free, so that the send/recv kernel of the halo can start beside it
-            // instead of behind it (8 of 512 workgroups; fir_ols_launch leaves them free by default anyway).
+            // The filter is ONE persistent launch that fills every CU (2 x 76 KiB of LDS) for the whole step: a few
+            // workgroup slots stay free, so that the send/recv kernel of the halo can start beside it instead of behind
+            // it (8 of 512 workgroups; fir_ols_launch leaves them free by default anyway).  Only tile 0 reads the halo:
+            // the launch walks it last, behind a device flag that a one-thread kernel on the halo stream sets once the
+            // RCCL receive is complete -- no second launch, no 1-workgroup tail (option shard_two_launches restores
+            // that form: interior tiles, stream wait on the halo event, tile 0 as its own launch).
             const int reserve = opt().shard_reserve;
-            r1 = fir_ols_launch(h, (char *)x_dev + (size_t)V * esz, n_local - V, V, (char *)y_dev + (size_t)V * esz, c.stream, 1, reserve);
+            if (opt().shard_two_launches) {
+                SK_HIP(hipEventRecord(c.ev_halo, c.comm_stream));
+                r1 = fir_ols_launch(h, (char *)x_dev + (size_t)V * esz, n_local - V, V, (char *)y_dev + (size_t)V * esz, c.stream, 1, reserve);
+                if (r1) return r1;
+                SK_HIP(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
+                return fir_ols_launch(h, x_dev, V, first ? 0 : halo, y_dev, c.stream);
+            }
+            unsigned *err_dev = nullptr;
+            SK_HIP(hipHostGetDevicePointer((void **)&err_dev, c.halo_err, 0));
+            const unsigned seq = ++c.halo_seq;
+            if (!first) {
+                r1 = fir_ols_publish_halo(c.halo_flag, seq, c.comm_stream);
+                if (r1) return r1;
+            }
+            SK_HIP(hipEventRecord(c.ev_halo, c.comm_stream));
+            r1 = fir_ols_launch(h, x_dev, n_local, first ? 0 : halo, y_dev, c.stream, 1, reserve, first ? nullptr : c.halo_flag, seq, err_dev);
             if (r1) return r1;
+            // whatever the caller queues next on the compute stream (it may overwrite x, whose tail is being sent) is
+            // ordered behind the exchange as well
             SK_HIP(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
-            return fir_ols_launch(h, x_dev, V, first ? 0 : halo, y_dev, c.stream);
+            return SKDSP_OK;
         }
         int r = halo_exchange_locked(x_dev, n_local, halo, h->dtype, nullptr, false);
         if (r) return r;

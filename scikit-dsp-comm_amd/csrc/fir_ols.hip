@@ -32,6 +32,12 @@
 #ifndef SKDSP_OLS_NT
 #define SKDSP_OLS_NT 1  // nontemporal x loads / y stores (streamed once): 0.300 -> 0.295 ms
 #endif
+#ifndef SKDSP_OLS_NT_LD
+#define SKDSP_OLS_NT_LD SKDSP_OLS_NT
+#endif
+#ifndef SKDSP_OLS_NT_ST
+#define SKDSP_OLS_NT_ST SKDSP_OLS_NT
+#endif
 
 namespace skdsp {
 
@@ -56,7 +62,33 @@ struct OlsArgs {
     int64_t ntiles;
     int dec;        // > 1: keep every dec-th output only (multirate_FIR.dn): y[g / dec] = out[g] for g % dec == 0
     int64_t n_keep; // dec * floor(n / dec)
+    // Sharded filter (dist.hip): the Ntaps-1 samples in front of x arrive over xGMI on another stream while this launch
+    // already runs.  Only tile 0 reads them, so tile 0 is walked LAST and whoever owns it waits for halo_flag >= halo_seq
+    // (set by a one-thread kernel behind the RCCL receive) right before requesting its samples.  null = no wait.
+    const unsigned *halo_flag;
+    unsigned halo_seq;
+    unsigned *halo_err;  // host-mapped: set if the bounded wait gave up (the caller reports it; the launch never hangs)
 };
+
+// The owner of tile 0 calls this (whole workgroup, uniform) before its first load of that tile: one lane polls with
+// relaxed agent-scope loads, then ONE agent-scope acquire (invalidates this CU's L1; the samples were written by another
+// kernel / another GPU), then the barrier releases the other waves to plain loads (MI355X_MICROARCH.md, inter-workgroup
+// visibility).  The halo left its sender ~0.2 ms earlier, so the loop normally exits on its first load.
+__device__ __forceinline__ void wait_halo(const OlsArgs &A)
+{
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while ((int)(__hip_atomic_load(A.halo_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.halo_seq) < 0) {
+            if (++spins > (1 << 21)) {  // seconds of polling: report instead of hanging the GPU
+                *A.halo_err = 1u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
 
 // volatile 16-byte load: keeps the request at its program position (the scheduler would
 // otherwise sink a prefetch down to its first use to save registers)
@@ -84,12 +116,12 @@ __device__ __forceinline__ void load_tile(const OlsArgs &A, int64_t tile, int t,
         // were then spilled and reloaded in front of every load)
         int tt = t;
         asm volatile("" : "+v"(tt));
-#if !SKDSP_OLS_NT
+#if !SKDSP_OLS_NT_LD
         const volatile float4 *xp = reinterpret_cast<const volatile float4 *>(A.x + in0);
 #endif
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-#if SKDSP_OLS_NT
+#if SKDSP_OLS_NT_LD
             const v4f_t nv = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(A.x + in0) + (unsigned)(a * 256 + tt));
             const float4 f = make_float4(nv.x, nv.y, nv.z, nv.w);
 #else
@@ -146,7 +178,7 @@ __device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t
         float4 *yp = reinterpret_cast<float4 *>(A.y + out0 + 2 * tt);
 #pragma unroll
         for (int a = 0; a < 16; ++a)
-#if SKDSP_OLS_NT
+#if SKDSP_OLS_NT_ST
             if (a >= A.a0) {
                 v4f_t nv;
                 nv.x = v[2 * a].x; nv.y = v[2 * a].y; nv.z = v[2 * a + 1].x; nv.w = v[2 * a + 1].y;
@@ -321,9 +353,15 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
     // being fetched twice from HBM (the 7.6 % of traffic above the algorithmic bytes)
     int64_t tile = (gridDim.x % 8 == 0 && !SKDSP_OLS_NO_XCD_MAP) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8
                                                                  : (int64_t)blockIdx.x;
+    // (sharded launches walk tile 0 last: walk index w stands for tile w + 1, the last index for tile 0)
+    const bool t0_last = A.halo_flag != nullptr;
+    auto phys = [&](int64_t w) -> int64_t { return t0_last ? (w + 1 < A.ntiles ? w + 1 : 0) : w; };
     cf v[32];
 #if SKDSP_OLS_PREFETCH
-    if (tile < A.ntiles) load_any<REAL>(A, tile, t, v);
+    if (tile < A.ntiles) {
+        if (t0_last && phys(tile) == 0) wait_halo(A);
+        load_any<REAL>(A, phys(tile), t, v);
+    }
     // the loop is entered with no load pending on either edge (see the note in front of the stores):
     // waits placed at the loop top for THIS load would otherwise also be paid by every later tile,
     // where the only pending vector-memory operations are the previous tile's stores
@@ -336,7 +374,8 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
     for (; tile < A.ntiles; tile += gridDim.x, ++it) {
         SK_STAMP(0);
 #if !SKDSP_OLS_PREFETCH
-        load_any<REAL>(A, tile, t, v);
+        if (t0_last && phys(tile) == 0) wait_halo(A);
+        load_any<REAL>(A, phys(tile), t, v);
 #endif
 #if !SKDSP_OLS_HREG
         float4 hh[16];
@@ -353,8 +392,8 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         {   // measurement aid: the tile walk's memory traffic alone (loads, prefetch, stores)
             const int64_t next = tile + gridDim.x;
             cf nx[32];
-            if (next < A.ntiles) load_any<REAL>(A, next, t, nx);
-            store_any<REAL>(A, tile, t, v);
+            if (next < A.ntiles) load_any<REAL>(A, phys(next), t, nx);
+            store_any<REAL>(A, phys(tile), t, v);
 #pragma unroll
             for (int i = 0; i < 32; ++i) v[i] = nx[i];
             continue;
@@ -373,7 +412,10 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         // the top of the next iteration -- in flight during the whole inverse FFT
         const int64_t next = tile + gridDim.x;
         cf nx[32];
-        if (next < A.ntiles) load_any<REAL>(A, next, t, nx);
+        if (next < A.ntiles) {
+            if (t0_last && phys(next) == 0) wait_halo(A);  // (uniform: the whole workgroup owns that tile)
+            load_any<REAL>(A, phys(next), t, nx);
+        }
 #endif
         inv_pass32(t, T2t, lds, Z);
         SK_STAMP(5);
@@ -393,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
                          "v"(nx[i + 6].x), "v"(nx[i + 6].y), "v"(nx[i + 7].x), "v"(nx[i + 7].y)
                          : "memory");
 #endif
-        store_any<REAL>(A, tile, t, v);
+        store_any<REAL>(A, phys(tile), t, v);
         SK_STAMP(8);
 #if SKDSP_OLS_PREFETCH
 #pragma unroll
@@ -459,7 +501,21 @@ int fir_ols_tile_outputs(FirHandle *h, int *V)
     return SKDSP_OK;
 }
 
-int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s, int dec, int reserve_wgs)
+__global__ void ols_halo_flag_kernel(unsigned *flag, unsigned seq)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int fir_ols_publish_halo(unsigned *flag, unsigned seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(ols_halo_flag_kernel, dim3(1), dim3(1), 0, s, flag, seq);
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s, int dec, int reserve_wgs,
+                   const unsigned *halo_flag, unsigned halo_seq, unsigned *halo_err)
 {
     if (n <= 0) return SKDSP_OK;
     if (dec > 1) n = (n / dec) * dec;  // the dropped tail is never computed
@@ -485,6 +541,8 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.ntiles = ntiles;
     A.dec = dec > 1 ? dec : 1;
     A.n_keep = n;
+    A.halo_flag = halo_flag; A.halo_seq = halo_seq; A.halo_err = halo_err;
+    SK_CHECK(!(halo_flag && real), SKDSP_ERR_UNSUPPORTED, "fir_ols: halo flag wait is for complex64 shards");
     int64_t grid = 2 * (int64_t)ctx().num_cus;  // 2 resident workgroups per CU (76 KiB LDS each)
     // 8 slots stay free: room for a concurrent kernel (the RCCL send/recv of a halo, another stream of the caller) at
     // no measurable cost (0.2375 vs 0.2375 ms at 2^26, alternating runs on one box)

@@ -50,6 +50,8 @@ struct Options {
     int iir_two_pass = 0;     // 1: K1 + carries + K3 even where the single-pass scan applies; -1: single pass wherever it applies
     int shard_no_overlap = 0; // sharded FIR: halo exchange in front of the whole filter instead of beside the interior tiles
     int shard_reserve = 8;
+    int shard_two_launches = 0; // sharded FIR: tile 0 as its own launch behind the halo event (instead of the in-kernel flag wait)
+    int shard_self_halo = 0;    // test hook: a 1-rank communicator sends its tail to ITSELF (exercises the whole halo path on one GPU)
     int dist_force_comm = 0;  // build an RCCL communicator for a 1-rank job too (exercises the plumbing on one GPU)
     int host_chunk_log2 = 24; // host-pointer entry points: samples per pipelined chunk (pinned double buffers)
     int host_pipeline = 1;    // 0: single staged copy in / kernel / copy out
@@ -66,6 +68,9 @@ struct Context {
     // grow-only device workspaces used by the host-pointer entry points
     hipStream_t comm_stream = nullptr;   // halo traffic of a sharded FIR, overlapped with the interior tiles
     hipEvent_t ev_in = nullptr, ev_halo = nullptr;
+    unsigned *halo_flag = nullptr;       // device word the halo stream bumps when a shard's history has landed
+    unsigned *halo_err = nullptr;        // host-mapped: a persistent launch gave up waiting for it
+    unsigned halo_seq = 0;
     void *ws[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t ws_bytes[4] = {0, 0, 0, 0};
     std::mutex mu;
@@ -136,7 +141,11 @@ int fir_ols_tile_outputs(FirHandle *h, int *V);  // outputs per overlap-save til
 int fir_algo_for(const FirHandle *h, int64_t n);  // SKDSP_FIR_OLS / SKDSP_FIR_DIRECT as skdsp_fir_filter_dev would pick
 int fir_ols_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, hipStream_t s,
                    int dec = 1,           // dec > 1: decimating store, y holds n / dec samples
-                   int reserve_wgs = -1);  // persistent grid smaller by this many workgroups (multiple of 8; -1: default 8)
+                   int reserve_wgs = -1,  // persistent grid smaller by this many workgroups (multiple of 8; -1: default 8)
+                   // sharded launches: tile 0 is walked last and waits until *halo_flag >= halo_seq (the history in front
+                   // of x is being received on another stream); halo_err (host-mapped) is set if that wait gives up
+                   const unsigned *halo_flag = nullptr, unsigned halo_seq = 0, unsigned *halo_err = nullptr);
+int fir_ols_publish_halo(unsigned *flag, unsigned seq, hipStream_t s);  // one-thread kernel: *flag = seq (agent-scope release)
 void fir_ols_free(OlsPlan *p);
 
 // ---- IIR -----------------------------------------------------------------
