@@ -25,8 +25,9 @@
  *     same allocation (x_dev[-n_hist..-1]).  0 = zero initial state, which is
  *     what every reference call uses (lfilter/sosfilt without zi).  The sharded
  *     path uses it for the Ntaps-1 halo received from the left neighbour.
- *   - a handle serialises its own calls; different handles may be used from
- *     different threads.  ctypes releases the GIL around each call.
+ *   - a handle serialises its own calls.  Calls lock the SLOT they run on (a slot = one GPU binding with its stream
+ *     and workspaces): caller threads all use slot 0, so their calls take turns on its stream; the worker threads of
+ *     a multi-slot host call run concurrently, one per slot.  ctypes releases the GIL around each call.
  */
 #ifndef SKDSP_H
 #define SKDSP_H
@@ -55,7 +56,13 @@ typedef enum { SKDSP_FIR_AUTO = 0, SKDSP_FIR_DIRECT = 1, SKDSP_FIR_OLS = 2 } skd
 typedef void *skdsp_handle;
 
 /* ---- runtime ------------------------------------------------------------ */
-int skdsp_init(int device);               /* bind this process to one GPU, create the stream */
+int skdsp_init(int device);               /* bind the caller's slot (slot 0) to one GPU, create its stream */
+/* Bind slots 0 .. ndev-1 to the listed GPUs (slot 0 = the device every *_dev entry point and handle uses).  With more
+ * than one slot bound, the host-pointer FIR entry points deal the chunks of a long vector to all of them, one worker
+ * thread, stream and PCIe link each (the reference's single call multirate_FIR(b).filter(x), multirate_helper.py:104-109,
+ * then scales over the node without a launcher).  A device may be listed more than once. */
+int skdsp_init_devices(const int *devices, int ndev);
+int skdsp_slot_count(void);
 int skdsp_shutdown(void);
 int skdsp_device_count(void);
 int skdsp_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes, int *clock_khz);
@@ -69,6 +76,11 @@ int skdsp_get_option(const char *name, int *value);
 
 int skdsp_malloc(void **dptr, int64_t bytes);
 int skdsp_free(void *dptr);
+/* Page-locked host memory.  A copy back into a FRESH pageable array (np.empty) runs at ~25-30 GB/s on this platform
+ * (page population + first device access), into page-locked memory at the link rate (56 GB/s): the Python layer hands
+ * out result arrays backed by recycled blocks from here. */
+int skdsp_host_alloc(void **hptr, int64_t bytes);
+int skdsp_host_free(void *hptr);
 int skdsp_memcpy_h2d(void *dst_dev, const void *src_host, int64_t bytes);
 int skdsp_memcpy_d2h(void *dst_host, const void *src_dev, int64_t bytes);
 int skdsp_memcpy_d2d(void *dst_dev, const void *src_dev, int64_t bytes);
@@ -140,6 +152,10 @@ int skdsp_downsample_dev(const void *x_dev, int64_t n, int M, int p, int dtype, 
 /* Host-pointer entry points of a float32/complex64 handle deliver y as float64/complex128 (the
  * reference's result dtype, multirate_helper.py:108 etc.): widened on the device before the copy
  * back, so y must hold twice the bytes.  Device-pointer (_dev) entry points are not affected. */
+/* The chunk planner of the host-pointer entry points (long vectors are pipelined in chunks of 2^chunk_log2 samples that
+ * are exact continuations of each other): ranges of chunk k.  Host-only, for tests and for callers who stream themselves. */
+int skdsp_host_chunk_plan(int64_t n, int L, int M, int64_t hist, int chunk_log2, int64_t k, int64_t *nchunks, int64_t *in_begin,
+                          int64_t *in_end, int64_t *in_hist, int64_t *out_begin, int64_t *out_end);
 int skdsp_set_wide_output(skdsp_handle h, int on);
 int skdsp_destroy(skdsp_handle h);
 

@@ -11,6 +11,10 @@
 #include <array>
 #include <algorithm>
 #include <cmath>
+#include <thread>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 
 namespace skdsp {
 
@@ -33,10 +37,20 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
     return SKDSP_ERR_HIP;
 }
 
-Context &ctx()
+static Context g_slots[kMaxSlots];
+static int g_nslots = 0;            // bound slots; slot 0 is bound by the first call that needs a device
+static std::mutex g_slots_mu;
+static thread_local int t_slot = 0;
+
+Context &ctx() { return g_slots[t_slot]; }
+Context &ctx_of(int slot) { return g_slots[slot]; }
+int slot_count() { return g_nslots; }
+int select_slot(int slot)
 {
-    static Context c;
-    return c;
+    SK_CHECK(slot >= 0 && slot < kMaxSlots && g_slots[slot].ready, SKDSP_ERR_BADARG, "select_slot: slot %d is not bound", slot);
+    t_slot = slot;
+    SK_HIP(hipSetDevice(g_slots[slot].device));
+    return SKDSP_OK;
 }
 
 // ---- options: environment read once, skdsp_set_option afterwards ----------------------------
@@ -44,14 +58,14 @@ namespace {
 struct OptEntry { const char *name; int Options::*field; };
 const OptEntry kOptTable[] = {
     {"device", &Options::device}, {"fir_algo", &Options::fir_algo}, {"dn_no_ols", &Options::dn_no_ols},
-    {"fir_mm", &Options::fir_mm}, {"fir_bx", &Options::fir_bx}, {"fir_no_sw", &Options::fir_no_sw},
+    {"fir_mm", &Options::fir_mm}, {"fir_bx", &Options::fir_bx}, {"fir_no_sw", &Options::fir_no_sw}, {"bx_even_odd", &Options::bx_even_odd},
     {"sw_no_tile", &Options::sw_no_tile}, {"sw_no_lpt", &Options::sw_no_lpt}, {"mm_ns", &Options::mm_ns},
     {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
     {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"shard_no_overlap", &Options::shard_no_overlap},
     {"shard_reserve", &Options::shard_reserve}, {"shard_two_launches", &Options::shard_two_launches},
     {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
-    {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline},
+    {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline}, {"host_multi_slot", &Options::host_multi_slot},
 };
 int parse_opt(const char *name, const char *v)
 {
@@ -88,7 +102,7 @@ static int init_locked(int device)
     Context &c = ctx();
     if (c.ready) {
         SK_CHECK(device < 0 || device == c.device, SKDSP_ERR_BADARG,
-                 "skdsp_init: already bound to device %d (one GPU per process)", c.device);
+                 "skdsp_init: slot %d is already bound to device %d", c.slot, c.device);
         return SKDSP_OK;
     }
     int ndev = 0;
@@ -109,14 +123,23 @@ static int init_locked(int device)
     SK_HIP(hipEventCreate(&c.ev_start));
     SK_HIP(hipEventCreate(&c.ev_stop));
     c.device = device;
+    c.slot = t_slot;
     c.ready = true;
+    {
+        std::lock_guard<std::mutex> lk(g_slots_mu);
+        if (g_nslots < t_slot + 1) g_nslots = t_slot + 1;
+    }
     return SKDSP_OK;
 }
 
 int ensure_init()
 {
     Context &c = ctx();
-    if (c.ready) return SKDSP_OK;
+    if (c.ready) {
+        // several slots: make sure this thread's HIP device is the slot's (threads start on device 0)
+        if (g_nslots > 1) SK_HIP(hipSetDevice(c.device));
+        return SKDSP_OK;
+    }
     std::lock_guard<std::mutex> lk(c.mu);
     return init_locked(opt().device);
 }
@@ -211,6 +234,263 @@ static int stage_out(void *y_host, const void *y_dev, size_t bytes, const Handle
     }
     if (bytes) SK_HIP(hipMemcpyAsync(y_host, y_dev, bytes, hipMemcpyDeviceToHost, ctx().stream));
     SK_HIP(hipStreamSynchronize(ctx().stream));
+    return SKDSP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Host-pointer entry points on LONG vectors: chunk pipeline.
+//
+// The reference call hands over a NumPy array and expects one back (multirate_helper.py:104-127, 169-192), so the
+// drop-in path crosses PCIe twice: 2 x 2.4 ms per 128 MiB against 0.06 ms of kernel.  Staging the whole vector,
+// filtering it and copying it back one after the other leaves each PCIe direction idle half of the time.  Here the
+// vector is cut into chunks of 2^host_chunk_log2 samples that are exact continuations of each other (FIR: the chunk's
+// copy starts Ntaps-1 samples early and the kernel gets them as n_hist; IIR: zi / zf), and three things run at once:
+//   the caller's thread   H2D of chunk k+1 (pageable source: the runtime's own staging runs at the link rate) and the
+//                         launches of chunk k (compute stream waits for the copy's event)
+//   a helper thread       D2H of chunk k-1 into the caller's result array (the other direction of the link)
+// with two device buffers per direction.  With several slots bound (skdsp_init_devices: one per GPU) the chunks of a FIR
+// are dealt to all of them -- each slot runs this pipeline over a contiguous range of chunks from its own worker thread
+// and over its own PCIe link; the history of a range's first chunk comes from the host vector like any other chunk's,
+// so the GPUs exchange nothing.
+struct HostPipe {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t in_ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    void *din[2] = {nullptr, nullptr}, *dout[2] = {nullptr, nullptr};
+    size_t cap_in = 0, cap_out = 0;
+};
+
+static void pipe_free(Context &c)
+{
+    HostPipe *p = c.pipe;
+    if (!p) return;
+    for (int i = 0; i < 2; ++i) {
+        if (p->din[i]) (void)hipFree(p->din[i]);
+        if (p->dout[i]) (void)hipFree(p->dout[i]);
+        if (p->in_ready[i]) (void)hipEventDestroy(p->in_ready[i]);
+        if (p->done[i]) (void)hipEventDestroy(p->done[i]);
+    }
+    if (p->s_in) (void)hipStreamDestroy(p->s_in);
+    if (p->s_out) (void)hipStreamDestroy(p->s_out);
+    delete p;
+    c.pipe = nullptr;
+}
+
+static int pipe_ensure(Context &c, size_t in_bytes, size_t out_bytes)
+{
+    if (!c.pipe) {
+        HostPipe *p = new HostPipe();
+        c.pipe = p;
+        SK_HIP(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+        SK_HIP(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            SK_HIP(hipEventCreateWithFlags(&p->in_ready[i], hipEventDisableTiming));
+            SK_HIP(hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming));
+        }
+    }
+    HostPipe *p = c.pipe;
+    if (in_bytes > p->cap_in) {
+        SK_HIP(hipStreamSynchronize(c.stream));
+        for (int i = 0; i < 2; ++i) {
+            if (p->din[i]) SK_HIP(hipFree(p->din[i]));
+            p->din[i] = nullptr;
+        }
+        p->cap_in = 0;
+        for (int i = 0; i < 2; ++i) SK_HIP(hipMalloc(&p->din[i], in_bytes));
+        p->cap_in = in_bytes;
+    }
+    if (out_bytes > p->cap_out) {
+        SK_HIP(hipStreamSynchronize(c.stream));
+        for (int i = 0; i < 2; ++i) {
+            if (p->dout[i]) SK_HIP(hipFree(p->dout[i]));
+            p->dout[i] = nullptr;
+        }
+        p->cap_out = 0;
+        for (int i = 0; i < 2; ++i) SK_HIP(hipMalloc(&p->dout[i], out_bytes));
+        p->cap_out = out_bytes;
+    }
+    return SKDSP_OK;
+}
+
+// how a long vector is cut: chunk k covers inputs [k C, min((k+1) C, n)) and outputs [(k C L) / M, (end L) / M)
+struct ChunkPlan {
+    int64_t n = 0, C = 0, nchunks = 0, hist = 0;
+    int L = 1, M = 1;
+    size_t esz = 0;       // bytes per input / output sample on the device
+    bool wide = false;    // results leave as float64 / complex128 (twice esz on the host side)
+    int64_t in_begin(int64_t k) const { return k * C; }
+    int64_t in_end(int64_t k) const { return std::min<int64_t>((k + 1) * C, n); }
+    int64_t hist_of(int64_t k) const { return std::min<int64_t>(hist, k * C); }
+    int64_t out_begin(int64_t k) const { return (in_begin(k) * L) / M; }
+    int64_t out_end(int64_t k) const { return k + 1 == nchunks ? (n * L) / M : (in_end(k) * L) / M; }
+};
+
+// the planner (also exported for the CPU tests: skdsp_host_chunk_plan)
+static ChunkPlan plan_chunks(int64_t n, int L, int M, int64_t hist, size_t esz, bool wide, int chunk_log2)
+{
+    ChunkPlan p;
+    p.n = n; p.L = L; p.M = M; p.hist = hist; p.esz = esz; p.wide = wide;
+    int64_t C = (int64_t)1 << std::max(10, std::min(chunk_log2, 30));
+    C = std::max<int64_t>(C / M, 1) * M;       // chunk starts stay multiples of M: output phase 0 stays aligned
+    if (C < hist) C = ((hist + M - 1) / M) * M;  // (keeps the staging buffers within twice a chunk)
+    p.C = C;
+    p.nchunks = std::max<int64_t>((n + C - 1) / C, 1);
+    return p;
+}
+
+typedef int (*chunk_kernel_fn)(void *self, const void *x_dev, int64_t n_k, int64_t n_hist, void *y_dev, int64_t k);
+
+// chunks [k0, k1) of the plan on the CURRENT slot; x / y: the caller's whole host vectors
+static int run_pipeline(const ChunkPlan &p, int64_t k0, int64_t k1, const char *x, char *y, chunk_kernel_fn kern, void *self)
+{
+    Context &c = ctx();
+    if (k1 <= k0) return SKDSP_OK;
+    const size_t esz = p.esz, esz_out = p.wide ? 2 * esz : esz;
+    const size_t in_cap = (size_t)(p.C + p.hist) * esz + kHeadroomBytes + 512;
+    const size_t out_cap = (size_t)((p.C * p.L) / p.M + 2) * esz_out + 512;
+    int rc = pipe_ensure(c, in_cap, out_cap);
+    if (rc) return rc;
+    HostPipe *hp = c.pipe;
+    void *narrow = nullptr;
+    if (p.wide && (rc = ws_reserve(1, (size_t)((p.C * p.L) / p.M + 2) * esz + 256, &narrow))) return rc;
+
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t posted = k0, drained = k0;   // chunks handed to / finished by the copy-back thread
+    bool abort_flag = false;
+    int helper_rc = SKDSP_OK;
+    char helper_err[256] = "";
+    const int device = c.device;
+    std::thread helper([&]() {
+        if (hipSetDevice(device) != hipSuccess) {
+            std::lock_guard<std::mutex> lk(mu);
+            helper_rc = SKDSP_ERR_HIP;
+            snprintf(helper_err, sizeof(helper_err), "host pipeline: hipSetDevice(%d) failed in the copy-back thread", device);
+            drained = k1;
+            cv.notify_all();
+            return;
+        }
+        for (int64_t k = k0; k < k1; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return posted > k || abort_flag; });
+                if (abort_flag && posted <= k) break;
+            }
+            const int b = (int)((k - k0) & 1);
+            const size_t bytes = (size_t)(p.out_end(k) - p.out_begin(k)) * esz_out;
+            hipError_t e = hipEventSynchronize(hp->done[b]);
+            if (e == hipSuccess && bytes)
+                e = hipMemcpyAsync(y + (size_t)p.out_begin(k) * esz_out, hp->dout[b], bytes, hipMemcpyDeviceToHost, hp->s_out);
+            if (e == hipSuccess) e = hipStreamSynchronize(hp->s_out);
+            std::lock_guard<std::mutex> lk(mu);
+            if (e != hipSuccess && helper_rc == SKDSP_OK) {
+                helper_rc = SKDSP_ERR_HIP;
+                snprintf(helper_err, sizeof(helper_err), "host pipeline: copy back of chunk %lld failed: %s", (long long)k, hipGetErrorString(e));
+            }
+            drained = k + 1;
+            cv.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        drained = k1;
+        cv.notify_all();
+    });
+
+    auto body = [&]() -> int {
+        for (int64_t k = k0; k < k1; ++k) {
+            const int b = (int)((k - k0) & 1);
+            const int64_t hk = p.hist_of(k), ib = p.in_begin(k), nk = p.in_end(k) - ib;
+            // din[b] was last read by the kernels of chunk k-2; dout[b] was last read by the copy back of chunk k-2
+            if (k - k0 >= 2) {
+                SK_HIP(hipEventSynchronize(hp->done[b]));
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return drained >= k - 1 || helper_rc != SKDSP_OK; });
+                if (helper_rc != SKDSP_OK) return helper_rc;
+            }
+            char *xd = (char *)hp->din[b] + kHeadroomBytes + (size_t)p.hist * esz;
+            xd = (char *)(((uintptr_t)xd + 255) & ~(uintptr_t)255);   // x[0] of the chunk 256-byte aligned, history in front of it
+            SK_HIP(hipMemcpyAsync(xd - (size_t)hk * esz, x + (size_t)(ib - hk) * esz, (size_t)(nk + hk) * esz, hipMemcpyHostToDevice, hp->s_in));
+            SK_HIP(hipEventRecord(hp->in_ready[b], hp->s_in));
+            SK_HIP(hipStreamWaitEvent(c.stream, hp->in_ready[b], 0));
+            const int64_t n_out = p.out_end(k) - p.out_begin(k);
+            void *yd = p.wide ? narrow : hp->dout[b];
+            int r = kern(self, xd, nk, hk, yd, k);
+            if (r) return r;
+            if (p.wide && n_out > 0 && (r = widen_launch(narrow, (int64_t)((size_t)n_out * esz / 4), hp->dout[b], c.stream))) return r;
+            SK_HIP(hipEventRecord(hp->done[b], c.stream));
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                posted = k + 1;
+            }
+            cv.notify_all();
+        }
+        return SKDSP_OK;
+    };
+    rc = body();
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc) abort_flag = true;
+    }
+    cv.notify_all();
+    helper.join();
+    (void)hipStreamSynchronize(c.stream);
+    if (rc) return rc;
+    if (helper_rc) {
+        set_error("%s", helper_err);
+        return helper_rc;
+    }
+    return SKDSP_OK;
+}
+
+// Deal the chunks of a plan to every bound slot (contiguous ranges); make_self(slot) gives the per-slot kernel argument
+// (the handle's clone on that slot).  One worker thread per extra slot; the caller's thread serves its own slot.
+static int run_on_slots(const ChunkPlan &p, const char *x, char *y, chunk_kernel_fn kern, void *(*make_self)(void *, int), void *base_self,
+                        bool allow_multi)
+{
+    const int home = ctx().slot;
+    int nslots = allow_multi && opt().host_multi_slot ? slot_count() : 1;
+    if (nslots > p.nchunks) nslots = (int)p.nchunks;
+    if (nslots <= 1) return run_pipeline(p, 0, p.nchunks, x, y, kern, base_self);
+    std::vector<void *> selfs((size_t)nslots, nullptr);
+    std::vector<int> slots;
+    slots.push_back(home);
+    for (int s = 0; s < slot_count() && (int)slots.size() < nslots; ++s)
+        if (s != home && ctx_of(s).ready) slots.push_back(s);
+    nslots = (int)slots.size();
+    for (int i = 0; i < nslots; ++i) {
+        selfs[i] = make_self(base_self, slots[i]);
+        if (!selfs[i]) return SKDSP_ERR_NOMEM;
+    }
+    std::vector<int> rcs((size_t)nslots, SKDSP_OK);
+    std::vector<std::string> errs((size_t)nslots);
+    std::vector<std::thread> workers;
+    auto range = [&](int i, int64_t &a, int64_t &b) {
+        a = p.nchunks * i / nslots;
+        b = p.nchunks * (i + 1) / nslots;
+    };
+    for (int i = 1; i < nslots; ++i) {
+        workers.emplace_back([&, i]() {
+            int r = select_slot(slots[i]);
+            if (!r) {
+                std::lock_guard<std::mutex> lk(ctx().mu);   // the slot's own lock: other callers' workers wait here
+                int64_t a, b;
+                range(i, a, b);
+                r = run_pipeline(p, a, b, x, y, kern, selfs[i]);
+            }
+            rcs[i] = r;
+            if (r) errs[i] = skdsp_last_error();
+        });
+    }
+    {
+        int64_t a, b;
+        range(0, a, b);
+        rcs[0] = run_pipeline(p, a, b, x, y, kern, selfs[0]);
+    }
+    for (auto &w : workers) w.join();
+    for (int i = 0; i < nslots; ++i)
+        if (rcs[i]) {
+            if (i > 0) set_error("%s", errs[i].c_str());
+            return rcs[i];
+        }
     return SKDSP_OK;
 }
 
@@ -500,12 +780,13 @@ int skdsp_init(int device)
     return init_locked(device);
 }
 
-int skdsp_shutdown(void)
+static int shutdown_slot(Context &c)
 {
-    Context &c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
     if (!c.ready) return SKDSP_OK;
+    (void)hipSetDevice(c.device);
     (void)hipStreamSynchronize(c.stream);
+    pipe_free(c);
     for (int i = 0; i < 4; ++i) {
         if (c.ws[i]) (void)hipFree(c.ws[i]);
         c.ws[i] = nullptr;
@@ -527,6 +808,47 @@ int skdsp_shutdown(void)
     (void)hipStreamDestroy(c.stream);
     c.ready = false;
     c.device = -1;
+    return SKDSP_OK;
+}
+
+int skdsp_shutdown(void)
+{
+    for (int s = kMaxSlots - 1; s >= 0; --s) (void)shutdown_slot(ctx_of(s));
+    std::lock_guard<std::mutex> lk(g_slots_mu);
+    g_nslots = 0;
+    return SKDSP_OK;
+}
+
+int skdsp_init_devices(const int *devices, int ndev)
+{
+    SK_CHECK(devices && ndev >= 1 && ndev <= kMaxSlots, SKDSP_ERR_BADARG, "init_devices: 1..%d devices", kMaxSlots);
+    const int home = t_slot;
+    int rc = SKDSP_OK;
+    for (int s = 0; s < ndev && !rc; ++s) {
+        t_slot = s;
+        std::lock_guard<std::mutex> lk(ctx().mu);
+        rc = init_locked(devices[s]);
+    }
+    t_slot = home;
+    if (!rc && ctx().ready) SK_HIP(hipSetDevice(ctx().device));
+    return rc;
+}
+
+int skdsp_slot_count(void) { return slot_count(); }
+
+// the chunk planner of the host pipeline, exported for tests: chunk k of (n, L, M, hist) -> input / output ranges
+int skdsp_host_chunk_plan(int64_t n, int L, int M, int64_t hist, int chunk_log2, int64_t k, int64_t *nchunks, int64_t *in_begin,
+                          int64_t *in_end, int64_t *in_hist, int64_t *out_begin, int64_t *out_end)
+{
+    SK_CHECK(n >= 0 && L >= 1 && M >= 1 && hist >= 0, SKDSP_ERR_BADARG, "host_chunk_plan: bad arguments");
+    const ChunkPlan p = plan_chunks(n, L, M, hist, 1, false, chunk_log2);
+    if (nchunks) *nchunks = p.nchunks;
+    SK_CHECK(k >= 0 && k < p.nchunks, SKDSP_ERR_BADARG, "host_chunk_plan: chunk %lld of %lld", (long long)k, (long long)p.nchunks);
+    if (in_begin) *in_begin = p.in_begin(k);
+    if (in_end) *in_end = p.in_end(k);
+    if (in_hist) *in_hist = p.hist_of(k);
+    if (out_begin) *out_begin = p.out_begin(k);
+    if (out_end) *out_end = p.out_end(k);
     return SKDSP_OK;
 }
 
@@ -568,6 +890,19 @@ int skdsp_free(void *dptr)
         SK_HIP(hipStreamSynchronize(ctx().stream));
         SK_HIP(hipFree(dptr));
     }
+    return SKDSP_OK;
+}
+// page-locked host memory for result arrays (the Python layer recycles these blocks: _ffi.PinnedPool)
+int skdsp_host_alloc(void **hptr, int64_t bytes)
+{
+    API_BEGIN;
+    SK_CHECK(hptr && bytes > 0, SKDSP_ERR_BADARG, "host_alloc: bad arguments");
+    SK_HIP(hipHostMalloc(hptr, (size_t)bytes, hipHostMallocPortable));
+    return SKDSP_OK;
+}
+int skdsp_host_free(void *hptr)
+{
+    if (hptr) SK_HIP(hipHostFree(hptr));
     return SKDSP_OK;
 }
 int skdsp_memcpy_h2d(void *dst, const void *src, int64_t bytes)
@@ -702,6 +1037,37 @@ int skdsp_fir_updn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int64_t n_
     return fir_direct_launch(h, x_dev, n, n_hist, L, M, (n * L) / M, y_dev, ctx().stream);
 }
 
+// one chunk of a long host vector (run_pipeline): the same launch as the single-shot path, with the chunk's history
+struct FirChunkJob {
+    FirHandle *h;
+    int mode, L, M;
+};
+static int fir_chunk_kernel(void *self, const void *x_dev, int64_t n_k, int64_t n_hist, void *y_dev, int64_t)
+{
+    const FirChunkJob *j = static_cast<const FirChunkJob *>(self);
+    if (j->mode == 0) return fir_filter_any(j->h, x_dev, n_k, n_hist, y_dev);
+    if (j->L == 1) return fir_dn_any(j->h, x_dev, n_k, n_hist, j->M, y_dev);
+    return fir_direct_launch(j->h, x_dev, n_k, n_hist, j->L, j->M, (n_k * j->L) / j->M, y_dev, ctx().stream);
+}
+// the job on another slot: same filter, tables on that slot's device (clone made once, owned by the handle)
+static void *fir_job_on_slot(void *base, int slot)
+{
+    FirChunkJob *j = static_cast<FirChunkJob *>(base);
+    if (slot == j->h->slot) return j;
+    FirHandle *h = j->h;
+    if ((int)h->clones.size() < kMaxSlots) h->clones.resize(kMaxSlots, nullptr);
+    if (!h->clones[slot]) {
+        FirHandle *c = new FirHandle();
+        c->kind = H_FIR; c->dtype = h->dtype; c->slot = slot; c->ntaps = h->ntaps; c->taps_complex = h->taps_complex;
+        c->algo = h->algo; c->taps_host = h->taps_host; c->wide_out = h->wide_out;
+        h->clones[slot] = c;
+    }
+    static thread_local std::vector<std::unique_ptr<FirChunkJob>> keep;  // lives until the caller's next multi-slot call
+    if (keep.size() > 64) keep.clear();
+    keep.emplace_back(new FirChunkJob{static_cast<FirHandle *>(h->clones[slot]), j->mode, j->L, j->M});
+    return keep.back().get();
+}
+
 static int fir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M, int mode, void *y)
 {
     API_BEGIN;
@@ -713,6 +1079,14 @@ static int fir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M
     if (n_out == 0) return SKDSP_OK;
     SK_CHECK(x && y, SKDSP_ERR_BADARG, "fir: null buffer");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (opt().host_pipeline && n > (((int64_t)3 << opt().host_chunk_log2) >> 1)) {
+        // long vector: chunk pipeline (and every bound slot); exact by construction (n_hist)
+        const int64_t hist = L > 1 ? (h->ntaps - 1 + L - 1) / L : h->ntaps - 1;
+        const ChunkPlan p = plan_chunks(n, mode == 0 ? 1 : L, mode == 0 ? 1 : M, hist, esz, h->wide_out && !dtype_double(h->dtype),
+                                        opt().host_chunk_log2);
+        FirChunkJob job{h, mode, L, M};
+        return run_on_slots(p, (const char *)x, (char *)y, fir_chunk_kernel, fir_job_on_slot, &job, true);
+    }
     void *x_dev = nullptr, *y_dev = nullptr;
     int rc = stage_in(x, (size_t)n * esz, &x_dev);
     if (rc) return rc;
@@ -886,6 +1260,20 @@ int skdsp_iir_dn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int M, void 
     return iir_dn_any(h, x_dev, n, M, y_dev);
 }
 
+struct IirChunkJob {
+    IirHandle *h;
+    std::vector<double> state;  // state after the previous chunk, in the caller-visible (scipy zi) convention
+};
+static int iir_chunk_kernel(void *self, const void *x_dev, int64_t n_k, int64_t, void *y_dev, int64_t k)
+{
+    IirChunkJob *j = static_cast<IirChunkJob *>(self);
+    std::vector<double> zf(j->state.size());
+    int rc = iir_any_dev(j->h, x_dev, n_k, y_dev, k == 0 ? nullptr : j->state.data(), zf.data());
+    j->state.swap(zf);
+    return rc;
+}
+static void *iir_job_on_slot(void *base, int) { return base; }
+
 static int iir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M, void *y)
 {
     API_BEGIN;
@@ -897,6 +1285,14 @@ static int iir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M
     if (n_out == 0) return SKDSP_OK;  // fewer than M samples: nothing to deliver (y may be NULL)
     SK_CHECK(x && y, SKDSP_ERR_BADARG, "iir: null buffer");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (L == 1 && M == 1 && opt().host_pipeline && n > (((int64_t)3 << opt().host_chunk_log2) >> 1)) {
+        // long vector: chunk pipeline on the caller's slot, the recursion carried from chunk to chunk as zi / zf
+        const ChunkPlan p = plan_chunks(n, 1, 1, 0, esz, h->wide_out && !dtype_double(h->dtype), opt().host_chunk_log2);
+        IirChunkJob job;
+        job.h = h;
+        job.state.assign((size_t)(dtype_complex(h->dtype) ? 2 : 1) * h->nsec * h->order, 0.0);
+        return run_on_slots(p, (const char *)x, (char *)y, iir_chunk_kernel, iir_job_on_slot, &job, false);
+    }
     void *x_dev = nullptr, *y_dev = nullptr;
     int rc = stage_in(x, (size_t)n * esz, &x_dev);
     if (rc) return rc;

@@ -44,6 +44,14 @@ struct BxArgs {
     int U0;    // lag offset
     int NS;    // columns per workgroup (multiple of 16)
     int win;   // staged samples per workgroup (multiple of 8) >= q_ds * (NS - 1) + 32 KB
+    // 1: a tile takes every second column of a 32-column span (tile 2 h: the even, 2 h + 1: the odd ones), in the row
+    // order 0-3 -> 0-3, 12-15 -> 4-7, 4-11 -> 8-15 of the 16 taken.  Lane (row r, group j) reads the 16-byte unit
+    // s col(r) + j + 4 kb of a plane (s = q_ds / 8 units per column), and ds_read_b128 serves the lanes in groups
+    // {rows 0-3, 12-15 of group j} + {rows 4-11 of group j + 1}.  With 16 CONSECUTIVE columns an odd s makes two of
+    // those 16 units share a bank whatever the row order (the two row sets must hit the same eight residues of
+    // s col mod 16 shifted by one): 2-way conflicts on a third of the reads, 42 % of the LDS cycles of L/M = 4/3
+    // (s = 3).  With every second column both row sets hit the eight EVEN (odd) residues exactly once: none.
+    int eo;
 };
 
 // (a, b) -> three packed bf16 pairs, a in the low half: a = a1 + a2 + a3 exactly (24 = 3 x 8 mantissa bits)
@@ -173,9 +181,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (; wdx < nwin; wdx += gridDim.x) {
         const int64_t S0 = wdx * a.NS;  // first column of this window
         v4f_bx big[RT][C], small[RT][C];
+        // column (within the window) of tile ct, tile row r
+        auto col_of = [&](int ct, int r) -> int {
+            if (!a.eo) return ct * 16 + r;
+            const int mu = r < 4 ? r : (r >= 12 ? r - 8 : r + 4);
+            return 32 * (ct >> 1) + 2 * mu + (ct & 1);
+        };
         auto mma_tile = [&](int ct) __attribute__((always_inline)) {
             // window element of (column n, block kb, group j, i): q_ds n + 32 kb + 8 j + i
-            const char *bbase = bx_smem + ((size_t)a.q_ds * (ct * 16 + ncol) + 8 * j) * 2;
+            const char *bbase = bx_smem + ((size_t)a.q_ds * col_of(ct, ncol) + 8 * j) * 2;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -223,7 +237,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // The window fragment is the A operand and the taps are B, so the tile comes out transposed: lane
             // (r = lane & 15, j) holds row 16 rt + r of the four columns 4 j + i -- the 16 lanes of a group write
             // 16 consecutive outputs (128 bytes of complex64) per store instead of 16-byte pieces 32 bytes apart.
-            const int64_t m_base = (int64_t)a.RS * (S0 + ct * 16 + 4 * j) + ncol;   // output of (row tile 0, i = 0)
+            // (the four columns of a lane are consecutive tile rows 4 j + i: consecutive columns, or every second one)
+            const int cstep = a.eo ? 2 * a.RS : a.RS;
+            const int64_t m_base = (int64_t)a.RS * (S0 + col_of(ct, 4 * j)) + ncol;   // output of (row tile 0, i = 0)
             float *yb = y + m_base * C;
             const int64_t left = a.n_out - m_base;
             const int rem = left > (int64_t)0x7fffffff ? 0x7fffffff : (left < 0 ? 0 : (int)left);
@@ -238,17 +254,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (big[0][0][0] != 12345.678f) return;
 #endif
             // whole tile inside the output and all 16 RT rows in use (uniform): no per-store guards
-            if ((a.RS & 15) == 0 && (int64_t)a.RS * (S0 + ct * 16 + 16) <= a.n_out) {
+            if ((a.RS & 15) == 0 && (int64_t)a.RS * (S0 + (a.eo ? 32 * (ct >> 1) + 32 : ct * 16 + 16)) <= a.n_out) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) put(rt, i, i * a.RS + 16 * rt);
+                    for (int i = 0; i < 4; ++i) put(rt, i, i * cstep + 16 * rt);
             } else {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int off = i * a.RS + 16 * rt;
+                        const int off = i * cstep + 16 * rt;
                         if (16 * rt + ncol < a.RS && off < rem) put(rt, i, off);
                     }
             }
@@ -432,6 +448,7 @@ int fir_bx_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L,
     a.NS = bx_columns(t, cplx ? 2 : 1, n_out);
     SK_CHECK(a.NS > 0, SKDSP_ERR_UNSUPPORTED, "fir_bx: window does not fit LDS (L=%d M=%d)", L, M);
     a.win = ((a.q_ds * (a.NS - 1) + 32 * t->KB) + 7) / 8 * 8;
+    a.eo = ((a.q_ds / 8) & 1) && a.NS % 32 == 0 && opt().bx_even_odd ? 1 : 0;
     const size_t lds = (size_t)(cplx ? 6 : 3) * (a.win * 2 + 16);  // (+ a dump row per plane)
     const int64_t ncols = (n_out + a.RS - 1) / a.RS;
     const int64_t nwin = (ncols + a.NS - 1) / a.NS;

@@ -37,6 +37,7 @@ struct Options {
     int dn_no_ols = 0;        // .dn never through the overlap-save decimating store
     int fir_mm = 1;           // 0: no matrix-pipe FIR kernels at all (register sliding-window kernels instead)
     int fir_bx = 1;           // 0: no bf16x3 matrix-pipe kernel (FP32 matrix pipe instead)
+    int bx_even_odd = 1;      // 0: fir_bx tiles of 16 consecutive columns also for odd column strides (bank conflicts; A/B switch)
     int fir_no_sw = 0;        // skip the register sliding-window kernel (generic polyphase fallback)
     int sw_no_tile = 0, sw_no_lpt = 0;
     int mm_ns = 256;          // column blocks per workgroup of fir_mm_kernel
@@ -53,15 +54,24 @@ struct Options {
     int shard_two_launches = 0; // sharded FIR: tile 0 as its own launch behind the halo event (instead of the in-kernel flag wait)
     int shard_self_halo = 0;    // test hook: a 1-rank communicator sends its tail to ITSELF (exercises the whole halo path on one GPU)
     int dist_force_comm = 0;  // build an RCCL communicator for a 1-rank job too (exercises the plumbing on one GPU)
-    int host_chunk_log2 = 24; // host-pointer entry points: samples per pipelined chunk (pinned double buffers)
+    int host_chunk_log2 = 22; // host-pointer entry points: samples per pipelined chunk (pinned double buffers)
     int host_pipeline = 1;    // 0: single staged copy in / kernel / copy out
+    int host_multi_slot = 1;  // 0: host-pointer FIR calls stay on the caller's slot even when several are bound
 };
 Options &opt();
 
 // ------------------------------------------------------------------ context
+// One Context per SLOT: a (device, stream, workspaces) binding.  Slot 0 is what every caller thread uses (skdsp_init);
+// skdsp_init_devices binds further slots -- one per GPU of the node, or several on one GPU -- which the host-pointer
+// entry points use from their own worker threads to spread a long host vector over all of them.  Each slot has its own
+// lock: calls that run on different slots do not serialise each other.
+constexpr int kMaxSlots = 16;
+struct HostPipe;  // capi.hip: pinned-free chunk pipeline state (streams, events, double buffers)
 struct Context {
     bool ready = false;
+    int slot = 0;
     int device = -1;
+    HostPipe *pipe = nullptr;
     int num_cus = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -75,7 +85,10 @@ struct Context {
     size_t ws_bytes[4] = {0, 0, 0, 0};
     std::mutex mu;
 };
-Context &ctx();
+Context &ctx();               // the calling thread's current slot (slot 0 unless a library worker selected another)
+Context &ctx_of(int slot);
+int slot_count();             // bound slots (0 before the first init)
+int select_slot(int slot);    // thread-local: subsequent ctx() / launches of this thread use that slot (and its device)
 int ensure_init();
 int ws_reserve(int slot, size_t bytes, void **out);  // grow-only workspace slot 0..3
 
@@ -94,9 +107,14 @@ enum HandleKind { H_FIR = 1, H_IIR = 2 };
 struct HandleBase {
     int kind;
     int dtype;
+    int slot = 0;           // slot whose device holds this handle's tables
+    std::vector<HandleBase *> clones;  // same filter on the other slots, made on demand by the multi-slot host path (owned)
     bool wide_out = false;  // host-pointer entry points deliver float64/complex128 (skdsp_set_wide_output)
     std::mutex mu;
-    virtual ~HandleBase() {}
+    virtual ~HandleBase()
+    {
+        for (HandleBase *c : clones) delete c;
+    }
 };
 
 // ---- FIR -----------------------------------------------------------------

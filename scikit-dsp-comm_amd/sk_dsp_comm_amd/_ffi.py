@@ -23,8 +23,8 @@ _CODE_OF = {np.dtype(np.float32): F32, np.dtype(np.complex64): C64, np.dtype(np.
 # every symbol include/skdsp.h declares (tests check the built library exports all of them)
 SYMBOLS = [
     "skdsp_init", "skdsp_shutdown", "skdsp_device_count", "skdsp_device_info", "skdsp_last_error", "skdsp_version",
-    "skdsp_set_option", "skdsp_get_option",
-    "skdsp_malloc", "skdsp_free", "skdsp_memcpy_h2d", "skdsp_memcpy_d2h", "skdsp_memcpy_d2d", "skdsp_memset",
+    "skdsp_set_option", "skdsp_get_option", "skdsp_init_devices", "skdsp_slot_count", "skdsp_host_chunk_plan",
+    "skdsp_host_alloc", "skdsp_host_free", "skdsp_malloc", "skdsp_free", "skdsp_memcpy_h2d", "skdsp_memcpy_d2h", "skdsp_memcpy_d2d", "skdsp_memset",
     "skdsp_sync", "skdsp_timer_start", "skdsp_timer_stop", "skdsp_fill_noise_dev",
     "skdsp_fir_create", "skdsp_fir_set_algo", "skdsp_fir_get_algo", "skdsp_fir_filter", "skdsp_fir_filter_dev",
     "skdsp_fir_up", "skdsp_fir_up_dev", "skdsp_fir_dn", "skdsp_fir_dn_dev", "skdsp_fir_updn", "skdsp_fir_updn_dev",
@@ -65,9 +65,14 @@ def load():
         L.skdsp_last_error.restype = ctypes.c_char_p
         L.skdsp_version.restype = ctypes.c_char_p
         L.skdsp_init.argtypes = [ci]
+        L.skdsp_init_devices.argtypes = [ctypes.POINTER(ci), ci]
+        p64 = ctypes.POINTER(i64)
+        L.skdsp_host_chunk_plan.argtypes = [i64, ci, ci, i64, ci, i64, p64, p64, p64, p64, p64, p64]
         L.skdsp_set_option.argtypes = [ctypes.c_char_p, ci]
         L.skdsp_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ci)]
         L.skdsp_device_info.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(ci), ctypes.POINTER(i64), ctypes.POINTER(ci)]
+        L.skdsp_host_alloc.argtypes = [pvp, i64]
+        L.skdsp_host_free.argtypes = [vp]
         L.skdsp_malloc.argtypes = [pvp, i64]
         L.skdsp_free.argtypes = [vp]
         for f in (L.skdsp_memcpy_h2d, L.skdsp_memcpy_d2h, L.skdsp_memcpy_d2d):
@@ -127,10 +132,41 @@ def check(rc):
 
 
 def init(device=None):
+    """Bind this process: one GPU (default: SKDSP_DEVICE, else LOCAL_RANK, else 0), or -- when SKDSP_DEVICES is set to
+    "all" or a list like "0,1,2,3" and no launcher gave this process a rank -- one slot per listed GPU (init_devices)."""
     L = load()
     if device is None:
+        devs = os.environ.get("SKDSP_DEVICES")
+        if devs and "LOCAL_RANK" not in os.environ and "SKDSP_DEVICE" not in os.environ:
+            return init_devices(devs)
         device = int(os.environ.get("SKDSP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     check(L.skdsp_init(int(device)))
+
+
+def init_devices(devices="all"):
+    """One slot per GPU: the host-array FIR calls (multirate_FIR.filter / .up / .dn on long NumPy vectors) then use all
+    of them from one process.  devices: "all", "0,1,2" or a sequence of indices; returns the number of slots."""
+    L = load()
+    if isinstance(devices, str):
+        devices = list(range(L.skdsp_device_count())) if devices.strip().lower() == "all" else [int(v) for v in devices.split(",") if v.strip()]
+    devices = [int(d) for d in devices]
+    if not devices:
+        raise SkdspError("no HIP device available: the MI355X path has no CPU fallback")
+    arr = (ctypes.c_int * len(devices))(*devices)
+    check(L.skdsp_init_devices(arr, len(devices)))
+    return L.skdsp_slot_count()
+
+
+def host_chunk_plan(n, L=1, M=1, hist=0, chunk_log2=24):
+    """[(in_begin, in_end, in_hist, out_begin, out_end)] of every chunk the host-pointer entry points would use."""
+    lib = load()
+    v = [ctypes.c_int64(0) for _ in range(6)]
+    check(lib.skdsp_host_chunk_plan(int(n), int(L), int(M), int(hist), int(chunk_log2), 0, *[ctypes.byref(a) for a in v]))
+    out = []
+    for k in range(v[0].value):
+        check(lib.skdsp_host_chunk_plan(int(n), int(L), int(M), int(hist), int(chunk_log2), k, *[ctypes.byref(a) for a in v]))
+        out.append(tuple(a.value for a in v[1:]))
+    return out
 
 
 def set_option(name, value):
@@ -275,6 +311,79 @@ def _destroy(h):
 _WIDE = {np.dtype(np.float32): np.dtype(np.float64), np.dtype(np.complex64): np.dtype(np.complex128)}
 
 
+class _PinnedBlock:
+    """One page-locked block; exposes its bytes through __array_interface__ and goes back to the pool when the last
+    ndarray view of it dies."""
+
+    def __init__(self, pool, ptr, nbytes):
+        self.pool, self.ptr, self.nbytes = pool, ptr, nbytes
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            self.pool._give_back(self.ptr, self.nbytes)
+        except Exception:
+            pass
+
+
+class PinnedPool:
+    """Result arrays of long host-array calls come from recycled page-locked blocks.
+
+    A copy back into a fresh np.empty array pays for the population of its pages and their first device access
+    (31 ms per 512 MiB instead of 12, and another 26 ms when NumPy unmaps it again: tools/host_pipe_time.py); a
+    page-locked block receives the DMA at the link rate and is handed to the next call of the same size when its
+    array is garbage collected.  The arrays are ordinary writable ndarrays (their .base chain ends in the block).
+    max_bytes bounds what the pool keeps for reuse (blocks in use by live arrays are not counted); 0 switches it off."""
+
+    GRANULE = 2 << 20
+
+    def __init__(self, max_bytes=4 << 30, min_bytes=32 << 20):
+        self.max_bytes, self.min_bytes = int(max_bytes), int(min_bytes)
+        self._free = {}      # rounded size -> [ptr]
+        self._kept = 0
+        self._lock = threading.Lock()
+
+    def empty(self, count, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = int(count) * dtype.itemsize
+        if self.max_bytes <= 0 or nbytes < self.min_bytes:
+            return np.empty(count, dtype=dtype)
+        size = -(-nbytes // self.GRANULE) * self.GRANULE
+        with self._lock:
+            lst = self._free.get(size)
+            ptr = lst.pop() if lst else None
+            if ptr is not None:
+                self._kept -= size
+        if ptr is None:
+            p = ctypes.c_void_p(0)
+            try:
+                check(load().skdsp_host_alloc(ctypes.byref(p), size))
+            except Exception:
+                return np.empty(count, dtype=dtype)   # no page-locked memory left: an ordinary array
+            ptr = p.value
+        block = _PinnedBlock(self, ptr, size)
+        return np.asarray(block)[:nbytes].view(dtype)
+
+    def _give_back(self, ptr, size):
+        with self._lock:
+            if self._kept + size <= self.max_bytes:
+                self._free.setdefault(size, []).append(ptr)
+                self._kept += size
+                return
+        load().skdsp_host_free(ctypes.c_void_p(ptr))
+
+    def trim(self):
+        """Release every block the pool holds for reuse."""
+        with self._lock:
+            ptrs = [p for lst in self._free.values() for p in lst]
+            self._free, self._kept = {}, 0
+        for p in ptrs:
+            load().skdsp_host_free(ctypes.c_void_p(p))
+
+
+result_pool = PinnedPool(int(os.environ.get("SKDSP_PINNED_POOL_BYTES", str(4 << 30))))
+
+
 class _HostCalls:
     """Shared by FirKernel / IirKernel: output allocation for the host-pointer entry points.
     wide=True asks the library for float64/complex128 results from a float32/complex64 handle
@@ -287,7 +396,7 @@ class _HostCalls:
         if wide != self._wide_state:
             check(load().skdsp_set_wide_output(ctypes.c_void_p(self.h), int(wide)))
             self._wide_state = wide
-        return np.empty(count, dtype=_WIDE[dtype] if wide else dtype)
+        return result_pool.empty(count, _WIDE[dtype] if wide else dtype)
 
 
 class FirKernel(_HostCalls):

@@ -1,0 +1,104 @@
+"""Host-array (NumPy in / NumPy out) path on long vectors: chunk pipeline and multi-slot dealing (run with -m gpu).
+
+The reference call is one function call on one array (multirate_helper.py:104-127, 169-192).  Long arrays are cut into
+chunks that are exact continuations of each other and pipelined over PCIe; with several slots bound the chunks of a FIR are
+dealt to all of them.  Everything here must equal the single-shot path and the oracle; the one-GPU box binds two slots
+to the same GPU, which runs every line of the multi-GPU code except the second PCIe link."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from sk_dsp_comm_amd import _ffi, multirate_helper as mrh, config
+from oracle import oracle as orc
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    _ffi.init()
+    yield
+
+
+def cnoise(rng, n):
+    return ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2)).astype(np.complex64)
+
+
+@pytest.mark.parametrize("dt", [np.complex64, np.float32, np.float64])
+def test_pipelined_fir_equals_single_shot(dt):
+    """filter / up / dn / updn of a vector that spans many chunks (host_chunk_log2 = 16) against the same calls with the
+    pipeline off, and windows against the oracle: chunk boundaries are invisible."""
+    rng = np.random.default_rng(3)
+    n = 1_000_003
+    x = cnoise(rng, n) if dt == np.complex64 else rng.standard_normal(n).astype(dt)
+    b = rng.standard_normal(301) / 17
+    k = _ffi.FirKernel(b, _ffi.code_of(dt))
+    with _ffi.option("host_chunk_log2", 16):
+        got = [k.filter(x), k.up(x[:200_000], 3), k.dn(x, 5), k.updn(x[:300_001], 4, 3), k.filter(x, wide=True)]
+    with _ffi.option("host_pipeline", 0):
+        want = [k.filter(x), k.up(x[:200_000], 3), k.dn(x, 5), k.updn(x[:300_001], 4, 3), k.filter(x, wide=True)]
+    for g, w, name in zip(got, want, ("filter", "up", "dn", "updn", "filter wide")):
+        assert g.dtype == w.dtype and g.shape == w.shape
+        e_max, e_l2 = rel_err(g, w)
+        assert e_max <= (2e-6 if dt != np.float64 else 1e-12), (name, e_max)   # (algorithm choice may differ per chunk length)
+    s0 = 65536 * 7 - 500
+    ref = orc.fir_filter(b, x[s0 - 300:s0 + 3000])[300:]
+    assert max(rel_err(got[0][s0:s0 + 3000], ref)) <= (1e-6 if dt != np.float64 else 1e-11)
+    ref = orc.fir_dn(b, x[:400_000], 5)
+    assert max(rel_err(got[2][:80_000], ref)) <= (1e-6 if dt != np.float64 else 1e-11)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64, np.float64])
+def test_pipelined_iir_carries_state_across_chunks(dt):
+    from scipy import signal
+    import bench
+    sos = bench.elliptic_bpf_sos()
+    rng = np.random.default_rng(4)
+    n = 700_001
+    x = cnoise(rng, n) if dt == np.complex64 else rng.standard_normal(n).astype(dt)
+    f = mrh.multirate_IIR(sos)
+    with _ffi.option("host_chunk_log2", 16):
+        y = f.filter(x)
+    ref = signal.sosfilt(sos, x.astype(np.complex128 if dt == np.complex64 else np.float64))
+    assert max(rel_err(y, ref)) <= (1e-6 if dt != np.float64 else 1e-10)
+
+
+def test_two_slots_on_one_gpu_deal_the_chunks():
+    """skdsp_init_devices([0, 0]): two slots (streams, workspaces, handle clones, worker threads) on the one GPU of this
+    box.  The multi-slot FIR host call must equal the oracle; reference surface (multirate_FIR) with reference dtypes."""
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'scikit-dsp-comm_amd'))
+from sk_dsp_comm_amd import _ffi, multirate_helper as mrh
+from oracle import oracle as orc
+assert _ffi.init_devices([0, 0, 0]) == 3
+_ffi.set_option('host_chunk_log2', 17)
+rng = np.random.default_rng(9)
+n = 3_000_001
+x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2)).astype(np.complex64)
+b = np.hamming(1024) * np.sinc(0.2 * (np.arange(1024) - 511.5)) * 0.2
+f = mrh.multirate_FIR(b)
+for rep in range(3):
+    y = f.filter(x)
+assert y.dtype == np.complex128
+for s0 in (0, 131072 * 7 - 2000, 131072 * 11 + 5, n - 5000):
+    lo = max(s0 - 1023, 0)
+    ref = orc.fir_filter(b, x[lo:s0 + 5000])[s0 - lo:]
+    e = np.max(np.abs(y[s0:s0 + 5000] - ref)) / np.max(np.abs(ref))
+    assert e < 1e-6, (s0, e)
+_ffi.set_option('host_multi_slot', 0)
+y1 = f.filter(x)
+assert np.max(np.abs(y1 - y)) / np.max(np.abs(y)) < 1e-6
+yd = f.dn(x, 12); yu = f.up(x[:200000], 12)
+_ffi.set_option('host_multi_slot', 1)
+assert np.array_equal(f.dn(x, 12), yd) and np.array_equal(f.up(x[:200000], 12), yu)
+print('SLOTS_OK')
+""" % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert b"SLOTS_OK" in out.stdout, out.stdout.decode()[-3000:]

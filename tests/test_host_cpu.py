@@ -287,3 +287,22 @@ def test_bench_self_launch_reaches_the_device_layer():
     text = out.stdout.decode()
     assert out.returncode != 0
     assert "no HIP device available" in text and "must be launched" not in text, text[-2000:]
+
+
+@pytest.mark.parametrize("n,L,M,hist,lg", [(1_000_003, 1, 1, 1023, 16), (999_999, 1, 3, 511, 14), (300_001, 4, 3, 128, 12),
+                                              (70_000, 12, 1, 86, 11), (5, 1, 1, 1023, 10), (2 ** 20, 1, 12, 767, 16)])
+def test_host_chunk_planner(n, L, M, hist, lg):
+    """The chunk planner of the host-pointer pipeline (no GPU needed): chunks tile the input, chunk starts are multiples
+    of M (output phase 0 stays aligned), each chunk reaches back `hist` samples (less at the start of the vector), the
+    output ranges tile [0, floor(n L / M)) and equal the outputs whose newest input lies in the chunk."""
+    from sk_dsp_comm_amd import _ffi
+    plan = _ffi.host_chunk_plan(n, L, M, hist, lg)
+    assert plan[0][0] == 0 and plan[-1][1] == n and plan[0][3] == 0 and plan[-1][4] == (n * L) // M
+    for k, (ib, ie, ih, ob, oe) in enumerate(plan):
+        assert ib % M == 0 and ie > ib and ih == min(hist, ib)
+        if k:
+            assert ib == plan[k - 1][1] and ob == plan[k - 1][4]
+        assert ob == (ib * L) // M and (oe == (ie * L) // M or k == len(plan) - 1)
+        # output m = needs inputs up to floor(m M / L): inside this chunk for every m of the range
+        if oe > ob:
+            assert ib <= (ob * M) // L and ((oe - 1) * M) // L < ie

@@ -33,6 +33,19 @@ for strict in (False, True, False):
     ms, y = best(lambda: f.filter(x))
     print("multirate_FIR.filter, 2^24 c64, strict_dtype=%s: %.1f ms -> %.0f MS/s (result %s)" % (strict, ms, n / ms / 1e3, y.dtype))
 
+# long vector: single staged copy vs the chunk pipeline (H2D of chunk k+1 | kernels of chunk k | D2H of chunk k-1)
+n2 = 1 << 26
+x2 = np.tile(x, 4)
+for strict in (False, True):
+    config.strict_dtype = strict
+    for pipe, lg in ((0, 22), (1, 24), (1, 23), (1, 22), (1, 21)):
+        _ffi.set_option("host_pipeline", pipe); _ffi.set_option("host_chunk_log2", lg)
+        ms, y = best(lambda: f.filter(x2), reps=3)
+        print("multirate_FIR.filter, 2^26 c64 (512 MiB), strict_dtype=%s, pipeline=%d chunk 2^%d: %.1f ms -> %.0f MS/s" % (strict, pipe, lg, ms, n2 / ms / 1e3))
+_ffi.set_option("host_pipeline", 1); _ffi.set_option("host_chunk_log2", 22)
+config.strict_dtype = False
+del x2, y
+
 # the pieces, through the C ABI directly
 k = _ffi.FirKernel(b, _ffi.C64)
 L = _ffi.load()
