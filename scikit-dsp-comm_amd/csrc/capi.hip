@@ -185,8 +185,67 @@ int fir_algo_for(const FirHandle *h, int64_t n) { return pick_fir_algo(h, n); }
 // beats Ntaps/M direct taps per kept sample (2^24 complex64, 512 taps, M = 3: 0.163 -> 0.085 ms).  Where the
 // bf16x3 matrix-pipe kernel covers the geometry it is the faster one up to ~4 M lag blocks for complex64
 // (2^26: 0.14-0.20 ms against a flat 0.24) and always for float32 (0.07-0.15 against 0.26).
+// ---- tap partitioning: filters longer than one launch takes ------------------------------------------------------
+// The reference accepts any tap count (lfilter(b,[1],x), multirate_helper.py:108).  One launch takes up to 4097 taps in
+// the overlap-save engine (float32 / complex64) and a few thousand in the float64 direct-form kernels (LDS window); a
+// longer b is cut into segments of `seg` taps,  y[m] = sum_s (b_s * x)[m - s seg]:  segment s is an ordinary filter
+// launch over the input shortened by its delay (with as much of the caller's history as it can still see), and its
+// result is added onto y from output s seg on.  For .dn the segment length is a multiple of M, so every partial
+// result keeps decimation phase 0.
+static int fir_part_len(const FirHandle *h)
+{
+    return dtype_double(h->dtype) ? 2048 : 4096;
+}
+static bool fir_needs_parts(const FirHandle *h)
+{
+    return h->ntaps > (dtype_double(h->dtype) ? 3000 : 4097);
+}
+static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev);
+static int fir_parts_run(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev)
+{
+    const int seg = std::max(fir_part_len(h) / M, 1) * M;
+    if (h->part_seg != seg) {
+        for (FirHandle *p : h->parts) delete p;
+        h->parts.clear();
+        const int comp = h->taps_complex ? 2 : 1;
+        for (int t0 = 0; t0 < h->ntaps; t0 += seg) {
+            FirHandle *p = new FirHandle();
+            p->kind = H_FIR; p->dtype = h->dtype; p->slot = h->slot; p->taps_complex = h->taps_complex;
+            p->ntaps = std::min(seg, h->ntaps - t0);
+            p->taps_host.assign(h->taps_host.begin() + (size_t)t0 * comp, h->taps_host.begin() + (size_t)(t0 + p->ntaps) * comp);
+            h->parts.push_back(p);
+        }
+        h->part_seg = seg;
+    }
+    const size_t esz = dtype_size(h->dtype);
+    const int scal = dtype_complex(h->dtype) ? 2 : 1;
+    hipStream_t s = ctx().stream;
+    void *tmp = nullptr;
+    int rc = ws_reserve(2, (size_t)(n / M + 1) * esz + 256, &tmp);
+    if (rc) return rc;
+    for (size_t si = 0; si < h->parts.size(); ++si) {
+        FirHandle *p = h->parts[si];
+        const int64_t delay = (int64_t)si * seg;                     // multiple of M
+        const int64_t d = (std::min(n_hist, delay) / M) * M;          // how far this segment starts inside the history
+        const int64_t n_s = n - delay + d;
+        if (n_s <= 0) break;
+        const char *xs = (const char *)x_dev - (size_t)d * esz;
+        void *dst = si == 0 ? y_dev : tmp;
+        rc = M > 1 ? fir_dn_any(p, xs, n_s, n_hist - d, M, dst)
+                   : (fir_algo_for(p, n_s) == SKDSP_FIR_OLS ? fir_ols_launch(p, xs, n_s, n_hist - d, dst, s)
+                                                            : fir_direct_launch(p, xs, n_s, n_hist - d, 1, 1, n_s, dst, s));
+        if (rc) return rc;
+        if (si > 0) {
+            const int64_t off = (delay - d) / M, cnt = n_s / M;
+            if ((rc = accumulate_launch((char *)y_dev + (size_t)off * esz, tmp, cnt * scal, dtype_double(h->dtype), s))) return rc;
+        }
+    }
+    return SKDSP_OK;
+}
+
 static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev)
 {
+    if (fir_needs_parts(h)) return fir_parts_run(h, x_dev, (n / M) * M, n_hist, M, y_dev);
     bool ols = M > 1 && fir_ols_supported(h) && pick_fir_algo(h, n) == SKDSP_FIR_OLS && !opt().dn_no_ols;
     if (ols) {
         const int kb = h->algo == SKDSP_FIR_OLS ? 0 : fir_bx_blocks(h, 1, M);
@@ -199,6 +258,7 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
 
 static int fir_filter_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev)
 {
+    if (fir_needs_parts(h)) return fir_parts_run(h, x_dev, n, n_hist, 1, y_dev);
     if (pick_fir_algo(h, n) == SKDSP_FIR_OLS) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream);
     return fir_direct_launch(h, x_dev, n, n_hist, 1, 1, n, y_dev, ctx().stream);
 }

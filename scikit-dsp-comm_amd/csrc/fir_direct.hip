@@ -563,6 +563,7 @@ FirHandle::~FirHandle()
     for (auto &t : mm) if (t.At) (void)hipFree(t.At);
     for (auto &t : bx) if (t.At) (void)hipFree(t.At);
     if (ols) fir_ols_free(ols);
+    for (FirHandle *p : parts) delete p;
 }
 
 // polyphase bank for interpolation factor L in the compute precision

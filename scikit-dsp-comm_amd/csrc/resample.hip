@@ -8,6 +8,7 @@
 // upsampler writes 16 B per lane (1 KiB per wave instruction); the downsampler
 // is a strided gather (only 1/M of every fetched line is useful -- inherent).
 #include "skdsp_internal.hpp"
+#include <algorithm>
 
 namespace skdsp {
 
@@ -248,6 +249,23 @@ __global__ __launch_bounds__(256) void widen_kernel(const float4 *__restrict__ s
         d[1] = make_double2((double)v.z, (double)v.w);
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst[4 * n4 + threadIdx.x] = (double)tail_src[threadIdx.x];
+}
+
+// y[i] += t[i] over real scalars (the partial results of a tap-partitioned FIR, capi.hip)
+template <typename R>
+__global__ __launch_bounds__(256) void accumulate_kernel(R *__restrict__ y, const R *__restrict__ t, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += t[i];
+}
+
+int accumulate_launch(void *y, const void *t, int64_t nscalars, bool dbl, hipStream_t s)
+{
+    if (nscalars <= 0) return SKDSP_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((nscalars + 255) / 256, 8192);
+    if (dbl) hipLaunchKernelGGL(accumulate_kernel<double>, dim3(blocks), dim3(256), 0, s, (double *)y, (const double *)t, nscalars);
+    else hipLaunchKernelGGL(accumulate_kernel<float>, dim3(blocks), dim3(256), 0, s, (float *)y, (const float *)t, nscalars);
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
 }
 
 int widen_launch(const void *src, int64_t nscalars, void *dst, hipStream_t s)

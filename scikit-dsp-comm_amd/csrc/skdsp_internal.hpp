@@ -137,6 +137,10 @@ struct FirHandle : HandleBase {
     struct BxTab { int L, M, Lp, q, DS, RS, RT, U0, KB; void *At; };
     std::vector<BxTab> bx;
     OlsPlan *ols = nullptr;
+    // Filters longer than one kernel launch takes (fir_part_len) run as partial FIRs over consecutive tap segments,
+    // each applied to the correspondingly delayed input and summed (capi.hip): parts[s] holds taps [s seg, (s+1) seg).
+    std::vector<FirHandle *> parts;
+    int part_seg = 0;
     ~FirHandle();
 };
 
@@ -199,6 +203,7 @@ int downsample_launch(const void *x_dev, int64_t n, int M, int p, int dtype, voi
 int deinterleave_launch(const void *x_dev, int64_t n, int dtype_complex_in, void *re_dev, void *im_dev, hipStream_t s);
 int interleave_launch(const void *re_dev, const void *im_dev, int64_t n, int dtype_complex_out, void *y_dev, hipStream_t s);
 int widen_launch(const void *src_dev, int64_t nscalars, void *dst_dev, hipStream_t s);  // float32 -> float64
+int accumulate_launch(void *y_dev, const void *t_dev, int64_t nscalars, bool dbl, hipStream_t s);  // y += t
 int fill_noise_launch(void *x_dev, int64_t n, int dtype, uint64_t seed, int64_t first, hipStream_t s);
 
 }  // namespace skdsp

@@ -33,7 +33,11 @@ def _signal(x, coef_complex=False):
     x = np.asarray(x)
     cplx = np.iscomplexobj(x) or coef_complex
     ref_dt = np.complex128 if cplx else np.float64
-    if x.dtype in (np.float64, np.complex128) or not (x.dtype in (np.float32, np.complex64, np.float16)):
+    mode = config.precision
+    if mode not in ("input", "double", "single"):
+        raise ValueError("config.precision must be 'input', 'double' or 'single' (got %r)" % (mode,))
+    narrow = x.dtype in (np.float32, np.complex64, np.float16)
+    if mode == "double" or (mode == "input" and not narrow):
         dev_dt = np.complex128 if cplx else np.float64     # double (and integer) callers: float64 kernels
     else:
         dev_dt = np.complex64 if cplx else np.float32

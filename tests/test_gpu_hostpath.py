@@ -102,3 +102,47 @@ print('SLOTS_OK')
 """ % (ROOT, ROOT)
     out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert b"SLOTS_OK" in out.stdout, out.stdout.decode()[-3000:]
+
+
+@pytest.mark.parametrize("dt,P", [(np.float32, 10_001), (np.complex64, 9_000), (np.float64, 7_001), (np.complex128, 5_000)])
+def test_fir_longer_than_one_launch_is_partitioned(dt, P):
+    """The reference takes any tap count (lfilter).  Beyond what one launch holds (4097 taps overlap-save, ~3000 in the
+    float64 direct kernels) the taps are cut into segments applied to delayed inputs and summed: .filter, .dn and block
+    streaming with history, against the oracle."""
+    rng = np.random.default_rng(P)
+    n = 60_000
+    x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if np.dtype(dt).kind == "c" else 0)
+    x = x.astype(dt)
+    b = rng.standard_normal(P) / np.sqrt(P)
+    tol = 2e-6 if np.dtype(dt).itemsize <= 8 and dt != np.float64 else 1e-11
+    f = mrh.multirate_FIR(b)
+    ref = orc.fir_filter(b, x)
+    assert max(rel_err(f.filter(x), ref)) <= tol
+    assert max(rel_err(f.dn(x, 3), ref[::3][:n // 3])) <= tol
+    y1, z = f.filter_stream(x[:25_000])
+    y2, _ = f.filter_stream(x[25_000:], zi=z)
+    assert max(rel_err(np.concatenate([y1, y2]), ref)) <= tol
+
+
+def test_precision_switch():
+    """config.precision: 'single' runs float64 callers through the float32 engines (1e-6), 'double' runs float32 callers in
+    float64 (the reference's own arithmetic: 1e-12, also in the stop band)."""
+    rng = np.random.default_rng(2)
+    b = np.ones(1024) / 1024
+    x64 = np.cos(2 * np.pi * 0.0123 * np.arange(50_000))       # attenuated by 32 dB: stop band of the boxcar
+    ref = orc.fir_filter(b, x64)
+    f = mrh.multirate_FIR(b)
+    old = config.precision
+    try:
+        config.precision = "single"
+        y = f.filter(x64)
+        assert y.dtype == np.float64 and 1e-9 < float(np.max(np.abs(y - ref))) <= 1e-6   # float32 arithmetic, input-relative bound
+        config.precision = "double"
+        y = f.filter(x64.astype(np.float32))
+        ref32 = orc.fir_filter(b, x64.astype(np.float32))
+        assert max(rel_err(y, ref32)) <= 1e-11
+        config.precision = "nonsense"
+        with pytest.raises(ValueError):
+            f.filter(x64)
+    finally:
+        config.precision = old
