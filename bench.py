@@ -160,25 +160,66 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
         w.wl = ("downsample(multirate_FIR.up(x,4),3): 512-tap prototype, complex64, %s input samples, fused polyphase "
                 "(Toeplitz product on the BF16 matrix pipe, 3-way bf16 split = float32 precision)" % lg)
         w.metric = "complex64 input MSamples/s (polyphase L=4/M=3, 512 taps, %s samples)" % lg
-    elif name == "iir8":
-        sos = elliptic_bpf_sos()
+    elif name == "fir1024c128":
+        b = firwin_lowpass(1024, 0.2)
+        w.taps, w.dtype, w.arith = b, np.complex128, "c128"
+        k = _ffi.FirKernel(b, _ffi.C128)
+        w.xd = _ffi.DeviceArray(n, w.dtype).fill_noise(2026)
+        w.yd = _ffi.DeviceArray(n, w.dtype)
+        w.step = lambda: k.filter_dev(w.xd, w.yd)
+        w.alg_bytes = 32.0 * n
+        w.compute = ("FP64 useful flops of the direct form (4 x Ntaps per complex128 sample, real taps)", 78.6, 4.0 * 1024 * n)
+        w.kern = "float64 FIR kernel"
+        w.wl = "multirate_FIR.filter: 1024-tap lowpass, complex128 (the reference's own arithmetic), %s samples" % lg
+        w.metric = "complex128 MSamples/s (FIR-1024 tap, %s samples)" % lg
+    elif name in ("iir8", "iir8sp", "iirlp8"):
+        if name == "iirlp8":   # rate_change(12)'s own design (multirate_helper.py:62): butter(8, 0.9 / 12), as biquads
+            sos = _ffi.tf2sos(*_butter8_rate_change12())
+        else:
+            sos = elliptic_bpf_sos()
         w.sos, w.dtype, w.arith = sos, np.float32, "f32 I/O, f64 state"
         w.xd = _ffi.DeviceArray(n, w.dtype).fill_noise(2026, first_index=rank * n)
         w.yd = _ffi.DeviceArray(n, w.dtype)
         if world == 1:
             k = _ffi.IirKernel(_ffi.F32, sos=sos)
-            w.step = lambda: k.filter_dev(w.xd, w.yd)
+            if name == "iir8sp":   # the single-pass scan also where the two-pass scan measured 5 % faster (config 4)
+                def step():
+                    with _ffi.option("iir_two_pass", -1):
+                        k.filter_dev(w.xd, w.yd)
+                w.step = step
+            else:
+                w.step = lambda: k.filter_dev(w.xd, w.yd)
         else:  # contiguous sample blocks, exact state hand-off rank r -> r+1 (16 doubles per hop)
             iir = sharding.ShardedIIR(sos, tr, dtype=w.dtype)
             w.step = lambda: iir.filter_local_dev(w.xd, w.yd, n)
         w.alg_bytes = 8.0 * n
         w.compute = ("FP64 vector (v_fma_f64)", 78.6, 72.0 * n)   # 9 flop per biquad per sample
-        w.kern = "iir_fused_kernel (single-pass scan)"
-        w.wl = "multirate_IIR.filter: 8-biquad elliptic bandpass, float32, %s samples, exact affine scan" % lg
-        w.metric = "float32 MSamples/s (8-biquad SOS IIR, %s samples)" % lg
+        w.kern = {"iir8": "iir_k1r_kernel + iir_carry_kernel + iir_chunk_kernel (two-pass scan: faster for this cascade)",
+                  "iir8sp": "iir_fused_kernel (single-pass scan)", "iirlp8": "iir_fused_kernel (single-pass scan)"}[name]
+        what = "order-8 Butterworth lowpass of rate_change(12), 4 biquads" if name == "iirlp8" else "8-biquad elliptic bandpass"
+        w.wl = "multirate_IIR.filter: %s, float32, %s samples, exact affine scan%s" % (
+            what, lg, " (single pass forced)" if name == "iir8sp" else "")
+        w.metric = "float32 MSamples/s (%s, %s samples)" % ("SOS IIR, " + what, lg)
+        if name == "iirlp8":
+            w.compute = ("FP64 vector (v_fma_f64)", 78.6, 36.0 * n)
     else:
         raise ValueError(name)
     return w
+
+
+def _butter8_rate_change12():
+    """(b, a) of scipy.signal.butter(8, 0.9 / 12) -- the design rate_change(12) makes (multirate_helper.py:58-62) --
+    restated (bilinear transform of the analog Butterworth prototype) so that the bench does not need SciPy."""
+    n, wn = 8, 0.9 / 12
+    warped = 2.0 * 2.0 * np.tan(np.pi * wn / 2.0)                      # fs = 2
+    m = np.arange(-n + 1, n, 2)
+    p = -np.exp(1j * np.pi * m / (2 * n)) * warped                     # analog poles, cutoff warped
+    k = warped ** n
+    pz = (4.0 + p) / (4.0 - p)                                         # bilinear, fs = 2
+    kz = k * np.real(1.0 / np.prod(4.0 - p))
+    b = kz * np.poly(-np.ones(n))
+    a = np.real(np.poly(pz))
+    return np.real(b), a
 
 
 def free_workload(w):
@@ -246,7 +287,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--settle-seconds", type=float, default=0.5,
                     help="untimed passes before the warm-up steps until the GPU clock has left its idle state")
-    ap.add_argument("--workload", default="fir1024", choices=["fir1024", "updn43", "iir8", "fir127"])
+    ap.add_argument("--workload", default="fir1024", choices=["fir1024", "updn43", "iir8", "fir127", "iir8sp", "iirlp8", "fir1024c128"])
     ap.add_argument("--log2n", type=int, default=26, help="weak scaling: samples per GPU = 2^log2n")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--total-log2n", type=int, default=30, help="strong scaling: 2^total samples shared by all GPUs")
@@ -334,10 +375,10 @@ def main():
     if world == 1 and args.workload == "fir1024" and not args.no_other_configs and args.scaling == "weak":
         free_workload(w)
         others = {}
-        for name in ("updn43", "iir8", "fir127"):
+        for name in ("updn43", "iir8", "fir127", "iir8sp", "iirlp8", "fir1024c128"):
             try:
                 o = make_workload(name, 1 << 26, 0, 1, tr, _ffi, sharding)
-                Ko = args.other_steps
+                Ko = args.other_steps if name != "fir1024c128" else max(args.other_steps // 5, 5)
                 el, ev, _ = timed_steps(o, Ko, max(10, Ko // 5), 0.1, tr, _ffi)
                 r = roofline_of(o, ev, Ko, 26)
                 others[name] = {"workload": o.wl, "value": float(o.units) * Ko / el / 1e6, "unit": "MSamples/s (input)",
@@ -396,7 +437,7 @@ def cpu_baseline_port(args, w):
     sample of the same workload."""
     from oracle import oracle as orc
     cores_avail = os.cpu_count()
-    if w.name == "iir8":
+    if w.name.startswith("iir"):
         x = w.xd.to_host(0, min(w.n, 1 << 26))
         m, dt = _sized_sample(lambda k: orc.sos_filter_f32in_timed(w.sos, x[:k]), 1 << 18, x.size, args.cpu_seconds)
         what = "sequential DF2T in float64 (sosfilt restated in C)"
@@ -405,8 +446,9 @@ def cpu_baseline_port(args, w):
         m, dt = _sized_sample(lambda k: orc.downsample(orc.fir_up(w.taps, x[:k], 4), 3), 1 << 14, x.size, args.cpu_seconds)
         what = "upsample -> 512-tap FIR at the 4x rate -> downsample (the reference's three passes, restated in C)"
     else:
-        x = w.xd.to_host(0, min(w.n, 1 << 26))
-        m, dt = _sized_sample(lambda k: orc.fir_filter_f32in_timed(w.taps, x[:k]), 1 << 16, x.size, args.cpu_seconds)
+        x = w.xd.to_host(0, min(w.n, 1 << 24))
+        fn = orc.fir_filter if x.dtype.itemsize > 8 or x.dtype == np.float64 else orc.fir_filter_f32in_timed
+        m, dt = _sized_sample(lambda k: fn(w.taps, x[:k]), 1 << 16, x.size, args.cpu_seconds)
         what = "direct-form float64 accumulation (lfilter FIR branch restated in C, 1 thread like the reference)"
     return {"value": m / dt / 1e6, "unit": "MSamples/s", "cores": 1, "kind": "port",
             "sample": "first %d samples of the workload: %s" % (m, what), "cores_available": cores_avail}
@@ -419,7 +461,7 @@ def cpu_baseline_scipy(args, w):
         from scipy import signal
     except Exception as e:
         return {"value": None, "kind": "scipy", "skipped": "scipy not importable on this box: %s" % e}
-    if w.name == "iir8":
+    if w.name.startswith("iir"):
         x = w.xd.to_host(0, min(w.n, 1 << 24))
         run = lambda k: signal.sosfilt(w.sos, x[:k])                                              # noqa: E731
         first, what = 1 << 16, "scipy.signal.sosfilt(sos, x) (multirate_helper.py:173)"

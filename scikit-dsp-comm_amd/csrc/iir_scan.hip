@@ -1179,10 +1179,10 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
             if (rc) return rc;
             p->fused_state = (p->n_lb == 1 && p->gt_T == Tf) ? 1 : -1;
             // Measured crossover (2^26 float32, same box): the single pass costs one from-rest scan plus a correction per
-            // 128-sample chunk -- 7 + 3.25 levels of a 16 x 16 transition for the 8-biquad elliptic band-pass of BASELINE
+            // 128-sample chunk -- 6 + 1.5 levels of a 16 x 16 transition for the 8-biquad elliptic band-pass of BASELINE
             // config 4 (0.206 ms) against 4 levels per 512-sample chunk in the two-pass scan (0.196 ms).  Up to 6 levels
             // (every low-pass design tried: 0.12-0.13 vs 0.16-0.17 ms) and for float64 signals (0.35 vs 0.44 ms) it wins.
-            if (!dtype_double(h->dtype) && p->n_lv >= 7 && D >= 14 && opt().iir_two_pass >= 0) p->fused_state = -1;
+            if (!dtype_double(h->dtype) && p->n_lv >= 6 && D >= 14 && opt().iir_two_pass >= 0) p->fused_state = -1;
             fused = p->fused_state == 1;
         }
     }

@@ -21,6 +21,8 @@ WORK = {  # workload -> (substring of every kernel of a step, substring of the k
     "fir127": ("skdsp::fir_", "skdsp::fir_", 8 * 2 ** 26),
     "updn43": ("skdsp::fir_", "skdsp::fir_", 8 * 2 ** 26 + 8 * ((2 ** 26 * 4) // 3)),
     "iir8": ("skdsp::iir_", "float, true", 8 * 2 ** 26),  # K1 (matrix pipe or recurrence) + carries/K2 + K3 (the WRITE = true instantiation runs once per step)
+    "iir8sp": ("skdsp::iir_fused", "skdsp::iir_fused", 8 * 2 ** 26),   # config 4 through the single-pass scan
+    "iirlp8": ("skdsp::iir_fused", "skdsp::iir_fused", 8 * 2 ** 26),   # rate_change(12)'s lowpass, single-pass scan
 }
 for w, (pat, marker, alg) in WORK.items():
     out = {}
