@@ -169,7 +169,7 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
         w.step = lambda: k.filter_dev(w.xd, w.yd)
         w.alg_bytes = 32.0 * n
         w.compute = ("FP64 useful flops of the direct form (4 x Ntaps per complex128 sample, real taps)", 78.6, 4.0 * 1024 * n)
-        w.kern = "float64 FIR kernel"
+        w.kern = "ols64_tile_kernel (float64 overlap-save, 4096-point tiles)"
         w.wl = "multirate_FIR.filter: 1024-tap lowpass, complex128 (the reference's own arithmetic), %s samples" % lg
         w.metric = "complex128 MSamples/s (FIR-1024 tap, %s samples)" % lg
     elif name in ("iir8", "iir8sp", "iirlp8"):

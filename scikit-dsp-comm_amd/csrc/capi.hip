@@ -169,8 +169,12 @@ static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static int pick_fir_algo(const FirHandle *h, int64_t n)
 {
     int algo = opt().fir_algo != SKDSP_FIR_AUTO ? opt().fir_algo : h->algo;
-    if (algo == SKDSP_FIR_OLS && !fir_ols_supported(h)) algo = SKDSP_FIR_DIRECT;
+    const bool ols64 = fir_ols64_supported(h);
+    if (algo == SKDSP_FIR_OLS && !fir_ols_supported(h) && !ols64) algo = SKDSP_FIR_DIRECT;
     if (algo != SKDSP_FIR_AUTO) return algo;
+    // float64 signals: the direct form costs 2 (4 for complex taps) FP64 FMA per tap and real sample; the float64
+    // overlap-save tile is flat in the tap count (measured crossovers at 2^26 samples: see DESIGN.md 4.1b)
+    if (ols64) return h->ntaps >= (h->dtype == SKDSP_C128 ? 80 : 160) && n >= 8192 ? SKDSP_FIR_OLS : SKDSP_FIR_DIRECT;
     // measured crossover at 2^26 samples (same box, alternating runs): the bf16x3 matrix-pipe kernel (real taps) stays
     // ahead of overlap-save up to 3 lag blocks for complex64 (0.21 vs 0.23 ms at 81 taps; 0.234 vs 0.227 at 96) and
     // 5 for float32 (0.135 vs 0.138 ms at 145 taps)
@@ -198,9 +202,10 @@ static int fir_part_len(const FirHandle *h)
 }
 static bool fir_needs_parts(const FirHandle *h)
 {
-    return h->ntaps > (dtype_double(h->dtype) ? 3000 : 4097);
+    return h->ntaps > (dtype_double(h->dtype) ? 2049 : 4097);
 }
 static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev);
+static int ols_launch_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, int dec = 1);
 static int fir_parts_run(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev)
 {
     const int seg = std::max(fir_part_len(h) / M, 1) * M;
@@ -232,7 +237,7 @@ static int fir_parts_run(FirHandle *h, const void *x_dev, int64_t n, int64_t n_h
         const char *xs = (const char *)x_dev - (size_t)d * esz;
         void *dst = si == 0 ? y_dev : tmp;
         rc = M > 1 ? fir_dn_any(p, xs, n_s, n_hist - d, M, dst)
-                   : (fir_algo_for(p, n_s) == SKDSP_FIR_OLS ? fir_ols_launch(p, xs, n_s, n_hist - d, dst, s)
+                   : (fir_algo_for(p, n_s) == SKDSP_FIR_OLS ? ols_launch_any(p, xs, n_s, n_hist - d, dst)
                                                             : fir_direct_launch(p, xs, n_s, n_hist - d, 1, 1, n_s, dst, s));
         if (rc) return rc;
         if (si > 0) {
@@ -243,9 +248,20 @@ static int fir_parts_run(FirHandle *h, const void *x_dev, int64_t n, int64_t n_h
     return SKDSP_OK;
 }
 
+static int ols_launch_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, int dec)
+{
+    if (dtype_double(h->dtype)) return fir_ols64_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, dec);
+    return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, dec);
+}
+
 static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev)
 {
     if (fir_needs_parts(h)) return fir_parts_run(h, x_dev, (n / M) * M, n_hist, M, y_dev);
+    if (dtype_double(h->dtype)) {  // float64: the decimating overlap-save store beats Ntaps / M direct FP64 taps per kept sample early
+        if (M > 1 && pick_fir_algo(h, n) == SKDSP_FIR_OLS && !opt().dn_no_ols && h->ntaps / M >= 24)
+            return fir_ols64_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
+        return fir_direct_launch(h, x_dev, n, n_hist, 1, M, n / M, y_dev, ctx().stream);
+    }
     bool ols = M > 1 && fir_ols_supported(h) && pick_fir_algo(h, n) == SKDSP_FIR_OLS && !opt().dn_no_ols;
     if (ols) {
         const int kb = h->algo == SKDSP_FIR_OLS ? 0 : fir_bx_blocks(h, 1, M);
@@ -259,7 +275,7 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
 static int fir_filter_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev)
 {
     if (fir_needs_parts(h)) return fir_parts_run(h, x_dev, n, n_hist, 1, y_dev);
-    if (pick_fir_algo(h, n) == SKDSP_FIR_OLS) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream);
+    if (pick_fir_algo(h, n) == SKDSP_FIR_OLS) return ols_launch_any(h, x_dev, n, n_hist, y_dev);
     return fir_direct_launch(h, x_dev, n, n_hist, 1, 1, n, y_dev, ctx().stream);
 }
 

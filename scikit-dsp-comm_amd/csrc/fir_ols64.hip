@@ -1,0 +1,341 @@
+// fir_ols64.hip -- FFT overlap-save FIR in FLOAT64 for gfx950 (MI355X): complex128 signals (any taps) and float64 signals
+// with real taps (two real tiles ride in one complex tile).
+//
+// Serves multirate_FIR.filter / .dn (multirate_helper.py:104-109, 121-127) for the callers whose arrays are float64 --
+// NumPy's default dtype, and the arithmetic the reference itself computes in (lfilter promotes everything to float64).
+// Without it a 1024-tap filter on complex128 data is 4096 FP64 flop per sample of direct form (6.6 ms per 2^26 samples);
+// in the frequency domain it is ~90.
+//
+// Tile: N = 4096 complex128 points, 256 threads x 16 points in registers, N = 16 x 16 x 16:
+//   n = 256 a + 16 b + c          k = k1 + 16 k2 + 256 k3            (all digits in [0, 16))
+//   pass 1  thread t = (b, c):   DFT16 over a  -> k1, times W_4096^(t k1)      (powers of W_4096^t, built on the fly)
+//   xchg 1  through LDS [k1][b][c] (one workgroup barrier)
+//   pass 2  thread (k1, c):      DFT16 over b  -> k2, times W_256^(c k2)
+//   xchg 2  through LDS [k1][k2][c] (inside one 16-lane group: wave-local, no barrier)
+//   pass 3  thread (k1, k2):     DFT16 over c  -> k3;   multiply by H[k] / N (64 KiB table, L2-resident)
+// and the mirror image back (decimation in time), so no bit reversal exists.  LDS image: 16 x (16 x 17) complex128 =
+// 68 KiB (row pitch 17: every 16-lane access pattern used here lands on 16 distinct 16-byte bank groups) -> two
+// persistent workgroups per CU.  V = 4096 - OV valid outputs per tile, OV = Ntaps-1 rounded up to 256 (<= 2048: longer
+// filters are partitioned by capi.hip).  Algorithmic bytes: 32 B per complex128 sample, 16 B per float64 sample.
+// Precision: float64 butterflies, twiddle powers by repeated multiplication (<= 15 products): 1e-14 of the peak.
+#include "skdsp_internal.hpp"
+#include <complex>
+#include <vector>
+#include <cmath>
+
+namespace skdsp {
+
+namespace {
+
+typedef double2 cdd;
+#ifndef SK_OLS64_WPE
+#define SK_OLS64_WPE 2
+#endif
+constexpr int kN64 = 4096;
+constexpr int kPitch64 = 16 * 17;  // complex elements per k1 row of the LDS image
+
+__device__ __forceinline__ cdd cadd(cdd a, cdd b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cdd csub(cdd a, cdd b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cdd cmul(cdd a, cdd w) { return make_double2(fma(a.x, w.x, -a.y * w.y), fma(a.x, w.y, a.y * w.x)); }
+__device__ __forceinline__ cdd cmulc(cdd a, cdd w) { return make_double2(fma(a.x, w.x, a.y * w.y), fma(a.y, w.x, -a.x * w.y)); }
+// a * (-i) (forward) / a * (+i) (inverse)
+template <bool INV> __device__ __forceinline__ cdd mul_mi(cdd a) { return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x); }
+
+// a * W_16^M forward (W = exp(-2 pi i / 16)) or its conjugate (INV); M compile-time
+template <int M, bool INV> __device__ __forceinline__ cdd tw16(cdd a)
+{
+    constexpr double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178, R2 = 0.70710678118654752440;
+    constexpr int m = M & 15;
+    if constexpr (m == 0) return a;
+    else if constexpr (m == 4) return mul_mi<INV>(a);
+    else if constexpr (m == 8) return make_double2(-a.x, -a.y);
+    else if constexpr (m == 12) return mul_mi<!INV>(a);
+    else {
+        constexpr double c = (m == 1 || m == 15) ? C1 : (m == 2 || m == 14) ? R2 : (m == 3 || m == 13) ? S1 : (m == 5 || m == 11) ? -S1
+                             : (m == 6 || m == 10) ? -R2 : -C1;                                   // cos(2 pi m / 16)
+        constexpr double s = (m == 1 || m == 7) ? S1 : (m == 2 || m == 6) ? R2 : (m == 3 || m == 5) ? C1 : (m == 9 || m == 15) ? -S1
+                             : (m == 10 || m == 14) ? -R2 : -C1;                                  // sin(2 pi m / 16)
+        const cdd w = make_double2(c, INV ? s : -s);
+        return cmul(a, w);
+    }
+}
+
+template <bool INV> __device__ __forceinline__ void dft4(cdd x0, cdd x1, cdd x2, cdd x3, cdd &X0, cdd &X1, cdd &X2, cdd &X3)
+{
+    const cdd s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = csub(x1, x3);
+    X0 = cadd(s02, s13);
+    X2 = csub(s02, s13);
+    const cdd r = mul_mi<INV>(d13);
+    X1 = cadd(d02, r);
+    X3 = csub(d02, r);
+}
+
+template <int I, int E, class F> __device__ __forceinline__ void static_for64(F &&f)
+{
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for64<I + 1, E>(static_cast<F &&>(f));
+    }
+}
+
+// 16-point DFT, natural order in and out, everything in registers (radix 4 x 4)
+template <bool INV> __device__ __forceinline__ void dft16(const cdd *x, cdd *X)
+{
+    cdd a[4][4];  // a[n1][k2] = DFT4 over n2 of x[n1 + 4 n2]
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) dft4<INV>(x[n1], x[n1 + 4], x[n1 + 8], x[n1 + 12], a[n1][0], a[n1][1], a[n1][2], a[n1][3]);
+    static_for64<0, 4>([&](auto kc) {
+        constexpr int k2 = decltype(kc)::value;
+        const cdd t0 = a[0][k2];
+        const cdd t1 = tw16<k2, INV>(a[1][k2]);
+        const cdd t2 = tw16<2 * k2, INV>(a[2][k2]);
+        const cdd t3 = tw16<3 * k2, INV>(a[3][k2]);
+        dft4<INV>(t0, t1, t2, t3, X[k2], X[k2 + 4], X[k2 + 8], X[k2 + 12]);
+    });
+}
+
+struct Ols64Args {
+    const double *x;
+    double *y;
+    int64_t n, n_hist;
+    const cdd *Hp;    // [16][256]: Hp[k3 * 256 + 16 k1 + k2] = H[k1 + 16 k2 + 256 k3] / N
+    const cdd *W1;    // [256]: W_4096^t
+    const cdd *W2;    // [16]:  W_256^c
+    int ov, V, a0;    // a0 = ov / 256: first stored 256-block
+    int64_t ntiles;
+    int dec;
+    int64_t n_keep;
+};
+
+template <bool REAL>
+__global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args A)
+{
+    __shared__ cdd img[16 * kPitch64];
+    const int t = threadIdx.x;
+    const int hi4 = t >> 4, lo4 = t & 15;
+    const cdd w1 = A.W1[t];        // W_4096^t            (pass 1: t = 16 b + c)
+    const cdd w2 = A.W2[lo4];      // W_256^c             (pass 2: thread (k1, c))
+
+    int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+    for (; tile < A.ntiles; tile += gridDim.x) {
+        cdd v[16], u[16];
+        // ---- load: v[a] = x[in0 + 256 a + t] (complex) or (xA, xB) of two real tiles ----
+        if (REAL) {
+            const int64_t inA = (2 * tile) * A.V - A.ov, inB = inA + A.V;
+            const bool interior = inA >= -A.n_hist && inB + kN64 <= A.n;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                const int64_t ga = inA + 256 * a + t, gb = ga + A.V;
+                double re = 0.0, im = 0.0;
+                if (interior) {
+                    re = __builtin_nontemporal_load(A.x + ga);
+                    im = __builtin_nontemporal_load(A.x + gb);
+                } else {
+                    if (ga >= -A.n_hist && ga < A.n) re = A.x[ga];
+                    if (gb >= -A.n_hist && gb < A.n) im = A.x[gb];
+                }
+                v[a] = make_double2(re, im);
+            }
+        } else {
+            const int64_t in0 = tile * A.V - A.ov;
+            const bool interior = in0 >= -A.n_hist && in0 + kN64 <= A.n;
+            typedef double v2d_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                const int64_t g = in0 + 256 * a + t;
+                if (interior) {
+                    const v2d_t q = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(A.x) + g);
+                    v[a] = make_double2(q.x, q.y);
+                } else {
+                    v[a] = (g >= -A.n_hist && g < A.n) ? make_double2(A.x[2 * g], A.x[2 * g + 1]) : make_double2(0.0, 0.0);
+                }
+            }
+        }
+        // ---- pass 1: DFT16 over a, twiddle W_4096^(t k1) (running power), write [k1][b][c] ----
+        dft16<false>(v, u);
+        {
+            cdd w = w1;
+            img[0 * kPitch64 + hi4 * 17 + lo4] = u[0];
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) {
+                img[k1 * kPitch64 + hi4 * 17 + lo4] = cmul(u[k1], w);
+                w = cmul(w, w1);
+            }
+        }
+        __syncthreads();
+        // ---- pass 2: thread (k1 = hi4, c = lo4): DFT16 over b, twiddle W_256^(c k2), write [k1][k2][c] (same 16-lane group) ----
+#pragma unroll
+        for (int b = 0; b < 16; ++b) v[b] = img[hi4 * kPitch64 + b * 17 + lo4];
+        dft16<false>(v, u);
+        {
+            cdd w = w2;
+            img[hi4 * kPitch64 + 0 * 17 + lo4] = u[0];
+#pragma unroll
+            for (int k2 = 1; k2 < 16; ++k2) {
+                img[hi4 * kPitch64 + k2 * 17 + lo4] = cmul(u[k2], w);
+                w = cmul(w, w2);
+            }
+        }
+        // ---- pass 3: thread (k1 = hi4, k2 = lo4): DFT16 over c; multiply by H ----
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = img[hi4 * kPitch64 + lo4 * 17 + c];
+        dft16<false>(v, u);
+        // (H streams from L2 every tile: keeping this thread's 16 bins in registers cost 104 spilled VGPRs)
+#pragma unroll
+        for (int k3 = 0; k3 < 16; ++k3) u[k3] = cmul(u[k3], A.Hp[k3 * 256 + t]);
+        // ---- inverse pass 3: over k3 -> c, conj twiddle W_256^(c k2) needs c per element: done by the reader ----
+        dft16<true>(u, v);   // v[c] for thread (k1, k2)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) img[hi4 * kPitch64 + lo4 * 17 + c] = v[c];
+        // thread (k1, c = lo4) reads over k2, applies conj W_256^(c k2), inverse DFT16 over k2 -> b
+        {
+            cdd w = w2;
+            v[0] = img[hi4 * kPitch64 + 0 * 17 + lo4];
+#pragma unroll
+            for (int k2 = 1; k2 < 16; ++k2) {
+                v[k2] = cmulc(img[hi4 * kPitch64 + k2 * 17 + lo4], w);
+                w = cmul(w, w2);
+            }
+        }
+        dft16<true>(v, u);   // u[b] for thread (k1, c)   (rows 4 wave .. 4 wave + 3 belong to this wave alone until here)
+#pragma unroll
+        for (int b = 0; b < 16; ++b) img[hi4 * kPitch64 + b * 17 + lo4] = u[b];
+        __syncthreads();
+        // thread t = (b = hi4, c = lo4) reads over k1, conj W_4096^(t k1), inverse DFT16 over k1 -> a
+        {
+            cdd w = w1;
+            v[0] = img[0 * kPitch64 + hi4 * 17 + lo4];
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) {
+                v[k1] = cmulc(img[k1 * kPitch64 + hi4 * 17 + lo4], w);
+                w = cmul(w, w1);
+            }
+        }
+        dft16<true>(v, u);   // u[a] = y[256 a + t]
+        // ---- store the last V points ----
+        if (REAL) {
+            const int64_t outA = (2 * tile) * A.V, outB = outA + A.V;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                if (a < A.a0) continue;
+                const int64_t loc = 256 * (a - A.a0) + t;
+                const int64_t ga = outA + loc, gb = outB + loc;
+                if (A.dec > 1) {
+                    if (ga < A.n_keep && ga % A.dec == 0) A.y[ga / A.dec] = u[a].x;
+                    if (gb < A.n_keep && gb % A.dec == 0) A.y[gb / A.dec] = u[a].y;
+                } else {
+                    if (ga < A.n) __builtin_nontemporal_store(u[a].x, A.y + ga);
+                    if (gb < A.n) __builtin_nontemporal_store(u[a].y, A.y + gb);
+                }
+            }
+        } else {
+            const int64_t out0 = tile * A.V;
+            typedef double v2d_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                if (a < A.a0) continue;
+                const int64_t g = out0 + 256 * (a - A.a0) + t;
+                v2d_t q;
+                q.x = u[a].x; q.y = u[a].y;
+                if (A.dec > 1) {
+                    if (g < A.n_keep && g % A.dec == 0) reinterpret_cast<v2d_t *>(A.y)[g / A.dec] = q;
+                } else if (g < A.n) {
+                    __builtin_nontemporal_store(q, reinterpret_cast<v2d_t *>(A.y) + g);
+                }
+            }
+        }
+        __syncthreads();  // the image is free for the next tile
+    }
+}
+
+}  // namespace
+
+struct Ols64Plan {
+    int ov = 0, V = 0;
+    cdd *Hp = nullptr, *W1 = nullptr, *W2 = nullptr;
+};
+
+void fir_ols64_free(Ols64Plan *p)
+{
+    if (!p) return;
+    if (p->Hp) (void)hipFree(p->Hp);
+    if (p->W1) (void)hipFree(p->W1);
+    if (p->W2) (void)hipFree(p->W2);
+    delete p;
+}
+
+bool fir_ols64_supported(const FirHandle *h)
+{
+    if (h->ntaps < 2 || h->ntaps - 1 > 2048) return false;
+    return h->dtype == SKDSP_C128 || (h->dtype == SKDSP_F64 && !h->taps_complex);
+}
+
+static int ensure_plan64(FirHandle *h)
+{
+    if (h->ols64) return SKDSP_OK;
+    typedef std::complex<long double> cl;
+    Ols64Plan *p = new Ols64Plan();
+    p->ov = ((h->ntaps - 1 + 255) / 256) * 256;
+    if (p->ov == 0) p->ov = 256;
+    p->V = kN64 - p->ov;
+    // H = DFT_4096(b) / N in long double (plain O(N P) sums: once per handle)
+    const int comp = h->taps_complex ? 2 : 1;
+    const long double two_pi = 6.283185307179586476925286766559L;
+    std::vector<cl> wn(kN64);
+    for (int k = 0; k < kN64; ++k) wn[k] = cl(cosl(two_pi * k / kN64), -sinl(two_pi * k / kN64));
+    std::vector<double> Hp((size_t)2 * kN64), W1(2 * 256), W2(2 * 16);
+    for (int k = 0; k < kN64; ++k) {
+        cl acc(0, 0);
+        for (int j = 0; j < h->ntaps; ++j) {
+            const cl bj = comp == 2 ? cl(h->taps_host[2 * j], h->taps_host[2 * j + 1]) : cl(h->taps_host[j], 0);
+            acc += bj * wn[(size_t)(((int64_t)k * j) % kN64)];
+        }
+        acc /= (long double)kN64;
+        const int k1 = k & 15, k2 = (k >> 4) & 15, k3 = k >> 8;
+        const size_t idx = (size_t)k3 * 256 + 16 * k1 + k2;
+        Hp[2 * idx] = (double)acc.real();
+        Hp[2 * idx + 1] = (double)acc.imag();
+    }
+    for (int t = 0; t < 256; ++t) { W1[2 * t] = (double)wn[t].real(); W1[2 * t + 1] = (double)wn[t].imag(); }
+    for (int c = 0; c < 16; ++c) { W2[2 * c] = (double)wn[16 * c].real(); W2[2 * c + 1] = (double)wn[16 * c].imag(); }
+    hipError_t e;
+    if ((e = hipMalloc((void **)&p->Hp, Hp.size() * 8)) != hipSuccess || (e = hipMalloc((void **)&p->W1, W1.size() * 8)) != hipSuccess ||
+        (e = hipMalloc((void **)&p->W2, W2.size() * 8)) != hipSuccess ||
+        (e = hipMemcpy(p->Hp, Hp.data(), Hp.size() * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(p->W1, W1.data(), W1.size() * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(p->W2, W2.data(), W2.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) {
+        fir_ols64_free(p);
+        return hip_fail(e, "ols64 tables", __FILE__, __LINE__);
+    }
+    h->ols64 = p;
+    return SKDSP_OK;
+}
+
+int fir_ols64_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s, int dec)
+{
+    if (n <= 0) return SKDSP_OK;
+    if (dec > 1) n = (n / dec) * dec;
+    if (n <= 0) return SKDSP_OK;
+    SK_CHECK(fir_ols64_supported(h), SKDSP_ERR_UNSUPPORTED, "fir_ols64: needs complex128 (or float64 with real taps) and 2..2049 taps");
+    int rc = ensure_plan64(h);
+    if (rc) return rc;
+    Ols64Plan *p = h->ols64;
+    Ols64Args A;
+    A.x = (const double *)x; A.y = (double *)y; A.n = n; A.n_hist = n_hist;
+    A.Hp = p->Hp; A.W1 = p->W1; A.W2 = p->W2;
+    A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 256;
+    const bool real = h->dtype == SKDSP_F64;
+    int64_t ntiles = (n + p->V - 1) / p->V;
+    if (real) ntiles = (ntiles + 1) / 2;
+    A.ntiles = ntiles;
+    A.dec = dec > 1 ? dec : 1;
+    A.n_keep = n;
+    int64_t grid = 2 * (int64_t)ctx().num_cus;
+    if (grid > ntiles) grid = ntiles;
+    if (real) hipLaunchKernelGGL(ols64_tile_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL(ols64_tile_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, A);
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+}  // namespace skdsp

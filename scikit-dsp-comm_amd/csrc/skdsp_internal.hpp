@@ -118,7 +118,8 @@ struct HandleBase {
 };
 
 // ---- FIR -----------------------------------------------------------------
-struct OlsPlan;  // fir_ols.hip
+struct OlsPlan;    // fir_ols.hip
+struct Ols64Plan;  // fir_ols64.hip
 struct FirHandle : HandleBase {
     int ntaps = 0;
     bool taps_complex = false;
@@ -137,6 +138,7 @@ struct FirHandle : HandleBase {
     struct BxTab { int L, M, Lp, q, DS, RS, RT, U0, KB; void *At; };
     std::vector<BxTab> bx;
     OlsPlan *ols = nullptr;
+    Ols64Plan *ols64 = nullptr;
     // Filters longer than one kernel launch takes (fir_part_len) run as partial FIRs over consecutive tap segments,
     // each applied to the correspondingly delayed input and summed (capi.hip): parts[s] holds taps [s seg, (s+1) seg).
     std::vector<FirHandle *> parts;
@@ -169,6 +171,10 @@ int fir_ols_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, v
                    const unsigned *halo_flag = nullptr, unsigned halo_seq = 0, unsigned *halo_err = nullptr);
 int fir_ols_publish_halo(unsigned *flag, unsigned seq, hipStream_t s);  // one-thread kernel: *flag = seq (agent-scope release)
 void fir_ols_free(OlsPlan *p);
+// FFT overlap-save in float64 (fir_ols64.hip): complex128, and float64 with real taps; 2..2049 taps
+bool fir_ols64_supported(const FirHandle *h);
+int fir_ols64_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, hipStream_t s, int dec = 1);
+void fir_ols64_free(Ols64Plan *p);
 
 // ---- IIR -----------------------------------------------------------------
 struct IirPlan;  // iir_scan.hip

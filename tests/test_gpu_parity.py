@@ -1486,3 +1486,55 @@ def test_iir_single_pass_not_taken_for_slow_decay():
     y = mrh.multirate_IIR(sos).filter(x)
     ref = signal.sosfilt(sos, x)
     assert_close(y[-(1 << 20):], ref[-(1 << 20):], 1e-9, "slow decay")
+
+
+# ----------------------------------------------------------------- float64 overlap-save (fir_ols64.hip)
+@pytest.mark.parametrize("dt", [np.complex128, np.float64])
+@pytest.mark.parametrize("P", [2, 97, 256, 1024, 2049])
+def test_fir_ols64_vs_oracle(dt, P):
+    """The float64 overlap-save tile (4096 complex128 points; float64 signals as two real tiles per complex tile):
+    .filter and the decimating store against the oracle at the float64 tolerance, ragged lengths, with history, complex
+    taps on complex128; and the same calls through the direct float64 kernels."""
+    rng = np.random.default_rng(P)
+    n = 3 * 4096 + 1234 if P > 1000 else 41_003
+    cplx = dt == np.complex128
+    x = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dt)
+    for ctaps in ((False, True) if cplx else (False,)):
+        b = rng.standard_normal(P) / np.sqrt(P) + (1j * rng.standard_normal(P) / np.sqrt(P) if ctaps else 0)
+        k = _ffi.FirKernel(b, _ffi.code_of(dt))
+        k.set_algo(_ffi.FIR_OLS)
+        ref = orc.fir_filter(b, x)
+        assert_close(k.filter(x), ref, TOL64, "ols64 filter P=%d" % P)
+        assert_close(k.dn(x, 5), ref[::5][:n // 5], TOL64, "ols64 dn P=%d" % P)
+        # history in front of the block (n_hist), as the sharded / streaming callers use it
+        nh = P - 1
+        xd = _ffi.DeviceArray(n - 5000, dt, headroom=max(nh, 1))
+        xd.write(x[5000:])
+        if nh:
+            xd.write(x[5000 - nh:5000], at=-nh)
+        yd = _ffi.DeviceArray(n - 5000, dt)
+        k.filter_dev(xd, yd, n_hist=nh)
+        assert_close(yd.to_host(), ref[5000:], TOL64, "ols64 with history P=%d" % P)
+        k2 = _ffi.FirKernel(b, _ffi.code_of(dt))
+        k2.set_algo(_ffi.FIR_DIRECT)
+        assert_close(k2.filter(x), ref, TOL64, "direct float64 P=%d" % P)
+
+
+def test_fir_ols64_full_size_windows():
+    """2^26 complex128 samples, 1024 taps (the float64 twin of the headline): windows against the oracle, and the
+    algorithm AUTO picks is the overlap-save one."""
+    import bench
+    n = 1 << 26
+    b = bench.firwin_lowpass(1024, 0.2)
+    k = _ffi.FirKernel(b, _ffi.C128)
+    assert k.algo_for(n) == _ffi.FIR_OLS
+    xd = _ffi.DeviceArray(n, np.complex128).fill_noise(11)
+    yd = _ffi.DeviceArray(n, np.complex128)
+    k.filter_dev(xd, yd)
+    _ffi.sync()
+    for s0 in (0, 3072 * 5000 - 300, n - 9000):
+        lo = max(s0 - 1023, 0)
+        ref = orc.fir_filter(b, xd.to_host(lo, s0 - lo + 9000))[s0 - lo:]
+        assert_close(yd.to_host(s0, 9000), ref, TOL64, "window @%d" % s0)
+    xd.free()
+    yd.free()
