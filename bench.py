@@ -239,7 +239,12 @@ def timed_steps(w, K, W, settle_s, tr, _ffi):
     # workload contains a send/recv pair, so a per-rank time-based loop would deadlock.)
     t_settle = time.perf_counter()
     for _ in range(10):
-        w.step()
+        try:
+            w.step()
+        except _ffi.SkdspError as e:  # (the sharded FIR switches itself to its two-launch form if the RCCL receive
+            if "two-launch" not in str(e):  # cannot run beside the persistent launch here; the step is simply repeated)
+                raise
+            print("bench.py: %s" % e, file=sys.stderr)
     _ffi.sync()
     per_pass = max((time.perf_counter() - t_settle) / 10, 1e-6)
     n_settle = int(tr.allreduce_max(float(min(20000, int(settle_s / per_pass) + 1)))) if settle_s > 0 else 0

@@ -295,8 +295,18 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
                 *c.halo_err = 0;
                 c.halo_seq = 0;
             }
-            SK_CHECK(*c.halo_err == 0, SKDSP_ERR_RCCL,
-                     "fir_filter_shard: an earlier sharded launch gave up waiting for its halo (RCCL receive never completed?)");
+            if (*c.halo_err != 0) {
+                // The persistent launch of an earlier step polled for seconds and gave up: the RCCL receive did not run
+                // beside it on this system.  Fall back to the two-launch form for the rest of the process and tell the
+                // caller once (that step's first tile is invalid).
+                SK_HIP(hipStreamSynchronize(c.stream));
+                SK_HIP(hipStreamSynchronize(c.comm_stream));
+                *c.halo_err = 0;
+                opt().shard_two_launches = 1;
+                SK_CHECK(false, SKDSP_ERR_RCCL,
+                         "fir_filter_shard: the previous sharded step gave up waiting for its halo inside the filter launch; "
+                         "switched to the two-launch form (option shard_two_launches) -- repeat that step");
+            }
             std::lock_guard<std::mutex> lk(h->mu);
             const size_t esz = dtype_size(h->dtype);
             SK_HIP(hipEventRecord(c.ev_in, c.stream));            // x (and its tail, which is sent) is ready
