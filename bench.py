@@ -245,6 +245,7 @@ def timed_steps(w, K, W, settle_s, tr, _ffi):
             if "two-launch" not in str(e):  # cannot run beside the persistent launch here; the step is simply repeated)
                 raise
             print("bench.py: %s" % e, file=sys.stderr)
+            w.step()   # (the refused call enqueued nothing: repeat it so that every rank has made the same number of exchanges)
     _ffi.sync()
     per_pass = max((time.perf_counter() - t_settle) / 10, 1e-6)
     n_settle = int(tr.allreduce_max(float(min(20000, int(settle_s / per_pass) + 1)))) if settle_s > 0 else 0
