@@ -33,10 +33,11 @@ struct IirPlan {
     std::vector<double> A_host;
     // single-pass scan (iir_fused_kernel)
     int fused_state = 0;                   // 0 untested, 1 applicable, -1 not (the segment transition does not vanish)
+    int fused_state_c = 0;                 // the same for interleaved complex signals (chunks half as long)
     unsigned long long *lbg_dev = nullptr;  // look-back granules [batch][nseg][32]
     size_t lbg_cap = 0;
     unsigned long long *ticket_dev = nullptr;  // [2] segment dispensers, monotonic
-    unsigned long long ticket_count = 0;       // their common value (every launch adds nseg to both)
+    unsigned long long ticket_count[2] = {0, 0};  // their values (a launch adds nseg to each dispenser it uses)
     unsigned epoch = 0;
     unsigned *err_host = nullptr;          // host-mapped: a look-back poll gave up
 };
@@ -106,6 +107,7 @@ typedef double v4d_t __attribute__((ext_vector_type(4)));
 // single-pass scan (iir_fused.hip); T = 128 (float) / 64 (double) samples per chunk; the plan's powers and G table
 // must already be those of that chunk length (ensure_powers in iir_scan.hip)
 int iir_fused_launch(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, const double *zi_dev,
-                     double *zf_dev, hipStream_t s, int dec = 1);
+                     double *zf_dev, hipStream_t s, int dec = 1,
+                     int interleaved = 0);  // 1: x / y interleaved complex (chunks of 64 / 32 complex samples), nbatch = 2
 
 }  // namespace skdsp

@@ -37,7 +37,7 @@ struct FusedArgs {
     const double *gt;            // G in MFMA A-operand order [T/4][64]
     unsigned long long *lb;      // [batch][nseg][32] look-back granules
     unsigned long long *ticket;  // [batch] segment dispenser (monotonic; ticket_base = its value before this launch)
-    unsigned long long ticket_base;
+    unsigned long long ticket_base[2];
     unsigned epoch;
     int nseg;
     int n_lv;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bat = blockIdx.y;
-    if (tid == 0) seg_sh = (int)(atomicAdd(a.ticket + bat, 1ull) - a.ticket_base);
+    if (tid == 0) seg_sh = (int)(atomicAdd(a.ticket + bat, 1ull) - a.ticket_base[bat]);
     for (int i = tid; i < (T / 4) * 64; i += kIirThreads) gl[i] = gtab[i];
     __syncthreads();
     const int seg = seg_sh;
@@ -316,13 +316,313 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
     }
 }
 
+// ---- interleaved complex signals ---------------------------------------------------------------------------------
+// A complex signal through a real-coefficient cascade is two independent real recurrences on one memory stream.  Same
+// structure as iir_fused_kernel with both components in one thread: a chunk is TC complex samples (64 complex64 /
+// 32 complex128: 128 VGPRs as re[] / im[]), a segment 256 chunks; the interleaved 16-byte segments are split into two real
+// LDS planes on the way in (as in iir_k3c_kernel) and re-joined on the way out; the matrix pipe takes the re and the im of
+// the staged samples as two B operands against the same A operand; scan, look-back (64 granules) and correction run once
+// per component; the two cascades of a sample run one after the other (2 waves per SIMD for <= 8 biquads).
+template <int NSEC, typename IO, bool UNIT>
+__global__ __launch_bounds__(kIirThreads, 2) void iir_fused_c_kernel(FusedArgs a, Coef<NSEC, 2> cf, const double *__restrict__ pw,
+                                                                     const double *__restrict__ gtab)
+{
+    constexpr int ORD = 2, D = NSEC * ORD;
+    constexpr int E = 16 / (int)sizeof(IO);        // scalars per 16 bytes (4 / 2)
+    constexpr int PC = 4 * E;                      // complex samples per staged row piece (16 / 8): 128 bytes interleaved
+    constexpr int TC = 256 / (int)sizeof(IO);      // complex samples per chunk (64 / 32)
+    constexpr int NP = TC / PC;                    // 4 pieces
+    constexpr int PITCH = 80 / (int)sizeof(IO);    // scalars per plane row (80 bytes: conflict-free b128 reads)
+    constexpr int kStageBytes = 2 * kIirThreads * 80;
+    constexpr int kScanBytes = kIirThreads * D * 8;
+    constexpr int kLdsBytes = kStageBytes > kScanBytes ? kStageBytes : kScanBytes;
+    __shared__ __attribute__((aligned(16))) char lds_raw[kLdsBytes];
+    __shared__ double gl[(TC / 4) * 64];
+    __shared__ unsigned cw[64];
+    __shared__ int seg_sh;
+    IO *st_re = reinterpret_cast<IO *>(lds_raw);
+    IO *st_im = st_re + kIirThreads * PITCH;
+    double *sc = reinterpret_cast<double *>(lds_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) seg_sh = (int)(atomicAdd(a.ticket, 1ull) - a.ticket_base[0]);
+    for (int i = tid; i < (TC / 4) * 64; i += kIirThreads) gl[i] = gtab[i];
+    __syncthreads();
+    const int seg = seg_sh;
+    const IO *x = reinterpret_cast<const IO *>(a.x);
+    IO *y = reinterpret_cast<IO *>(a.y);
+    const int64_t row0 = (int64_t)seg * kIirThreads;
+    const bool interior = (row0 + kIirThreads) * TC <= a.n;
+
+    typedef float pre_t __attribute__((ext_vector_type(4)));
+    pre_t pre[8];
+    auto load_piece = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = i * kIirThreads + tid;
+            const int row = idx >> 3, sg = idx & 7;  // 8 x 16-byte segments per 128-byte row piece
+            const int64_t g = (row0 + row) * TC + (int64_t)p * PC + (int64_t)sg * (E / 2);  // complex index
+            pre[i] = __builtin_nontemporal_load(reinterpret_cast<const pre_t *>(x + 2 * g));
+        }
+    };
+    auto split_store = [&](const IO *e, int row, int sg) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < E / 2; ++k) {
+            st_re[row * PITCH + sg * (E / 2) + k] = e[2 * k];
+            st_im[row * PITCH + sg * (E / 2) + k] = e[2 * k + 1];
+        }
+    };
+    auto stage_slow = [&](int p) {
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+            const int idx = i * kIirThreads + tid;
+            const int row = idx >> 3, sg = idx & 7;
+            const int64_t g = (row0 + row) * TC + (int64_t)p * PC + (int64_t)sg * (E / 2);
+            IO tmp[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) tmp[e] = (g + e / 2 < a.n) ? x[2 * g + e] : IO(0);
+            split_store(tmp, row, sg);
+        }
+    };
+
+    // ---- A: stream in, rows to registers, V = G x for both components ----
+    IO xr[TC], xi[TC];
+    v4d_t accr[4], acci[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) accr[g] = acci[g] = v4d_t{0.0, 0.0, 0.0, 0.0};
+    const int c = lane & 15, j = lane >> 4;
+    IO *rr = st_re + tid * PITCH, *ri = st_im + tid * PITCH;
+    if (interior) load_piece(0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = i * kIirThreads + tid;
+                split_store(reinterpret_cast<const IO *>(&pre[i]), idx >> 3, idx & 7);
+            }
+        } else {
+            stage_slow(p);
+        }
+        __syncthreads();
+        if (interior && p + 1 < NP) load_piece(p + 1);
+#pragma unroll
+        for (int c4 = 0; c4 < PC / E; ++c4) {
+            const float4 qa = *reinterpret_cast<const float4 *>(rr + c4 * E), qb = *reinterpret_cast<const float4 *>(ri + c4 * E);
+            const IO *ea = reinterpret_cast<const IO *>(&qa), *eb = reinterpret_cast<const IO *>(&qb);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                xr[p * PC + c4 * E + e] = ea[e];
+                xi[p * PC + c4 * E + e] = eb[e];
+            }
+        }
+        const IO *sr = st_re + (wave * 64 + c) * PITCH + j, *si = st_im + (wave * 64 + c) * PITCH + j;
+#pragma unroll
+        for (int s4 = 0; s4 < PC / 4; ++s4) {
+            const double ga = gl[(p * (PC / 4) + s4) * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                accr[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, (double)sr[g * 16 * PITCH + 4 * s4], accr[g], 0, 0, 0);
+                acci[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, (double)si[g * 16 * PITCH + 4 * s4], acci[g], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- S / L: per component: chunk states to one thread per chunk, from-rest scan, publish the segment's end state ----
+    double z0[D], z1[D];
+    auto scan_component = [&](const v4d_t (&acc)[4], double (&z)[D], int comp) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = j + 4 * r;
+                if (d < D) sc[d * kIirThreads + wave * 64 + g * 16 + c] = acc[g][r];
+            }
+        __syncthreads();
+        double v[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) v[d] = sc[d * kIirThreads + tid];
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 0; l < a.n_lv; ++l) {
+            const int s = 1 << l;
+#pragma unroll
+            for (int d = 0; d < D; ++d) sc[d * kIirThreads + tid] = v[d];
+            __syncthreads();
+            if (tid >= s) {
+                double left[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) left[d] = sc[d * kIirThreads + tid - s];
+                matvec_acc<D, ORD>(pw + (size_t)l * D * D, left, v);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) sc[d * kIirThreads + tid] = v[d];
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < D; ++d) z[d] = tid ? sc[d * kIirThreads + tid - 1] : 0.0;
+        if (tid < 2 * D) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(sc[(tid >> 1) * kIirThreads + kIirThreads - 1]);
+            const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+            __hip_atomic_store(a.lb + (size_t)seg * 64 + comp * 32 + tid, ((unsigned long long)a.epoch << 32) | half, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    };
+    scan_component(accr, z0, 0);
+    scan_component(acci, z1, 1);
+    if (tid < 4 * D) {   // lanes [0, 2 D): re, [2 D, 4 D): im
+        const int comp = tid >= 2 * D, q = tid - comp * 2 * D;
+        unsigned got = 0;
+        if (seg > 0) {
+            const unsigned long long *src = a.lb + (size_t)(seg - 1) * 64 + comp * 32 + q;
+            unsigned long long g = 0;
+            int spins = 0;
+            for (;;) {
+                g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(g >> 32) == a.epoch) break;
+                if (++spins > (1 << 22)) {
+                    *a.err = 1u;
+                    g = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            got = (unsigned)g;
+        } else if (a.zi) {
+            const unsigned long long zb = (unsigned long long)__double_as_longlong(a.zi[(size_t)comp * D + (q >> 1)]);
+            got = (q & 1) ? (unsigned)(zb >> 32) : (unsigned)zb;
+        }
+        cw[comp * 32 + q] = got;
+    }
+    __syncthreads();
+
+    // ---- C: z_j += M^j c, per component ----
+    if ((wave << 6) < (1 << a.n_lv)) {
+#pragma unroll 1
+        for (int comp = 0; comp < 2; ++comp) {
+            double u[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                u[d] = __longlong_as_double((long long)(((unsigned long long)cw[comp * 32 + 2 * d + 1] << 32) | cw[comp * 32 + 2 * d]));
+#pragma unroll 1
+            for (int l = 0; l < a.n_lv; ++l) {
+                if ((tid >> l) & 1) {
+                    double t2[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) t2[d] = 0.0;
+                    matvec_acc<D, ORD>(pw + (size_t)l * D * D, u, t2);
+#pragma unroll
+                    for (int d = 0; d < D; ++d) u[d] = t2[d];
+                }
+            }
+            if (tid < (1 << a.n_lv)) {
+                if (comp == 0) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) z0[d] += u[d];
+                } else {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) z1[d] += u[d];
+                }
+            }
+        }
+    }
+
+    // ---- B: both recurrences over the register-resident chunk; outputs re-joined through the planes ----
+    const int64_t cj = row0 + tid;
+    const bool zf_owner = a.zf != nullptr && cj == (a.n - 1) / TC;
+    const int zf_off = (int)((a.n - 1) % TC);
+#pragma unroll 1
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int k = 0; k < PC; ++k) {
+            xr[k] = (IO)cascade_step<NSEC, ORD, UNIT>(cf, z0, (double)xr[k]);
+            if (zf_owner && zf_off == p * PC + k) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) a.zf[d] = z0[d];
+            }
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < PC; ++k) {
+            xi[k] = (IO)cascade_step<NSEC, ORD, UNIT>(cf, z1, (double)xi[k]);
+            if (zf_owner && zf_off == p * PC + k) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) a.zf[D + d] = z1[d];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c4 = 0; c4 < PC / E; ++c4) {
+            float4 qa, qb;
+            IO *ea = reinterpret_cast<IO *>(&qa), *eb = reinterpret_cast<IO *>(&qb);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                ea[e] = xr[c4 * E + e];
+                eb[e] = xi[c4 * E + e];
+            }
+            *reinterpret_cast<float4 *>(rr + c4 * E) = qa;
+            *reinterpret_cast<float4 *>(ri + c4 * E) = qb;
+        }
+#pragma unroll
+        for (int k = 0; k + PC < TC; ++k) {
+            xr[k] = xr[k + PC];
+            xi[k] = xi[k + PC];
+        }
+        __syncthreads();
+        int64_t dq_run = 0;
+        int dr_run = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = i * kIirThreads + tid;
+            const int row = idx >> 3, sg = idx & 7;
+            const int64_t g = (row0 + row) * TC + (int64_t)p * PC + (int64_t)sg * (E / 2);
+            IO out[E];
+#pragma unroll
+            for (int k = 0; k < E / 2; ++k) {
+                out[2 * k] = st_re[row * PITCH + sg * (E / 2) + k];
+                out[2 * k + 1] = st_im[row * PITCH + sg * (E / 2) + k];
+            }
+            if (a.dec > 1) {   // at most one of the E / 2 <= 2 <= dec complex samples of a segment is kept
+                if (i == 0) {
+                    dq_run = g / a.dec;
+                    dr_run = (int)(g - dq_run * a.dec);
+                }
+                const int e0 = dr_run == 0 ? 0 : a.dec - dr_run;
+                if (e0 < E / 2 && g + e0 < a.n_keep) {
+                    IO re = out[0], im = out[1];
+#pragma unroll
+                    for (int k = 1; k < E / 2; ++k) {
+                        re = (e0 == k) ? out[2 * k] : re;
+                        im = (e0 == k) ? out[2 * k + 1] : im;
+                    }
+                    IO *dst = y + 2 * (dq_run + (dr_run != 0));
+                    dst[0] = re;
+                    dst[1] = im;
+                }
+                dq_run += a.dec_dq;
+                dr_run += a.dec_dr;
+                if (dr_run >= a.dec) { dr_run -= a.dec; ++dq_run; }
+            } else if (interior || g + E / 2 <= a.n) {
+                __builtin_nontemporal_store(*reinterpret_cast<const pre_t *>(out), reinterpret_cast<pre_t *>(y + 2 * g));
+            } else if (g < a.n) {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (g + e / 2 < a.n) y[2 * g + e] = out[e];
+            }
+        }
+    }
+}
+
 // single-pass scan: one workgroup per segment of 256 chunks, segments handed out by ticket
 template <typename IO>
 static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, const double *zi_dev,
-                        double *zf_dev, hipStream_t s, int dec)
+                        double *zf_dev, hipStream_t s, int dec, int interleaved)
 {
     IirPlan *p = h->plan;
-    constexpr int T = 512 / (int)sizeof(IO);
+    const int T = (interleaved ? 256 : 512) / (int)sizeof(IO);
     const int64_t S = (int64_t)kIirThreads * T;
     const int64_t nseg = (n + S - 1) / S;
     SK_CHECK(nseg < (1 << 30), SKDSP_ERR_BADARG, "iir: too many segments");
@@ -331,10 +631,10 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
         SK_HIP(hipMemsetAsync(p->ticket_dev, 0, 16, s));
         SK_HIP(hipHostMalloc((void **)&p->err_host, sizeof(unsigned), hipHostMallocMapped));
         *p->err_host = 0;
-        p->ticket_count = 0;
+        p->ticket_count[0] = p->ticket_count[1] = 0;
     }
     SK_CHECK(*p->err_host == 0, SKDSP_ERR_HIP, "iir: a look-back poll of an earlier single-pass launch timed out (results of that call are invalid)");
-    const size_t need = (size_t)nbatch * nseg * 32 * 8;
+    const size_t need = (size_t)(interleaved ? 2 : nbatch) * nseg * 32 * 8;
     if (need > p->lbg_cap) {
         if (p->lbg_dev) {
             SK_HIP(hipStreamSynchronize(s));
@@ -348,7 +648,8 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
     FusedArgs a;
     a.x = x; a.y = y; a.n = n; a.batch_stride = batch_stride;
     a.pw = p->pw_dev; a.gt = p->gt_dev;
-    a.lb = p->lbg_dev; a.ticket = p->ticket_dev; a.ticket_base = p->ticket_count;
+    a.lb = p->lbg_dev; a.ticket = p->ticket_dev;
+    a.ticket_base[0] = p->ticket_count[0]; a.ticket_base[1] = p->ticket_count[1];
     a.epoch = ++p->epoch;
     if (a.epoch == 0) a.epoch = ++p->epoch;
     a.nseg = (int)nseg; a.n_lv = p->n_lv < 8 ? p->n_lv : 8;
@@ -356,15 +657,36 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
     a.dec = dec > 1 ? dec : 1;
     a.n_keep = (n / a.dec) * a.dec;
     {
-        const int64_t step = (int64_t)(kIirThreads / Stage<IO>::segs) * T;  // samples between a thread's staged segments
+        // samples between a thread's staged segments (the interleaved kernel stages 8 segments per row piece)
+        const int64_t step = (int64_t)(interleaved ? kIirThreads / 8 : kIirThreads / Stage<IO>::segs) * T;
         a.dec_dq = (int)(step / a.dec);
         a.dec_dr = (int)(step % a.dec);
     }
     unsigned *err_dev = nullptr;
     SK_HIP(hipHostGetDevicePointer((void **)&err_dev, p->err_host, 0));
     a.err = err_dev;
-    p->ticket_count += (unsigned long long)nseg;
-    const dim3 grid((unsigned)nseg, (unsigned)nbatch);
+    for (int b = 0; b < (interleaved ? 1 : nbatch); ++b) p->ticket_count[b] += (unsigned long long)nseg;
+    const dim3 grid((unsigned)nseg, (unsigned)(interleaved ? 1 : nbatch));
+    if (interleaved) {
+#define SK_FUSEDC(N)                                                                                                  \
+    case N: {                                                                                                        \
+        Coef<N, 2> cf;                                                                                               \
+        std::memcpy(cf.c, h->coef.data(), sizeof(cf.c));                                                             \
+        if (N >= 2 && h->unit_tail) hipLaunchKernelGGL((iir_fused_c_kernel<N, IO, (N >= 2)>), grid, dim3(kIirThreads), 0, s, a, cf, a.pw, a.gt); \
+        else hipLaunchKernelGGL((iir_fused_c_kernel<N, IO, false>), grid, dim3(kIirThreads), 0, s, a, cf, a.pw, a.gt); \
+        break;                                                                                                       \
+    }
+        switch (h->nsec) {
+#ifndef SK_FUSED_ONLY8
+            SK_FUSEDC(1) SK_FUSEDC(2) SK_FUSEDC(3) SK_FUSEDC(4) SK_FUSEDC(5) SK_FUSEDC(6) SK_FUSEDC(7)
+#endif
+            SK_FUSEDC(8)
+            default: SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "iir: single-pass scan takes 1..8 biquads");
+        }
+#undef SK_FUSEDC
+        SK_HIP(hipGetLastError());
+        return SKDSP_OK;
+    }
 #define SK_FUSED(N)                                                                                                  \
     case N: {                                                                                                        \
         Coef<N, 2> cf;                                                                                               \
@@ -386,10 +708,10 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
 }
 
 int iir_fused_launch(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, const double *zi_dev,
-                     double *zf_dev, hipStream_t s, int dec)
+                     double *zf_dev, hipStream_t s, int dec, int interleaved)
 {
-    return dtype_double(h->dtype) ? launch_fused<double>(h, x, n, nbatch, batch_stride, y, zi_dev, zf_dev, s, dec)
-                                  : launch_fused<float>(h, x, n, nbatch, batch_stride, y, zi_dev, zf_dev, s, dec);
+    return dtype_double(h->dtype) ? launch_fused<double>(h, x, n, nbatch, batch_stride, y, zi_dev, zf_dev, s, dec, interleaved)
+                                  : launch_fused<float>(h, x, n, nbatch, batch_stride, y, zi_dev, zf_dev, s, dec, interleaved);
 }
 
 }  // namespace skdsp

@@ -998,7 +998,7 @@ static int ensure_powers(IirHandle *h, int64_t T, hipStream_t s)
         SK_HIP(hipStreamSynchronize(s));
     }
     p->gt_T = -1;
-    if (D <= 32 && (T % kMmPiece == 0 || T == 64)) {
+    if (D <= 32 && (T % kMmPiece == 0 || T == 64 || T == 32)) {
         // G[:, k] = A^(T-1-k) b, b = the state one sample x = 1 leaves behind; stored as the MFMA A operand
         // of step s = k / 4: lane l holds row l & 15, column 4 s + (l >> 4)
         std::vector<long double> g(D, 0.0L);
@@ -1171,19 +1171,24 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     // is below 1e-30 (n_lb == 1 for the segment's chunk length), enough segments to fill the chip.
     bool fused = false;
     {
-        const int64_t Tf = dtype_double(h->dtype) ? 64 : 128;
-        if (!interleaved && h->order == 2 && D <= 16 && opt().iir_two_pass <= 0 && p->fused_state >= 0 &&
-            (dec <= 1 || (nbatch == 1 && zf_host == nullptr)) &&
+        // chunk length: 128 float32 / 64 float64 samples (real), 64 complex64 / 32 complex128 samples (interleaved)
+        const int64_t Tf = (dtype_double(h->dtype) ? 64 : 128) / (interleaved ? 2 : 1);
+        int &fstate = interleaved ? p->fused_state_c : p->fused_state;
+        if (h->order == 2 && D <= 16 && opt().iir_two_pass <= 0 && fstate >= 0 &&
+            (dec <= 1 || ((nbatch == 1 || interleaved) && zf_host == nullptr)) &&
             n >= Tf * kIirThreads * (int64_t)ctx().num_cus) {
             rc = ensure_powers(h, Tf, s);
             if (rc) return rc;
-            p->fused_state = (p->n_lb == 1 && p->gt_T == Tf) ? 1 : -1;
+            fstate = (p->n_lb == 1 && p->gt_T == Tf) ? 1 : -1;
             // Measured crossover (2^26 float32, same box): the single pass costs one from-rest scan plus a correction per
             // 128-sample chunk -- 6 + 1.5 levels of a 16 x 16 transition for the 8-biquad elliptic band-pass of BASELINE
             // config 4 (0.206 ms) against 4 levels per 512-sample chunk in the two-pass scan (0.196 ms).  Up to 6 levels
             // (every low-pass design tried: 0.12-0.13 vs 0.16-0.17 ms) and for float64 signals (0.35 vs 0.44 ms) it wins.
-            if (!dtype_double(h->dtype) && p->n_lv >= 6 && D >= 14 && opt().iir_two_pass >= 0) p->fused_state = -1;
-            fused = p->fused_state == 1;
+            if (!interleaved && !dtype_double(h->dtype) && p->n_lv >= 6 && D >= 14 && opt().iir_two_pass >= 0) fstate = -1;
+            // interleaved complex64 (two scans per 64-sample chunk): 0.24-0.30 vs 0.42-0.43 ms for low-pass designs (<= 4
+            // levels), 0.63 vs 0.46 ms for the config-4 cascade (7 levels)
+            if (interleaved && !dtype_double(h->dtype) && p->n_lv >= 6 && opt().iir_two_pass >= 0) fstate = -1;
+            fused = fstate == 1;
         }
     }
     int maxW = kMaxPairs / D;
@@ -1236,7 +1241,7 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     if (zf_host) a.zf = p->state_dev + 2 * D;
     SK_CHECK(nbatch >= 1 && nbatch <= 2, SKDSP_ERR_BADARG, "iir: batch must be 1 or 2");
     if (fused)
-        rc = iir_fused_launch(h, x, n, nbatch, batch_stride, y, a.zi, a.zf, s, dec);
+        rc = iir_fused_launch(h, x, n, nbatch, batch_stride, y, a.zi, a.zf, s, dec, interleaved);
     else
         rc = dtype_double(h->dtype) ? dispatch_shape<double>(h, a, nbatch, W, s) : dispatch_shape<float>(h, a, nbatch, W, s);
     if (rc) return rc;  // (1 = interleaved path not applicable, nothing was launched)

@@ -1428,7 +1428,8 @@ def test_iir_dn_decimating_store(dt, M, n):
 
 
 # ----------------------------------------------------------------- single-pass IIR scan (iir_fused.hip)
-@pytest.mark.parametrize("dt,n", [(np.float32, 9_000_017), (np.float32, 2 ** 24), (np.float64, 4_400_003)])
+@pytest.mark.parametrize("dt,n", [(np.float32, 9_000_017), (np.float32, 2 ** 24), (np.float64, 4_400_003), (np.complex64, 4_300_009),
+                                  (np.complex128, 2_200_001)])
 @pytest.mark.parametrize("filt", ["ellip8", "butter4", "biquad"])
 def test_iir_single_pass_scan_matches_two_pass_and_oracle(dt, n, filt):
     """The single-pass scan (one launch, x read once: segments of 256 register-resident chunks, from-rest scan,
@@ -1440,34 +1441,41 @@ def test_iir_single_pass_scan_matches_two_pass_and_oracle(dt, n, filt):
            "biquad": signal.tf2sos(*signal.iirpeak(0.1, 30))}[filt]
     nsec = sos.shape[0]
     rng = np.random.default_rng(5)
-    zi = rng.standard_normal((nsec, 2)) * 0.1
+    cplx = np.dtype(dt).kind == "c"
+    single = dt in (np.float32, np.complex64)
+    zi = rng.standard_normal((nsec, 2)) * 0.1 + (1j * rng.standard_normal((nsec, 2)) * 0.1 if cplx else 0)
+    zi_flat = np.concatenate([zi.real.ravel(), zi.imag.ravel()]) if cplx else zi.ravel()   # C ABI: states of re, then of im
     k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
     xd = _ffi.DeviceArray(n, dt).fill_noise(77)
     y1 = _ffi.DeviceArray(n, dt)
     y2 = _ffi.DeviceArray(n, dt)
+    D = 2 * nsec
+    unflat = (lambda z: (z[:D] + 1j * z[D:])) if cplx else (lambda z: z)
     try:
         with _ffi.option("iir_two_pass", -1):  # (-1: single pass wherever it applies, also where the two-pass scan measured faster)
-            zf1 = k.filter_state_dev(xd, y1, zi=zi.ravel())
+            zf1 = unflat(k.filter_state_dev(xd, y1, zi=zi_flat))
         with _ffi.option("iir_two_pass", 1):
-            zf2 = k.filter_state_dev(xd, y2, zi=zi.ravel())
-        tol = TOL32 if dt == np.float32 else 1e-12
+            zf2 = unflat(k.filter_state_dev(xd, y2, zi=zi_flat))
+        tol = TOL32 if single else 1e-12
         w = 1 << 20
         for s0 in (0, n // 2 - 12345, n - w):
             assert_close(y1.to_host(s0, w), y2.to_host(s0, w), tol, "single-pass vs two-pass @%d" % s0)
         assert_close(zf1, zf2, 1e-9, "final state")
         m = 300_000
-        ref, _ = signal.sosfilt(sos, xd.to_host(0, m).astype(np.float64), zi=zi)
-        assert_close(y1.to_host(0, m), ref, TOL32 if dt == np.float32 else 1e-10, "head vs sosfilt(zi)")
+        wide = np.complex128 if cplx else np.float64
+        ref, _ = signal.sosfilt(sos, xd.to_host(0, m).astype(wide), zi=zi.astype(wide))
+        assert_close(y1.to_host(0, m), ref, TOL32 if single else 1e-10, "head vs sosfilt(zi)")
         lo = n - m - 60_000
-        ref2, zf_ref = signal.sosfilt(sos, xd.to_host(lo, n - lo).astype(np.float64), zi=np.zeros((nsec, 2)))
-        assert_close(y1.to_host(n - m, m), ref2[-m:], TOL32 if dt == np.float32 else 1e-10, "tail vs sosfilt")
+        ref2, zf_ref = signal.sosfilt(sos, xd.to_host(lo, n - lo).astype(wide), zi=np.zeros((nsec, 2), dtype=wide))
+        assert_close(y1.to_host(n - m, m), ref2[-m:], TOL32 if single else 1e-10, "tail vs sosfilt")
         assert_close(zf1, zf_ref.ravel(), 1e-9, "final state vs sosfilt")
         # back-to-back launches reuse the look-back slots with a new epoch each: results must not change
         first = y1.to_host(n - w, w)
         for _ in range(5):
             k.filter_dev(xd, y1)
         _ffi.sync()
-        k.filter_state_dev(xd, y1, zi=zi.ravel(), want_zf=False)
+        with _ffi.option("iir_two_pass", -1):
+            k.filter_state_dev(xd, y1, zi=zi_flat, want_zf=False)
         assert np.array_equal(y1.to_host(n - w, w), first)
     finally:
         xd.free()
