@@ -5,6 +5,7 @@ the GPU (sigsys.pulse_shape -> multirate_FIR.up -> fir_direct.hip / fir_ols.hip)
 
   qam_gray_encode_bb(n_symb, ns, mod, pulse, alpha, m_span, ext_data)   digitalcom.py:1584-1681
   mpsk_gray_encode_bb(n_symb, ns, mod, pulse, alpha, m_span, ext_data)  digitalcom.py:1742-1826
+  qam_bb, mpsk_bb, gmsk_bb, rz_bits, time_delay (constant delay)         digitalcom.py:418-492, 613-667, 585-610, 998-1048, 1089-1131
 """
 import numpy as np
 
@@ -79,3 +80,75 @@ def mpsk_gray_encode_bb(n_symb, ns, mod=4, pulse='rect', alpha=0.35, m_span=6, e
         x, b = _shape(x_iq, ns, pulse, alpha, m_span)
         return x, b, data
     return x_iq, 1, data
+
+
+# ---- the remaining lfilter(b, 1, .) callers of digitalcom.py (488, 608, 666, 1047, 1130) ------------------------------
+def qam_bb(n_symb, ns, mod='16qam', pulse='rect', alpha=0.35):
+    """Square-QAM complex baseband transmitter without Gray mapping (digitalcom.py:418-492): (x, b, tx_data).  The
+    random symbols are drawn exactly as the reference draws them (I levels, then Q levels)."""
+    b = _pulse(pulse, ns, alpha, 6, err='pulse shape must be src, rc, or rect')
+    levels = {'qpsk': 2, '16qam': 4, '64qam': 8, '256qam': 16}.get(mod.lower())
+    if levels is None:
+        raise ValueError('Unknown mod_type')
+    x_i = 2 * np.random.randint(0, levels, n_symb) - (levels - 1)
+    x_q = 2 * np.random.randint(0, levels, n_symb) - (levels - 1)
+    symb = (x_i + 1j * x_q).astype(np.complex128)
+    if levels > 2:
+        symb = symb / (levels - 1)
+    x = pulse_shape(symb, b, ns) if n_symb else np.zeros(0, dtype=np.complex128)
+    return x, b / sum(b), x_i + 1j * x_q
+
+
+def mpsk_bb(n_symb, ns, mod, pulse='rect', alpha=0.25, m=6):
+    """M-ary PSK complex baseband transmitter (digitalcom.py:613-667): (x, b / ns, data)."""
+    data = np.random.randint(0, mod, n_symb)
+    xs = np.exp(1j * 2 * np.pi / mod * data)
+    b = _pulse(pulse, ns, alpha, m, err='pulse type must be rec, rc, or src')
+    x = pulse_shape(xs, b, ns) if n_symb else np.zeros(0, dtype=np.complex128)
+    if mod == 4:
+        x = x * np.exp(1j * np.pi / 4)
+    return x, b / float(ns), data
+
+
+def rz_bits(n_bits, ns, pulse='rect', alpha=0.25, m=6):
+    """Return-to-zero 0/1 waveform from random bits (digitalcom.py:998-1048): (x, b / ns, data)."""
+    data = np.random.randint(0, 2, n_bits)
+    b = _pulse(pulse, ns, alpha, m, err='pulse type must be rec, rc, or src')
+    x = pulse_shape(data, b, ns) if n_bits else np.zeros(0)
+    return x, b / float(ns), data
+
+
+def gmsk_bb(n_bits, ns, msk=0, bt=0.35):
+    """MSK / GMSK complex baseband transmitter (digitalcom.py:585-610): (y, data).  The NRZ shaping and the Gaussian
+    pre-modulation filter (8 ns + 1 taps) run on the GPU; the phase accumulation is a host cumsum as in the reference."""
+    from .sigsys import nrz_bits
+    from . import multirate_helper as mrh
+    x, b, data = nrz_bits(n_bits, ns)
+    span = 4
+    n = np.arange(-span * ns, span * ns + 1)
+    p = np.exp(-2 * np.pi ** 2 * bt ** 2 / np.log(2) * (n / float(ns)) ** 2)
+    p = p / np.sum(p)
+    if msk != 0:
+        x = mrh.multirate_FIR(p).filter(x)
+    y = np.exp(1j * np.pi / 2 * np.cumsum(x) / ns)
+    return y, data
+
+
+def time_delay(x, d, n=4):
+    """Farrow-structure time delay (digitalcom.py:1089-1160) for a CONSTANT delay d (the branch that is one lfilter call,
+    :1110-1131): cubic Lagrange taps behind fix(d) whole samples, filtered on the GPU.  A delay that varies per sample
+    is the reference's per-sample Python loop and is not on the accelerated path."""
+    from . import multirate_helper as mrh
+    if np.ndim(d) != 0 and len(np.atleast_1d(d)) != 1:
+        raise NotImplementedError("time_delay: only a constant delay (scalar d) runs on the GPU path")
+    d = float(np.atleast_1d(d)[0])
+    if int(np.fix(d)) < 1 or int(np.fix(d)) > n - 2:
+        raise ValueError("time_delay: the integer part of d must lie in [1, n - 2]")
+    frac = d - np.fix(d)
+    nd = int(np.fix(d))
+    b = np.zeros(nd + 4)
+    b[nd] = -(frac - 1) * (frac - 2) * (frac - 3) / 6.
+    b[nd + 1] = frac * (frac - 2) * (frac - 3) / 2.
+    b[nd + 2] = -frac * (frac - 1) * (frac - 3) / 2.
+    b[nd + 3] = frac * (frac - 1) * (frac - 2) / 6.
+    return mrh.multirate_FIR(b).filter(np.asarray(x))

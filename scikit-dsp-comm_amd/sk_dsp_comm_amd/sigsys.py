@@ -115,19 +115,45 @@ def _transform_domain_fir(x, h, N, mode, name):
     L = int(N) - P + 1
     if L <= 0:
         raise ValueError("%s: FFT size N=%d must exceed the filter length P=%d - 1" % (name, int(N), P))
-    if mode == 1:
-        raise NotImplementedError("%s(mode=1): the per-frame diagnostic matrix is a teaching aid of the "
-                                  "reference's Python loop and is not produced by the GPU path" % name)
     x = np.asarray(x)
     if len(x) == 0:
-        return np.zeros(0)
+        return (np.zeros(0), np.zeros((0, 0))) if mode == 1 else np.zeros(0)
     saved = config.strict_dtype
     config.strict_dtype = True
     try:
         y = mrh.multirate_FIR(np.asarray(h)).filter(x)
     finally:
         config.strict_dtype = saved
-    return np.ascontiguousarray(np.real(y), dtype=np.float64)
+    y = np.ascontiguousarray(np.real(y), dtype=np.float64)
+    if mode == 1:
+        return y, _frame_matrix(x, np.asarray(h), int(N), name)
+    return y
+
+
+def _frame_matrix(x, h, N, name):
+    """The diagnostic matrix of os_filter / oa_filter(mode=1): row k holds the N outputs of frame k's circular
+    convolution at the frame's position (sigsys.py:517-540, 582-598).  It is a teaching aid of the reference's frame
+    loop (Nframe x Nx float64 -- quadratic in the signal length), computed here on the host with one batched FFT;
+    the filtered signal itself comes from the GPU."""
+    P, Nx0 = len(h), len(x)
+    L = N - P + 1
+    H = np.fft.fft(h, N)
+    if name == "os_filter":
+        xp = np.concatenate([np.zeros(P - 1), x])
+        Nx = len(xp)
+        nframe = int(np.ceil(Nx / float(L)))
+        xp = np.concatenate([xp, np.zeros(nframe * L - Nx + N)])
+        frames = np.stack([xp[k * L:k * L + N] for k in range(nframe)])
+    else:
+        Nx = Nx0
+        nframe = int(np.ceil(Nx / float(L)))
+        xp = np.concatenate([x, np.zeros(nframe * L - Nx)])
+        frames = xp.reshape(nframe, L)
+    yk = np.real(np.fft.ifft(np.fft.fft(frames, N, axis=1) * H, axis=1))
+    y_mat = np.zeros((nframe, nframe * N))
+    for k in range(nframe):
+        y_mat[k, k * L:k * L + N] = yk[k]
+    return y_mat[:, P - 1:Nx] if name == "os_filter" else y_mat[:, 0:Nx]
 
 
 def os_filter(x, h, N, mode=0):
@@ -286,6 +312,42 @@ def nrz_bits(n_bits, ns, pulse='rect', alpha=0.25, m=6):
     data = np.random.randint(0, 2, n_bits)
     x, b = nrz_bits2(data, ns, pulse, alpha, m)
     return x, b, data
+
+
+def env_det(x):
+    """Ideal envelope detector: half-wave rectifier (sigsys.py:2913-2942)."""
+    x = np.asarray(x)
+    return np.where(x >= 0, x, 0).astype(np.float64)
+
+
+def am_tx(m, a_mod, fc=75e3):
+    """AM transmitter of the Chapter-17 case study (sigsys.py:2784-2819): the message is interpolated by 24 on the GPU
+    (interp24), the carrier is applied on the host.  Returns (x192, t192, m24)."""
+    m24 = interp24(m)
+    t192 = np.arange(len(m24)) / 192.0e3
+    m_max = np.max(np.abs(m24))
+    x192 = (1 + a_mod * m24 / m_max) * np.cos(2 * np.pi * fc * t192)
+    return x192, t192, m24
+
+
+def am_rx(x192):
+    """AM envelope-detector receiver (sigsys.py:2822-2866): env_det -> deci24 (GPU) -> DC removal, plus the 192 ksps
+    monitor output through two passes of a 5th-order Butterworth at 5 kHz (one 10th-order cascade launch here).
+    Returns (m_rx8, t8, m_rx192, x_edet192)."""
+    import scipy.signal as signal
+    x_edet192 = env_det(x192)
+    m_rx8 = deci24(x_edet192)
+    m_rx8 = m_rx8 - np.mean(m_rx8)
+    t8 = np.arange(len(m_rx8)) / 8.0e3
+    b192, a192 = signal.butter(5, 2 * 5.0e3 / 192.0e3)
+    if len(x_edet192):
+        sos = _ffi.tf2sos(b192, a192)
+        from . import multirate_helper as mrh
+        m_rx192 = mrh.multirate_IIR(np.vstack([sos, sos])).filter(x_edet192)   # lfilter(b, a, lfilter(b, a, .))
+    else:
+        m_rx192 = np.zeros(0)
+    m_rx192 = m_rx192 - np.mean(m_rx192) if len(m_rx192) else m_rx192
+    return m_rx8, t8, m_rx192, x_edet192
 
 
 def fft_filt_bank(x_in, h_filt, n_fft2=512, n_bands2=0, bs=0.2, fs=1.0, n_band_odd=True):

@@ -303,8 +303,8 @@ def test_os_oa_filter_next_row():
     assert y.dtype == np.float64 and y.shape == g["osc_os"].shape
     assert_close(y, g["osc_os"], TOL64, "os_filter complex in")
     assert_close(ss.oa_filter(g["osc_x"].astype(np.complex64), g["osc_h"], 256), g["osc_oa"], TOL32, "oa_filter c64")
-    with pytest.raises(NotImplementedError):
-        ss.os_filter(g["os_x"], g["os_b"], 1024, mode=1)
+    y1, ymat = ss.os_filter(g["os_x"], g["os_b"], 1024, mode=1)   # (the diagnostic matrix: test_wideners_match_reference)
+    assert ymat.shape[1] == len(y1)
     with pytest.raises(ValueError):
         ss.oa_filter(g["os_x"], g["os_b"], 4)
     assert ss.os_filter(np.zeros(0), g["os_b"], 64).shape == (0,)
@@ -1546,3 +1546,55 @@ def test_fir_ols64_full_size_windows():
         assert_close(yd.to_host(s0, 9000), ref, TOL64, "window @%d" % s0)
     xd.free()
     yd.free()
+
+
+# ----------------------------------------------------------------- round-2 wideners (vectors captured from the reference: G14)
+def test_wideners_match_reference():
+    """os_filter / oa_filter with the diagnostic matrix, the AM case-study pair around interp24 / deci24, the remaining
+    lfilter(b, 1, .) transmitters of digitalcom and the constant-delay Farrow filter, against tests/golden/g14_wideners.npz
+    (captured by tests/golden/gen_golden_wideners.py from the real reference; random transmitters under np.random.seed)."""
+    from sk_dsp_comm_amd import digitalcom as dcm
+    g = load("g14_wideners.npz")
+    for name, fn in (("os", ss.os_filter), ("oa", ss.oa_filter)):
+        y, ym = fn(g[name + "_x"], g[name + "_h"], 32, mode=1)
+        assert_close(y, g[name + "_y"], 1e-11, name + "_filter")
+        assert ym.shape == g[name + "_ymat"].shape
+        assert_close(ym, g[name + "_ymat"], 1e-12, name + "_filter frame matrix")
+    x192, t192, m24 = ss.am_tx(g["am_m"], 0.8, fc=75e3)
+    assert np.array_equal(t192, g["am_t192"])
+    assert_close(m24, g["am_m24"], 1e-8, "am_tx m24")
+    assert_close(x192, g["am_x192"], 1e-8, "am_tx x192")
+    m_rx8, t8, m_rx192, x_edet = ss.am_rx(g["am_x192"])
+    assert np.array_equal(x_edet, g["am_edet"]) and np.array_equal(t8, g["am_t8"])
+    assert_close(m_rx8, g["am_rx8"], 1e-8, "am_rx 8 ksps")
+    assert_close(m_rx192, g["am_rx192"], 1e-8, "am_rx 192 ksps")
+    np.random.seed(2024)
+    x, b, d = dcm.qam_bb(300, 8, '16qam', 'src', 0.25)
+    assert np.array_equal(d, g["qam_d"]) and np.allclose(b, g["qam_b"], rtol=0, atol=1e-15)
+    assert_close(x, g["qam_x"], 1e-11, "qam_bb")
+    np.random.seed(2025)
+    x, b, d = dcm.qam_bb(200, 4, 'qpsk', 'rect')
+    assert np.array_equal(d, g["qpsk_d"])
+    assert_close(x, g["qpsk_x"], 1e-11, "qam_bb qpsk")
+    np.random.seed(2026)
+    x, b, d = dcm.mpsk_bb(256, 10, 8, 'rc', 0.35, 5)
+    assert np.array_equal(d, g["mpsk_d"]) and np.allclose(b, g["mpsk_b"], rtol=0, atol=1e-15)
+    assert_close(x, g["mpsk_x"], 1e-11, "mpsk_bb")
+    np.random.seed(2027)
+    x, b, d = dcm.mpsk_bb(128, 6, 4, 'rect')
+    assert_close(x, g["mpsk4_x"], 1e-11, "mpsk_bb qpsk rotation")
+    np.random.seed(2028)
+    x, b, d = dcm.rz_bits(500, 12, 'src', 0.5, 4)
+    assert np.array_equal(d, g["rz_d"])
+    assert_close(x, g["rz_x"], 1e-11, "rz_bits")
+    np.random.seed(2029)
+    y, d = dcm.gmsk_bb(400, 8, 1, 0.3)
+    assert np.array_equal(d, g["gmsk_d"])
+    assert_close(y, g["gmsk_y"], 1e-9, "gmsk_bb")
+    np.random.seed(2030)
+    y, d = dcm.gmsk_bb(300, 6, 0)
+    assert_close(y, g["msk_y"], 1e-9, "msk")
+    assert_close(dcm.time_delay(g["td_x"], 1.37, 4), g["td_y"], 1e-12, "time_delay")
+    assert_close(dcm.time_delay(g["td_x"], 2.0, 6), g["td_y2"], 1e-12, "time_delay integer")
+    with pytest.raises(NotImplementedError):
+        dcm.time_delay(g["td_x"], np.full(len(g["td_x"]), 1.5))
