@@ -174,7 +174,7 @@ static int pick_fir_algo(const FirHandle *h, int64_t n)
     if (algo != SKDSP_FIR_AUTO) return algo;
     // float64 signals: the direct form costs 2 (4 for complex taps) FP64 FMA per tap and real sample; the float64
     // overlap-save tile is flat in the tap count (measured crossovers at 2^26 samples: see DESIGN.md 4.1b)
-    if (ols64) return h->ntaps >= (h->dtype == SKDSP_C128 ? 80 : 160) && n >= 8192 ? SKDSP_FIR_OLS : SKDSP_FIR_DIRECT;
+    if (ols64) return h->ntaps >= (h->dtype == SKDSP_C128 ? 24 : 128) && n >= 8192 ? SKDSP_FIR_OLS : SKDSP_FIR_DIRECT;
     // measured crossover at 2^26 samples (same box, alternating runs): the bf16x3 matrix-pipe kernel (real taps) stays
     // ahead of overlap-save up to 3 lag blocks for complex64 (0.21 vs 0.23 ms at 81 taps; 0.234 vs 0.227 at 96) and
     // 5 for float32 (0.135 vs 0.138 ms at 145 taps)

@@ -28,6 +28,12 @@ namespace skdsp {
 namespace {
 
 typedef double2 cdd;
+#ifndef SK_OLS64_HREG
+#define SK_OLS64_HREG -1  // -1: per kernel (see below); 0 / 1: force
+#endif
+#ifndef SK_OLS64_PF
+#define SK_OLS64_PF 0
+#endif
 #ifndef SK_OLS64_WPE
 #define SK_OLS64_WPE 2
 #endif
@@ -78,20 +84,54 @@ template <int I, int E, class F> __device__ __forceinline__ void static_for64(F 
     }
 }
 
-// 16-point DFT, natural order in and out, everything in registers (radix 4 x 4)
-template <bool INV> __device__ __forceinline__ void dft16(const cdd *x, cdd *X)
+// 16-point DFTs IN PLACE (radix 4 x 4), so that a pass needs one 16-element register array instead of three:
+//   dft16_f  natural order in, output X[k] at slot P16(k) = 4 (k & 3) + (k >> 2)   (decimation in frequency)
+//   dft16_g  input Z[m] at slot P16(m), natural order out; unnormalised inverse      (decimation in time)
+// P16 is its own inverse (the transpose of the 4 x 4 index grid) and every index below is a compile-time constant, so
+// the permutation costs nothing: the forward passes hand their output to LDS / H through P16, the inverse pass 3 takes
+// the spectrum exactly where the forward pass 3 left it.
+__device__ __host__ constexpr int P16(int k) { return ((k & 3) << 2) | (k >> 2); }
+
+template <bool INV> __device__ __forceinline__ void dft4_ip(cdd &x0, cdd &x1, cdd &x2, cdd &x3)
 {
-    cdd a[4][4];  // a[n1][k2] = DFT4 over n2 of x[n1 + 4 n2]
+    const cdd s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = csub(x1, x3);
+    const cdd r = mul_mi<INV>(d13);
+    x0 = cadd(s02, s13);
+    x2 = csub(s02, s13);
+    x1 = cadd(d02, r);
+    x3 = csub(d02, r);
+}
+
+__device__ __forceinline__ void dft16_f(cdd *v)
+{
+    // stage 1: DFT4 over n2 for each n1 (slots n1, n1 + 4, n1 + 8, n1 + 12): slot n1 + 4 k2 = a[n1][k2]
 #pragma unroll
-    for (int n1 = 0; n1 < 4; ++n1) dft4<INV>(x[n1], x[n1 + 4], x[n1 + 8], x[n1 + 12], a[n1][0], a[n1][1], a[n1][2], a[n1][3]);
+    for (int n1 = 0; n1 < 4; ++n1) dft4_ip<false>(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
+    // twiddle W_16^(n1 k2), stage 2: DFT4 over n1 for each k2 (slots 4 k2 .. 4 k2 + 3): slot 4 k2 + k1 = X[k2 + 4 k1]
     static_for64<0, 4>([&](auto kc) {
         constexpr int k2 = decltype(kc)::value;
-        const cdd t0 = a[0][k2];
-        const cdd t1 = tw16<k2, INV>(a[1][k2]);
-        const cdd t2 = tw16<2 * k2, INV>(a[2][k2]);
-        const cdd t3 = tw16<3 * k2, INV>(a[3][k2]);
-        dft4<INV>(t0, t1, t2, t3, X[k2], X[k2 + 4], X[k2 + 8], X[k2 + 12]);
+        v[4 * k2 + 1] = tw16<k2, false>(v[4 * k2 + 1]);
+        v[4 * k2 + 2] = tw16<2 * k2, false>(v[4 * k2 + 2]);
+        v[4 * k2 + 3] = tw16<3 * k2, false>(v[4 * k2 + 3]);
     });
+    #pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) dft4_ip<false>(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
+}
+
+__device__ __forceinline__ void dft16_g(cdd *v)
+{
+    // input Z[m1 + 4 m2] at slot 4 m1 + m2.  stage A: inverse DFT4 over m2 for each m1 (slots 4 m1 .. 4 m1 + 3): slot 4 m1 + r
+#pragma unroll
+    for (int m1 = 0; m1 < 4; ++m1) dft4_ip<true>(v[4 * m1], v[4 * m1 + 1], v[4 * m1 + 2], v[4 * m1 + 3]);
+    // conj twiddle W_16^(m1 r) on slot 4 m1 + r; stage B: inverse DFT4 over m1 for each r (slots r, r + 4, r + 8, r + 12): x[r + 4 q] at slot r + 4 q
+    static_for64<1, 4>([&](auto mc) {
+        constexpr int m1 = decltype(mc)::value;
+        v[4 * m1 + 1] = tw16<m1, true>(v[4 * m1 + 1]);
+        v[4 * m1 + 2] = tw16<2 * m1, true>(v[4 * m1 + 2]);
+        v[4 * m1 + 3] = tw16<3 * m1, true>(v[4 * m1 + 3]);
+    });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dft4_ip<true>(v[r], v[r + 4], v[r + 8], v[r + 12]);
 }
 
 struct Ols64Args {
@@ -115,17 +155,24 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
     const int hi4 = t >> 4, lo4 = t & 15;
     const cdd w1 = A.W1[t];        // W_4096^t            (pass 1: t = 16 b + c)
     const cdd w2 = A.W2[lo4];      // W_256^c             (pass 2: thread (k1, c))
+    // This thread's 16 bins of H: in registers for the whole launch in the complex kernel (0.691 vs 0.738 ms at 2^26), streamed
+    // from L2 per tile in the two-real-tiles kernel (registers there: 0.487 vs 0.401 ms -- its loads and stores need more of them)
+    constexpr bool HREG = SK_OLS64_HREG < 0 ? !REAL : SK_OLS64_HREG != 0;
+    cdd hh[HREG ? 16 : 1];
+    if (HREG) {
+#pragma unroll
+        for (int k3 = 0; k3 < (HREG ? 16 : 1); ++k3) hh[k3] = A.Hp[k3 * 256 + t];
+    }
+#define SK_OLS64_H(k3) (HREG ? hh[HREG ? (k3) : 0] : A.Hp[(k3) * 256 + th])
 
-    int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
-    for (; tile < A.ntiles; tile += gridDim.x) {
-        cdd v[16], u[16];
-        // ---- load: v[a] = x[in0 + 256 a + t] (complex) or (xA, xB) of two real tiles ----
+    // x[in0 + 256 a + t] -> dst[a] (complex), or (xA, xB) of two real tiles; zero outside [-n_hist, n)
+    auto load_tile = [&](int64_t tile, int tl, cdd *dst) __attribute__((always_inline)) {
         if (REAL) {
             const int64_t inA = (2 * tile) * A.V - A.ov, inB = inA + A.V;
             const bool interior = inA >= -A.n_hist && inB + kN64 <= A.n;
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
-                const int64_t ga = inA + 256 * a + t, gb = ga + A.V;
+                const int64_t ga = inA + 256 * a + tl, gb = ga + A.V;
                 double re = 0.0, im = 0.0;
                 if (interior) {
                     re = __builtin_nontemporal_load(A.x + ga);
@@ -134,7 +181,7 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
                     if (ga >= -A.n_hist && ga < A.n) re = A.x[ga];
                     if (gb >= -A.n_hist && gb < A.n) im = A.x[gb];
                 }
-                v[a] = make_double2(re, im);
+                dst[a] = make_double2(re, im);
             }
         } else {
             const int64_t in0 = tile * A.V - A.ov;
@@ -142,23 +189,40 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
             typedef double v2d_t __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
-                const int64_t g = in0 + 256 * a + t;
+                const int64_t g = in0 + 256 * a + tl;
                 if (interior) {
                     const v2d_t q = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(A.x) + g);
-                    v[a] = make_double2(q.x, q.y);
+                    dst[a] = make_double2(q.x, q.y);
                 } else {
-                    v[a] = (g >= -A.n_hist && g < A.n) ? make_double2(A.x[2 * g], A.x[2 * g + 1]) : make_double2(0.0, 0.0);
+                    dst[a] = (g >= -A.n_hist && g < A.n) ? make_double2(A.x[2 * g], A.x[2 * g + 1]) : make_double2(0.0, 0.0);
                 }
             }
         }
+    };
+    int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+#if SK_OLS64_PF
+    cdd v[16];   // (carried across iterations: the next tile's samples are requested one tile ahead)
+    if (tile < A.ntiles) load_tile(tile, t, v);
+#endif
+    for (; tile < A.ntiles; tile += gridDim.x) {
+#if !SK_OLS64_PF
+        cdd v[16];
+#endif
+        // opaque copies of the thread index: stop LICM from hoisting the 16 + 16 + 16 loop-invariant 64-bit addresses of the
+        // loads, the H bins and the stores out of the tile loop (they were spilled and reloaded in front of every access)
+        int tl = t, th = t, ts = t;
+        asm volatile("" : "+v"(tl));
+#if !SK_OLS64_PF
+        load_tile(tile, tl, v);
+#endif
         // ---- pass 1: DFT16 over a, twiddle W_4096^(t k1) (running power), write [k1][b][c] ----
-        dft16<false>(v, u);
+        dft16_f(v);   // X[k1] at v[P16(k1)]
         {
             cdd w = w1;
-            img[0 * kPitch64 + hi4 * 17 + lo4] = u[0];
+            img[0 * kPitch64 + hi4 * 17 + lo4] = v[0];
 #pragma unroll
             for (int k1 = 1; k1 < 16; ++k1) {
-                img[k1 * kPitch64 + hi4 * 17 + lo4] = cmul(u[k1], w);
+                img[k1 * kPitch64 + hi4 * 17 + lo4] = cmul(v[P16(k1)], w);
                 w = cmul(w, w1);
             }
         }
@@ -166,25 +230,35 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
         // ---- pass 2: thread (k1 = hi4, c = lo4): DFT16 over b, twiddle W_256^(c k2), write [k1][k2][c] (same 16-lane group) ----
 #pragma unroll
         for (int b = 0; b < 16; ++b) v[b] = img[hi4 * kPitch64 + b * 17 + lo4];
-        dft16<false>(v, u);
+        dft16_f(v);
         {
             cdd w = w2;
-            img[hi4 * kPitch64 + 0 * 17 + lo4] = u[0];
+            img[hi4 * kPitch64 + 0 * 17 + lo4] = v[0];
 #pragma unroll
             for (int k2 = 1; k2 < 16; ++k2) {
-                img[hi4 * kPitch64 + k2 * 17 + lo4] = cmul(u[k2], w);
+                img[hi4 * kPitch64 + k2 * 17 + lo4] = cmul(v[P16(k2)], w);
                 w = cmul(w, w2);
             }
         }
         // ---- pass 3: thread (k1 = hi4, k2 = lo4): DFT16 over c; multiply by H ----
 #pragma unroll
         for (int c = 0; c < 16; ++c) v[c] = img[hi4 * kPitch64 + lo4 * 17 + c];
-        dft16<false>(v, u);
-        // (H streams from L2 every tile: keeping this thread's 16 bins in registers cost 104 spilled VGPRs)
+        dft16_f(v);   // Z[k3] at v[P16(k3)]
+        asm volatile("" : "+v"(th));
 #pragma unroll
-        for (int k3 = 0; k3 < 16; ++k3) u[k3] = cmul(u[k3], A.Hp[k3 * 256 + t]);
-        // ---- inverse pass 3: over k3 -> c, conj twiddle W_256^(c k2) needs c per element: done by the reader ----
-        dft16<true>(u, v);   // v[c] for thread (k1, k2)
+        for (int k3 = 0; k3 < 16; ++k3) v[P16(k3)] = cmul(v[P16(k3)], SK_OLS64_H(k3));
+        // ---- inverse pass 3: over k3 -> c (takes the spectrum where it lies); the conj twiddle W_256^(c k2) is applied by the reader ----
+#if SK_OLS64_PF
+        // the next tile's samples: requested now, in flight during the whole inverse transform, consumed at the top of the next iteration
+        cdd nx[16];
+        {
+            int tn = t;
+            asm volatile("" : "+v"(tn));
+            const int64_t next = tile + gridDim.x;
+            if (next < A.ntiles) load_tile(next, tn, nx);
+        }
+#endif
+        dft16_g(v);   // v[c] for thread (k1, k2)
 #pragma unroll
         for (int c = 0; c < 16; ++c) img[hi4 * kPitch64 + lo4 * 17 + c] = v[c];
         // thread (k1, c = lo4) reads over k2, applies conj W_256^(c k2), inverse DFT16 over k2 -> b
@@ -193,13 +267,13 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
             v[0] = img[hi4 * kPitch64 + 0 * 17 + lo4];
 #pragma unroll
             for (int k2 = 1; k2 < 16; ++k2) {
-                v[k2] = cmulc(img[hi4 * kPitch64 + k2 * 17 + lo4], w);
+                v[P16(k2)] = cmulc(img[hi4 * kPitch64 + k2 * 17 + lo4], w);
                 w = cmul(w, w2);
             }
         }
-        dft16<true>(v, u);   // u[b] for thread (k1, c)   (rows 4 wave .. 4 wave + 3 belong to this wave alone until here)
+        dft16_g(v);   // v[b] for thread (k1, c)   (rows 4 wave .. 4 wave + 3 belong to this wave alone until here)
 #pragma unroll
-        for (int b = 0; b < 16; ++b) img[hi4 * kPitch64 + b * 17 + lo4] = u[b];
+        for (int b = 0; b < 16; ++b) img[hi4 * kPitch64 + b * 17 + lo4] = v[b];
         __syncthreads();
         // thread t = (b = hi4, c = lo4) reads over k1, conj W_4096^(t k1), inverse DFT16 over k1 -> a
         {
@@ -207,25 +281,26 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
             v[0] = img[0 * kPitch64 + hi4 * 17 + lo4];
 #pragma unroll
             for (int k1 = 1; k1 < 16; ++k1) {
-                v[k1] = cmulc(img[k1 * kPitch64 + hi4 * 17 + lo4], w);
+                v[P16(k1)] = cmulc(img[k1 * kPitch64 + hi4 * 17 + lo4], w);
                 w = cmul(w, w1);
             }
         }
-        dft16<true>(v, u);   // u[a] = y[256 a + t]
+        dft16_g(v);   // v[a] = y[256 a + t]
+        asm volatile("" : "+v"(ts));
         // ---- store the last V points ----
         if (REAL) {
             const int64_t outA = (2 * tile) * A.V, outB = outA + A.V;
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
                 if (a < A.a0) continue;
-                const int64_t loc = 256 * (a - A.a0) + t;
+                const int64_t loc = 256 * (a - A.a0) + ts;
                 const int64_t ga = outA + loc, gb = outB + loc;
                 if (A.dec > 1) {
-                    if (ga < A.n_keep && ga % A.dec == 0) A.y[ga / A.dec] = u[a].x;
-                    if (gb < A.n_keep && gb % A.dec == 0) A.y[gb / A.dec] = u[a].y;
+                    if (ga < A.n_keep && ga % A.dec == 0) A.y[ga / A.dec] = v[a].x;
+                    if (gb < A.n_keep && gb % A.dec == 0) A.y[gb / A.dec] = v[a].y;
                 } else {
-                    if (ga < A.n) __builtin_nontemporal_store(u[a].x, A.y + ga);
-                    if (gb < A.n) __builtin_nontemporal_store(u[a].y, A.y + gb);
+                    if (ga < A.n) __builtin_nontemporal_store(v[a].x, A.y + ga);
+                    if (gb < A.n) __builtin_nontemporal_store(v[a].y, A.y + gb);
                 }
             }
         } else {
@@ -234,9 +309,9 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
                 if (a < A.a0) continue;
-                const int64_t g = out0 + 256 * (a - A.a0) + t;
+                const int64_t g = out0 + 256 * (a - A.a0) + ts;
                 v2d_t q;
-                q.x = u[a].x; q.y = u[a].y;
+                q.x = v[a].x; q.y = v[a].y;
                 if (A.dec > 1) {
                     if (g < A.n_keep && g % A.dec == 0) reinterpret_cast<v2d_t *>(A.y)[g / A.dec] = q;
                 } else if (g < A.n) {
@@ -244,6 +319,10 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
                 }
             }
         }
+#if SK_OLS64_PF
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = nx[a];
+#endif
         __syncthreads();  // the image is free for the next tile
     }
 }
