@@ -263,14 +263,16 @@ __device__ __forceinline__ void store_tile_real(const OlsArgs &A, int64_t pair, 
         return;
     }
     if (full) {
+        int tt = t;  // (opaque copy: keeps the 28 store addresses from being hoisted out of the tile loop and spilled)
+        asm volatile("" : "+v"(tt));
 #pragma unroll
         for (int a = 0; a < 16; ++a)
             if (a >= A.a0) {
                 v2f_t ra, rb;
                 ra.x = v[2 * a].x; ra.y = v[2 * a + 1].x;
                 rb.x = v[2 * a].y; rb.y = v[2 * a + 1].y;
-                __builtin_nontemporal_store(ra, reinterpret_cast<v2f_t *>(yr + outA + 2 * t) + (a - A.a0) * 256);
-                __builtin_nontemporal_store(rb, reinterpret_cast<v2f_t *>(yr + outB + 2 * t) + (a - A.a0) * 256);
+                __builtin_nontemporal_store(ra, reinterpret_cast<v2f_t *>(yr + outA + 2 * tt) + (a - A.a0) * 256);
+                __builtin_nontemporal_store(rb, reinterpret_cast<v2f_t *>(yr + outB + 2 * tt) + (a - A.a0) * 256);
             }
     } else {
 #pragma unroll

@@ -31,9 +31,6 @@ typedef double2 cdd;
 #ifndef SK_OLS64_HREG
 #define SK_OLS64_HREG -1  // -1: per kernel (see below); 0 / 1: force
 #endif
-#ifndef SK_OLS64_PF
-#define SK_OLS64_PF 0
-#endif
 #ifndef SK_OLS64_WPE
 #define SK_OLS64_WPE 2
 #endif
@@ -200,21 +197,13 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
         }
     };
     int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
-#if SK_OLS64_PF
-    cdd v[16];   // (carried across iterations: the next tile's samples are requested one tile ahead)
-    if (tile < A.ntiles) load_tile(tile, t, v);
-#endif
     for (; tile < A.ntiles; tile += gridDim.x) {
-#if !SK_OLS64_PF
         cdd v[16];
-#endif
         // opaque copies of the thread index: stop LICM from hoisting the 16 + 16 + 16 loop-invariant 64-bit addresses of the
         // loads, the H bins and the stores out of the tile loop (they were spilled and reloaded in front of every access)
         int tl = t, th = t, ts = t;
         asm volatile("" : "+v"(tl));
-#if !SK_OLS64_PF
         load_tile(tile, tl, v);
-#endif
         // ---- pass 1: DFT16 over a, twiddle W_4096^(t k1) (running power), write [k1][b][c] ----
         dft16_f(v);   // X[k1] at v[P16(k1)]
         {
@@ -248,16 +237,6 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
 #pragma unroll
         for (int k3 = 0; k3 < 16; ++k3) v[P16(k3)] = cmul(v[P16(k3)], SK_OLS64_H(k3));
         // ---- inverse pass 3: over k3 -> c (takes the spectrum where it lies); the conj twiddle W_256^(c k2) is applied by the reader ----
-#if SK_OLS64_PF
-        // the next tile's samples: requested now, in flight during the whole inverse transform, consumed at the top of the next iteration
-        cdd nx[16];
-        {
-            int tn = t;
-            asm volatile("" : "+v"(tn));
-            const int64_t next = tile + gridDim.x;
-            if (next < A.ntiles) load_tile(next, tn, nx);
-        }
-#endif
         dft16_g(v);   // v[c] for thread (k1, k2)
 #pragma unroll
         for (int c = 0; c < 16; ++c) img[hi4 * kPitch64 + lo4 * 17 + c] = v[c];
@@ -319,10 +298,6 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
                 }
             }
         }
-#if SK_OLS64_PF
-#pragma unroll
-        for (int a = 0; a < 16; ++a) v[a] = nx[a];
-#endif
         __syncthreads();  // the image is free for the next tile
     }
 }
