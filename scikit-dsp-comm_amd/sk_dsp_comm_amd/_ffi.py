@@ -389,6 +389,17 @@ class _HostCalls:
     wide=True asks the library for float64/complex128 results from a float32/complex64 handle
     (widened on the device: skdsp_set_wide_output)."""
     _wide_state = False
+    _call_lock = None
+
+    def _host(self, count, dtype, wide, call):
+        """One host-pointer call: the per-handle result-width switch and the call it applies to form one critical section,
+        so an object shared between threads cannot get the other thread's width."""
+        if self._call_lock is None:
+            self.__dict__.setdefault("_call_lock", threading.Lock())
+        with self._call_lock:
+            y = self._out(count, dtype, wide)
+            call(y)
+            return y
 
     def _out(self, count, dtype, wide):
         dtype = np.dtype(dtype)
@@ -424,24 +435,16 @@ class FirKernel(_HostCalls):
 
     # host vectors ------------------------------------------------------
     def filter(self, x, wide=False):
-        y = self._out(x.size, x.dtype, wide)
-        check(load().skdsp_fir_filter(ctypes.c_void_p(self.h), _ptr(x), x.size, _ptr(y)))
-        return y
+        return self._host(x.size, x.dtype, wide, lambda y: check(load().skdsp_fir_filter(ctypes.c_void_p(self.h), _ptr(x), x.size, _ptr(y))))
 
     def up(self, x, L, wide=False):
-        y = self._out(x.size * L, x.dtype, wide)
-        check(load().skdsp_fir_up(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), _ptr(y)))
-        return y
+        return self._host(x.size * L, x.dtype, wide, lambda y: check(load().skdsp_fir_up(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), _ptr(y))))
 
     def dn(self, x, M, wide=False):
-        y = self._out(x.size // M, x.dtype, wide)
-        check(load().skdsp_fir_dn(ctypes.c_void_p(self.h), _ptr(x), x.size, int(M), _ptr(y)))
-        return y
+        return self._host(x.size // M, x.dtype, wide, lambda y: check(load().skdsp_fir_dn(ctypes.c_void_p(self.h), _ptr(x), x.size, int(M), _ptr(y))))
 
     def updn(self, x, L, M, wide=False):
-        y = self._out((x.size * L) // M, x.dtype, wide)
-        check(load().skdsp_fir_updn(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), int(M), _ptr(y)))
-        return y
+        return self._host((x.size * L) // M, x.dtype, wide, lambda y: check(load().skdsp_fir_updn(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), int(M), _ptr(y))))
 
     # device vectors ----------------------------------------------------
     def filter_dev(self, xd, yd, n=None, n_hist=0):
@@ -484,19 +487,13 @@ class IirKernel(_HostCalls):
         self._fin = weakref.finalize(self, _destroy, self.h)
 
     def filter(self, x, wide=False):
-        y = self._out(x.size, x.dtype, wide)
-        check(load().skdsp_iir_filter(ctypes.c_void_p(self.h), _ptr(x), x.size, _ptr(y)))
-        return y
+        return self._host(x.size, x.dtype, wide, lambda y: check(load().skdsp_iir_filter(ctypes.c_void_p(self.h), _ptr(x), x.size, _ptr(y))))
 
     def up(self, x, L, wide=False):
-        y = self._out(x.size * L, x.dtype, wide)
-        check(load().skdsp_iir_up(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), _ptr(y)))
-        return y
+        return self._host(x.size * L, x.dtype, wide, lambda y: check(load().skdsp_iir_up(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), _ptr(y))))
 
     def dn(self, x, M, wide=False):
-        y = self._out(x.size // M, x.dtype, wide)
-        check(load().skdsp_iir_dn(ctypes.c_void_p(self.h), _ptr(x), x.size, int(M), _ptr(y)))
-        return y
+        return self._host(x.size // M, x.dtype, wide, lambda y: check(load().skdsp_iir_dn(ctypes.c_void_p(self.h), _ptr(x), x.size, int(M), _ptr(y))))
 
     def filter_dev(self, xd, yd, n=None):
         n = xd.n if n is None else n

@@ -146,3 +146,39 @@ def test_precision_switch():
             f.filter(x64)
     finally:
         config.precision = old
+
+
+def test_threads_share_objects_and_library():
+    """Four caller threads, one shared multirate_FIR and one shared multirate_IIR, mixed result widths: calls take turns on
+    slot 0 (per-slot lock), the width switch and its call are one critical section, results equal the single-threaded ones."""
+    import threading
+    from scipy import signal
+    rng = np.random.default_rng(12)
+    b = rng.standard_normal(200) / 14
+    sos = signal.butter(6, 0.2, output="sos")
+    f, g = mrh.multirate_FIR(b), mrh.multirate_IIR(sos)
+    xs = [cnoise(rng, 200_000 + 1000 * i) for i in range(4)]
+    want = [(orc.fir_filter(b, x), signal.sosfilt(sos, x.astype(np.complex128))) for x in xs]
+    errs = []
+
+    def work(i):
+        try:
+            for rep in range(6):
+                old = config.strict_dtype
+                y = f.filter(xs[i])
+                z = g.filter(xs[i])
+                k = _ffi.FirKernel(b, _ffi.C64)          # and a private low-level object with explicit widths
+                y2 = k.filter(xs[i], wide=bool((i + rep) & 1))
+                assert y2.dtype == (np.complex128 if (i + rep) & 1 else np.complex64)
+                for got, ref in ((y, want[i][0]), (z, want[i][1]), (y2, want[i][0])):
+                    e = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+                    assert e < 1e-6, e
+        except Exception as ex:  # noqa: BLE001
+            errs.append((i, repr(ex)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs

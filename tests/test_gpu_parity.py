@@ -1598,3 +1598,35 @@ def test_wideners_match_reference():
     assert_close(dcm.time_delay(g["td_x"], 2.0, 6), g["td_y2"], 1e-12, "time_delay integer")
     with pytest.raises(NotImplementedError):
         dcm.time_delay(g["td_x"], np.full(len(g["td_x"]), 1.5))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_iir_single_pass_soak(dt):
+    """400 back-to-back single-pass launches alternating two lengths (different segment counts, look-back slots reused
+    with a new epoch every launch, the ticket dispensers running on): every output equals that of the first launch of
+    its length."""
+    from scipy import signal
+    sos = signal.cheby1(6, 0.05, 0.2, output="sos")
+    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+    per = 128 if dt == np.float32 else 64
+    sizes = (300 * 256 * per + 777, 517 * 256 * per - 3)
+    xd = _ffi.DeviceArray(max(sizes), dt).fill_noise(5)
+    yd = _ffi.DeviceArray(max(sizes), dt)
+    ref = {}
+    w = 1 << 18
+    with _ffi.option("iir_two_pass", -1):
+        for it in range(400):
+            n = sizes[it & 1] if it % 7 else sizes[0]
+            k.filter_dev(xd, yd, n)
+            if it < 2 or it % 50 == 49:
+                got = (yd.to_host(n - w, w), yd.to_host(n // 2, 4096))
+                if n not in ref:
+                    ref[n] = got
+                else:
+                    assert np.array_equal(got[0], ref[n][0]) and np.array_equal(got[1], ref[n][1]), it
+    m = 100_000
+    want = signal.sosfilt(sos, xd.to_host(0, m).astype(np.complex128 if dt == np.complex64 else np.float64))
+    k.filter_dev(xd, yd, sizes[0])
+    assert_close(yd.to_host(0, m), want, TOL32, "after the soak")
+    xd.free()
+    yd.free()
