@@ -36,6 +36,13 @@
 // algorithmic bytes = 8 B per f32 sample (4 in + 4 out).
 #include "iir_common.hpp"
 
+#ifndef SK_IIR_NT_ST
+#define SK_IIR_NT_ST 1   // nontemporal y stores in K3: config 4 0.2011 -> 0.1875 ms (same box, alternating)
+#endif
+#ifndef SK_IIR_NT_STC
+#define SK_IIR_NT_STC 0  // ... in the interleaved complex K3: no gain (0.470 vs 0.458-0.47 ms)
+#endif
+
 namespace skdsp {
 
 struct IirArgs {
@@ -264,7 +271,15 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
                     dr_run += a.dec_dr;
                     if (dr_run >= a.dec) { dr_run -= a.dec; ++dq_run; }
                 } else if (interior || g + St::elems <= a.n) {
+#if SK_IIR_NT_ST
+                    {
+                        typedef float nt4_t __attribute__((ext_vector_type(4)));
+                        nt4_t q = {val.x, val.y, val.z, val.w};
+                        __builtin_nontemporal_store(q, reinterpret_cast<nt4_t *>(y + g));
+                    }
+#else
                     *reinterpret_cast<float4 *>(y + g) = val;
+#endif
                 } else if (g < a.n) {
                     const IO *tmp = reinterpret_cast<const IO *>(&val);
 #pragma unroll
@@ -830,7 +845,14 @@ __global__ __launch_bounds__(kIirThreads) __attribute__((amdgpu_waves_per_eu(NSE
                 dr_run += a.dec_dr;
                 if (dr_run >= a.dec) { dr_run -= a.dec; ++dq_run; }
             } else if (interior || g + E / 2 <= a.n) {
+#if SK_IIR_NT_STC
+                {
+                    typedef float nt4_t __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(*reinterpret_cast<const nt4_t *>(out), reinterpret_cast<nt4_t *>(y + 2 * g));
+                }
+#else
                 *reinterpret_cast<float4 *>(y + 2 * g) = *reinterpret_cast<const float4 *>(out);
+#endif
             } else if (g < a.n) {
 #pragma unroll
                 for (int e = 0; e < E; ++e)

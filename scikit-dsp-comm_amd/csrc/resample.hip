@@ -44,8 +44,9 @@ __global__ __launch_bounds__(256) void upsample_kernel(const T *__restrict__ x, 
             if (++r == L) { r = 0; ++q; }
         }
         if (o0 + VEC <= n_out) {
-            // 16-byte store
-            *reinterpret_cast<float4 *>(y + o0) = *reinterpret_cast<const float4 *>(out);
+            // 16-byte store, nontemporal: the stuffed signal is written once and read by the next kernel from HBM anyway
+            typedef float nt4_t __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(*reinterpret_cast<const nt4_t *>(out), reinterpret_cast<nt4_t *>(y + o0));
         } else {
             for (int e = 0; e < VEC && o0 + e < n_out; ++e) y[o0 + e] = out[e];
         }
