@@ -30,6 +30,9 @@
 #ifndef SK_BX_NT_ST
 #define SK_BX_NT_ST 1  // nontemporal output stores: 0.317 -> 0.312 ms (config 3), 0.1365 -> 0.1243 ms (127-tap float32); nontemporal window LOADS cost 25 %: neighbours share halos through the cache
 #endif
+#ifndef SK_BX_PRIO
+#define SK_BX_PRIO 1  // raised wave priority while stores and the window prefetch are issued: config 3 0.3214 -> 0.3154 ms
+#endif
 #ifndef SK_BX_NT_LD
 #define SK_BX_NT_LD 0
 #endif
@@ -296,7 +299,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll 1
         for (; ct + 4 < ntiles; ct += 4) {
             mma_tile(ct);
+#if SK_BX_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
             store_tile(ct);
+#if SK_BX_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         const bool has_last = ct < ntiles;
         if (has_last) mma_tile(ct);
@@ -306,11 +315,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (fast) store_window();
             else stage_window_slow(wnext);
         }
+#if SK_BX_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         if (has_last) store_tile(ct);
+#if SK_BX_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();  // the planes hold window w+1
         const int64_t wnext2 = wnext + gridDim.x;
         fast = wnext2 < nwin && interior(wnext2);
+#if SK_BX_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         if (fast) load_window(wnext2);
+#if SK_BX_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
 }
 
