@@ -11,6 +11,7 @@
 #include <array>
 #include <algorithm>
 #include <cmath>
+#include <numeric>
 #include <thread>
 #include <atomic>
 #include <condition_variable>
@@ -200,15 +201,22 @@ static int fir_part_len(const FirHandle *h)
 {
     return dtype_double(h->dtype) ? 2048 : 4096;
 }
-static bool fir_needs_parts(const FirHandle *h)
+static bool fir_needs_parts(const FirHandle *h, int L = 1)
 {
-    return h->ntaps > (dtype_double(h->dtype) ? 2049 : 4097);
+    // per launch: 4097 taps (float32 overlap-save / direct) or 2049 (float64); an interpolator holds ceil(Ntaps / L) per phase
+    const int per_phase = (h->ntaps + L - 1) / L;
+    return per_phase > (dtype_double(h->dtype) ? 2049 : 4097);
 }
 static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev);
 static int ols_launch_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, int dec = 1);
-static int fir_parts_run(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev)
+// y[j] = L sum_t b[(j M mod L) + L t] x[(j M div L) - t] with b cut into segments of `seg` taps, seg a multiple of lcm(L, M):
+// segment s delays the up-rate signal by s seg samples = s seg / L input samples = s seg / M outputs, so it is the same
+// operation over the input shortened by s seg / L samples, added onto y from output s seg / M on.  With history in front
+// of x the segment starts d input samples early (d a multiple of M / gcd(L, M): whole outputs) and lands d L / M outputs earlier.
+static int fir_parts_run(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev)
 {
-    const int seg = std::max(fir_part_len(h) / M, 1) * M;
+    const int g = std::gcd(L, M), lcm = L / g * M, q = M / g;
+    const int seg = std::max(fir_part_len(h) * L / lcm, 1) * lcm;   // <= fir_part_len taps per phase
     if (h->part_seg != seg) {
         for (FirHandle *p : h->parts) delete p;
         h->parts.clear();
@@ -225,25 +233,29 @@ static int fir_parts_run(FirHandle *h, const void *x_dev, int64_t n, int64_t n_h
     const size_t esz = dtype_size(h->dtype);
     const int scal = dtype_complex(h->dtype) ? 2 : 1;
     hipStream_t s = ctx().stream;
+    const int64_t n_out = (n * L) / M;
     void *tmp = nullptr;
-    int rc = ws_reserve(2, (size_t)(n / M + 1) * esz + 256, &tmp);
+    int rc = ws_reserve(2, (size_t)(n_out + 1) * esz + 256, &tmp);
     if (rc) return rc;
     for (size_t si = 0; si < h->parts.size(); ++si) {
         FirHandle *p = h->parts[si];
-        const int64_t delay = (int64_t)si * seg;                     // multiple of M
-        const int64_t d = (std::min(n_hist, delay) / M) * M;          // how far this segment starts inside the history
-        const int64_t n_s = n - delay + d;
-        if (n_s <= 0) break;
+        const int64_t delay_in = (int64_t)si * seg / L, delay_out = (int64_t)si * seg / M;
+        const int64_t d = (std::min(n_hist, delay_in) / q) * q;       // how far this segment starts inside the history
+        const int64_t n_s = n - delay_in + d;
+        const int64_t off = delay_out - d * L / M;                    // first output this segment contributes to
+        const int64_t cnt = std::min((n_s * L) / M, n_out - off);
+        if (n_s <= 0 || cnt <= 0) break;
         const char *xs = (const char *)x_dev - (size_t)d * esz;
         void *dst = si == 0 ? y_dev : tmp;
-        rc = M > 1 ? fir_dn_any(p, xs, n_s, n_hist - d, M, dst)
-                   : (fir_algo_for(p, n_s) == SKDSP_FIR_OLS ? ols_launch_any(p, xs, n_s, n_hist - d, dst)
-                                                            : fir_direct_launch(p, xs, n_s, n_hist - d, 1, 1, n_s, dst, s));
+        if (L == 1 && M == 1)
+            rc = fir_algo_for(p, n_s) == SKDSP_FIR_OLS ? ols_launch_any(p, xs, n_s, n_hist - d, dst)
+                                                        : fir_direct_launch(p, xs, n_s, n_hist - d, 1, 1, n_s, dst, s);
+        else if (L == 1)
+            rc = fir_dn_any(p, xs, n_s, n_hist - d, M, dst);
+        else
+            rc = fir_direct_launch(p, xs, n_s, n_hist - d, L, M, cnt, dst, s);
         if (rc) return rc;
-        if (si > 0) {
-            const int64_t off = (delay - d) / M, cnt = n_s / M;
-            if ((rc = accumulate_launch((char *)y_dev + (size_t)off * esz, tmp, cnt * scal, dtype_double(h->dtype), s))) return rc;
-        }
+        if (si > 0 && (rc = accumulate_launch((char *)y_dev + (size_t)off * esz, tmp, cnt * scal, dtype_double(h->dtype), s))) return rc;
     }
     return SKDSP_OK;
 }
@@ -256,7 +268,7 @@ static int ols_launch_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_
 
 static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev)
 {
-    if (fir_needs_parts(h)) return fir_parts_run(h, x_dev, (n / M) * M, n_hist, M, y_dev);
+    if (fir_needs_parts(h)) return fir_parts_run(h, x_dev, (n / M) * M, n_hist, 1, M, y_dev);
     if (dtype_double(h->dtype)) {  // float64: the decimating overlap-save store beats Ntaps / M direct FP64 taps per kept sample early
         if (M > 1 && pick_fir_algo(h, n) == SKDSP_FIR_OLS && !opt().dn_no_ols && h->ntaps / M >= 24)
             return fir_ols64_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
@@ -272,9 +284,17 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
     return fir_direct_launch(h, x_dev, n, n_hist, 1, M, n / M, y_dev, ctx().stream);
 }
 
+// .up / fused L over M: one polyphase launch, or tap segments when a phase holds more taps than a launch takes
+static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev)
+{
+    if (L == 1) return fir_dn_any(h, x_dev, n, n_hist, M, y_dev);
+    if (fir_needs_parts(h, L)) return fir_parts_run(h, x_dev, n, n_hist, L, M, y_dev);
+    return fir_direct_launch(h, x_dev, n, n_hist, L, M, (n * L) / M, y_dev, ctx().stream);
+}
+
 static int fir_filter_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev)
 {
-    if (fir_needs_parts(h)) return fir_parts_run(h, x_dev, n, n_hist, 1, y_dev);
+    if (fir_needs_parts(h)) return fir_parts_run(h, x_dev, n, n_hist, 1, 1, y_dev);
     if (pick_fir_algo(h, n) == SKDSP_FIR_OLS) return ols_launch_any(h, x_dev, n, n_hist, y_dev);
     return fir_direct_launch(h, x_dev, n, n_hist, 1, 1, n, y_dev, ctx().stream);
 }
@@ -1090,7 +1110,7 @@ int skdsp_fir_up_dev(skdsp_handle hh, const void *x_dev, int64_t n, int64_t n_hi
     SK_CHECK(h, SKDSP_ERR_BADARG, "fir_up: not a FIR handle");
     SK_CHECK(L >= 1, SKDSP_ERR_BADARG, "fir_up: L must be >= 1");
     std::lock_guard<std::mutex> lk(h->mu);
-    return fir_direct_launch(h, x_dev, n, n_hist, L, 1, n * L, y_dev, ctx().stream);
+    return fir_updn_any(h, x_dev, n, n_hist, L, 1, y_dev);
 }
 
 int skdsp_fir_dn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev)
@@ -1110,7 +1130,7 @@ int skdsp_fir_updn_dev(skdsp_handle hh, const void *x_dev, int64_t n, int64_t n_
     SK_CHECK(h, SKDSP_ERR_BADARG, "fir_updn: not a FIR handle");
     SK_CHECK(L >= 1 && M >= 1, SKDSP_ERR_BADARG, "fir_updn: L, M must be >= 1");
     std::lock_guard<std::mutex> lk(h->mu);
-    return fir_direct_launch(h, x_dev, n, n_hist, L, M, (n * L) / M, y_dev, ctx().stream);
+    return fir_updn_any(h, x_dev, n, n_hist, L, M, y_dev);
 }
 
 // one chunk of a long host vector (run_pipeline): the same launch as the single-shot path, with the chunk's history
@@ -1123,7 +1143,7 @@ static int fir_chunk_kernel(void *self, const void *x_dev, int64_t n_k, int64_t 
     const FirChunkJob *j = static_cast<const FirChunkJob *>(self);
     if (j->mode == 0) return fir_filter_any(j->h, x_dev, n_k, n_hist, y_dev);
     if (j->L == 1) return fir_dn_any(j->h, x_dev, n_k, n_hist, j->M, y_dev);
-    return fir_direct_launch(j->h, x_dev, n_k, n_hist, j->L, j->M, (n_k * j->L) / j->M, y_dev, ctx().stream);
+    return fir_updn_any(j->h, x_dev, n_k, n_hist, j->L, j->M, y_dev);
 }
 // the job on another slot: same filter, tables on that slot's device (clone made once, owned by the handle)
 static void *fir_job_on_slot(void *base, int slot)
@@ -1169,7 +1189,7 @@ static int fir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M
     if ((rc = ws_reserve(1, (size_t)n_out * esz + 256, &y_dev))) return rc;
     if (mode == 0) rc = fir_filter_any(h, x_dev, n, 0, y_dev);
     else if (L == 1) rc = fir_dn_any(h, x_dev, n, 0, M, y_dev);
-    else rc = fir_direct_launch(h, x_dev, n, 0, L, M, n_out, y_dev, ctx().stream);
+    else rc = fir_updn_any(h, x_dev, n, 0, L, M, y_dev);
     if (rc) return rc;
     return stage_out(y, y_dev, (size_t)n_out * esz, h);
 }

@@ -182,3 +182,21 @@ def test_threads_share_objects_and_library():
     for t in th:
         t.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("dt,P,L,M", [(np.float32, 50_000, 12, 1), (np.complex64, 17_000, 4, 3), (np.float64, 26_000, 12, 1),
+                                       (np.complex128, 9_000, 4, 3)])
+def test_interpolators_longer_than_one_launch(dt, P, L, M):
+    """.up / the fused L-over-M resampler with more taps per phase than one launch takes (4097 / 2049): tap segments whose
+    length is a multiple of lcm(L, M), each applied to the input shortened by its delay and summed."""
+    rng = np.random.default_rng(P + L)
+    n = 3000 - 3000 % M
+    x = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if np.dtype(dt).kind == "c" else 0)).astype(dt)
+    b = rng.standard_normal(P) / np.sqrt(P)
+    tol = 2e-6 if dt in (np.float32, np.complex64) else 1e-11
+    f = mrh.multirate_FIR(b)
+    ref = orc.fir_up(b, x, L)
+    if M == 1:
+        assert max(rel_err(f.up(x, L), ref)) <= tol
+    else:
+        assert max(rel_err(f.updn(x, L, M), ref[::M][:(n * L) // M])) <= tol
