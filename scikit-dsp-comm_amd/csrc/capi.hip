@@ -545,7 +545,7 @@ static int run_on_slots(const ChunkPlan &p, const char *x, char *y, chunk_kernel
     const int home = ctx().slot;
     int nslots = allow_multi && opt().host_multi_slot ? slot_count() : 1;
     if (nslots > p.nchunks) nslots = (int)p.nchunks;
-    if (nslots <= 1) return run_pipeline(p, 0, p.nchunks, x, y, kern, base_self);
+    if (nslots <= 1) return run_pipeline(p, 0, p.nchunks, x, y, kern, make_self(base_self, home));
     std::vector<void *> selfs((size_t)nslots, nullptr);
     std::vector<int> slots;
     slots.push_back(home);
@@ -1146,22 +1146,24 @@ static int fir_chunk_kernel(void *self, const void *x_dev, int64_t n_k, int64_t 
     return fir_updn_any(j->h, x_dev, n_k, n_hist, j->L, j->M, y_dev);
 }
 // the job on another slot: same filter, tables on that slot's device (clone made once, owned by the handle)
+struct FirChunkJobs {
+    FirChunkJob home;                 // the caller's handle
+    FirChunkJob other[kMaxSlots];     // its clones, filled as slots ask for them
+};
 static void *fir_job_on_slot(void *base, int slot)
 {
-    FirChunkJob *j = static_cast<FirChunkJob *>(base);
-    if (slot == j->h->slot) return j;
-    FirHandle *h = j->h;
+    FirChunkJobs *js = static_cast<FirChunkJobs *>(base);
+    FirHandle *h = js->home.h;
+    if (slot == h->slot) return &js->home;
     if ((int)h->clones.size() < kMaxSlots) h->clones.resize(kMaxSlots, nullptr);
     if (!h->clones[slot]) {
         FirHandle *c = new FirHandle();
         c->kind = H_FIR; c->dtype = h->dtype; c->slot = slot; c->ntaps = h->ntaps; c->taps_complex = h->taps_complex;
-        c->algo = h->algo; c->taps_host = h->taps_host; c->wide_out = h->wide_out;
+        c->algo = h->algo; c->taps_host = h->taps_host;
         h->clones[slot] = c;
     }
-    static thread_local std::vector<std::unique_ptr<FirChunkJob>> keep;  // lives until the caller's next multi-slot call
-    if (keep.size() > 64) keep.clear();
-    keep.emplace_back(new FirChunkJob{static_cast<FirHandle *>(h->clones[slot]), j->mode, j->L, j->M});
-    return keep.back().get();
+    js->other[slot] = FirChunkJob{static_cast<FirHandle *>(h->clones[slot]), js->home.mode, js->home.L, js->home.M};
+    return &js->other[slot];
 }
 
 static int fir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M, int mode, void *y)
@@ -1180,8 +1182,9 @@ static int fir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M
         const int64_t hist = L > 1 ? (h->ntaps - 1 + L - 1) / L : h->ntaps - 1;
         const ChunkPlan p = plan_chunks(n, mode == 0 ? 1 : L, mode == 0 ? 1 : M, hist, esz, h->wide_out && !dtype_double(h->dtype),
                                         opt().host_chunk_log2);
-        FirChunkJob job{h, mode, L, M};
-        return run_on_slots(p, (const char *)x, (char *)y, fir_chunk_kernel, fir_job_on_slot, &job, true);
+        FirChunkJobs jobs;
+        jobs.home = FirChunkJob{h, mode, L, M};
+        return run_on_slots(p, (const char *)x, (char *)y, fir_chunk_kernel, fir_job_on_slot, &jobs, true);
     }
     void *x_dev = nullptr, *y_dev = nullptr;
     int rc = stage_in(x, (size_t)n * esz, &x_dev);
