@@ -19,6 +19,7 @@ struct IirPlan {
     // per call geometry is recomputed; matrix powers are cached per chunk length T
     int64_t cached_T = -1;
     double *pw_dev = nullptr;    // kPowers matrices M^(2^l), each D x D row-major
+    double *pwa_dev = nullptr;   // M^(2^l), l = 0..7, zero-padded to 16 x 16, as MFMA A operands [l][k / 4][64] (D <= 16)
     double *lb_dev = nullptr;    // look-back matrices (M^256)^k, k = 1..7
     double *lbk_dev = nullptr;   // chunk look-back powers M^k, k = 0..31, lane-contiguous (aggregate-free mode)
     double *gt_dev = nullptr;    // G = [A^(T-1-k) b]_k in MFMA A-operand order: [T/4][64], grown on demand

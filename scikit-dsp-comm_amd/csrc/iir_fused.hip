@@ -2,12 +2,82 @@
 // Serves scipy.signal.sosfilt(sos, x) (multirate_helper.py:173) / lfilter(b, a, x) (:74, :81) for real signals and
 // decaying cascades of up to 8 biquads; everything else takes the K1 / carries / K3 path of iir_scan.hip.
 #include "iir_common.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #ifndef SK_FUSED_DIAG
 #define SK_FUSED_DIAG 0  // developer builds: 1 no recurrence, 2 no scan / correction, 4 no MFMAs, 8 no look-back poll (wrong results)
 #endif
 
 namespace skdsp {
+
+// ---- the chunk-level scan on the FP64 matrix pipe ---------------------------------------------------------------------
+// Phase A leaves the from-rest end states of a wave's 64 chunks as four accumulator tiles of v_mfma_f64_16x16x4: tile g,
+// register r, lane t holds state row (t >> 4) + 4 r of chunk column 16 g + (t & 15).  Register r of such a tile is, lane
+// for lane, the B operand of reduction step r of the same instruction (B[k = 4 r + (t >> 4)][col = t & 15]), so one
+// Hillis-Steele level  v_j += M^(2^l) v_(j - 2^l)  is four MFMAs per tile with the level's matrix as A operand and the
+// column-shifted OLD tiles as B: shifts below 16 columns are DPP row rotations (+ a select for the columns that come from
+// the tile on the left), shifts by 16 / 32 columns just name another tile.  No LDS, no barrier and no scalar matrix loads
+// for the six levels inside a wave; the VALU version (matvec_acc per thread, 144 FMAs per level, matrices through the
+// scalar cache, two barriers per level) took 9.7 + 5.8 us of a 53 us segment (tools/fused_trace.py) and a quarter of the
+// kernel's FP64 VALU instructions.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)  // lanes without a source read 0
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+constexpr int kDppRowShr = 0x110, kDppRowRor = 0x120;
+
+// tiles[g] += M_L * (tiles shifted right by 2^L columns inside the wave), L < 4;  A = the level's matrix as A operands
+// (IirPlan::pwa_dev, [level][step][64]: read from global memory one level ahead of their use)
+struct AOps { double a[4]; };
+__device__ __forceinline__ AOps load_aops(const double *__restrict__ pwa, int level, int lane)
+{
+    AOps o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o.a[r] = pwa[(level * 4 + r) * 64 + lane];  // 512 contiguous bytes per wave and step, L1 / L2 resident
+    return o;
+}
+template <int L>
+__device__ __forceinline__ void scan_level_rows(v4d_t (&t)[4], const AOps &A, int lane)
+{
+    constexpr int S = 1 << L;
+    const bool own = (lane & 15) >= S;
+    double rot[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rot[g][r] = dpp_f64<kDppRowRor + S>(t[g][r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double a = A.a[r];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const double b = own ? rot[g][r] : (g > 0 ? rot[g - 1][r] : 0.0);
+            t[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, t[g], 0, 0, 0);
+        }
+    }
+}
+// one tile: t += M_L * (t shifted right by SH columns, zero fill)
+template <int SH>
+__device__ __forceinline__ void tile_level(v4d_t &t, const AOps &A)
+{
+    double sh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[r] = dpp_f64<kDppRowShr + SH>(t[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t = __builtin_amdgcn_mfma_f64_16x16x4f64(A.a[r], sh[r], t, 0, 0, 0);
+}
+// dst += M_level * src (whole tiles)
+__device__ __forceinline__ void tile_mul_acc(v4d_t &dst, const v4d_t &src, const AOps &A)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst = __builtin_amdgcn_mfma_f64_16x16x4f64(A.a[r], src[r], dst, 0, 0, 0);
+}
 
 // ------------------------------------------------------------------ single-pass scan
 // One launch, x read once, y written once (decaying cascades of <= 8 biquads, real signals).
@@ -47,16 +117,18 @@ struct FusedArgs {
     int dec;                     // > 1: only y[k * dec] is stored (at y[k]), k < n_keep / dec  (.dn: no full-rate result in HBM)
     int dec_dq, dec_dr;          // (rows between a thread's staged segments x T) div / mod dec
     int64_t n_keep;              // (n / dec) * dec
+    unsigned long long *trace;   // developer builds (-DSK_FUSED_TRACE_BUILD): [nseg][16] phase stamps, else null
 };
 
 template <int NSEC, typename IO, bool UNIT>
 __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, Coef<NSEC, 2> cf, const double *__restrict__ pw,
-                                                                   const double *__restrict__ gtab)
+                                                                   const double *__restrict__ gtab, const double *__restrict__ pwa)
 {
     // (pw / gtab are separate __restrict__ parameters: the ticket atomic and the look-back stores precede the scan, and
     // only loads through a noalias pointer stay scalar loads behind them -- as plain members of `a` every matrix
     // entry of every scan level became a per-lane global load: 6.3 M vector loads per launch instead of 0.33 M)
     constexpr int ORD = 2, D = NSEC * ORD;
+    constexpr bool MSCAN = NSEC >= 6;
     constexpr int T = 512 / (int)sizeof(IO);
     constexpr int NP = T / kPiece;
     using St = Stage<IO>;
@@ -65,6 +137,7 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
     constexpr int kLdsBytes = kStageBytes > kScanBytes ? kStageBytes : kScanBytes;
     __shared__ __attribute__((aligned(16))) char lds_raw[kLdsBytes];
     __shared__ double gl[(T / 4) * 64];
+    __shared__ double qsh[4 * 16], esh[4 * 16], aggsh[16];
     __shared__ unsigned cw[32];
     __shared__ int seg_sh;
     IO *stage = reinterpret_cast<IO *>(lds_raw);
@@ -76,6 +149,13 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
     for (int i = tid; i < (T / 4) * 64; i += kIirThreads) gl[i] = gtab[i];
     __syncthreads();
     const int seg = seg_sh;
+#ifdef SK_FUSED_TRACE_BUILD  // developer build: s_memrealtime (100 MHz) stamps of thread 0 at the phase boundaries (tools/fused_trace.py)
+#define SK_STAMP(slot) do { if (a.trace && tid == 0) a.trace[(size_t)seg * 16 + (slot)] = wall_clock64(); } while (0)
+    const long long c0_trace = clock64();
+#else
+#define SK_STAMP(slot) do { } while (0)
+#endif
+    SK_STAMP(0);
 #ifdef SK_FUSED_STAGGER
     // the two workgroups of a CU start together and would walk their phases in lock step (memory | matrix | LDS | VALU);
     // delaying every second one of the first round by about half a segment's duration lets one's memory phases run
@@ -151,95 +231,242 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
         __syncthreads();
     }
 
-    // chunk end states from the accumulator layout (col = lane & 15, row = (lane >> 4) + 4 reg) to one thread per chunk
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
+    double z[D];
+    // The scan of the 256 chunk maps: on the matrix pipe for cascades of 6+ biquads (a 12 x 12 .. 16 x 16 transition: 84+
+    // FMAs per thread and level on the VALU), per thread on the VALU for smaller ones (the MFMA tiles are 16 x 16 whatever D
+    // is: one biquad 0.121 -> 0.147 ms, order 8 0.138 -> 0.148 ms with them; 8 biquads 0.197 -> 0.182 ms, float64 0.321 -> 0.277)
+    if constexpr (MSCAN) {
+        SK_STAMP(1);
+        // ---- S: from-rest inclusive scan of each wave's 64 chunk maps, on the matrix pipe (scan_level_rows) ----------------
+        {
+            AOps A0 = load_aops(pwa, 0, lane), A1 = load_aops(pwa, 1, lane);
+            if (a.n_lv > 0) scan_level_rows<0>(acc, A0, lane);
+            A0 = load_aops(pwa, 2, lane);
+            if (a.n_lv > 1) scan_level_rows<1>(acc, A1, lane);
+            A1 = load_aops(pwa, 3, lane);
+            if (a.n_lv > 2) scan_level_rows<2>(acc, A0, lane);
+            A0 = load_aops(pwa, 4, lane);
+            if (a.n_lv > 3) scan_level_rows<3>(acc, A1, lane);
+            A1 = load_aops(pwa, 5, lane);
+            if (a.n_lv > 4) {
+    #pragma unroll
+                for (int g = 3; g >= 1; --g) tile_mul_acc(acc[g], acc[g - 1], A0);   // descending: the right-hand tiles are still old
+            }
+            if (a.n_lv > 5) {
+                tile_mul_acc(acc[3], acc[1], A1);
+                tile_mul_acc(acc[2], acc[0], A1);
+            }
+        }
+        AOps A6 = {}, A7 = {};
+    if (a.n_lv > 6) {   // (a filter that remembers more than 64 chunks: most do not)
+        A6 = load_aops(pwa, 6, lane);
+        A7 = load_aops(pwa, 7, lane);
+    }
+        // across the four waves: Q_w = the wave's last column; P = inclusive scan of (Q_0 .. Q_3) with M^64 (levels 6, 7) as a
+        // 4-column tile, every wave for itself
+        if (c == 15) {
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) qsh[wave * 16 + j + 4 * r] = acc[3][r];
+        }
+        __syncthreads();
+        v4d_t pm;
+    #pragma unroll
+        for (int r = 0; r < 4; ++r) pm[r] = c < 4 ? qsh[c * 16 + j + 4 * r] : 0.0;
+        if (a.n_lv > 6) tile_level<1>(pm, A6);
+        if (a.n_lv > 7) tile_level<2>(pm, A7);
+        if (wave == 0 && c == 3) {
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) aggsh[j + 4 * r] = pm[r];   // the segment's end state from rest
+        }
+        __syncthreads();
+
+        SK_STAMP(2);
+        // ---- L: publish the segment's end state from rest, fetch the predecessor's ------------------------------------
+        if (tid < 2 * D) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(aggsh[tid >> 1]);
+            const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+            unsigned long long *slot = a.lb + ((size_t)bat * a.nseg + seg) * 32 + tid;
+            __hip_atomic_store(slot, ((unsigned long long)a.epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned got = 0;
+            if (seg > 0 && !(SK_FUSED_DIAG & 8)) {
+                const unsigned long long *src = a.lb + ((size_t)bat * a.nseg + seg - 1) * 32 + tid;
+                unsigned long long g = 0;
+                int spins = 0;
+                for (;;) {
+                    g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(g >> 32) == a.epoch) break;
+                    if (++spins > (1 << 22)) {  // ~ seconds: never in a healthy run; fail loudly instead of hanging the GPU
+                        *a.err = 1u;
+                        g = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                got = (unsigned)g;
+            } else if (a.zi) {
+                const unsigned long long zb = (unsigned long long)__double_as_longlong(a.zi[(size_t)bat * D + (tid >> 1)]);
+                got = (tid & 1) ? (unsigned)(zb >> 32) : (unsigned)zb;
+            }
+            cw[tid] = got;
+        } else if (tid < 32) {
+            cw[tid] = 0u;
+        }
+        __syncthreads();
+
+        SK_STAMP(3);
+        // ---- C: the exact state e_w at the start of wave w = M^(64 w) c + P_(w-1); correction columns M^(jl+1) e_w by doubling;
+        //         z_j = (scan + correction) of the column to the left -----------------------------------------------------------
+        v4d_t cm;
+    #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int d = j + 4 * r;
-            if (d < D) sc[d * kIirThreads + wave * 64 + g * 16 + c] = acc[g][r];
+            cm[r] = c == 0 ? __longlong_as_double((long long)(((unsigned long long)cw[2 * d + 1] << 32) | cw[2 * d])) : 0.0;
         }
-    __syncthreads();
-    double v[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) v[d] = sc[d * kIirThreads + tid];
-    __syncthreads();
+        if (a.n_lv > 6) tile_level<1>(cm, A6);   // column w: M^(64 w) c
+        if (a.n_lv > 7) tile_level<2>(cm, A7);
+        if (c == wave) {
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) esh[wave * 16 + j + 4 * r] = cm[r];
+        }
+        {
+            const double p_left0 = dpp_f64<kDppRowShr + 1>(pm[0]), p_left1 = dpp_f64<kDppRowShr + 1>(pm[1]);
+            const double p_left2 = dpp_f64<kDppRowShr + 1>(pm[2]), p_left3 = dpp_f64<kDppRowShr + 1>(pm[3]);
+            if (c == wave) {
+                esh[wave * 16 + j] += p_left0;
+                esh[wave * 16 + j + 4] += p_left1;
+                esh[wave * 16 + j + 8] += p_left2;
+                esh[wave * 16 + j + 12] += p_left3;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // (esh[wave] is written and read by this wave only: LDS serves a wave in order)
+        v4d_t u[4];
+        {
+            const v4d_t zero = {0.0, 0.0, 0.0, 0.0};
+            v4d_t e0;
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) e0[r] = c == 0 ? esh[wave * 16 + j + 4 * r] : 0.0;
+            u[0] = u[1] = u[2] = u[3] = zero;
+            AOps A0 = load_aops(pwa, 0, lane), A1 = load_aops(pwa, 1, lane);
+            tile_mul_acc(u[0], e0, A0);                    // column 0: M e_w
+            if (a.n_lv > 0) tile_level<1>(u[0], A0);       // columns [2^l, 2^(l+1)) = M^(2^l) * columns [0, 2^l)
+            A0 = load_aops(pwa, 2, lane);
+            if (a.n_lv > 1) tile_level<2>(u[0], A1);
+            A1 = load_aops(pwa, 3, lane);
+            if (a.n_lv > 2) tile_level<4>(u[0], A0);
+            A0 = load_aops(pwa, 4, lane);
+            if (a.n_lv > 3) tile_level<8>(u[0], A1);
+            A1 = load_aops(pwa, 5, lane);
+            if (a.n_lv > 4) tile_mul_acc(u[1], u[0], A0);
+            if (a.n_lv > 5) {
+                tile_mul_acc(u[2], u[0], A1);
+                tile_mul_acc(u[3], u[1], A1);
+            }
+        }
+    #pragma unroll
+        for (int g = 0; g < 4; ++g)
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = j + 4 * r;
+                if (d < D) sc[d * kIirThreads + wave * 64 + g * 16 + c] = acc[g][r] + u[g][r];
+            }
+        __syncthreads();
+    #pragma unroll
+        for (int d = 0; d < D; ++d) z[d] = lane ? sc[d * kIirThreads + tid - 1] : esh[wave * 16 + d];
 
-    // ---- S: from-rest inclusive scan of the 256 chunk maps ---------------------------------------------------------
-    if (SK_FUSED_DIAG & 2) a.n_lv = 0;
-#pragma unroll 1
-    for (int l = 0; l < a.n_lv; ++l) {
-        const int s = 1 << l;
-#pragma unroll
+    } else {
+    SK_STAMP(1);
+        // chunk end states from the accumulator layout (col = lane & 15, row = (lane >> 4) + 4 reg) to one thread per chunk
+    #pragma unroll
+        for (int g = 0; g < 4; ++g)
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = j + 4 * r;
+                if (d < D) sc[d * kIirThreads + wave * 64 + g * 16 + c] = acc[g][r];
+            }
+        __syncthreads();
+        double v[D];
+    #pragma unroll
+        for (int d = 0; d < D; ++d) v[d] = sc[d * kIirThreads + tid];
+        __syncthreads();
+
+        // ---- S: from-rest inclusive scan of the 256 chunk maps ---------------------------------------------------------
+        if (SK_FUSED_DIAG & 2) a.n_lv = 0;
+    #pragma unroll 1
+        for (int l = 0; l < a.n_lv; ++l) {
+            const int s = 1 << l;
+    #pragma unroll
+            for (int d = 0; d < D; ++d) sc[d * kIirThreads + tid] = v[d];
+            __syncthreads();
+            if (tid >= s) {
+                double left[D];
+    #pragma unroll
+                for (int d = 0; d < D; ++d) left[d] = sc[d * kIirThreads + tid - s];
+                matvec_acc<D, ORD>(pw + (size_t)l * D * D, left, v);
+            }
+            __syncthreads();
+        }
+    #pragma unroll
         for (int d = 0; d < D; ++d) sc[d * kIirThreads + tid] = v[d];
         __syncthreads();
-        if (tid >= s) {
-            double left[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) left[d] = sc[d * kIirThreads + tid - s];
-            matvec_acc<D, ORD>(pw + (size_t)l * D * D, left, v);
+    #pragma unroll
+        for (int d = 0; d < D; ++d) z[d] = tid ? sc[d * kIirThreads + tid - 1] : 0.0;
+
+        SK_STAMP(2);
+        // ---- L: publish the segment's end state from rest, fetch the predecessor's ------------------------------------
+        if (tid < 2 * D) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(sc[(tid >> 1) * kIirThreads + kIirThreads - 1]);
+            const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+            unsigned long long *slot = a.lb + ((size_t)bat * a.nseg + seg) * 32 + tid;
+            __hip_atomic_store(slot, ((unsigned long long)a.epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned got = 0;
+            if (seg > 0 && !(SK_FUSED_DIAG & 8)) {
+                const unsigned long long *src = a.lb + ((size_t)bat * a.nseg + seg - 1) * 32 + tid;
+                unsigned long long g = 0;
+                int spins = 0;
+                for (;;) {
+                    g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(g >> 32) == a.epoch) break;
+                    if (++spins > (1 << 22)) {  // ~ seconds: never in a healthy run; fail loudly instead of hanging the GPU
+                        *a.err = 1u;
+                        g = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                got = (unsigned)g;
+            } else if (a.zi) {
+                const unsigned long long zb = (unsigned long long)__double_as_longlong(a.zi[(size_t)bat * D + (tid >> 1)]);
+                got = (tid & 1) ? (unsigned)(zb >> 32) : (unsigned)zb;
+            }
+            cw[tid] = got;
         }
         __syncthreads();
-    }
-#pragma unroll
-    for (int d = 0; d < D; ++d) sc[d * kIirThreads + tid] = v[d];
-    __syncthreads();
-    double z[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) z[d] = tid ? sc[d * kIirThreads + tid - 1] : 0.0;
 
-    // ---- L: publish the segment's end state from rest, fetch the predecessor's ------------------------------------
-    if (tid < 2 * D) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(sc[(tid >> 1) * kIirThreads + kIirThreads - 1]);
-        const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
-        unsigned long long *slot = a.lb + ((size_t)bat * a.nseg + seg) * 32 + tid;
-        __hip_atomic_store(slot, ((unsigned long long)a.epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned got = 0;
-        if (seg > 0 && !(SK_FUSED_DIAG & 8)) {
-            const unsigned long long *src = a.lb + ((size_t)bat * a.nseg + seg - 1) * 32 + tid;
-            unsigned long long g = 0;
-            int spins = 0;
-            for (;;) {
-                g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(g >> 32) == a.epoch) break;
-                if (++spins > (1 << 22)) {  // ~ seconds: never in a healthy run; fail loudly instead of hanging the GPU
-                    *a.err = 1u;
-                    g = 0;
-                    break;
+        SK_STAMP(3);
+        // ---- C: z_j = p_(j-1) + M^j c ------------------------------------------------------------------------------------
+        if ((wave << 6) < (1 << a.n_lv)) {  // (M^j c is below 1e-30 of c for j >= 2^n_lv)
+            double u[D];
+    #pragma unroll
+            for (int d = 0; d < D; ++d) u[d] = __longlong_as_double((long long)(((unsigned long long)cw[2 * d + 1] << 32) | cw[2 * d]));
+    #pragma unroll 1
+            for (int l = 0; l < a.n_lv; ++l) {
+                if ((tid >> l) & 1) {
+                    double t2[D];
+    #pragma unroll
+                    for (int d = 0; d < D; ++d) t2[d] = 0.0;
+                    matvec_acc<D, ORD>(pw + (size_t)l * D * D, u, t2);
+    #pragma unroll
+                    for (int d = 0; d < D; ++d) u[d] = t2[d];
                 }
-                __builtin_amdgcn_s_sleep(8);
             }
-            got = (unsigned)g;
-        } else if (a.zi) {
-            const unsigned long long zb = (unsigned long long)__double_as_longlong(a.zi[(size_t)bat * D + (tid >> 1)]);
-            got = (tid & 1) ? (unsigned)(zb >> 32) : (unsigned)zb;
-        }
-        cw[tid] = got;
-    }
-    __syncthreads();
-
-    // ---- C: z_j = p_(j-1) + M^j c ------------------------------------------------------------------------------------
-    if ((wave << 6) < (1 << a.n_lv)) {  // (M^j c is below 1e-30 of c for j >= 2^n_lv)
-        double u[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) u[d] = __longlong_as_double((long long)(((unsigned long long)cw[2 * d + 1] << 32) | cw[2 * d]));
-#pragma unroll 1
-        for (int l = 0; l < a.n_lv; ++l) {
-            if ((tid >> l) & 1) {
-                double t2[D];
-#pragma unroll
-                for (int d = 0; d < D; ++d) t2[d] = 0.0;
-                matvec_acc<D, ORD>(pw + (size_t)l * D * D, u, t2);
-#pragma unroll
-                for (int d = 0; d < D; ++d) u[d] = t2[d];
+            if (tid < (1 << a.n_lv)) {
+    #pragma unroll
+                for (int d = 0; d < D; ++d) z[d] += u[d];
             }
         }
-        if (tid < (1 << a.n_lv)) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) z[d] += u[d];
-        }
-    }
 
+    }
+    SK_STAMP(4);
     // ---- B: the recurrence over the register-resident chunk; outputs leave through the LDS image --------------------
     const int64_t cj = row0 + tid;
     const bool zf_owner = a.zf != nullptr && cj == (a.n - 1) / T;
@@ -257,6 +484,7 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
                 for (int d = 0; d < D; ++d) a.zf[(size_t)bat * D + d] = z[d];
             }
         }
+        SK_STAMP(5 + 2 * p);
         __syncthreads();  // the image is free (phase A / the previous piece's stores have read it)
 #pragma unroll
         for (int sgi = 0; sgi < St::segs; ++sgi) {
@@ -313,7 +541,16 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
                     if (g + e < a.n) y[g + e] = tmp[e];
             }
         }
+        SK_STAMP(6 + 2 * p);
     }
+#ifdef SK_FUSED_TRACE_BUILD
+    SK_STAMP(13);
+    if (a.trace && tid == 0) {
+        a.trace[(size_t)seg * 16 + 14] = clock64() - c0_trace;
+        a.trace[(size_t)seg * 16 + 15] = (unsigned long long)blockIdx.x << 32;
+    }
+#endif
+#undef SK_STAMP
 }
 
 // ---- interleaved complex signals ---------------------------------------------------------------------------------
@@ -665,8 +902,17 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
     unsigned *err_dev = nullptr;
     SK_HIP(hipHostGetDevicePointer((void **)&err_dev, p->err_host, 0));
     a.err = err_dev;
+    a.trace = nullptr;
     for (int b = 0; b < (interleaved ? 1 : nbatch); ++b) p->ticket_count[b] += (unsigned long long)nseg;
     const dim3 grid((unsigned)nseg, (unsigned)(interleaved ? 1 : nbatch));
+#ifdef SK_FUSED_TRACE_BUILD  // developer build only: dump the phase stamps of every segment of this launch (real signals)
+    const char *trace_path = interleaved ? nullptr : getenv("SKDSP_FUSED_TRACE");
+    if (trace_path) {
+        SK_HIP(hipMalloc((void **)&a.trace, (size_t)nseg * 16 * 8));
+        SK_HIP(hipMemsetAsync(a.trace, 0, (size_t)nseg * 16 * 8, s));
+    }
+    if (const char *e = getenv("SKDSP_FUSED_NLV")) a.n_lv = atoi(e);  // timing experiment (wrong results)
+#endif
     if (interleaved) {
 #define SK_FUSEDC(N)                                                                                                  \
     case N: {                                                                                                        \
@@ -691,8 +937,8 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
     case N: {                                                                                                        \
         Coef<N, 2> cf;                                                                                               \
         std::memcpy(cf.c, h->coef.data(), sizeof(cf.c));                                                             \
-        if (N >= 2 && h->unit_tail) hipLaunchKernelGGL((iir_fused_kernel<N, IO, (N >= 2)>), grid, dim3(kIirThreads), 0, s, a, cf, a.pw, a.gt); \
-        else hipLaunchKernelGGL((iir_fused_kernel<N, IO, false>), grid, dim3(kIirThreads), 0, s, a, cf, a.pw, a.gt);  \
+        if (N >= 2 && h->unit_tail) hipLaunchKernelGGL((iir_fused_kernel<N, IO, (N >= 2)>), grid, dim3(kIirThreads), 0, s, a, cf, a.pw, a.gt, (const double *)p->pwa_dev); \
+        else hipLaunchKernelGGL((iir_fused_kernel<N, IO, false>), grid, dim3(kIirThreads), 0, s, a, cf, a.pw, a.gt, (const double *)p->pwa_dev);  \
         break;                                                                                                       \
     }
     switch (h->nsec) {
@@ -704,6 +950,19 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
     }
 #undef SK_FUSED
     SK_HIP(hipGetLastError());
+#ifdef SK_FUSED_TRACE_BUILD
+    if (trace_path) {
+        std::vector<unsigned long long> hbuf((size_t)nseg * 16);
+        SK_HIP(hipMemcpyAsync(hbuf.data(), a.trace, hbuf.size() * 8, hipMemcpyDeviceToHost, s));
+        SK_HIP(hipStreamSynchronize(s));
+        SK_HIP(hipFree(a.trace));
+        if (FILE *f = fopen(trace_path, "w")) {
+            for (int64_t r = 0; r < nseg; ++r)
+                for (int q = 0; q < 16; ++q) fprintf(f, "%llu%s", hbuf[(size_t)r * 16 + q], q == 15 ? "\n" : ",");
+            fclose(f);
+        }
+    }
+#endif
     return SKDSP_OK;
 }
 

@@ -926,6 +926,7 @@ void iir_free(IirPlan *p)
 {
     if (!p) return;
     if (p->pw_dev) (void)hipFree(p->pw_dev);
+    if (p->pwa_dev) (void)hipFree(p->pwa_dev);
     if (p->lb_dev) (void)hipFree(p->lb_dev);
     if (p->lbk_dev) (void)hipFree(p->lbk_dev);
     if (p->gt_dev) (void)hipFree(p->gt_dev);
@@ -980,6 +981,7 @@ static int ensure_plan(IirHandle *h)
     }
     hipError_t e;
     if ((e = hipMalloc((void **)&p->pw_dev, (size_t)kPowers * D * D * 8)) != hipSuccess ||
+        (e = hipMalloc((void **)&p->pwa_dev, (size_t)8 * 4 * 64 * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&p->lb_dev, (size_t)8 * D * D * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&p->lbk_dev, (size_t)32 * D * D * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&p->state_dev, (size_t)4 * D * 8)) != hipSuccess ||
@@ -1083,7 +1085,17 @@ static int ensure_powers(IirHandle *h, int64_t T, hipStream_t s)
         SK_HIP(hipStreamSynchronize(s));
     }
     SK_HIP(hipMemcpyAsync(p->pw_dev, pw.data(), pw.size() * 8, hipMemcpyHostToDevice, s));
-    SK_HIP(hipStreamSynchronize(s));  // pw is a stack-lifetime host buffer
+    std::vector<double> pwa((size_t)8 * 4 * 64, 0.0);
+    if (D <= 16) {  // the same powers as A operands of v_mfma_f64_16x16x4: step r of level l, lane t: M_l[t & 15][4 r + (t >> 4)]
+        for (int l = 0; l < 8; ++l)
+            for (int r = 0; r < 4; ++r)
+                for (int t = 0; t < 64; ++t) {
+                    const int row = t & 15, col = 4 * r + (t >> 4);
+                    if (row < D && col < D) pwa[((size_t)l * 4 + r) * 64 + t] = pw[(size_t)l * D * D + (size_t)row * D + col];
+                }
+    }
+    SK_HIP(hipMemcpyAsync(p->pwa_dev, pwa.data(), pwa.size() * 8, hipMemcpyHostToDevice, s));
+    SK_HIP(hipStreamSynchronize(s));  // pw / pwa are stack-lifetime host buffers
     p->cached_T = T;
     return SKDSP_OK;
 }
@@ -1202,11 +1214,10 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
             rc = ensure_powers(h, Tf, s);
             if (rc) return rc;
             fstate = (p->n_lb == 1 && p->gt_T == Tf) ? 1 : -1;
-            // Measured crossover (2^26 float32, same box): the single pass costs one from-rest scan plus a correction per
-            // 128-sample chunk -- 6 + 1.5 levels of a 16 x 16 transition for the 8-biquad elliptic band-pass of BASELINE
-            // config 4 (0.206 ms) against 4 levels per 512-sample chunk in the two-pass scan (0.196 ms).  Up to 6 levels
-            // (every low-pass design tried: 0.12-0.13 vs 0.16-0.17 ms) and for float64 signals (0.35 vs 0.44 ms) it wins.
-            if (!interleaved && !dtype_double(h->dtype) && p->n_lv >= 6 && D >= 14 && opt().iir_two_pass >= 0) fstate = -1;
+            // Real signals: the single pass wins or ties everywhere it applies (tools/ab_iir.py, 2^26, same box): low-pass designs
+            // 0.12-0.13 vs 0.15 ms, float64 0.20-0.29 vs 0.36-0.42 ms; the 8-biquad elliptic band-pass of BASELINE config 4
+            // (6 scan levels of a 16 x 16 transition per 128-sample chunk) 0.184 vs 0.185 ms since its scan runs on the
+            // matrix pipe (iir_fused.hip: 0.197 ms with the per-thread VALU scan) -- and it moves 8 instead of 12 bytes per sample.
             // interleaved complex64 (two scans per 64-sample chunk): 0.24-0.30 vs 0.42-0.43 ms for low-pass designs (<= 4
             // levels), 0.63 vs 0.46 ms for the config-4 cascade (7 levels)
             if (interleaved && !dtype_double(h->dtype) && p->n_lv >= 6 && opt().iir_two_pass >= 0) fstate = -1;

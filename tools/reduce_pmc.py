@@ -20,8 +20,8 @@ WORK = {  # workload -> (substring of every kernel of a step, substring of the k
     "fir1024": ("ols_tile_kernel", "ols_tile_kernel", 16 * 2 ** 26),
     "fir127": ("skdsp::fir_", "skdsp::fir_", 8 * 2 ** 26),
     "updn43": ("skdsp::fir_", "skdsp::fir_", 8 * 2 ** 26 + 8 * ((2 ** 26 * 4) // 3)),
-    "iir8": ("skdsp::iir_", "float, true", 8 * 2 ** 26),  # K1 (matrix pipe or recurrence) + carries/K2 + K3 (the WRITE = true instantiation runs once per step)
-    "iir8sp": ("skdsp::iir_fused", "skdsp::iir_fused", 8 * 2 ** 26),   # config 4 through the single-pass scan
+    "iir8": ("skdsp::iir_fused", "skdsp::iir_fused", 8 * 2 ** 26),   # config 4: the single-pass scan (the default since round 2)
+    "iir8tp": ("skdsp::iir_", "float, true", 8 * 2 ** 26),  # ... forced through K1 (matrix pipe) + carries + K3 (the WRITE = true instantiation runs once per step)
     "iirlp8": ("skdsp::iir_fused", "skdsp::iir_fused", 8 * 2 ** 26),   # rate_change(12)'s lowpass, single-pass scan
 }
 for w, (pat, marker, alg) in WORK.items():
