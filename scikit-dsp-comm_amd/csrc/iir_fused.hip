@@ -471,18 +471,28 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
     const int64_t cj = row0 + tid;
     const bool zf_owner = a.zf != nullptr && cj == (a.n - 1) / T;
     const int zf_off = (int)((a.n - 1) % T);
+    const int zf_piece = (a.zf != nullptr && (a.n - 1) / T >= row0 && (a.n - 1) / T < row0 + kIirThreads) ? zf_off / kPiece : -1;  // uniform
     // ONE copy of the 32-sample body (8 biquads: ~1300 FP64 instructions, 10 KiB of code; four copies would not stay in
     // the instruction cache the two CUs share): the piece at hand always sits in xr[0 .. 31], the rest moves down behind it
 #pragma unroll 1
     for (int p = 0; p < NP; ++p) {
+        if (p == zf_piece && zf_owner) {
+            // streaming: the ONE thread of the launch whose piece holds sample n - 1 walks a copy of its state up to that sample
+            // (rolled loop, samples re-read from x: this piece of x is not overwritten before its outputs are stored below).
+            // A per-sample test inside the unrolled body cost 6 scalar instructions next to the 7 .. 42 vector ones.
+            double zt[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) zt[d] = z[d];
+            const IO *xp = x + cj * T + (int64_t)p * kPiece;
+#pragma unroll 1
+            for (int k = 0; k <= zf_off - p * kPiece; ++k) (void)cascade_step<NSEC, ORD, UNIT>(cf, zt, (double)xp[k]);
+#pragma unroll
+            for (int d = 0; d < D; ++d) a.zf[(size_t)bat * D + d] = zt[d];
+        }
 #pragma unroll
         for (int k = 0; k < kPiece; ++k) {
             const double yv = (SK_FUSED_DIAG & 1) ? (double)xr[k] + z[0] : cascade_step<NSEC, ORD, UNIT>(cf, z, (double)xr[k]);
             xr[k] = (IO)yv;
-            if (zf_owner && zf_off == p * kPiece + k) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) a.zf[(size_t)bat * D + d] = z[d];
-            }
         }
         SK_STAMP(5 + 2 * p);
         __syncthreads();  // the image is free (phase A / the previous piece's stores have read it)
@@ -771,25 +781,27 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_c_kernel(FusedArgs a
     const int64_t cj = row0 + tid;
     const bool zf_owner = a.zf != nullptr && cj == (a.n - 1) / TC;
     const int zf_off = (int)((a.n - 1) % TC);
+    const int zf_piece = (a.zf != nullptr && (a.n - 1) / TC >= row0 && (a.n - 1) / TC < row0 + kIirThreads) ? zf_off / PC : -1;  // uniform
 #pragma unroll 1
     for (int p = 0; p < NP; ++p) {
+        if (p == zf_piece && zf_owner) {  // (see iir_fused_kernel)
+            double zt0[D], zt1[D];
 #pragma unroll
-        for (int k = 0; k < PC; ++k) {
-            xr[k] = (IO)cascade_step<NSEC, ORD, UNIT>(cf, z0, (double)xr[k]);
-            if (zf_owner && zf_off == p * PC + k) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) a.zf[d] = z0[d];
+            for (int d = 0; d < D; ++d) { zt0[d] = z0[d]; zt1[d] = z1[d]; }
+            const IO *xp = x + 2 * (cj * TC + (int64_t)p * PC);
+#pragma unroll 1
+            for (int k = 0; k <= zf_off - p * PC; ++k) {
+                (void)cascade_step<NSEC, ORD, UNIT>(cf, zt0, (double)xp[2 * k]);
+                (void)cascade_step<NSEC, ORD, UNIT>(cf, zt1, (double)xp[2 * k + 1]);
             }
+#pragma unroll
+            for (int d = 0; d < D; ++d) { a.zf[d] = zt0[d]; a.zf[D + d] = zt1[d]; }
         }
+#pragma unroll
+        for (int k = 0; k < PC; ++k) xr[k] = (IO)cascade_step<NSEC, ORD, UNIT>(cf, z0, (double)xr[k]);
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < PC; ++k) {
-            xi[k] = (IO)cascade_step<NSEC, ORD, UNIT>(cf, z1, (double)xi[k]);
-            if (zf_owner && zf_off == p * PC + k) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) a.zf[D + d] = z1[d];
-            }
-        }
+        for (int k = 0; k < PC; ++k) xi[k] = (IO)cascade_step<NSEC, ORD, UNIT>(cf, z1, (double)xi[k]);
         __syncthreads();
 #pragma unroll
         for (int c4 = 0; c4 < PC / E; ++c4) {

@@ -1,5 +1,5 @@
 """Developer aid: phase timeline of the single-pass IIR kernel (library built with -DSK_FUSED_TRACE_BUILD):
-   SKDSP_LIB=.../libskdsp_hip_tr.so python tools/fused_trace.py [out.csv]"""
+   SKDSP_LIB=.../libskdsp_hip_tr.so python tools/fused_trace.py [out.csv] [sos8 | lp8 | bq1]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scikit-dsp-comm_amd"))
@@ -7,7 +7,15 @@ import numpy as np
 out = sys.argv[1] if len(sys.argv) > 1 else "/tmp/fused_trace.csv"
 from sk_dsp_comm_amd import _ffi
 n = 1 << 26
-sos = np.load(os.path.join(ROOT, "tests", "golden", "g7_iir_sos.npz"))["sos8"]
+which = sys.argv[2] if len(sys.argv) > 2 else "sos8"
+if which == "sos8":
+    sos = np.load(os.path.join(ROOT, "tests", "golden", "g7_iir_sos.npz"))["sos8"]   # BASELINE config 4
+elif which == "lp8":
+    from scipy import signal
+    sos = signal.butter(8, 0.9 / 12, output="sos")                                  # rate_change(12)'s default design
+else:
+    from scipy import signal
+    sos = signal.tf2sos(*signal.iirpeak(0.1, 30))
 _ffi.init(0)
 _ffi.set_option("iir_two_pass", -1)
 xd = _ffi.DeviceArray(n, np.float32).fill_noise(7)
