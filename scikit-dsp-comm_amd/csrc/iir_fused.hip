@@ -32,6 +32,14 @@ __device__ __forceinline__ double dpp_f64(double v)  // lanes without a source r
 }
 constexpr int kDppRowShr = 0x110, kDppRowRor = 0x120;
 
+// LDS hand-over between the lanes of ONE wave: the hardware serves a wave's LDS instructions in order; the fence keeps the
+// compiler from moving a lane's reads above its writes
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // tiles[g] += M_L * (tiles shifted right by 2^L columns inside the wave), L < 4;  A = the level's matrix as A operands
 // (IirPlan::pwa_dev, [level][step][64]: read from global memory one level ahead of their use)
 struct AOps { double a[4]; };
@@ -173,8 +181,8 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
     auto load_piece = [&](int p) {  // interior segments only
 #pragma unroll
         for (int i = 0; i < St::per_thread; ++i) {
-            const int idx = i * kIirThreads + tid;
-            const int row = idx / St::segs, sg = idx % St::segs;
+            const int idx = i * 64 + lane;
+            const int row = wave * 64 + idx / St::segs, sg = idx % St::segs;
             const int64_t g = (row0 + row) * T + (int64_t)p * kPiece + (int64_t)sg * St::elems;
             pre[i] = __builtin_nontemporal_load(reinterpret_cast<const pre_t *>(x + g));
         }
@@ -182,8 +190,8 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
     auto stage_slow = [&](int p) {  // zero beyond the signal
 #pragma unroll 1
         for (int i = 0; i < St::per_thread; ++i) {
-            const int idx = i * kIirThreads + tid;
-            const int row = idx / St::segs, sg = idx % St::segs;
+            const int idx = i * 64 + lane;
+            const int row = wave * 64 + idx / St::segs, sg = idx % St::segs;
             const int64_t g = (row0 + row) * T + (int64_t)p * kPiece + (int64_t)sg * St::elems;
             IO *dst = stage + row * St::pitch + sg * St::elems;
 #pragma unroll
@@ -192,6 +200,8 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
     };
 
     // ---- A: stream the segment in; chunk rows to registers; V = G x on the matrix pipe --------------------------
+    // (every wave stages, transposes and multiplies ITS OWN 64 rows: phases A and B need no workgroup barrier, the four waves
+    // drift apart and one's LDS work runs under another's MFMAs or recurrence)
     IO xr[T];
     v4d_t acc[4];
 #pragma unroll
@@ -204,14 +214,14 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
         if (interior) {
 #pragma unroll
             for (int i = 0; i < St::per_thread; ++i) {
-                const int idx = i * kIirThreads + tid;
-                const int row = idx / St::segs, sg = idx % St::segs;
+                const int idx = i * 64 + lane;
+                const int row = wave * 64 + idx / St::segs, sg = idx % St::segs;
                 *reinterpret_cast<pre_t *>(stage + row * St::pitch + sg * St::elems) = pre[i];
             }
         } else {
             stage_slow(p);
         }
-        __syncthreads();
+        wave_lds_sync();
         if (interior && p + 1 < NP) load_piece(p + 1);  // in flight during the MFMAs
 #pragma unroll
         for (int sgi = 0; sgi < St::segs; ++sgi) {
@@ -228,8 +238,9 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
             for (int g = 0; g < 4; ++g)
                 if (!(SK_FUSED_DIAG & 4)) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, (double)xs[g * 16 * St::pitch + 4 * s], acc[g], 0, 0, 0);
         }
-        __syncthreads();
+        wave_lds_sync();
     }
+    __syncthreads();  // the scan's exchange array lies over every wave's rows
 
     double z[D];
     // The scan of the 256 chunk maps: on the matrix pipe for cascades of 6+ biquads (a 12 x 12 .. 16 x 16 transition: 84+
@@ -472,6 +483,7 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
     const bool zf_owner = a.zf != nullptr && cj == (a.n - 1) / T;
     const int zf_off = (int)((a.n - 1) % T);
     const int zf_piece = (a.zf != nullptr && (a.n - 1) / T >= row0 && (a.n - 1) / T < row0 + kIirThreads) ? zf_off / kPiece : -1;  // uniform
+    __syncthreads();  // (the image is free again: every wave has read its scan result)
     // ONE copy of the 32-sample body (8 biquads: ~1300 FP64 instructions, 10 KiB of code; four copies would not stay in
     // the instruction cache the two CUs share): the piece at hand always sits in xr[0 .. 31], the rest moves down behind it
 #pragma unroll 1
@@ -495,7 +507,7 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
             xr[k] = (IO)yv;
         }
         SK_STAMP(5 + 2 * p);
-        __syncthreads();  // the image is free (phase A / the previous piece's stores have read it)
+        wave_lds_sync();  // the wave's rows are free (its previous piece's stores have read them)
 #pragma unroll
         for (int sgi = 0; sgi < St::segs; ++sgi) {
             float4 raw;
@@ -506,13 +518,13 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
         }
 #pragma unroll
         for (int k = 0; k + kPiece < T; ++k) xr[k] = xr[k + kPiece];
-        __syncthreads();
+        wave_lds_sync();
         int64_t dq_run = 0;
         int dr_run = 0;
 #pragma unroll
         for (int i = 0; i < St::per_thread; ++i) {
-            const int idx = i * kIirThreads + tid;
-            const int row = idx / St::segs, sg = idx % St::segs;
+            const int idx = i * 64 + lane;
+            const int row = wave * 64 + idx / St::segs, sg = idx % St::segs;
             const int64_t g = (row0 + row) * T + (int64_t)p * kPiece + (int64_t)sg * St::elems;
             const pre_t val = *reinterpret_cast<const pre_t *>(stage + row * St::pitch + sg * St::elems);
             if (a.dec > 1) {
@@ -907,7 +919,7 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
     a.n_keep = (n / a.dec) * a.dec;
     {
         // samples between a thread's staged segments (the interleaved kernel stages 8 segments per row piece)
-        const int64_t step = (int64_t)(interleaved ? kIirThreads / 8 : kIirThreads / Stage<IO>::segs) * T;
+        const int64_t step = (int64_t)(interleaved ? kIirThreads / 8 : 64 / Stage<IO>::segs) * T;
         a.dec_dq = (int)(step / a.dec);
         a.dec_dr = (int)(step % a.dec);
     }
