@@ -618,8 +618,8 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_c_kernel(FusedArgs a
     auto load_piece = [&](int p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int idx = i * kIirThreads + tid;
-            const int row = idx >> 3, sg = idx & 7;  // 8 x 16-byte segments per 128-byte row piece
+            const int idx = i * 64 + lane;
+            const int row = wave * 64 + (idx >> 3), sg = idx & 7;  // 8 x 16-byte segments per 128-byte row piece
             const int64_t g = (row0 + row) * TC + (int64_t)p * PC + (int64_t)sg * (E / 2);  // complex index
             pre[i] = __builtin_nontemporal_load(reinterpret_cast<const pre_t *>(x + 2 * g));
         }
@@ -634,8 +634,8 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_c_kernel(FusedArgs a
     auto stage_slow = [&](int p) {
 #pragma unroll 1
         for (int i = 0; i < 8; ++i) {
-            const int idx = i * kIirThreads + tid;
-            const int row = idx >> 3, sg = idx & 7;
+            const int idx = i * 64 + lane;
+            const int row = wave * 64 + (idx >> 3), sg = idx & 7;
             const int64_t g = (row0 + row) * TC + (int64_t)p * PC + (int64_t)sg * (E / 2);
             IO tmp[E];
 #pragma unroll
@@ -657,13 +657,13 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_c_kernel(FusedArgs a
         if (interior) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int idx = i * kIirThreads + tid;
-                split_store(reinterpret_cast<const IO *>(&pre[i]), idx >> 3, idx & 7);
+                const int idx = i * 64 + lane;   // every wave stages its own 64 rows (as in iir_fused_kernel)
+                split_store(reinterpret_cast<const IO *>(&pre[i]), wave * 64 + (idx >> 3), idx & 7);
             }
         } else {
             stage_slow(p);
         }
-        __syncthreads();
+        wave_lds_sync();
         if (interior && p + 1 < NP) load_piece(p + 1);
 #pragma unroll
         for (int c4 = 0; c4 < PC / E; ++c4) {
@@ -685,8 +685,9 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_c_kernel(FusedArgs a
                 acci[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, (double)si[g * 16 * PITCH + 4 * s4], acci[g], 0, 0, 0);
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
+    __syncthreads();  // the scan's exchange array lies over every wave's rows
 
     // ---- S / L: per component: chunk states to one thread per chunk, from-rest scan, publish the segment's end state ----
     double z0[D], z1[D];
@@ -794,6 +795,7 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_c_kernel(FusedArgs a
     const bool zf_owner = a.zf != nullptr && cj == (a.n - 1) / TC;
     const int zf_off = (int)((a.n - 1) % TC);
     const int zf_piece = (a.zf != nullptr && (a.n - 1) / TC >= row0 && (a.n - 1) / TC < row0 + kIirThreads) ? zf_off / PC : -1;  // uniform
+    __syncthreads();  // (the planes are free again: every wave has read its scan results)
 #pragma unroll 1
     for (int p = 0; p < NP; ++p) {
         if (p == zf_piece && zf_owner) {  // (see iir_fused_kernel)
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_c_kernel(FusedArgs a
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int k = 0; k < PC; ++k) xi[k] = (IO)cascade_step<NSEC, ORD, UNIT>(cf, z1, (double)xi[k]);
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int c4 = 0; c4 < PC / E; ++c4) {
             float4 qa, qb;
@@ -832,13 +834,13 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_c_kernel(FusedArgs a
             xr[k] = xr[k + PC];
             xi[k] = xi[k + PC];
         }
-        __syncthreads();
+        wave_lds_sync();
         int64_t dq_run = 0;
         int dr_run = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int idx = i * kIirThreads + tid;
-            const int row = idx >> 3, sg = idx & 7;
+            const int idx = i * 64 + lane;
+            const int row = wave * 64 + (idx >> 3), sg = idx & 7;
             const int64_t g = (row0 + row) * TC + (int64_t)p * PC + (int64_t)sg * (E / 2);
             IO out[E];
 #pragma unroll
@@ -918,8 +920,9 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
     a.dec = dec > 1 ? dec : 1;
     a.n_keep = (n / a.dec) * a.dec;
     {
-        // samples between a thread's staged segments (the interleaved kernel stages 8 segments per row piece)
-        const int64_t step = (int64_t)(interleaved ? kIirThreads / 8 : 64 / Stage<IO>::segs) * T;
+        // samples between a thread's staged segments: a wave stages 64 / segs rows per step (8 segments per row piece in the
+        // interleaved kernel)
+        const int64_t step = (int64_t)(interleaved ? 64 / 8 : 64 / Stage<IO>::segs) * T;
         a.dec_dq = (int)(step / a.dec);
         a.dec_dr = (int)(step % a.dec);
     }
