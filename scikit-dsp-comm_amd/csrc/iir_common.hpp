@@ -105,6 +105,15 @@ template <> struct Stage<double> {
 
 typedef double v4d_t __attribute__((ext_vector_type(4)));
 
+// LDS hand-over between the lanes of ONE wave: the hardware serves a wave's LDS instructions in order; the fence keeps the
+// compiler from moving a lane's reads above its writes
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+
 // single-pass scan (iir_fused.hip); T = 128 (float) / 64 (double) samples per chunk; the plan's powers and G table
 // must already be those of that chunk length (ensure_powers in iir_scan.hip)
 int iir_fused_launch(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, const double *zi_dev,

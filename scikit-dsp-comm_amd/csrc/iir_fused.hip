@@ -32,13 +32,6 @@ __device__ __forceinline__ double dpp_f64(double v)  // lanes without a source r
 }
 constexpr int kDppRowShr = 0x110, kDppRowRor = 0x120;
 
-// LDS hand-over between the lanes of ONE wave: the hardware serves a wave's LDS instructions in order; the fence keeps the
-// compiler from moving a lane's reads above its writes
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 
 // tiles[g] += M_L * (tiles shifted right by 2^L columns inside the wave), L < 4;  A = the level's matrix as A operands
 // (IirPlan::pwa_dev, [level][step][64]: read from global memory one level ahead of their use)
