@@ -35,6 +35,7 @@ struct IirPlan {
     // single-pass scan (iir_fused_kernel)
     int fused_state = 0;                   // 0 untested, 1 applicable, -1 not (the segment transition does not vanish)
     int fused_state_c = 0;                 // the same for interleaved complex signals (chunks half as long)
+    int fused_nlv = 0, fused_nlv_c = 0;    // scan levels (n_lv) at the single-pass chunk length, for the path policy
     unsigned long long *lbg_dev = nullptr;  // look-back granules [batch][nseg][32]
     size_t lbg_cap = 0;
     unsigned long long *ticket_dev = nullptr;  // [2] segment dispensers, monotonic

@@ -1207,21 +1207,29 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     {
         // chunk length: 128 float32 / 64 float64 samples (real), 64 complex64 / 32 complex128 samples (interleaved)
         const int64_t Tf = (dtype_double(h->dtype) ? 64 : 128) / (interleaved ? 2 : 1);
-        int &fstate = interleaved ? p->fused_state_c : p->fused_state;
-        if (h->order == 2 && D <= 16 && opt().iir_two_pass <= 0 && fstate >= 0 &&
-            (dec <= 1 || ((nbatch == 1 || interleaved) && zf_host == nullptr)) &&
-            n >= Tf * kIirThreads * (int64_t)ctx().num_cus) {
+        int &fstate = interleaved ? p->fused_state_c : p->fused_state;   // applicability only (cached); the policy is per call
+        int &fnlv = interleaved ? p->fused_nlv_c : p->fused_nlv;
+        const bool wanted = h->order == 2 && D <= 16 && opt().iir_two_pass <= 0 && fstate >= 0 &&
+                            (dec <= 1 || ((nbatch == 1 || interleaved) && zf_host == nullptr)) &&
+                            n >= Tf * kIirThreads * (int64_t)ctx().num_cus;
+        if (wanted && fstate == 0) {
             rc = ensure_powers(h, Tf, s);
             if (rc) return rc;
             fstate = (p->n_lb == 1 && p->gt_T == Tf) ? 1 : -1;
+            fnlv = p->n_lv;
+        }
+        if (wanted && fstate == 1) {
             // Real signals: the single pass wins or ties everywhere it applies (tools/ab_iir.py, 2^26, same box): low-pass designs
-            // 0.12-0.13 vs 0.15 ms, float64 0.20-0.29 vs 0.36-0.42 ms; the 8-biquad elliptic band-pass of BASELINE config 4
-            // (6 scan levels of a 16 x 16 transition per 128-sample chunk) 0.184 vs 0.185 ms since its scan runs on the
+            // 0.11-0.13 vs 0.15 ms, float64 0.19-0.28 vs 0.36-0.42 ms; the 8-biquad elliptic band-pass of BASELINE config 4
+            // (6 scan levels of a 16 x 16 transition per 128-sample chunk) 0.175 vs 0.184 ms since its scan runs on the
             // matrix pipe (iir_fused.hip: 0.197 ms with the per-thread VALU scan) -- and it moves 8 instead of 12 bytes per sample.
-            // interleaved complex64 (two scans per 64-sample chunk): 0.24-0.30 vs 0.42-0.43 ms for low-pass designs (<= 4
-            // levels), 0.63 vs 0.46 ms for the config-4 cascade (7 levels)
-            if (interleaved && !dtype_double(h->dtype) && p->n_lv >= 6 && opt().iir_two_pass >= 0) fstate = -1;
-            fused = fstate == 1;
+            // interleaved complex64 (two scans per 64-sample chunk): 0.22-0.29 vs 0.42-0.45 ms for low-pass designs (<= 4
+            // levels), 0.56 vs 0.46 ms for the config-4 cascade (7 levels): those stay two-pass unless iir_two_pass = -1
+            fused = !(interleaved && !dtype_double(h->dtype) && fnlv >= 6 && opt().iir_two_pass >= 0);
+            if (fused) {
+                rc = ensure_powers(h, Tf, s);   // (a no-op unless a two-pass call re-made the tables for its chunk length)
+                if (rc) return rc;
+            }
         }
     }
     int maxW = kMaxPairs / D;

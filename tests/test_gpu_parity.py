@@ -1430,15 +1430,17 @@ def test_iir_dn_decimating_store(dt, M, n):
 # ----------------------------------------------------------------- single-pass IIR scan (iir_fused.hip)
 @pytest.mark.parametrize("dt,n", [(np.float32, 9_000_017), (np.float32, 2 ** 24), (np.float64, 4_400_003), (np.complex64, 4_300_009),
                                   (np.complex128, 2_200_001)])
-@pytest.mark.parametrize("filt", ["ellip8", "butter4", "biquad"])
+@pytest.mark.parametrize("filt", ["ellip8", "butter4", "biquad", "butter12", "cheby14"])
 def test_iir_single_pass_scan_matches_two_pass_and_oracle(dt, n, filt):
     """The single-pass scan (one launch, x read once: segments of 256 register-resident chunks, from-rest scan,
     decoupled look-back, correction by binary powers) against the K1 / carries / K3 path (option iir_two_pass) and the
-    oracle: ragged lengths, initial state in, final state out, repeated launches (look-back epochs)."""
+    oracle: ragged lengths, initial state in, final state out, repeated launches (look-back epochs).  Cascades of 6+ biquads
+    (butter12, cheby14, ellip8) run their chunk scan on the matrix pipe: 2 .. 8 levels depending on filter and precision."""
     from scipy import signal
     import bench
     sos = {"ellip8": bench.elliptic_bpf_sos(), "butter4": signal.butter(4, 0.25, output="sos"),
-           "biquad": signal.tf2sos(*signal.iirpeak(0.1, 30))}[filt]
+           "biquad": signal.tf2sos(*signal.iirpeak(0.1, 30)), "butter12": signal.butter(12, 0.4, output="sos"),
+           "cheby14": signal.cheby1(14, 0.5, 0.15, output="sos")}[filt]
     nsec = sos.shape[0]
     rng = np.random.default_rng(5)
     cplx = np.dtype(dt).kind == "c"
