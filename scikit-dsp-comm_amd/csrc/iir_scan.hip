@@ -43,6 +43,13 @@
 #define SK_IIR_NT_STC 0  // ... in the interleaved complex K3: no gain (0.470 vs 0.458-0.47 ms)
 #endif
 
+// SK_SCAN_PART: this file is compiled twice so that its ~150 kernel instantiations (the long pole of the build: 136 s in one
+// piece) compile side by side: 1 = host side + the float32 kernels (build/iir_scan.o), 2 = the float64 kernels and their dispatch
+// only (build/iir_scan_f64.o); 0 = everything in one object (variant builds)
+#ifndef SK_SCAN_PART
+#define SK_SCAN_PART 0
+#endif
+
 namespace skdsp {
 
 struct IirArgs {
@@ -915,6 +922,7 @@ __global__ __launch_bounds__(1024) void iir_wg_scan_kernel(const double *__restr
 }
 
 // ------------------------------------------------------------------ host side
+#if SK_SCAN_PART != 2
 bool iir_shape_supported(int nsec, int order)
 {
     return order == 2 && nsec >= 1 && nsec <= 12;
@@ -1100,6 +1108,8 @@ static int ensure_powers(IirHandle *h, int64_t T, hipStream_t s)
     return SKDSP_OK;
 }
 
+#endif  // SK_SCAN_PART != 2
+
 template <int NSEC, int ORD, typename IO>
 static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t s)
 {
@@ -1185,6 +1195,13 @@ static int dispatch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream
     SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "iir: unsupported cascade shape (%d sections of order %d)", h->nsec, h->order);
 }
 
+// the float64 half of the dispatch lives in its own object (SK_SCAN_PART)
+int iir_dispatch_shape_f64(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t s);
+#if SK_SCAN_PART != 1
+int iir_dispatch_shape_f64(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t s) { return dispatch_shape<double>(h, a, nbatch, W, s); }
+#endif
+
+#if SK_SCAN_PART != 2
 // x_dev/y_dev: real planar arrays (float or double per h->dtype's precision); complex
 // callers deinterleave first (capi) and pass nbatch = 2 with batch_stride.
 int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, hipStream_t s,
@@ -1284,7 +1301,7 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     if (fused)
         rc = iir_fused_launch(h, x, n, nbatch, batch_stride, y, a.zi, a.zf, s, dec, interleaved);
     else
-        rc = dtype_double(h->dtype) ? dispatch_shape<double>(h, a, nbatch, W, s) : dispatch_shape<float>(h, a, nbatch, W, s);
+        rc = dtype_double(h->dtype) ? iir_dispatch_shape_f64(h, a, nbatch, W, s) : dispatch_shape<float>(h, a, nbatch, W, s);
     if (rc) return rc;  // (1 = interleaved path not applicable, nothing was launched)
     if (zf_host) {
         SK_HIP(hipMemcpyAsync(zf_host, p->state_dev + 2 * D, (size_t)nbatch * D * 8, hipMemcpyDeviceToHost, s));
@@ -1295,5 +1312,7 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     }
     return SKDSP_OK;
 }
+
+#endif  // SK_SCAN_PART != 2
 
 }  // namespace skdsp
