@@ -134,6 +134,16 @@ int skdsp_iir_filter_dev(skdsp_handle h, const void *x_dev, int64_t n, void *y_d
  * zi == NULL means rest; zf == NULL means "not wanted" (no stream synchronisation). */
 int skdsp_iir_state_len(skdsp_handle h, int *len);
 int skdsp_iir_filter_state_dev(skdsp_handle h, const void *x_dev, int64_t n, const double *zi, double *zf, void *y_dev);
+/* N-D inputs: scipy filters along the last axis in ONE call (multirate_helper.py:173: sosfilt(sos, x), x of any
+ * shape).  nrow rows of n samples, x_stride / y_stride elements apart (>= n), zero initial state per row, one launch
+ * (one staged copy each way for the host-pointer form, rows contiguous).  */
+int skdsp_iir_filter_rows(skdsp_handle h, const void *x, int64_t n, int64_t nrow, void *y);
+int skdsp_iir_filter_rows_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t nrow, int64_t x_stride, int64_t y_stride, void *y_dev);
+/* host-only (no GPU): the partial-fraction expansion the parallel-form scan (csrc/iir_par.hip) runs for the transfer
+ * function of an (n_sections x 6) sos array, H(z) = c0 + sum_k (r0_k + r1_k z^-1) / (1 + a1_k z^-1 + a2_k z^-2):
+ * out = [c0, (a1, a2, r0, r1) x n_sections, branch-cancellation factor, impulse-response error vs the cascade];
+ * *accepted = 1 when the expansion passed its acceptance test (else the cascade kernels serve the handle). */
+int skdsp_sos_par_info(const double *sos, int nsec, double *out, int *accepted);
 /* .up: filter(L*upsample(x,L)) (:69-75, :177-183); y has n*L samples */
 int skdsp_iir_up(skdsp_handle h, const void *x, int64_t n, int L, void *y);
 int skdsp_iir_up_dev(skdsp_handle h, const void *x_dev, int64_t n, int L, void *y_dev);

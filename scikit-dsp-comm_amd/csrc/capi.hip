@@ -54,6 +54,54 @@ int select_slot(int slot)
     return SKDSP_OK;
 }
 
+// ---- failures reported after the fact (bounded device-side waits) ------------------------------
+unsigned *async_err_dev(int which)
+{
+    Context &c = ctx();
+    if (!c.async_err) {
+        if (hipHostMalloc((void **)&c.async_err, kAsyncErrWords * sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            c.async_err = nullptr;
+            return nullptr;
+        }
+        for (int i = 0; i < kAsyncErrWords; ++i) c.async_err[i] = 0;
+    }
+    unsigned *dev = nullptr;
+    if (hipHostGetDevicePointer((void **)&dev, c.async_err, 0) != hipSuccess) return nullptr;
+    return dev + which;
+}
+
+int async_err_check(Context &c)
+{
+    if (!c.async_err) return SKDSP_OK;
+    volatile unsigned *w = c.async_err;
+    if (w[kAsyncErrHalo]) {
+        // The persistent launch of a sharded FIR step polled for seconds and gave up: the RCCL receive did not run beside
+        // it on this system.  Tile 0 of that step was not written from a valid halo.  The two-launch form is used from now
+        // on; the caller repeats the step -- COLLECTIVELY, on every rank (each step is one send/recv pair).
+        w[kAsyncErrHalo] = 0;
+        opt().shard_two_launches = 1;
+        set_error("fir_filter_shard: a sharded step since the last synchronisation gave up waiting for its halo inside the filter "
+                  "launch (the first tile of that step is invalid); switched to the two-launch form (option shard_two_launches) -- "
+                  "repeat the step on every rank");
+        return SKDSP_ERR_RCCL;
+    }
+    if (w[kAsyncErrIirLookback]) {
+        w[kAsyncErrIirLookback] = 0;
+        set_error("iir: a look-back poll of a single-pass scan launched since the last synchronisation timed out (the results of "
+                  "that call are invalid; option iir_two_pass = 1 selects the two-pass scan)");
+        return SKDSP_ERR_HIP;
+    }
+    return SKDSP_OK;
+}
+
+// stream sync of the calling slot + the deferred failures of what ran on it
+static int sync_checked()
+{
+    SK_HIP(hipStreamSynchronize(ctx().stream));
+    return async_err_check(ctx());
+}
+
 // ---- options: environment read once, skdsp_set_option afterwards ----------------------------
 namespace {
 struct OptEntry { const char *name; int Options::*field; };
@@ -63,7 +111,7 @@ const OptEntry kOptTable[] = {
     {"sw_no_tile", &Options::sw_no_tile}, {"sw_no_lpt", &Options::sw_no_lpt}, {"mm_ns", &Options::mm_ns},
     {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
-    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"shard_no_overlap", &Options::shard_no_overlap},
+    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
     {"shard_reserve", &Options::shard_reserve}, {"shard_two_launches", &Options::shard_two_launches},
     {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
     {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline}, {"host_multi_slot", &Options::host_multi_slot},
@@ -329,8 +377,7 @@ static int stage_out(void *y_host, const void *y_dev, size_t bytes, const Handle
         bytes *= 2;
     }
     if (bytes) SK_HIP(hipMemcpyAsync(y_host, y_dev, bytes, hipMemcpyDeviceToHost, ctx().stream));
-    SK_HIP(hipStreamSynchronize(ctx().stream));
-    return SKDSP_OK;
+    return sync_checked();
 }
 
 
@@ -534,7 +581,7 @@ static int run_pipeline(const ChunkPlan &p, int64_t k0, int64_t k1, const char *
         set_error("%s", helper_err);
         return helper_rc;
     }
-    return SKDSP_OK;
+    return async_err_check(c);
 }
 
 // Deal the chunks of a plan to every bound slot (contiguous ranges); make_self(slot) gives the per-slot kernel argument
@@ -895,13 +942,14 @@ static int shutdown_slot(Context &c)
         (void)hipEventDestroy(c.ev_in);
         (void)hipEventDestroy(c.ev_halo);
         if (c.halo_flag) (void)hipFree(c.halo_flag);
-        if (c.halo_err) (void)hipHostFree(c.halo_err);
-        c.halo_flag = nullptr; c.halo_err = nullptr;
+        c.halo_flag = nullptr;
         (void)hipStreamDestroy(c.comm_stream);
         c.comm_stream = nullptr;
         c.ev_in = c.ev_halo = nullptr;
     }
     (void)hipStreamDestroy(c.stream);
+    if (c.async_err) (void)hipHostFree(c.async_err);
+    c.async_err = nullptr;
     c.ready = false;
     c.device = -1;
     return SKDSP_OK;
@@ -1005,15 +1053,13 @@ int skdsp_memcpy_h2d(void *dst, const void *src, int64_t bytes)
 {
     API_BEGIN;
     if (bytes > 0) SK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx().stream));
-    SK_HIP(hipStreamSynchronize(ctx().stream));
-    return SKDSP_OK;
+    return sync_checked();
 }
 int skdsp_memcpy_d2h(void *dst, const void *src, int64_t bytes)
 {
     API_BEGIN;
     if (bytes > 0) SK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx().stream));
-    SK_HIP(hipStreamSynchronize(ctx().stream));
-    return SKDSP_OK;
+    return sync_checked();
 }
 int skdsp_memcpy_d2d(void *dst, const void *src, int64_t bytes)
 {
@@ -1030,8 +1076,7 @@ int skdsp_memset(void *dst, int value, int64_t bytes)
 int skdsp_sync(void)
 {
     API_BEGIN;
-    SK_HIP(hipStreamSynchronize(ctx().stream));
-    return SKDSP_OK;
+    return sync_checked();
 }
 int skdsp_timer_start(void)
 {
@@ -1047,7 +1092,7 @@ int skdsp_timer_stop(float *ms)
     float t = 0.f;
     SK_HIP(hipEventElapsedTime(&t, ctx().ev_start, ctx().ev_stop));
     if (ms) *ms = t;
-    return SKDSP_OK;
+    return async_err_check(ctx());
 }
 int skdsp_fill_noise_dev(void *x_dev, int64_t n, int dtype, uint64_t seed, int64_t first_index)
 {
@@ -1301,6 +1346,65 @@ int skdsp_iir_filter_dev(skdsp_handle hh, const void *x_dev, int64_t n, void *y_
     SK_CHECK(h, SKDSP_ERR_BADARG, "iir_filter: not an IIR handle");
     std::lock_guard<std::mutex> lk(h->mu);
     return iir_any_dev(h, x_dev, n, y_dev);
+}
+
+int skdsp_sos_par_info(const double *sos, int nsec, double *out, int *accepted)
+{
+    SK_CHECK(sos && out && accepted, SKDSP_ERR_BADARG, "sos_par_info: null argument");
+    SK_CHECK(nsec >= 1 && nsec <= 8, SKDSP_ERR_UNSUPPORTED, "sos_par_info: 1..8 biquads");
+    std::vector<double> coef((size_t)nsec * 5);
+    for (int s = 0; s < nsec; ++s) {
+        const double *q = sos + 6 * s;
+        SK_CHECK(q[3] == 1.0, SKDSP_ERR_BADARG, "sos[:, 3] should be all ones");
+        double *c = coef.data() + 5 * s;
+        c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; c[3] = q[4]; c[4] = q[5];
+    }
+    return iir_par_expand_host(coef.data(), nsec, out, accepted);
+}
+
+// rows of one launch (parallel form) or, where that does not apply, row by row through the cascade kernels
+static int iir_rows_dev(IirHandle *h, const void *x_dev, int64_t n, int64_t nrow, int64_t x_stride, int64_t y_stride, void *y_dev)
+{
+    if (n <= 0 || nrow <= 0) return SKDSP_OK;
+    SK_CHECK(x_stride >= n && y_stride >= n, SKDSP_ERR_BADARG, "iir_filter_rows: row stride below the row length");
+    SK_CHECK(nrow < (1 << 24), SKDSP_ERR_BADARG, "iir_filter_rows: too many rows");
+    const size_t esz = dtype_size(h->dtype);
+    if (!dtype_complex(h->dtype) && opt().iir_par > 0) {
+        const int r = iir_par_launch(h, x_dev, n, (int)nrow, x_stride, y_stride, y_dev, ctx().stream);
+        if (r != 1) return r;
+    }
+    for (int64_t r = 0; r < nrow; ++r) {
+        const int rc = iir_any_dev(h, (const char *)x_dev + (size_t)r * x_stride * esz, n, (char *)y_dev + (size_t)r * y_stride * esz);
+        if (rc) return rc;
+    }
+    return SKDSP_OK;
+}
+
+int skdsp_iir_filter_rows_dev(skdsp_handle hh, const void *x_dev, int64_t n, int64_t nrow, int64_t x_stride, int64_t y_stride, void *y_dev)
+{
+    API_BEGIN;
+    IirHandle *h = as_handle<IirHandle>(hh, H_IIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "iir_filter_rows: not an IIR handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return iir_rows_dev(h, x_dev, n, nrow, x_stride, y_stride, y_dev);
+}
+
+int skdsp_iir_filter_rows(skdsp_handle hh, const void *x, int64_t n, int64_t nrow, void *y)
+{
+    API_BEGIN;
+    IirHandle *h = as_handle<IirHandle>(hh, H_IIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "iir_filter_rows: not an IIR handle");
+    SK_CHECK(n >= 0 && nrow >= 0, SKDSP_ERR_BADARG, "iir_filter_rows: bad arguments");
+    if (n == 0 || nrow == 0) return SKDSP_OK;
+    SK_CHECK(x && y, SKDSP_ERR_BADARG, "iir_filter_rows: null buffer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    const size_t esz = dtype_size(h->dtype), bytes = (size_t)n * (size_t)nrow * esz;
+    void *x_dev = nullptr, *y_dev = nullptr;
+    int rc = stage_in(x, bytes, &x_dev);
+    if (rc) return rc;
+    if ((rc = ws_reserve(1, bytes + 256, &y_dev))) return rc;
+    if ((rc = iir_rows_dev(h, x_dev, n, nrow, n, n, y_dev))) return rc;
+    return stage_out(y, y_dev, bytes, h);
 }
 
 int skdsp_iir_state_len(skdsp_handle hh, int *len)

@@ -291,21 +291,17 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
                 SK_HIP(hipEventCreateWithFlags(&c.ev_halo, hipEventDisableTiming));
                 SK_HIP(hipMalloc((void **)&c.halo_flag, 256));
                 SK_HIP(hipMemsetAsync(c.halo_flag, 0, 256, c.stream));
-                SK_HIP(hipHostMalloc((void **)&c.halo_err, sizeof(unsigned), hipHostMallocMapped));
-                *c.halo_err = 0;
                 c.halo_seq = 0;
             }
-            if (*c.halo_err != 0) {
-                // The persistent launch of an earlier step polled for seconds and gave up: the RCCL receive did not run
-                // beside it on this system.  Fall back to the two-launch form for the rest of the process and tell the
-                // caller once (that step's first tile is invalid).
+            unsigned *err_dev = async_err_dev(kAsyncErrHalo);
+            SK_CHECK(err_dev, SKDSP_ERR_HIP, "fir_filter_shard: no host-mapped error word");
+            if (c.async_err[kAsyncErrHalo] != 0) {
+                // An earlier step's persistent launch gave up waiting for its halo (async_err_check reports it at the next
+                // synchronising call; seen here first when the caller queues steps back to back): drain, switch to the
+                // two-launch form, and refuse this step -- nothing is enqueued, the caller repeats it on every rank.
                 SK_HIP(hipStreamSynchronize(c.stream));
                 SK_HIP(hipStreamSynchronize(c.comm_stream));
-                *c.halo_err = 0;
-                opt().shard_two_launches = 1;
-                SK_CHECK(false, SKDSP_ERR_RCCL,
-                         "fir_filter_shard: the previous sharded step gave up waiting for its halo inside the filter launch; "
-                         "switched to the two-launch form (option shard_two_launches) -- repeat that step");
+                return async_err_check(c);
             }
             std::lock_guard<std::mutex> lk(h->mu);
             const size_t esz = dtype_size(h->dtype);
@@ -327,8 +323,6 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
                 SK_HIP(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
                 return fir_ols_launch(h, x_dev, V, first ? 0 : halo, y_dev, c.stream);
             }
-            unsigned *err_dev = nullptr;
-            SK_HIP(hipHostGetDevicePointer((void **)&err_dev, c.halo_err, 0));
             const unsigned seq = ++c.halo_seq;
             if (!first) {
                 r1 = fir_ols_publish_halo(c.halo_flag, seq, c.comm_stream);

@@ -41,7 +41,6 @@ struct IirPlan {
     unsigned long long *ticket_dev = nullptr;  // [2] segment dispensers, monotonic
     unsigned long long ticket_count[2] = {0, 0};  // their values (a launch adds nseg to each dispenser it uses)
     unsigned epoch = 0;
-    unsigned *err_host = nullptr;          // host-mapped: a look-back poll gave up
 };
 
 template <int NSEC, int ORD> struct Coef { double c[NSEC * (2 * ORD + 1)]; };

@@ -885,11 +885,8 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
     if (!p->ticket_dev) {
         SK_HIP(hipMalloc((void **)&p->ticket_dev, 16));
         SK_HIP(hipMemsetAsync(p->ticket_dev, 0, 16, s));
-        SK_HIP(hipHostMalloc((void **)&p->err_host, sizeof(unsigned), hipHostMallocMapped));
-        *p->err_host = 0;
         p->ticket_count[0] = p->ticket_count[1] = 0;
     }
-    SK_CHECK(*p->err_host == 0, SKDSP_ERR_HIP, "iir: a look-back poll of an earlier single-pass launch timed out (results of that call are invalid)");
     const size_t need = (size_t)(interleaved ? 2 : nbatch) * nseg * 32 * 8;
     if (need > p->lbg_cap) {
         if (p->lbg_dev) {
@@ -919,9 +916,11 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
         a.dec_dq = (int)(step / a.dec);
         a.dec_dr = (int)(step % a.dec);
     }
-    unsigned *err_dev = nullptr;
-    SK_HIP(hipHostGetDevicePointer((void **)&err_dev, p->err_host, 0));
-    a.err = err_dev;
+    // a poll that gives up is reported (and cleared) by the call that next synchronises this slot's stream (async_err_check):
+    // every workgroup has drawn its ticket before it polls and the granules carry the launch's epoch, so the dispenser and
+    // the look-back array stay consistent and later calls on this handle are unaffected
+    a.err = async_err_dev(kAsyncErrIirLookback);
+    SK_CHECK(a.err, SKDSP_ERR_HIP, "iir: no host-mapped error word");
     a.trace = nullptr;
     for (int b = 0; b < (interleaved ? 1 : nbatch); ++b) p->ticket_count[b] += (unsigned long long)nseg;
     const dim3 grid((unsigned)nseg, (unsigned)(interleaved ? 1 : nbatch));

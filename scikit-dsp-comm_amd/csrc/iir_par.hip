@@ -1,0 +1,732 @@
+// iir_par.hip -- single-pass exact IIR scan in PARALLEL FORM for gfx950 (MI355X): one launch, the signal read once and
+// written once, every wavefront an independent segment.
+// Serves scipy.signal.sosfilt(sos, x) (multirate_helper.py:173, :181, :190) / lfilter(b, a, x) (:74, :81) for decaying
+// cascades of up to 8 biquads with simple poles when no state crosses the call (zi / zf callers keep the cascade kernels
+// of iir_fused.hip / iir_scan.hip, whose state coordinates are scipy's).
+//
+// Why a second formulation.  The cascade runs 5 (4 in unit-tail form) DEPENDENT FP64 instructions per biquad and sample --
+// 40 per sample for 8 biquads, one chain -- and its one-chunk transition is a dense block-triangular 16 x 16 matrix, so
+// every level of the chunk scan is a 16 x 16 matrix-vector product per chunk.  The same transfer function expanded in
+// partial fractions,
+//     H(z) = c0 + sum_k (r0_k + r1_k z^-1) / (1 + a1_k z^-1 + a2_k z^-2),
+// is 8 INDEPENDENT two-state recurrences (2 FMA each) plus a 17-term output sum that depends on the previous states only:
+// 33 FP64 instructions per sample with no chain longer than two, and a block-DIAGONAL transition -- a scan level is 8
+// 2 x 2 products (32 FMA) instead of 144-256.  The expansion is done on the host in long double by arithmetic modulo each
+// section's denominator (no root finding, so a section may hold a complex pair, two real poles or a double pole); it is
+// accepted only when the impulse response of the expansion, with its coefficients rounded to double, reproduces the cascade's to
+// 1e-12 and its branches do not cancel (sum of the branch l1 norms <= 1e3 x the l1 norm of h): every design scipy makes for
+// rate_change / IIR_bpf / IIR_lpf passes with a factor of 2-20, i.e. a roundoff of ~1e-14 of the output.
+//
+// Structure (real signals).  A WAVE owns one segment of 64 chunks x T samples (T = 128 float32 / 64 float64: 8192 / 4096
+// samples) and keeps it on chip -- each lane its own chunk in registers:
+//   A  the segment streams in through a wave-private [64 rows x 32 samples] LDS image (full-line 16-byte loads, next piece in
+//      flight); each lane copies its row into registers and the same image feeds the FP64 matrix pipe with the B operands
+//      of V = G x, the from-rest end states (w[T-1], w[T-2]) of all 8 sections of the wave's 64 chunks
+//      (v_mfma_f64_16x16x4_f64, 16 state rows = one tile height exactly)
+//   S  from-rest Hillis-Steele scan of the wave's 64 chunk states: per level 8 ds_read_b128 + 32 FMA per lane, matrices
+//      through the scalar cache; only levels whose power of the chunk transition is not negligible
+//   L  decoupled look-back: the wave publishes its from-rest end state (32 eight-byte {half, epoch} granules, relaxed
+//      agent-scope atomics: the data is its own flag) and reads those of its K predecessors.  K = the number of segments the
+//      filter remembers (config 4: 1); the state at the start of the segment is c = sum_j Psi^j P_(s-1-j), exact to the
+//      negligibility threshold, from FROM-REST values only -- no wave waits for a chain.  Segments are handed out by a
+//      ticket counter, so a predecessor is a wave that already runs; the poll is bounded and reports through a host-mapped
+//      word instead of hanging
+//   C  z_j = p_(j-1) + Phi^j c by binary powers
+//   B  the recurrence over the register-resident samples; outputs leave through the LDS image as full lines
+// Nothing in A..B meets another wave: no workgroup barrier after the table load, so the 8 waves of a CU drift through
+// their memory / matrix / LDS / VALU phases independently.  N-D inputs are rows of the same launch (row = ticket / nseg).
+#include "iir_common.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+namespace skdsp {
+
+constexpr int kParMaxK = 4;   // look-back depth served (segments the filter may remember)
+constexpr int kParTickets = 16;   // segment dispensers per launch
+#ifndef SK_PAR_T32
+#define SK_PAR_T32 128   // samples per lane (float32 signals); float64 signals: half
+#endif
+#ifndef SK_PAR_OCC
+#define SK_PAR_OCC 2     // waves per SIMD the register budget is set for
+#endif
+
+template <int NSEC> struct ParCoef {
+    double na1[NSEC], na2[NSEC];   // -a1, -a2
+    double al[NSEC], be[NSEC];     // output taps on (w[n-1], w[n-2])
+    double gamma;                  // direct term
+};
+
+struct ParArgs {
+    const void *x;
+    void *y;
+    int64_t n;                   // samples per row
+    int64_t x_stride, y_stride;  // elements between rows
+    int nseg;                    // segments per row
+    int total;                   // rows x nseg
+    unsigned long long *lb;      // [total][32] look-back granules
+    unsigned long long *ticket;  // [kParTickets] segment dispensers (monotonic; ticket_base = their common value before this launch)
+    unsigned long long ticket_base;
+    unsigned epoch;
+    int n_lv;                    // scan levels inside a wave that matter (0..6)
+    int K;                       // look-back depth (1..kParMaxK)
+    unsigned *err;               // host-mapped: a look-back poll gave up
+    int aligned;                 // rows start 16-byte aligned (vector loads / stores)
+    int dec;                     // > 1: only y[k * dec] is stored (at y[k])
+    int dec_dq, dec_dr;          // (rows between a lane's staged segments x T) div / mod dec
+    int64_t n_keep;              // (n / dec) * dec
+    int dbg;                     // developer timing switches (option iir_par_dbg; wrong results): 1 no MFMAs, 2 no recurrence, 4 no scan / look-back, 8 no stores, 16 no loads
+};
+
+// v += P * left, P = the level's 2 x 2 block of every section (row-major), through the scalar cache
+template <int NSEC>
+__device__ __forceinline__ void blocks_acc(const double *__restrict__ P, const double (&in)[2 * NSEC], double (&out)[2 * NSEC])
+{
+#pragma unroll
+    for (int k = 0; k < NSEC; ++k) {
+        out[2 * k] = fma(P[4 * k + 1], in[2 * k + 1], fma(P[4 * k], in[2 * k], out[2 * k]));
+        out[2 * k + 1] = fma(P[4 * k + 3], in[2 * k + 1], fma(P[4 * k + 2], in[2 * k], out[2 * k + 1]));
+    }
+}
+
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+template <int NSEC, typename IO, bool DEC>
+__global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
+                                                                 const double *__restrict__ lvl, const double *__restrict__ psi)
+{
+    constexpr int D = 2 * NSEC;
+    constexpr int T = SK_PAR_T32 * 4 / (int)sizeof(IO);
+    constexpr int NP = T / kPiece;
+    using St = Stage<IO>;
+    constexpr int kRowBytes = St::pitch * (int)sizeof(IO);
+    constexpr int kWaveStage = 64 * kRowBytes;                    // 9216 (float) / 17408 (double) bytes: also holds the 8 KiB scan exchange
+    static_assert(kWaveStage >= 64 * 16 * 8, "scan exchange must fit the wave's stage image");
+    __shared__ __attribute__((aligned(16))) char lds_raw[4 * kWaveStage];
+    __shared__ double gl[(T / 4) * 64];
+    __shared__ __attribute__((aligned(16))) unsigned cwsh[4][kParMaxK * 32];
+    __shared__ int base_sh;
+
+    // (the wave index through readfirstlane: segment, row and every base address are then wave-uniform SGPR values)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // kParTickets dispensers, one per workgroup residue (a single word serialises the 2048 draws of a 2^26-sample launch in
+    // the L2 atomic unit: 22 us of an otherwise empty launch): workgroup b draws q from dispenser b mod kParTickets and serves
+    // wave segments 4 (kParTickets q + b mod kParTickets) ...; every dispenser hands out exactly the numbers of its residue
+    // class, so the launch covers every segment once, and the smallest segment not yet drawn is drawn by the next workgroup
+    // of its class that starts -- which needs only that running workgroups finish, and those wait for smaller segments only
+    if (tid == 0) {
+        const unsigned res = blockIdx.x % kParTickets;
+        base_sh = 4 * (int)((unsigned)(atomicAdd(a.ticket + res, 1ull) - a.ticket_base) * kParTickets + res);
+    }
+    for (int i = tid; i < (T / 4) * 64; i += kIirThreads) gl[i] = gtab[i];
+    __syncthreads();   // the only workgroup barrier
+    const int tk = __builtin_amdgcn_readfirstlane(base_sh) + wave;
+    if (tk >= a.total) return;
+    const int row = a.nseg == a.total ? 0 : __builtin_amdgcn_readfirstlane(tk / a.nseg), seg = tk - row * a.nseg;
+    const IO *x = reinterpret_cast<const IO *>(a.x) + (size_t)row * a.x_stride;
+    IO *y = reinterpret_cast<IO *>(a.y) + (size_t)row * a.y_stride;
+    IO *stage = reinterpret_cast<IO *>(lds_raw + wave * kWaveStage);
+    double *E = reinterpret_cast<double *>(lds_raw + wave * kWaveStage);   // scan exchange [section][lane][2] (aliases the image)
+    const int64_t row0 = (int64_t)seg * 64;   // first chunk of the segment
+    const bool interior = a.aligned && (row0 + 64) * T <= a.n;
+
+    typedef float pre_t __attribute__((ext_vector_type(4)));
+    pre_t pre[NP][St::per_thread];
+    // (uniform segment base + one 32-bit lane offset + constants: hipcc then addresses every access of the segment as
+    // SGPR base + VGPR offset + immediate instead of keeping a 64-bit address pair per access alive)
+    const IO *xseg = x + row0 * T;
+    IO *yseg = y + row0 * T;
+    const unsigned loff = (unsigned)((lane / St::segs) * T + (lane % St::segs) * St::elems);
+    constexpr unsigned kRowStep = (64 / St::segs) * T;   // elements between a lane's consecutive staged segments
+    auto load_piece = [&](int p) {  // interior segments only
+#pragma unroll
+        for (int i = 0; i < St::per_thread; ++i)
+            pre[p][i] = __builtin_nontemporal_load(reinterpret_cast<const pre_t *>(xseg + (loff + i * kRowStep + p * kPiece)));
+    };
+    auto stage_slow = [&](int p) {  // zero beyond the signal
+#pragma unroll 1
+        for (int i = 0; i < St::per_thread; ++i) {
+            const int idx = i * 64 + lane;
+            const int r = idx / St::segs, sg = idx % St::segs;
+            const int64_t g = (row0 + r) * T + (int64_t)p * kPiece + (int64_t)sg * St::elems;
+            IO *dst = stage + r * St::pitch + sg * St::elems;
+#pragma unroll
+            for (int e = 0; e < St::elems; ++e) dst[e] = (g + e < a.n) ? x[g + e] : IO(0);
+        }
+    };
+
+    // ---- A: stream the segment in; chunk rows to registers; V = G x on the matrix pipe --------------------------------
+    // (the chunk as 16-byte vectors: as a scalar array hipcc's SROA left half of it in scratch memory)
+    typedef IO xv_t __attribute__((ext_vector_type(St::elems)));
+    xv_t xq[T / St::elems];
+    v4d_t acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = v4d_t{0.0, 0.0, 0.0, 0.0};
+    const int c = lane & 15, j = lane >> 4;
+    IO *myrow = stage + lane * St::pitch;
+    // (every piece of the segment is requested up front: the landing registers are the ones the chunk will occupy anyway)
+    if (interior && !(a.dbg & 16)) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) load_piece(p);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < St::per_thread; ++i) {
+                const int idx = i * 64 + lane;
+                const int r = idx / St::segs, sg = idx % St::segs;
+                *reinterpret_cast<pre_t *>(stage + r * St::pitch + sg * St::elems) = pre[p][i];
+            }
+        } else {
+            stage_slow(p);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int sgi = 0; sgi < St::segs; ++sgi) xq[p * St::segs + sgi] = *reinterpret_cast<const xv_t *>(myrow + sgi * St::elems);
+        const IO *xs = stage + c * St::pitch + j;
+        if (!(a.dbg & 1))
+#pragma unroll
+        for (int s = 0; s < kPiece / 4; ++s) {
+            const double ga = gl[(p * (kPiece / 4) + s) * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, (double)xs[g * 16 * St::pitch + 4 * s], acc[g], 0, 0, 0);
+        }
+        wave_lds_sync();
+    }
+
+    // chunk end states from the accumulator layout (column = lane & 15, state row = (lane >> 4) + 4 reg) to one lane per chunk
+    double v[D];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = j + 4 * r;   // state row: section d >> 1, component d & 1
+            if (4 * r < D) {
+                if (d < D) E[(((d >> 1) * 64) + 16 * g + c) * 2 + (d & 1)] = acc[g][r];
+            }
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < NSEC; ++k) {
+        const v2d_t t = *reinterpret_cast<const v2d_t *>(E + (k * 64 + lane) * 2);
+        v[2 * k] = t[0];
+        v[2 * k + 1] = t[1];
+    }
+
+    // ---- S: from-rest inclusive scan of the wave's 64 chunk states ------------------------------------------------------
+    if (a.dbg & 4) a.n_lv = 0;
+#pragma unroll 1
+    for (int l = 0; l < a.n_lv; ++l) {
+        const int s = 1 << l;
+        const int src = lane >= s ? lane - s : lane;
+        double left[D];
+#pragma unroll
+        for (int k = 0; k < NSEC; ++k) {
+            const v2d_t t = *reinterpret_cast<const v2d_t *>(E + (k * 64 + src) * 2);
+            left[2 * k] = t[0];
+            left[2 * k + 1] = t[1];
+        }
+        wave_lds_sync();
+        if (lane >= s) blocks_acc<NSEC>(lvl + (size_t)l * NSEC * 4, left, v);
+#pragma unroll
+        for (int k = 0; k < NSEC; ++k) *reinterpret_cast<v2d_t *>(E + (k * 64 + lane) * 2) = v2d_t{v[2 * k], v[2 * k + 1]};
+        wave_lds_sync();
+    }
+    double z[D];
+#pragma unroll
+    for (int k = 0; k < NSEC; ++k) {
+        const v2d_t t = *reinterpret_cast<const v2d_t *>(E + (k * 64 + (lane ? lane - 1 : 0)) * 2);
+        z[2 * k] = lane ? t[0] : 0.0;
+        z[2 * k + 1] = lane ? t[1] : 0.0;
+    }
+
+    // ---- L: publish the segment's end state from rest, fetch the K predecessors' ----------------------------------------
+    unsigned *cw = cwsh[wave];
+    if (lane < 2 * D) {
+        const int d = lane >> 1;
+        const unsigned half = reinterpret_cast<const unsigned *>(E)[((((d >> 1) * 64) + 63) * 2 + (d & 1)) * 2 + (lane & 1)];
+        __hip_atomic_store(a.lb + (size_t)tk * 32 + lane, ((unsigned long long)a.epoch << 32) | half, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (seg > 0 && !(a.dbg & 4)) {
+#pragma unroll 1
+        for (int k0 = 0; k0 < a.K; k0 += 2) {
+            const int back = k0 + (lane >> 5) + 1;   // this lane's predecessor distance
+            unsigned got = 0;
+            if (back <= a.K && back <= seg && (lane & 31) < 2 * D) {
+                const unsigned long long *srcp = a.lb + (size_t)(tk - back) * 32 + (lane & 31);
+                unsigned long long g = 0;
+                int spins = 0;
+                for (;;) {
+                    g = __hip_atomic_load(srcp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(g >> 32) == a.epoch) break;
+                    if (++spins > (1 << 22)) {  // ~ seconds: never in a healthy run; fail loudly instead of hanging the GPU
+                        *a.err = 1u;
+                        g = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                got = (unsigned)g;
+            }
+            if (back <= kParMaxK) cw[(back - 1) * 32 + (lane & 31)] = got;
+        }
+        wave_lds_sync();
+
+        // ---- C: z_j += Phi^j c,  c = sum_m Psi^m P_(s-1-m) ---------------------------------------------------------------
+        double u[D];
+        const double *cwd = reinterpret_cast<const double *>(cw);
+#pragma unroll
+        for (int k = 0; k < NSEC; ++k) {
+            const v2d_t t = *reinterpret_cast<const v2d_t *>(cwd + 2 * k);
+            u[2 * k] = t[0];
+            u[2 * k + 1] = t[1];
+        }
+#pragma unroll 1
+        for (int m = 1; m < a.K; ++m) {
+            double pm[D];
+#pragma unroll
+            for (int k = 0; k < NSEC; ++k) {
+                const v2d_t t = *reinterpret_cast<const v2d_t *>(cwd + m * 16 + 2 * k);
+                pm[2 * k] = t[0];
+                pm[2 * k + 1] = t[1];
+            }
+            blocks_acc<NSEC>(psi + (size_t)(m - 1) * NSEC * 4, pm, u);
+        }
+#pragma unroll 1
+        for (int l = 0; l < a.n_lv; ++l) {
+            if ((lane >> l) & 1) {
+                double t2[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) t2[d] = 0.0;
+                blocks_acc<NSEC>(lvl + (size_t)l * NSEC * 4, u, t2);
+#pragma unroll
+                for (int d = 0; d < D; ++d) u[d] = t2[d];
+            }
+        }
+        if ((lane >> a.n_lv) == 0) {   // (Phi^j c is negligible for j >= 2^n_lv)
+#pragma unroll
+            for (int d = 0; d < D; ++d) z[d] += u[d];
+        }
+    }
+    wave_lds_sync();  // the image is free again
+
+    // ---- B: the recurrence over the register-resident chunk; outputs leave through the LDS image ------------------------
+    // (the output taps live in VGPRs: 33 double coefficients next to the addresses do not fit a wave's 102 SGPRs, and
+    // hipcc then shuffles them through v_readlane / re-reads them from the kernel arguments inside the body)
+    double al[NSEC], be[NSEC], gam = cf.gamma;
+#pragma unroll
+    for (int s = 0; s < NSEC; ++s) {
+        al[s] = cf.al[s];
+        be[s] = cf.be[s];
+        asm volatile("" : "+v"(be[s]));
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (!(a.dbg & 2))
+#pragma unroll
+        for (int k = 0; k < kPiece; ++k) {
+            const double xd = (double)xq[(p * kPiece + k) / St::elems][(p * kPiece + k) % St::elems];
+            double yv = gam * xd;
+#pragma unroll
+            for (int s = 0; s < NSEC; ++s) {
+                yv = fma(al[s], z[2 * s], yv);
+                yv = fma(be[s], z[2 * s + 1], yv);
+            }
+#pragma unroll
+            for (int s = 0; s < NSEC; ++s) {
+                const double w0 = fma(cf.na2[s], z[2 * s + 1], fma(cf.na1[s], z[2 * s], xd));
+                z[2 * s + 1] = z[2 * s];
+                z[2 * s] = w0;
+            }
+            xq[(p * kPiece + k) / St::elems][(p * kPiece + k) % St::elems] = (IO)yv;
+        }
+        wave_lds_sync();  // the wave's rows are free (its previous piece's stores have read them)
+#pragma unroll
+        for (int sgi = 0; sgi < St::segs; ++sgi) *reinterpret_cast<xv_t *>(myrow + sgi * St::elems) = xq[p * St::segs + sgi];
+        wave_lds_sync();
+        if (!DEC && interior) {
+            if (!(a.dbg & 8))
+#pragma unroll
+            for (int i = 0; i < St::per_thread; ++i) {
+                const int idx = i * 64 + lane;
+                const int r = idx / St::segs, sg = idx % St::segs;
+                const pre_t val = *reinterpret_cast<const pre_t *>(stage + r * St::pitch + sg * St::elems);
+                __builtin_nontemporal_store(val, reinterpret_cast<pre_t *>(yseg + (loff + i * kRowStep + p * kPiece)));
+            }
+            continue;
+        }
+        int64_t dq_run = 0;
+        int dr_run = 0;
+#pragma unroll 1
+        for (int i = 0; i < St::per_thread; ++i) {
+            const int idx = i * 64 + lane;
+            const int r = idx / St::segs, sg = idx % St::segs;
+            const int64_t g = (row0 + r) * T + (int64_t)p * kPiece + (int64_t)sg * St::elems;
+            const pre_t val = *reinterpret_cast<const pre_t *>(stage + r * St::pitch + sg * St::elems);
+            const IO *tmp = reinterpret_cast<const IO *>(&val);
+            if (DEC) {
+                // decimating store (as in iir_fused_kernel): segment i of this lane starts a fixed number of samples after
+                // segment i - 1, so its (quotient, remainder) by dec follow from the first by adding (dec_dq, dec_dr)
+                if (i == 0) {
+                    dq_run = g / a.dec;
+                    dr_run = (int)(g - dq_run * a.dec);
+                }
+                if (a.dec >= St::elems) {  // at most one kept sample per 16-byte segment
+                    const int e0 = dr_run == 0 ? 0 : a.dec - dr_run;
+                    if (e0 < St::elems && g + e0 < a.n_keep) {
+                        IO pick = tmp[0];
+#pragma unroll
+                        for (int e = 1; e < St::elems; ++e) pick = (e0 == e) ? tmp[e] : pick;
+                        y[dq_run + (dr_run != 0)] = pick;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < St::elems; ++e) {
+                        const int t = dr_run + e;  // < dec + elems
+                        const int m = (t >= a.dec) + (t >= 2 * a.dec) + (t >= 3 * a.dec) + (t >= 4 * a.dec);
+                        if (t == m * a.dec && g + e < a.n_keep) y[dq_run + m] = tmp[e];
+                    }
+                }
+                dq_run += a.dec_dq;
+                dr_run += a.dec_dr;
+                if (dr_run >= a.dec) { dr_run -= a.dec; ++dq_run; }
+            } else if (g < a.n) {
+#pragma unroll
+                for (int e = 0; e < St::elems; ++e)
+                    if (g + e < a.n) y[g + e] = tmp[e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------- host side
+struct ParTables {
+    int T = 0;
+    int n_lv = 0, K = 0;         // K = 0: the filter remembers more than kParMaxK segments of this length (not served)
+    double *gt_dev = nullptr;    // G in MFMA A-operand order [T / 4][64]
+    double *lvl_dev = nullptr;   // Phi^(2^l), l = 0..5: [6][nsec][4]
+    double *psi_dev = nullptr;   // Psi^m, m = 1..kParMaxK-1, Psi = Phi^64: [3][nsec][4]
+};
+
+struct ParPlan {
+    int state = 0;               // 0 untested, 1 expansion accepted, -1 not applicable
+    int nsec = 0;
+    long double a1[8], a2[8], r0[8], r1[8], c0 = 0.0L;
+    double na1[8], na2[8], al[8], be[8], gamma = 0.0;
+    double kappa = 0.0, ir_err = 0.0;
+    ParTables tab[2];            // [0] float32 signals (T = 128), [1] float64 signals (T = 64)
+    unsigned long long *lbg_dev = nullptr;
+    size_t lbg_cap = 0;
+    unsigned long long *ticket_dev = nullptr;
+    unsigned long long ticket_count = 0;
+    unsigned epoch = 0;
+};
+
+void iir_par_free(ParPlan *p)
+{
+    if (!p) return;
+    for (ParTables &t : p->tab) {
+        if (t.gt_dev) (void)hipFree(t.gt_dev);
+        if (t.lvl_dev) (void)hipFree(t.lvl_dev);
+        if (t.psi_dev) (void)hipFree(t.psi_dev);
+    }
+    if (p->lbg_dev) (void)hipFree(p->lbg_dev);
+    if (p->ticket_dev) (void)hipFree(p->ticket_dev);
+    delete p;
+}
+
+namespace {
+struct Q2 { long double u, v; };   // u + v q  in R[q] / (1 + a1 q + a2 q^2)
+
+// partial fractions of prod_k B_k(q) / A_k(q), q = z^-1, by arithmetic modulo each denominator
+bool par_expand(const double *coef, int nsec, ParPlan &P)
+{
+    long double b[8][3], a[8][3];
+    int degA[8], degB[8], sumA = 0, sumB = 0;
+    for (int k = 0; k < nsec; ++k) {
+        const double *c = coef + 5 * k;
+        b[k][0] = c[0]; b[k][1] = c[1]; b[k][2] = c[2];
+        a[k][0] = 1.0L; a[k][1] = c[3]; a[k][2] = c[4];
+        for (int i = 0; i < 5; ++i)
+            if (!std::isfinite(c[i])) return false;
+        degA[k] = a[k][2] != 0.0L ? 2 : (a[k][1] != 0.0L ? 1 : 0);
+        degB[k] = b[k][2] != 0.0L ? 2 : (b[k][1] != 0.0L ? 1 : 0);
+        sumA += degA[k];
+        sumB += degB[k];
+    }
+    if (sumB > sumA) return false;   // a polynomial part beyond the direct term: not a sum of these branches
+    P.c0 = 0.0L;
+    if (sumB == sumA) {
+        P.c0 = 1.0L;
+        for (int k = 0; k < nsec; ++k) P.c0 *= b[k][degB[k]] / a[k][degA[k]];
+    }
+    for (int k = 0; k < nsec; ++k) {
+        P.a1[k] = a[k][1];
+        P.a2[k] = a[k][2];
+        P.r0[k] = P.r1[k] = 0.0L;
+        if (degA[k] == 2) {
+            const long double a1 = a[k][1], a2 = a[k][2];
+            auto red = [&](const long double *c) { return Q2{c[0] - c[2] / a2, c[1] - c[2] * a1 / a2}; };
+            auto mul = [&](Q2 x, Q2 y) {
+                const long double vv = x.v * y.v;
+                return Q2{x.u * y.u - vv / a2, x.u * y.v + x.v * y.u - vv * a1 / a2};
+            };
+            Q2 acc{1.0L, 0.0L};
+            for (int jx = 0; jx < nsec; ++jx) {
+                acc = mul(acc, red(b[jx]));
+                if (jx == k) continue;
+                const Q2 d = red(a[jx]);
+                // inverse of d: [u, -v/a2; v, u - v a1/a2] [s; t] = [1; 0]
+                const long double m11 = d.u, m12 = -d.v / a2, m21 = d.v, m22 = d.u - d.v * a1 / a2;
+                const long double det = m11 * m22 - m12 * m21;
+                const long double scale = fabsl(m11 * m22) + fabsl(m12 * m21);
+                if (!(fabsl(det) > 1e-12L * scale) || !std::isfinite((double)det)) return false;   // a pole shared with another section
+                acc = mul(acc, Q2{m22 / det, -m21 / det});
+            }
+            P.r0[k] = acc.u;
+            P.r1[k] = acc.v;
+        } else if (degA[k] == 1) {
+            const long double q0 = -1.0L / a[k][1];
+            long double val = 1.0L;
+            for (int jx = 0; jx < nsec; ++jx) {
+                val *= b[jx][0] + b[jx][1] * q0 + b[jx][2] * q0 * q0;
+                if (jx == k) continue;
+                const long double den = a[jx][0] + a[jx][1] * q0 + a[jx][2] * q0 * q0;
+                if (!(fabsl(den) > 1e-12L)) return false;
+                val /= den;
+            }
+            P.r0[k] = val;
+        }
+        if (!std::isfinite((double)P.r0[k]) || !std::isfinite((double)P.r1[k])) return false;
+    }
+    if (!std::isfinite((double)P.c0)) return false;
+    long double gam = P.c0;
+    for (int k = 0; k < nsec; ++k) {
+        P.na1[k] = (double)(-P.a1[k]);
+        P.na2[k] = (double)(-P.a2[k]);
+        P.al[k] = (double)(P.r1[k] - P.r0[k] * P.a1[k]);
+        P.be[k] = (double)(-P.r0[k] * P.a2[k]);
+        gam += P.r0[k];
+    }
+    P.gamma = (double)gam;
+    // acceptance: the expansion with its double coefficients against the cascade (long double DF2T), impulse response
+    const int NI = 8192;
+    long double zc[16] = {0}, w1[8] = {0}, w2[8] = {0};
+    long double hmax = 0.0L, emax = 0.0L, l1h = 0.0L, l1b = fabsl((long double)P.gamma);
+    for (int n = 0; n < NI; ++n) {
+        long double xin = n == 0 ? 1.0L : 0.0L, xc = xin;
+        for (int s = 0; s < nsec; ++s) {
+            const double *c = coef + 5 * s;
+            const long double yv = (long double)c[0] * xc + zc[2 * s];
+            zc[2 * s] = (long double)c[1] * xc - (long double)c[3] * yv + zc[2 * s + 1];
+            zc[2 * s + 1] = (long double)c[2] * xc - (long double)c[4] * yv;
+            xc = yv;
+        }
+        long double yp = (long double)P.gamma * xin;
+        for (int s = 0; s < nsec; ++s) {
+            const long double br = (long double)P.al[s] * w1[s] + (long double)P.be[s] * w2[s];
+            yp += br;
+            if (n > 0) l1b += fabsl(br);
+            const long double w0 = xin + (long double)P.na1[s] * w1[s] + (long double)P.na2[s] * w2[s];
+            w2[s] = w1[s];
+            w1[s] = w0;
+        }
+        hmax = std::max(hmax, fabsl(xc));
+        emax = std::max(emax, fabsl(xc - yp));
+        l1h += fabsl(xc);
+    }
+    if (!(hmax > 0.0L) || !std::isfinite((double)emax) || !std::isfinite((double)l1b)) return false;
+    P.ir_err = (double)(emax / hmax);
+    P.kappa = (double)(l1b / l1h);
+    return P.ir_err <= 1e-12 && P.kappa <= 1e3;
+}
+
+struct M2 { long double m[4]; };
+M2 m2mul(const M2 &x, const M2 &y)
+{
+    return M2{{x.m[0] * y.m[0] + x.m[1] * y.m[2], x.m[0] * y.m[1] + x.m[1] * y.m[3], x.m[2] * y.m[0] + x.m[3] * y.m[2],
+               x.m[2] * y.m[1] + x.m[3] * y.m[3]}};
+}
+long double m2max(const M2 &x) { return std::max(std::max(fabsl(x.m[0]), fabsl(x.m[1])), std::max(fabsl(x.m[2]), fabsl(x.m[3]))); }
+
+int par_tables(ParPlan &P, ParTables &tb, int T, long double negl, hipStream_t s)
+{
+    const int N = P.nsec;
+    tb.T = T;
+    std::vector<double> lvl((size_t)6 * N * 4), psi((size_t)(kParMaxK - 1) * N * 4), gt((size_t)T * 16, 0.0);
+    long double lvmax[7] = {0}, psimax[kParMaxK + 1] = {0};
+    for (int k = 0; k < N; ++k) {
+        // one-sample zero-input transition of (w[n-1], w[n-2]);  Phi = its T-th power
+        M2 one{{-P.a1[k], -P.a2[k], 1.0L, 0.0L}}, Phi{{1.0L, 0.0L, 0.0L, 1.0L}}, sq = one;
+        for (int e = T; e; e >>= 1) {
+            if (e & 1) Phi = m2mul(Phi, sq);
+            sq = m2mul(sq, sq);
+        }
+        M2 pw = Phi;
+        for (int l = 0; l <= 6; ++l) {
+            lvmax[l] = std::max(lvmax[l], m2max(pw));
+            if (!std::isfinite((double)m2max(pw))) return 1;
+            if (l < 6)
+                for (int i = 0; i < 4; ++i) lvl[((size_t)l * N + k) * 4 + i] = (double)pw.m[i];
+            if (l < 6) pw = m2mul(pw, pw);
+        }
+        const M2 Psi = pw;   // Phi^64
+        M2 pk = Psi;
+        for (int m = 1; m <= kParMaxK; ++m) {
+            psimax[m] = std::max(psimax[m], m2max(pk));
+            if (m < kParMaxK)
+                for (int i = 0; i < 4; ++i) psi[((size_t)(m - 1) * N + k) * 4 + i] = (double)pk.m[i];
+            pk = m2mul(pk, Psi);
+        }
+        // G rows 2k, 2k+1: g[T-1-t], g[T-2-t], g = impulse response of 1 / A_k; as the MFMA A operand of step t / 4:
+        // lane l holds row l & 15, column 4 (t / 4) + (l >> 4)
+        long double g0 = 1.0L, g1 = 0.0L;   // g[i], g[i-1]
+        for (int t = T - 1; t >= 0; --t) {
+            const size_t at = (size_t)(t / 4) * 64 + (size_t)(t % 4) * 16;
+            gt[at + 2 * k] = (double)g0;
+            gt[at + 2 * k + 1] = (double)g1;
+            const long double g2 = -P.a1[k] * g0 - P.a2[k] * g1;
+            g1 = g0;
+            g0 = g2;
+        }
+    }
+    tb.n_lv = 6;
+    for (int l = 6; l >= 0; --l)
+        if (lvmax[l] < negl) tb.n_lv = std::min(tb.n_lv, l);
+    tb.K = 0;
+    for (int m = 1; m <= kParMaxK; ++m)
+        if (psimax[m] < negl) { tb.K = m; break; }
+    if (tb.K == 0) return 1;   // remembers more than kParMaxK segments
+    if (tb.n_lv < 6) tb.K = 1;
+    SK_HIP(hipMalloc((void **)&tb.gt_dev, gt.size() * 8));
+    SK_HIP(hipMalloc((void **)&tb.lvl_dev, lvl.size() * 8));
+    SK_HIP(hipMalloc((void **)&tb.psi_dev, psi.size() * 8));
+    SK_HIP(hipMemcpyAsync(tb.gt_dev, gt.data(), gt.size() * 8, hipMemcpyHostToDevice, s));
+    SK_HIP(hipMemcpyAsync(tb.lvl_dev, lvl.data(), lvl.size() * 8, hipMemcpyHostToDevice, s));
+    SK_HIP(hipMemcpyAsync(tb.psi_dev, psi.data(), psi.size() * 8, hipMemcpyHostToDevice, s));
+    SK_HIP(hipStreamSynchronize(s));
+    return SKDSP_OK;
+}
+}  // namespace
+
+// host-only: the expansion of a handle's cascade (tests; no GPU needed).  out = [c0, (a1, a2, r0, r1) x nsec, kappa, ir_err]
+int iir_par_expand_host(const double *coef, int nsec, double *out, int *accepted)
+{
+    ParPlan P;
+    P.nsec = nsec;
+    const bool ok = nsec >= 1 && nsec <= 8 && par_expand(coef, nsec, P);
+    if (accepted) *accepted = ok ? 1 : 0;
+    if (out) {
+        out[0] = (double)P.c0;
+        for (int k = 0; k < nsec && k < 8; ++k) {
+            out[1 + 4 * k] = (double)P.a1[k];
+            out[2 + 4 * k] = (double)P.a2[k];
+            out[3 + 4 * k] = (double)P.r0[k];
+            out[4 + 4 * k] = (double)P.r1[k];
+        }
+        out[1 + 4 * nsec] = P.kappa;
+        out[2 + 4 * nsec] = P.ir_err;
+    }
+    return SKDSP_OK;
+}
+
+template <typename IO>
+static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
+                      void *y, hipStream_t s, int dec)
+{
+    const int T = tb.T;
+    const int64_t S = (int64_t)64 * T;
+    const int64_t nseg = (n + S - 1) / S;
+    SK_CHECK(nseg * nrow < (1 << 30), SKDSP_ERR_BADARG, "iir: too many segments");
+    const int total = (int)(nseg * nrow);
+    if (!p->ticket_dev) {
+        SK_HIP(hipMalloc((void **)&p->ticket_dev, 8 * kParTickets));
+        SK_HIP(hipMemsetAsync(p->ticket_dev, 0, 8 * kParTickets, s));
+        p->ticket_count = 0;
+    }
+    const size_t need = (size_t)total * 32 * 8;
+    if (need > p->lbg_cap) {
+        if (p->lbg_dev) {
+            SK_HIP(hipStreamSynchronize(s));
+            SK_HIP(hipFree(p->lbg_dev));
+        }
+        p->lbg_dev = nullptr; p->lbg_cap = 0;
+        SK_HIP(hipMalloc((void **)&p->lbg_dev, need));
+        SK_HIP(hipMemsetAsync(p->lbg_dev, 0, need, s));  // epoch 0 is never used as a tag
+        p->lbg_cap = need;
+    }
+    ParArgs a;
+    a.x = x; a.y = y; a.n = n; a.x_stride = x_stride; a.y_stride = y_stride;
+    a.nseg = (int)nseg; a.total = total;
+    a.lb = p->lbg_dev; a.ticket = p->ticket_dev; a.ticket_base = p->ticket_count;
+    a.epoch = ++p->epoch;
+    if (a.epoch == 0) a.epoch = ++p->epoch;
+    a.n_lv = tb.n_lv; a.K = tb.K;
+    a.err = async_err_dev(kAsyncErrIirLookback);
+    SK_CHECK(a.err, SKDSP_ERR_HIP, "iir: no host-mapped error word");
+    a.aligned = ((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (nrow == 1 || ((x_stride * sizeof(IO)) % 16 == 0 && (y_stride * sizeof(IO)) % 16 == 0))) ? 1 : 0;
+    a.dec = dec > 1 ? dec : 1;
+    a.dbg = opt().iir_par_dbg;
+    a.n_keep = (n / a.dec) * a.dec;
+    {
+        const int64_t step = (int64_t)(64 / Stage<IO>::segs) * T;   // samples between a lane's staged segments
+        a.dec_dq = (int)(step / a.dec);
+        a.dec_dr = (int)(step % a.dec);
+    }
+    // (whole rounds of kParTickets workgroups, so that every dispenser advances by the same amount: the surplus workgroups
+    // draw segments beyond the last and leave)
+    const unsigned grid = (unsigned)(((total + 3) / 4 + kParTickets - 1) / kParTickets * kParTickets);
+    p->ticket_count += (unsigned long long)(grid / kParTickets);
+#define SK_PAR(N)                                                                                                       \
+    case N: {                                                                                                           \
+        ParCoef<N> cf;                                                                                                  \
+        for (int k = 0; k < N; ++k) { cf.na1[k] = p->na1[k]; cf.na2[k] = p->na2[k]; cf.al[k] = p->al[k]; cf.be[k] = p->be[k]; } \
+        cf.gamma = p->gamma;                                                                                            \
+        if (a.dec > 1)                                                                                                  \
+            hipLaunchKernelGGL((iir_par_kernel<N, IO, true>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,               \
+                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);      \
+        else                                                                                                            \
+            hipLaunchKernelGGL((iir_par_kernel<N, IO, false>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,              \
+                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);      \
+        break;                                                                                                          \
+    }
+    switch (h->nsec) {
+#ifndef SK_FUSED_ONLY8
+        SK_PAR(1) SK_PAR(2) SK_PAR(3) SK_PAR(4) SK_PAR(5) SK_PAR(6) SK_PAR(7)
+#endif
+        SK_PAR(8)
+        default: SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "iir: parallel-form scan takes 1..8 biquads");
+    }
+#undef SK_PAR
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+// returns 1 when the parallel form does not apply to this handle / call (nothing was launched)
+int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y, hipStream_t s, int dec)
+{
+    if (h->order != 2 || h->nsec < 1 || h->nsec > 8) return 1;
+    if (!h->par) {
+        h->par = new ParPlan();
+        h->par->nsec = h->nsec;
+        h->par->state = par_expand(h->coef.data(), h->nsec, *h->par) ? 1 : -1;
+    }
+    ParPlan *p = h->par;
+    if (p->state != 1) return 1;
+    const bool dbl = dtype_double(h->dtype);
+    ParTables &tb = p->tab[dbl ? 1 : 0];
+    if (tb.T == 0) {
+        // negligibility as in iir_scan.hip: 1e-30 for float64 signals, 1e-18 for float32 signals (a tenth of an ulp of the
+        // float64 state the dropped term would be added to)
+        const int rc = par_tables(*p, tb, dbl ? SK_PAR_T32 / 2 : SK_PAR_T32, dbl ? 1e-30L : 1e-18L, s);
+        if (rc < 0) return rc;
+    }
+    if (tb.K == 0) return 1;
+    return dbl ? launch_par<double>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec)
+               : launch_par<float>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec);
+}
+
+}  // namespace skdsp

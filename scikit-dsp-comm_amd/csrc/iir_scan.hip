@@ -928,7 +928,11 @@ bool iir_shape_supported(int nsec, int order)
     return order == 2 && nsec >= 1 && nsec <= 12;
 }
 
-IirHandle::~IirHandle() { if (plan) iir_free(plan); }
+IirHandle::~IirHandle()
+{
+    if (plan) iir_free(plan);
+    if (par) iir_par_free(par);
+}
 
 void iir_free(IirPlan *p)
 {
@@ -943,7 +947,6 @@ void iir_free(IirPlan *p)
     if (p->agg_dev) (void)hipFree(p->agg_dev);
     if (p->lbg_dev) (void)hipFree(p->lbg_dev);
     if (p->ticket_dev) (void)hipFree(p->ticket_dev);
-    if (p->err_host) (void)hipHostFree(p->err_host);
     delete p;
 }
 
@@ -1213,6 +1216,13 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
             else memset(zf_host, 0, (size_t)nbatch * h->nsec * h->order * 8);
         }
         return SKDSP_OK;
+    }
+    // Parallel form (iir_par.hip): the same transfer function as independent two-state branches, every wave its own segment.
+    // No state crosses these calls (scipy's zi / zf live in the cascade's coordinates: such calls keep the kernels below).
+    if (!interleaved && zi_host == nullptr && zf_host == nullptr && opt().iir_par > 0 && h->order == 2 && h->nsec <= 8 &&
+        (dec <= 1 || nbatch == 1)) {
+        const int r = iir_par_launch(h, x, n, nbatch, batch_stride, batch_stride, y, s, dec);
+        if (r != 1) return r;   // (1 = not applicable: poles shared between sections, slow decay, ...)
     }
     int rc = ensure_plan(h);
     if (rc) return rc;

@@ -49,6 +49,8 @@ struct Options {
     int iir_no_k1r = 0;
     int k1r_wgs = 2;
     int iir_two_pass = 0;     // 1: K1 + carries + K3 even where the single-pass scan applies; -1: single pass wherever it applies
+    int iir_par = 1;          // 0: never the parallel-form scan (iir_par.hip); the cascade kernels everywhere
+    int iir_par_dbg = 0;      // developer timing switches of iir_par_kernel (ParArgs::dbg; wrong results)
     int shard_no_overlap = 0; // sharded FIR: halo exchange in front of the whole filter instead of beside the interior tiles
     int shard_reserve = 8;
     int shard_two_launches = 0; // sharded FIR: tile 0 as its own launch behind the halo event (instead of the in-kernel flag wait)
@@ -79,12 +81,18 @@ struct Context {
     hipStream_t comm_stream = nullptr;   // halo traffic of a sharded FIR, overlapped with the interior tiles
     hipEvent_t ev_in = nullptr, ev_halo = nullptr;
     unsigned *halo_flag = nullptr;       // device word the halo stream bumps when a shard's history has landed
-    unsigned *halo_err = nullptr;        // host-mapped: a persistent launch gave up waiting for it
+    unsigned *async_err = nullptr;       // host-mapped [kAsyncErrWords]: kernels of this slot report here (async_err_check)
     unsigned halo_seq = 0;
     void *ws[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t ws_bytes[4] = {0, 0, 0, 0};
     std::mutex mu;
 };
+// Failures a kernel can only report after the fact (a bounded device-side wait that gave up) land in host-mapped words of
+// the slot; every entry point that synchronises the slot's stream tests them right after the sync, so the error is
+// returned by the call that makes the affected results visible (and the word is cleared: later calls are not poisoned).
+enum { kAsyncErrHalo = 0, kAsyncErrIirLookback = 1, kAsyncErrWords = 4 };
+unsigned *async_err_dev(int which);   // device alias of the calling slot's word (allocated on first use); null on failure
+int async_err_check(Context &c);      // call after a stream sync of slot c
 Context &ctx();               // the calling thread's current slot (slot 0 unless a library worker selected another)
 Context &ctx_of(int slot);
 int slot_count();             // bound slots (0 before the first init)
@@ -190,6 +198,7 @@ struct IirHandle : HandleBase {
     bool unit_tail = false;
     std::vector<double> state_scale;
     IirPlan *plan = nullptr;
+    struct ParPlan *par = nullptr;   // partial-fraction form of the same transfer function (iir_par.hip), made on first use
     ~IirHandle();
 };
 // x/y: real planar arrays in the handle's precision; complex callers pass nbatch=2 planes
@@ -199,6 +208,12 @@ int iir_launch_planar(IirHandle *h, const void *x_dev, int64_t n, int nbatch, in
                       int interleaved = 0,   // 1: x / y interleaved complex, nbatch = 2; returns 1 if not applicable
                       int dec = 1);          // > 1 (real signals): y receives only every dec-th output (n / dec samples)
 void iir_free(IirPlan *p);
+// Parallel-form single-pass scan (iir_par.hip): real signals, <= 8 biquads with simple poles, zero initial state, no state
+// output; nrow rows x_stride / y_stride elements apart in one launch.  Returns 1 when it does not apply (nothing launched).
+int iir_par_launch(IirHandle *h, const void *x_dev, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y_dev, hipStream_t s,
+                   int dec = 1);
+int iir_par_expand_host(const double *coef, int nsec, double *out, int *accepted);   // host-only (tests): [c0, (a1,a2,r0,r1) x nsec, kappa, ir_err]
+void iir_par_free(ParPlan *p);
 bool iir_shape_supported(int nsec, int order);
 
 // ---- resamplers (resample.hip) ---------------------------------------------

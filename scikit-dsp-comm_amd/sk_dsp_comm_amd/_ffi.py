@@ -30,6 +30,7 @@ SYMBOLS = [
     "skdsp_fir_up", "skdsp_fir_up_dev", "skdsp_fir_dn", "skdsp_fir_dn_dev", "skdsp_fir_updn", "skdsp_fir_updn_dev",
     "skdsp_sos_create", "skdsp_tf_create", "skdsp_tf2sos", "skdsp_iir_filter", "skdsp_iir_filter_dev", "skdsp_iir_up",
     "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev", "skdsp_iir_state_len", "skdsp_iir_filter_state_dev",
+    "skdsp_iir_filter_rows", "skdsp_iir_filter_rows_dev", "skdsp_sos_par_info",
     "skdsp_upsample", "skdsp_upsample_dev", "skdsp_downsample", "skdsp_downsample_dev", "skdsp_set_wide_output", "skdsp_destroy",
     "skdsp_dist_unique_id", "skdsp_dist_init", "skdsp_dist_shutdown", "skdsp_dist_comm_count", "skdsp_dist_barrier",
     "skdsp_dist_allreduce_max", "skdsp_dist_allreduce_sum", "skdsp_dist_sendrecv", "skdsp_dist_allgather", "skdsp_dist_halo_exchange", "skdsp_fir_filter_shard_dev",
@@ -98,6 +99,9 @@ def load():
         L.skdsp_iir_filter_dev.argtypes = [vp, vp, i64, vp]
         L.skdsp_iir_state_len.argtypes = [vp, ctypes.POINTER(ci)]
         L.skdsp_iir_filter_state_dev.argtypes = [vp, vp, i64, vp, vp, vp]
+        L.skdsp_iir_filter_rows.argtypes = [vp, vp, i64, i64, vp]
+        L.skdsp_iir_filter_rows_dev.argtypes = [vp, vp, i64, i64, i64, i64, vp]
+        L.skdsp_sos_par_info.argtypes = [vp, ci, vp, ctypes.POINTER(ci)]
         L.skdsp_iir_up.argtypes = [vp, vp, i64, ci, vp]
         L.skdsp_iir_up_dev.argtypes = [vp, vp, i64, ci, vp]
         L.skdsp_iir_dn.argtypes = [vp, vp, i64, ci, vp]
@@ -489,6 +493,17 @@ class IirKernel(_HostCalls):
     def filter(self, x, wide=False):
         return self._host(x.size, x.dtype, wide, lambda y: check(load().skdsp_iir_filter(ctypes.c_void_p(self.h), _ptr(x), x.size, _ptr(y))))
 
+    def filter_rows(self, x2, wide=False):
+        """x2: C-contiguous (rows, n): every row filtered from rest in ONE call (one copy each way, one launch where the
+        parallel-form scan applies)."""
+        rows, n = x2.shape
+        y = self._host(x2.size, x2.dtype, wide, lambda y: check(load().skdsp_iir_filter_rows(ctypes.c_void_p(self.h), _ptr(x2), n, rows, _ptr(y))))
+        return y.reshape(rows, n)
+
+    def filter_rows_dev(self, xd, yd, n, rows, x_stride=None, y_stride=None):
+        check(load().skdsp_iir_filter_rows_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, rows, n if x_stride is None else x_stride,
+                                                n if y_stride is None else y_stride, ctypes.c_void_p(yd.ptr)))
+
     def up(self, x, L, wide=False):
         return self._host(x.size * L, x.dtype, wide, lambda y: check(load().skdsp_iir_up(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), _ptr(y))))
 
@@ -539,6 +554,18 @@ class IirKernel(_HostCalls):
             xd.free()
             yd.free()
         return y, zf
+
+
+def sos_par_info(sos):
+    """Host only: the partial-fraction expansion the parallel-form scan runs for this cascade (c0, sections (a1, a2, r0, r1),
+    cancellation factor, impulse-response error against the cascade, accepted)."""
+    s = np.ascontiguousarray(sos, dtype=np.float64).reshape(-1, 6)
+    ns = s.shape[0]
+    out = np.zeros(3 + 4 * ns)
+    ok = ctypes.c_int(0)
+    check(load().skdsp_sos_par_info(_ptr(s), ns, _ptr(out), ctypes.byref(ok)))
+    return {"c0": out[0], "sections": out[1:1 + 4 * ns].reshape(ns, 4).copy(), "kappa": out[1 + 4 * ns], "ir_err": out[2 + 4 * ns],
+            "accepted": bool(ok.value)}
 
 
 def tf2sos(b, a):

@@ -242,7 +242,15 @@ class multirate_IIR(object):
     def filter(self, x):
         """y = sosfilt(sos, x)  (multirate_helper.py:169-174)"""
         xg, ref_dt = self._prep(x)
-        return _finish(_rows(lambda r: self._chain(r, lambda k, v, w: k.filter(v, wide=w)), xg), ref_dt)
+        if xg.ndim > 1:
+            # N-D: sosfilt filters along the last axis in one call; so does this -- the rows travel as one block and
+            # (where the parallel-form scan applies) run as one launch
+            ks = self._kern.get(xg.dtype)
+            y = xg.reshape(-1, xg.shape[-1])
+            for i, k in enumerate(ks):
+                y = k.filter_rows(y, wide=_wide() and i == len(ks) - 1)
+            return _finish(y.reshape(xg.shape), ref_dt)
+        return _finish(self._chain(xg, lambda k, v, w: k.filter(v, wide=w)), ref_dt)
 
     # --- extension: block streaming (SURVEY.md 8f-3; the reference always restarts from rest) ---
     def filter_stream(self, x, zi=None):

@@ -1,0 +1,191 @@
+"""GPU parity tests of the parallel-form single-pass IIR scan (csrc/iir_par.hip): through the C ABI, against the CPU
+oracle / scipy.signal.sosfilt (the reference's call, multirate_helper.py:173) and against the cascade kernels
+(option iir_par = 0) on the same device data.
+
+Tolerances: float32 signals 1e-6 (north_star), float64 signals 1e-11 -- the expansion itself is good to ~1e-14
+(tests/test_host_cpu.py::test_parallel_form_expansion_reproduces_the_cascade)."""
+import os
+
+import numpy as np
+import pytest
+
+import sk_dsp_comm_amd as sk
+from sk_dsp_comm_amd import _ffi, multirate_helper as mrh
+from oracle import oracle as orc
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-6
+TOL64 = 1e-11
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    _ffi.init()
+    assert "gfx950" in _ffi.device_info()["name"]
+    yield
+
+
+def assert_close(y, ref, tol, what=""):
+    e_max, e_l2 = rel_err(y, ref)
+    assert e_max <= tol and e_l2 <= tol, "%s: max/peak %.3g, rel-L2 %.3g > %.1g" % (what, e_max, e_l2, tol)
+
+
+def designs():
+    from scipy import signal
+    return {
+        "ellip8": np.load(os.path.join(GOLDEN, "g7_iir_sos.npz"))["sos8"],   # BASELINE config 4
+        "butter8rc12": signal.butter(8, 0.9 / 12, output="sos"),             # rate_change(12)
+        "cheby6": signal.cheby1(6, 0.05, 0.2, output="sos"),
+        "butter5": signal.butter(5, 0.2, output="sos"),                      # odd order: a first-order section
+        "biquad": signal.tf2sos(*signal.iirpeak(0.1, 30)),
+        "butter3": signal.butter(3, 0.45, output="sos"),                     # decays within a chunk: 1-2 scan levels
+        "narrow8": signal.butter(4, [0.2, 0.204], btype="bandpass", output="sos"),   # remembers several wave segments (look-back depth > 1)
+    }
+
+
+@pytest.mark.parametrize("dt,n", [(np.float32, 5_000_017), (np.float32, 8192 * 3), (np.float32, 8192 * 64 + 1), (np.float32, 4099),
+                                  (np.float64, 2_100_003), (np.float64, 4096 * 5)])
+@pytest.mark.parametrize("filt", ["ellip8", "butter8rc12", "cheby6", "butter5", "biquad", "butter3", "narrow8"])
+def test_parallel_form_vs_cascade_kernels_and_scipy(dt, n, filt):
+    from scipy import signal
+    sos = designs()[filt]
+    assert _ffi.sos_par_info(sos)["accepted"]
+    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+    xd = _ffi.DeviceArray(n, dt).fill_noise(31)
+    y1, y2 = _ffi.DeviceArray(n, dt), _ffi.DeviceArray(n, dt)
+    single = dt == np.float32
+    tol = TOL32 if single else TOL64
+    try:
+        with _ffi.option("iir_par", 1):
+            k.filter_dev(xd, y1)
+        with _ffi.option("iir_par", 0):
+            k.filter_dev(xd, y2)
+        w = min(n, 1 << 20)
+        for s0 in sorted({0, max(0, n // 2 - 12345), n - w}):
+            m = min(w, n - s0)
+            assert_close(y1.to_host(s0, m), y2.to_host(s0, m), tol, "parallel form vs cascade kernels @%d" % s0)
+        m = min(n, 200_000)
+        ref = signal.sosfilt(sos, xd.to_host(0, m).astype(np.float64))
+        assert_close(y1.to_host(0, m), ref, tol, "head vs sosfilt")
+        if n > 400_000:   # a window deep inside, reference started early enough to have forgotten its start
+            lead = 150_000
+            lo = n - m - lead
+            ref2 = signal.sosfilt(sos, xd.to_host(lo, n - lo).astype(np.float64))
+            assert_close(y1.to_host(n - m, m), ref2[-m:], tol, "tail vs sosfilt")
+        # back-to-back launches reuse the look-back slots under a new epoch: bit-identical results
+        first = y1.to_host(n - w, w)
+        with _ffi.option("iir_par", 1):
+            for _ in range(4):
+                k.filter_dev(xd, y1)
+        assert np.array_equal(y1.to_host(n - w, w), first)
+    finally:
+        xd.free()
+        y1.free()
+        y2.free()
+
+
+def test_parallel_form_is_what_config4_runs():
+    """BASELINE config 4 (8-biquad elliptic band-pass, float32) takes the parallel-form launch by default: the result
+    changes in the last bits when it is switched off (different arithmetic), never beyond the tolerance."""
+    sos = designs()["ellip8"]
+    n = 1 << 22
+    k = _ffi.IirKernel(_ffi.F32, sos=sos)
+    xd = _ffi.DeviceArray(n, np.float32).fill_noise(2026)
+    y1, y2 = _ffi.DeviceArray(n, np.float32), _ffi.DeviceArray(n, np.float32)
+    try:
+        k.filter_dev(xd, y1)
+        with _ffi.option("iir_par", 0):
+            k.filter_dev(xd, y2)
+        a, b = y1.to_host(), y2.to_host()
+        assert_close(a, b, 2e-7, "default vs cascade kernels")
+        ref = orc.sos_filter(sos, xd.to_host(0, 300_000))
+        assert_close(a[:300_000], ref, TOL32, "vs oracle")
+    finally:
+        xd.free()
+        y1.free()
+        y2.free()
+
+
+@pytest.mark.parametrize("M", [2, 3, 4, 12, 5000])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_parallel_form_decimating_store(dt, M):
+    """.dn: only every M-th output is stored (multirate_helper.py:186-192: downsample(sosfilt(sos, x), M))."""
+    from scipy import signal
+    sos = designs()["ellip8"]
+    n = 1_300_007
+    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+    xd = _ffi.DeviceArray(n, dt).fill_noise(9)
+    yd = _ffi.DeviceArray(n // M + 8, dt)
+    try:
+        k.dn_dev(xd, yd, M)
+        got = yd.to_host(0, n // M)
+        ref = signal.sosfilt(sos, xd.to_host().astype(np.float64))[::M][:n // M]
+        assert_close(got, ref, TOL32 if dt == np.float32 else TOL64, "dn M=%d" % M)
+    finally:
+        xd.free()
+        yd.free()
+
+
+@pytest.mark.parametrize("shape", [(7, 3, 5000), (4096, 16384), (3, 8192 * 2 + 5), (33, 100)])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_nd_rows_in_one_call(dt, shape):
+    """N-D input: sosfilt filters along the last axis in one call (multirate_helper.py:173); so does the drop-in -- one
+    copy each way and one launch for all rows, every row from rest."""
+    from scipy import signal
+    if shape == (4096, 16384) and dt == np.float64:
+        pytest.skip("float32 covers the large case")
+    sos = designs()["cheby6"]
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(shape).astype(dt)
+    old = sk.config.strict_dtype
+    sk.config.strict_dtype = False
+    try:
+        y = mrh.multirate_IIR(sos).filter(x)
+    finally:
+        sk.config.strict_dtype = old
+    assert y.shape == x.shape
+    ref = signal.sosfilt(sos, x.astype(np.float64), axis=-1)
+    flat_y, flat_r = y.reshape(-1, shape[-1]), ref.reshape(-1, shape[-1])
+    rows = sorted({0, 1, flat_y.shape[0] // 2, flat_y.shape[0] - 1})
+    for r in rows:
+        assert_close(flat_y[r], flat_r[r], TOL32 if dt == np.float32 else TOL64, "row %d" % r)
+    assert_close(flat_y, flat_r, TOL32 if dt == np.float32 else TOL64, "all rows")
+
+
+def test_rows_dev_strided():
+    """Device-resident rows with a pitch larger than the row (the tail of every pitch is not touched)."""
+    from scipy import signal
+    sos = designs()["butter8rc12"]
+    n, rows, pitch = 20_000, 9, 20_480
+    rng = np.random.default_rng(2)
+    x = np.zeros((rows, pitch), np.float32)
+    x[:, :n] = rng.standard_normal((rows, n))
+    k = _ffi.IirKernel(_ffi.F32, sos=sos)
+    xd = _ffi.DeviceArray.from_host(x.ravel())
+    yd = _ffi.DeviceArray.from_host(np.full(rows * pitch, 7.0, np.float32))
+    try:
+        k.filter_rows_dev(xd, yd, n, rows, pitch, pitch)
+        y = yd.to_host().reshape(rows, pitch)
+        assert np.all(y[:, n:] == 7.0)
+        assert_close(y[:, :n], signal.sosfilt(sos, x[:, :n].astype(np.float64), axis=-1), TOL32, "strided rows")
+    finally:
+        xd.free()
+        yd.free()
+
+
+@pytest.mark.parametrize("kind", ["dc", "tone", "step"])
+def test_parallel_form_coherent_inputs(kind):
+    """Inputs whose rounding errors add up instead of averaging out, through the pass band of the config-4 filter and of
+    rate_change(12)'s low-pass: the branch sum of the expansion must not lose what the cascade keeps."""
+    from scipy import signal
+    n = 600_000
+    t = np.arange(n)
+    for name, f0 in (("ellip8", 0.25 * np.pi), ("butter8rc12", 0.01 * np.pi)):
+        sos = designs()[name]
+        x = {"dc": np.ones(n), "tone": np.cos(f0 * t + 0.3), "step": (t > 1000).astype(float) * 0.75}[kind].astype(np.float32)
+        y = _ffi.IirKernel(_ffi.F32, sos=sos).filter(x)
+        ref = signal.sosfilt(sos, x.astype(np.float64))
+        scale = max(np.max(np.abs(ref)), 1e-3 * np.max(np.abs(x)))   # (the band-pass removes DC: judge against the input scale there)
+        assert np.max(np.abs(y - ref)) <= 5e-7 * scale, (name, kind, np.max(np.abs(y - ref)) / scale)

@@ -306,3 +306,47 @@ def test_host_chunk_planner(n, L, M, hist, lg):
         # output m = needs inputs up to floor(m M / L): inside this chunk for every m of the range
         if oe > ob:
             assert ib <= (ob * M) // L and ((oe - 1) * M) // L < ie
+
+
+# ---- parallel-form expansion of the IIR cascade (host side of csrc/iir_par.hip; no GPU) -----------------------------
+def _par_designs():
+    from scipy import signal
+    sos8 = np.load(os.path.join(GOLDEN, "g7_iir_sos.npz"))["sos8"]
+    return {
+        "ellip_bpf8": sos8,                                                        # BASELINE config 4
+        "butter8_rate_change12": signal.butter(8, 0.9 / 12, output="sos"),         # rate_change(12) (multirate_helper.py:62)
+        "cheby1_8_rate_change12": signal.cheby1(8, 0.05, 0.9 / 12, output="sos"),  # rate_change(12, ftype='cheby1') (:64)
+        "butter5_odd": signal.butter(5, 0.2, output="sos"),                        # a first-order section (b2 = a2 = 0)
+        "ellip_bandstop": signal.ellip(6, 1, 60, [0.2, 0.3], btype="bandstop", output="sos"),
+        "single_biquad": signal.butter(2, 0.3, output="sos"),
+    }
+
+
+@pytest.mark.parametrize("name", ["ellip_bpf8", "butter8_rate_change12", "cheby1_8_rate_change12", "butter5_odd", "ellip_bandstop",
+                                  "single_biquad"])
+def test_parallel_form_expansion_reproduces_the_cascade(name):
+    """H(z) = c0 + sum_k (r0_k + r1_k z^-1) / (1 + a1_k z^-1 + a2_k z^-2) as the library expands it (long double, arithmetic
+    modulo each denominator) against scipy.signal.sosfilt on an impulse and on noise: float64 roundoff level."""
+    from scipy import signal
+    sos = _par_designs()[name]
+    info = _ffi.sos_par_info(sos)
+    assert info["accepted"], info
+    assert info["ir_err"] < 1e-12 and info["kappa"] < 100
+    rng = np.random.default_rng(5)
+    for x in (np.r_[1.0, np.zeros(4095)], rng.standard_normal(20000)):
+        ref = signal.sosfilt(sos, x)
+        y = info["c0"] * x
+        for a1, a2, r0, r1 in info["sections"]:
+            y = y + signal.lfilter([r0, r1], [1.0, a1, a2], x)
+        assert np.max(np.abs(y - ref)) <= 2e-13 * max(np.max(np.abs(ref)), 1e-300)
+
+
+def test_parallel_form_refuses_what_it_cannot_expand():
+    from scipy import signal
+    one = signal.butter(2, 0.3, output="sos")
+    twice = np.vstack([one, one])                       # the same pole pair in two sections: no simple-pole expansion
+    assert not _ffi.sos_par_info(twice)["accepted"]
+    fir_heavy = np.array([[1.0, 0.5, 0.25, 1.0, 0.0, 0.0], [1.0, 0.2, 0.1, 1.0, -0.5, 0.0]])   # numerator degree > denominator degree
+    assert not _ffi.sos_par_info(fir_heavy)["accepted"]
+    unstable_ok = np.array([[1.0, 0.0, 0.0, 1.0, -1.0, 0.0]])   # an integrator expands (one real pole); the launcher refuses it by its decay test
+    assert _ffi.sos_par_info(unstable_ok)["accepted"]

@@ -9,7 +9,7 @@ EXTRA=""
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I../../include $EXTRA $FLAGS -c $SRC -o build/${SRC%.hip}_$NAME.o
 OBJS=""
 # (iir_scan.hip is two objects in the product build -- SK_SCAN_PART; a variant of it is one object holding both parts)
-LIST="capi dist fir_bx fir_direct fir_mm fir_ols fir_ols64 iir_fused iir_scan resample"
+LIST="capi dist fir_bx fir_direct fir_mm fir_ols fir_ols64 iir_fused iir_par iir_scan resample"
 [ "$SRC" = iir_scan.hip ] || LIST="$LIST iir_scan_f64"
 for f in $LIST; do
   if [ "$f.hip" = "$SRC" ]; then OBJS="$OBJS build/${f}_$NAME.o"; else OBJS="$OBJS build/$f.o"; fi
