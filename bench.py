@@ -62,6 +62,50 @@ def elliptic_bpf_sos():
     return np.load(os.path.join(ROOT, "tests", "golden", "g7_iir_sos.npz"))["sos8"]
 
 
+# ------------------------------------------------------------------------------ per-rank parity of a sharded run
+PARITY_TOL = 1e-6   # north_star: float32 / complex64 filtering within 1e-6 of the reference
+
+
+def shard_parity(kind, coeffs, n_local, rank, get_x, get_y):
+    """Checks what a rank just computed against the oracle (checker only), on the outputs that DEPEND on its left
+    neighbour -- the first samples of the shard consume the Ntaps-1 halo (FIR) / the handed-over state (IIR) -- and on
+    one interior window.  get_x(g0, count): `count` input samples of the GLOBAL signal from global index g0 (any rank's
+    block: bench.py regenerates them from the counter-based noise, which is keyed by global index);
+    get_y(i0, count): this rank's outputs.  -> (halo_err, interior_err), max-abs error / max-abs reference."""
+    from oracle import oracle as orc
+    g_start = rank * n_local
+    m = min(2048, n_local)
+
+    def rel(got, ref):
+        return float(np.max(np.abs(got - ref)) / max(np.max(np.abs(ref)), 1e-300))
+
+    if kind == "fir":
+        b = coeffs
+        hist = len(b) - 1
+        h = min(hist, g_start)                                   # rank 0 starts from rest (lfilter's zero state)
+        xs = get_x(g_start - h, h + m)
+        halo_err = rel(get_y(0, m), orc.fir_filter(b, xs[h:], hist=xs[:h] if h else None))
+        s0 = max(0, min(3 * 7168 - 100, n_local - m))
+        h2 = min(hist, g_start + s0)
+        xs = get_x(g_start + s0 - h2, h2 + m)
+        return halo_err, rel(get_y(s0, m), orc.fir_filter(b, xs[h2:], hist=xs[:h2] if h2 else None))
+    sos = coeffs
+    lead = 1 << 15                                               # the cascade forgets its start within ~8000 samples (1e-18)
+    h = min(lead, g_start)
+    halo_err = rel(get_y(0, m), orc.sos_filter(sos, get_x(g_start - h, h + m))[h:])
+    s0 = max(0, n_local // 2 - m)
+    h2 = min(lead, g_start + s0)
+    return halo_err, rel(get_y(s0, m), orc.sos_filter(sos, get_x(g_start + s0 - h2, h2 + m))[h2:])
+
+
+def reduce_parity(tr, halo_err, interior_err, fallback_used):
+    """All ranks -> (max halo error, max interior error, per-rank fallback flags, ok)."""
+    tab = tr.allgather_state(np.array([halo_err, interior_err, float(fallback_used)]))
+    hmax, imax = float(np.max(tab[:, 0])), float(np.max(tab[:, 1]))
+    ok = bool(np.isfinite(hmax) and np.isfinite(imax) and hmax <= PARITY_TOL and imax <= PARITY_TOL)
+    return hmax, imax, [int(v) for v in tab[:, 2]], ok
+
+
 # ------------------------------------------------------------------------------ launcher
 def self_launch(args):
     """No launcher set WORLD_SIZE: spawn one rank per GPU ourselves (torchrun's environment contract)."""
@@ -110,7 +154,7 @@ class Workload:
 
 def make_workload(name, n, rank, world, tr, _ffi, sharding):
     w = Workload()
-    w.name, w.n, w.units, w.compute, w.check, w.taps = name, n, n, None, None, None
+    w.name, w.n, w.units, w.compute, w.check, w.taps, w.shard = name, n, n, None, None, None, None
     lg = "2^%d" % (n.bit_length() - 1) if n & (n - 1) == 0 else str(n)
     if name == "fir1024":
         b = firwin_lowpass(1024, 0.2)
@@ -119,6 +163,7 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
         w.xd = fir.new_shard_buffer(n).fill_noise(2026, first_index=rank * n)
         w.yd = _ffi.DeviceArray(n, w.dtype)
         w.step = lambda: fir.filter_local_dev(w.xd, w.yd, n)
+        w.shard = ("fir", b, 2026)                               # per-rank halo / interior parity (shard_parity)
         w.alg_bytes = 16.0 * n                                   # 8 B in + 8 B out per sample
         w.kern = "ols_tile_kernel"
         w.wl = "multirate_FIR.filter: 1024-tap lowpass, complex64, %s samples per GPU, FFT overlap-save" % lg
@@ -168,7 +213,6 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
         w.yd = _ffi.DeviceArray(n, w.dtype)
         w.step = lambda: k.filter_dev(w.xd, w.yd)
         w.alg_bytes = 32.0 * n
-        w.compute = ("FP64 useful flops of the direct form (4 x Ntaps per complex128 sample, real taps)", 78.6, 4.0 * 1024 * n)
         w.kern = "ols64_tile_kernel (float64 overlap-save, 4096-point tiles)"
         w.wl = "multirate_FIR.filter: 1024-tap lowpass, complex128 (the reference's own arithmetic), %s samples" % lg
         w.metric = "complex128 MSamples/s (FIR-1024 tap, %s samples)" % lg
@@ -197,6 +241,8 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
         else:  # contiguous sample blocks, exact state hand-off rank r -> r+1 (16 doubles per hop)
             iir = sharding.ShardedIIR(sos, tr, dtype=w.dtype)
             w.step = lambda: iir.filter_local_dev(w.xd, w.yd, n)
+        if name == "iir8":
+            w.shard = ("iir", sos, 2026)
         w.alg_bytes = 8.0 * n
         w.compute = ("FP64 vector (v_fma_f64)", 78.6, 72.0 * n)   # 9 flop per biquad per sample
         w.kern = {"iir8": "iir_par_kernel (parallel-form single-pass scan, one segment per wave)",
@@ -253,7 +299,12 @@ def timed_steps(w, K, W, settle_s, tr, _ffi):
                 raise
             print("bench.py: %s" % e, file=sys.stderr)
             w.step()   # (the refused call enqueued nothing: repeat it so that every rank has made the same number of exchanges)
-    _ffi.sync()
+    try:
+        _ffi.sync()
+    except _ffi.SkdspError as e:   # a step of the settle phase gave up waiting for its halo inside the launch: reported at
+        if "two-launch" not in str(e):   # this sync, the library has switched to the two-launch form; the timed steps use it
+            raise
+        print("bench.py: %s" % e, file=sys.stderr)
     per_pass = max((time.perf_counter() - t_settle) / 10, 1e-6)
     n_settle = int(tr.allreduce_max(float(min(20000, int(settle_s / per_pass) + 1)))) if settle_s > 0 else 0
     for _ in range(n_settle):
@@ -277,8 +328,9 @@ def timed_steps(w, K, W, settle_s, tr, _ffi):
 def roofline_of(w, ev_ms, K, log2n_for_traffic):
     t_kernel = ev_ms * 1e-3 / K  # average launch (+ halo) duration from HIP events
     achieved = w.alg_bytes / t_kernel / 1e9
+    traffic, traffic_source = measured_traffic(w.name, log2n_for_traffic)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": measured_traffic(w.name, log2n_for_traffic), "kernel": w.kern, "kernel_ms": t_kernel * 1e3,
+            "traffic": traffic, "traffic_source": traffic_source, "kernel": w.kern, "kernel_ms": t_kernel * 1e3,
             "algorithmic_bytes_per_launch": w.alg_bytes}
 
 
@@ -288,8 +340,13 @@ def compute_of(w, ev_ms, K):
     # these workloads are also priced against arithmetic: useful flops of the reference
     # formulation against the peak of the unit that executes them
     tf = w.compute[2] / (ev_ms * 1e-3 / K) / 1e12
-    return {"unit": "TFLOP/s", "what": w.compute[0], "useful_flop_per_step": w.compute[2], "achieved": tf,
-            "peak": w.compute[1], "frac": tf / w.compute[1]}
+    out = {"unit": "TFLOP/s", "what": w.compute[0], "useful_flop_per_step": w.compute[2], "achieved": tf, "peak": w.compute[1]}
+    if tf <= w.compute[1]:
+        out["frac"] = tf / w.compute[1]
+    else:   # the kernel does not execute the formulation these flops were counted in: a fraction above 1 would mean nothing
+        out["frac"] = None
+        out["note"] = "useful flops of the reference formulation exceed the peak of the unit named: the kernel runs a cheaper algorithm"
+    return out
 
 
 # ------------------------------------------------------------------------------ main
@@ -341,6 +398,20 @@ def main():
 
     # quick parity spot check of what was just computed (oracle = checker only)
     check = w.check() if (rank == 0 and w.check is not None) else None
+    # N > 1: EVERY rank checks the outputs that consumed its neighbour's halo / state and one interior window; the line
+    # carries the maximum over ranks and the run fails (exit code 3) above the tolerance
+    parity = None
+    if world > 1 and w.shard is not None:
+        kind, coeffs, seed = w.shard
+
+        def get_x(g0, count):
+            t = _ffi.DeviceArray(count, w.dtype).fill_noise(seed, first_index=g0)
+            try:
+                return t.to_host()
+            finally:
+                t.free()
+        herr, ierr = shard_parity(kind, coeffs, n, rank, get_x, lambda i0, c: w.yd.to_host(i0, c))
+        parity = reduce_parity(tr, herr, ierr, _ffi.get_option("shard_two_launches"))
 
     out = None
     if rank == 0:
@@ -376,6 +447,11 @@ def main():
             out["per_rank"] = per_rank
         if check is not None:
             out["parity_spot_check_max_err"] = check
+        if parity is not None:
+            out["parity_halo_max_err"], out["parity_interior_max_err"], out["halo_fallback_used"], out["parity_ok"] = parity
+            out["parity_what"] = ("every rank: first 2048 outputs of its shard (they consume the %s from rank r-1) and one interior "
+                                  "window vs the CPU oracle on inputs regenerated by global index; max over ranks; tolerance %g"
+                                  % ("Ntaps-1 halo" if w.shard[0] == "fir" else "handed-over filter state", PARITY_TOL))
 
     # ------------------------------------------- CPU baselines (rank 0 of a 1-GPU run only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -409,16 +485,38 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     tr.close()
+    if parity is not None and not parity[3]:
+        sys.exit(3)   # a wrong halo / state hand-off must not look like a result
+
+
+# kernel sources whose change makes a committed PMC measurement stale (workload -> files under scikit-dsp-comm_amd/csrc)
+TRAFFIC_SOURCES = {
+    "fir1024": ["fir_ols.hip", "ols_core.hpp"], "fir127": ["fir_bx.hip"], "updn43": ["fir_bx.hip"],
+    "fir1024c128": ["fir_ols64.hip"], "iir8": ["iir_par.hip"], "iirlp8": ["iir_par.hip"],
+    "iir8cas": ["iir_fused.hip", "iir_common.hpp"], "iir8tp": ["iir_scan.hip", "iir_common.hpp"],
+}
+
+
+def source_hashes(workload):
+    import hashlib
+    out = {}
+    for f in TRAFFIC_SOURCES.get(workload, []):
+        try:
+            out[f] = hashlib.sha256(open(os.path.join(ROOT, "scikit-dsp-comm_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+        except OSError:
+            out[f] = None
+    return out
 
 
 def measured_traffic(workload, log2n):
-    """HBM bytes per step from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE,
+    """(HBM bytes per step, provenance) from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE,
     WRITE_SIZE; separate --pmc runs, read side doubled per the gfx950 correction of
     MI355X_MICROARCH.md; tools/collect_profiles.sh + tools/reduce_pmc.py).  PMC counters cannot be
     read inside an un-profiled run, so this is the committed measurement of the same workload at
-    the same size (the newest profiles/rNN that has one), or null when none applies."""
+    the same size (the newest profiles/rNN that has one).  The profile records the hashes of the kernel sources it was
+    collected with: when the sources have changed since, the number is withheld (null) instead of going stale silently."""
     if log2n != 26:
-        return None
+        return None, None
     prof = os.path.join(ROOT, "profiles")
     best = None
     for d in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
@@ -426,11 +524,17 @@ def measured_traffic(workload, log2n):
         if os.path.exists(f):
             best = f
     if best is None:
-        return None
+        return None, None
     try:
-        return float(json.load(open(best))["derived"]["hbm_total_bytes_per_step"])
+        j = json.load(open(best))
+        src = {"profile": os.path.relpath(best, ROOT), "collected_at_commit": j.get("collected_at_commit"),
+               "kernel_source_sha256": j.get("source_sha256")}
+        if j.get("source_sha256") != source_hashes(workload):
+            src["stale"] = "the kernel sources changed after this profile was collected: traffic withheld"
+            return None, src
+        return float(j["derived"]["hbm_total_bytes_per_step"]), src
     except Exception:
-        return None
+        return None, None
 
 
 def _sized_sample(run, first, n_max, seconds):
@@ -488,10 +592,10 @@ def cpu_baseline_scipy(args, w):
             return y[0::3]                                                                        # sigsys.py:3078-3083
         first, what = 1 << 12, "upsample (hstack/flatten) -> scipy.signal.lfilter(b,[1],4*x_up) -> strided view"
     else:
-        x = w.xd.to_host(0, min(w.n, 1 << 24))
+        x = w.xd.to_host(0, min(w.n, 1 << 26))   # the whole 2^26 workload when ~10 s of one host core suffice
         run = lambda k: signal.lfilter(w.taps, [1], x[:k])                                        # noqa: E731
         first, what = 1 << 14, "scipy.signal.lfilter(b, [1], x) (multirate_helper.py:108)"
-    m, dt = _sized_sample(run, first, x.size, args.cpu_seconds)
+    m, dt = _sized_sample(run, first, x.size, max(args.cpu_seconds, 10.0) if w.name == "fir1024" else args.cpu_seconds)
     threads = None
     try:
         from threadpoolctl import threadpool_info

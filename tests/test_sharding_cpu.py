@@ -75,6 +75,18 @@ def test_gloo_world2_sharded_fir(tmp_path):
         assert float(tmax) == 2.0
         spans.append((int(s0), int(s1)))
     assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == 20011
+    # bench.py's self-verification of an N > 1 run (shard_parity / reduce_parity), driven through the same gloo group:
+    # a correct halo passes on every rank, a result computed without the halo is caught on every rank (max-reduced),
+    # the per-rank fallback flags arrive in rank order
+    import json
+    for r in range(2):
+        par = json.load(open(os.path.join(str(tmp_path), "parity%d.json" % r)))
+        hmax, imax, flags, ok = par["good"]
+        assert ok and hmax < 1e-12 and imax < 1e-12 and flags == [0, 0]
+        hmax, imax, flags, ok = par["bad"]
+        assert not ok and hmax > 1e-3 and imax < 1e-12 and flags == [0, 1]
+        hmax, imax, flags, ok = par["good_iir"]
+        assert ok and hmax < 1e-12 and imax < 1e-12
 
 
 class _Mailbox:

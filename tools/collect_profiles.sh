@@ -3,20 +3,22 @@
 #   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r01'
 # Writes gpurun_out/profiles_<round>/ ; copy what should be judged into profiles/<round>/.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$R
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for w in fir1024 updn43 iir8 fir127 iir8tp iirlp8 fir1024c128; do
+for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 fir1024c128; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python $ROOT/bench.py --workload $w --no-cpu-baseline --no-other-configs > /dev/null 2>&1
   cp $OUT/trace_$w/*/*kernel_stats.csv $OUT/kernel_stats_$w.csv
   rm -rf $OUT/trace_$w
 done
 # PMC passes, each counter group in its own run (never combined with other trace domains)
-for w in fir1024 updn43 iir8 fir127 iir8tp iirlp8; do
+for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 fir1024c128; do
   sets=("FETCH_SIZE" "WRITE_SIZE")
   [ $w = fir1024 ] && sets+=("SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES")
+  # the issue / wait picture of config 4, before (cascade form) and after (parallel form)
+  case $w in iir8|iir8cas) sets+=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS");; esac
   for set in "${sets[@]}"; do
     tag=$(echo $set | cut -d' ' -f1)
     rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$tag -- python $ROOT/bench.py --workload $w --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
@@ -26,7 +28,7 @@ for w in fir1024 updn43 iir8 fir127 iir8tp iirlp8; do
 done
 cd $ROOT
 python bench.py > $OUT/bench_fir1024.json 2>$OUT/bench_fir1024.err
-for w in updn43 iir8 fir127 iir8tp iirlp8 fir1024c128; do
+for w in updn43 iir8 fir127 iir8tp iir8cas iirlp8 fir1024c128; do
   python bench.py --workload $w --no-other-configs > $OUT/bench_$w.json 2>/dev/null
 done
 python bench.py --scaling strong --total-log2n 30 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_fir1024_2p30_one_gpu.json 2>/dev/null

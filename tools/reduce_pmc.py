@@ -16,17 +16,27 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import subprocess
+import bench  # TRAFFIC_SOURCES / source_hashes: the profile records which kernel sources it was collected with
+try:
+    COMMIT = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE).stdout.decode().strip() or None
+except Exception:
+    COMMIT = None
 WORK = {  # workload -> (substring of every kernel of a step, substring of the kernel that runs once per step, algorithmic bytes)
     "fir1024": ("ols_tile_kernel", "ols_tile_kernel", 16 * 2 ** 26),
     "fir127": ("skdsp::fir_", "skdsp::fir_", 8 * 2 ** 26),
     "updn43": ("skdsp::fir_", "skdsp::fir_", 8 * 2 ** 26 + 8 * ((2 ** 26 * 4) // 3)),
-    "iir8": ("skdsp::iir_fused", "skdsp::iir_fused", 8 * 2 ** 26),   # config 4: the single-pass scan (the default since round 2)
+    "iir8": ("skdsp::iir_par", "skdsp::iir_par", 8 * 2 ** 26),   # config 4: the parallel-form single-pass scan (the default since round 3)
+    "iir8cas": ("skdsp::iir_fused", "skdsp::iir_fused", 8 * 2 ** 26),   # ... forced through the cascade-form single pass (round 2's default)
+    "fir1024c128": ("ols64_tile_kernel", "ols64_tile_kernel", 32 * 2 ** 26),
     "iir8tp": ("skdsp::iir_", "float, true", 8 * 2 ** 26),  # ... forced through K1 (matrix pipe) + carries + K3 (the WRITE = true instantiation runs once per step)
-    "iirlp8": ("skdsp::iir_fused", "skdsp::iir_fused", 8 * 2 ** 26),   # rate_change(12)'s lowpass, single-pass scan
+    "iirlp8": ("skdsp::iir_par", "skdsp::iir_par", 8 * 2 ** 26),   # rate_change(12)'s lowpass, parallel-form single-pass scan
 }
 for w, (pat, marker, alg) in WORK.items():
     out = {}
-    for tag in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+    for tag in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_INSTS_MFMA"):
         f = os.path.join(src, "pmc_%s_%s.csv" % (w, tag))
         if not os.path.exists(f):
             continue
@@ -49,5 +59,7 @@ for w, (pat, marker, alg) in WORK.items():
         "note": "FETCH_SIZE/WRITE_SIZE in KiB; read side doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM); "
                 "separate --pmc passes of `bench.py --workload %s`; all kernels matching '%s' summed per bench step" % (w, pat),
     }
+    out["source_sha256"] = bench.source_hashes(w)     # (uncommitted edits at collection time show up as a hash no commit has)
+    out["collected_at_commit"] = COMMIT
     json.dump(out, open(os.path.join(dst, "pmc_%s.json" % w), "w"), indent=1)
     print(w, "traffic/algorithmic = %.3f  (%.1f MB read + %.1f MB written per step)" % ((rd + wr) / alg, rd / 1e6, wr / 1e6))
