@@ -102,6 +102,11 @@ int skdsp_fir_get_algo(skdsp_handle h, int64_t n, int *algo_used);
 /* .filter(x): signal.lfilter(b,[1],x), multirate_helper.py:104-109.  y has n samples. */
 int skdsp_fir_filter(skdsp_handle h, const void *x, int64_t n, void *y);
 int skdsp_fir_filter_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev);
+/* N-D inputs: lfilter filters along the last axis in ONE call (multirate_helper.py:108).  nrow rows of n samples, each
+ * filtered from rest: one pitched copy in, one launch over the rows laid end to end with Ntaps-1 zeros between them,
+ * one pitched copy out (host form: rows contiguous; device form: x_stride / y_stride elements between rows, >= n). */
+int skdsp_fir_filter_rows(skdsp_handle h, const void *x, int64_t n, int64_t nrow, void *y);
+int skdsp_fir_filter_rows_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t nrow, int64_t x_stride, int64_t y_stride, void *y_dev);
 /* .up(x,L): lfilter(b,[1], L*upsample(x,L)), multirate_helper.py:112-118.  y has n*L samples. */
 int skdsp_fir_up(skdsp_handle h, const void *x, int64_t n, int L, void *y);
 int skdsp_fir_up_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev);

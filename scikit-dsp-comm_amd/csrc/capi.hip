@@ -272,11 +272,23 @@ static int fir_parts_run(FirHandle *h, const void *x_dev, int64_t n, int64_t n_h
         for (int t0 = 0; t0 < h->ntaps; t0 += seg) {
             FirHandle *p = new FirHandle();
             p->kind = H_FIR; p->dtype = h->dtype; p->slot = h->slot; p->taps_complex = h->taps_complex;
+            p->algo = h->algo;
             p->ntaps = std::min(seg, h->ntaps - t0);
             p->taps_host.assign(h->taps_host.begin() + (size_t)t0 * comp, h->taps_host.begin() + (size_t)(t0 + p->ntaps) * comp);
             h->parts.push_back(p);
         }
         h->part_seg = seg;
+    }
+    for (FirHandle *p : h->parts) p->algo = h->algo;   // (skdsp_fir_set_algo after the parts were made)
+    // A segment may start inside the history only by whole output periods (q inputs).  A history that covers a segment's
+    // delay is used in full; a shorter one is used up to a multiple of q -- if it is not one itself, the samples
+    // x[-n_hist .. -d-1] would be dropped from the outputs just below that segment's first one, so such a call is refused
+    // (the host pipeline and the sharded path always hand over a history that is complete or a multiple of q).
+    {
+        const int64_t last_delay = (int64_t)(h->parts.size() - 1) * seg / L;
+        SK_CHECK(q == 1 || n_hist >= last_delay || n_hist % q == 0, SKDSP_ERR_UNSUPPORTED,
+                 "fir: %d taps run as %d tap segments; with L/M = %d/%d a partial history (n_hist = %lld < %lld) must be a multiple of %d samples",
+                 h->ntaps, (int)h->parts.size(), L, M, (long long)n_hist, (long long)last_delay, q);
     }
     const size_t esz = dtype_size(h->dtype);
     const int scal = dtype_complex(h->dtype) ? 2 : 1;
@@ -1240,6 +1252,76 @@ static int fir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M
     else rc = fir_updn_any(h, x_dev, n, 0, L, M, y_dev);
     if (rc) return rc;
     return stage_out(y, y_dev, (size_t)n_out * esz, h);
+}
+
+// ---- N-D inputs: rows of one launch ---------------------------------------------------------------------------------
+// lfilter(b, [1], x) filters along the last axis of an N-D array in one call (multirate_helper.py:108).  A FIR forgets
+// after Ntaps-1 samples, so the rows are laid end to end with Ntaps-1 zeros between them and filtered as ONE signal from
+// rest: every output sees exactly the window a launch over its row alone would see (zeros in front of every row), so the
+// results agree to the kernels' rounding (the overlap-save tile boundaries fall elsewhere).  Host form: one pitched copy in, one launch, one pitched copy out;
+// device form: the two pitched copies are device-to-device.  Costs (Ntaps-1)/n extra samples.
+static int64_t fir_rows_pitch(const FirHandle *h, int64_t n) { return (int64_t)round_up((size_t)(n + h->ntaps - 1), 4); }
+
+static int fir_rows_run(FirHandle *h, int64_t n, int64_t nrow, int64_t pitch, void *xp, void *yp)
+{
+    const size_t esz = dtype_size(h->dtype);
+    // zeros between the rows (the last row needs none behind it)
+    if (nrow > 1)
+        SK_HIP(hipMemset2DAsync((char *)xp + (size_t)n * esz, (size_t)pitch * esz, 0, (size_t)(pitch - n) * esz, (size_t)(nrow - 1), ctx().stream));
+    return fir_filter_any(h, xp, (nrow - 1) * pitch + n, 0, yp);
+}
+
+int skdsp_fir_filter_rows(skdsp_handle hh, const void *x, int64_t n, int64_t nrow, void *y)
+{
+    API_BEGIN;
+    FirHandle *h = as_handle<FirHandle>(hh, H_FIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "fir_filter_rows: not a FIR handle");
+    SK_CHECK(n >= 0 && nrow >= 0 && nrow < ((int64_t)1 << 31), SKDSP_ERR_BADARG, "fir_filter_rows: bad arguments");
+    if (n == 0 || nrow == 0) return SKDSP_OK;
+    SK_CHECK(x && y, SKDSP_ERR_BADARG, "fir_filter_rows: null buffer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    const size_t esz = dtype_size(h->dtype);
+    const int64_t pitch = fir_rows_pitch(h, n);
+    const size_t total = (size_t)nrow * (size_t)pitch * esz;
+    void *base = nullptr, *yp = nullptr;
+    const bool wide = h->wide_out && !dtype_double(h->dtype);
+    int rc = ws_reserve(0, kHeadroomBytes + (wide ? 2 : 1) * total + 256, &base);
+    if (rc) return rc;
+    void *xp = (char *)base + kHeadroomBytes;
+    if ((rc = ws_reserve(1, total + 256, &yp))) return rc;
+    SK_HIP(hipMemcpy2DAsync(xp, (size_t)pitch * esz, x, (size_t)n * esz, (size_t)n * esz, (size_t)nrow, hipMemcpyHostToDevice, ctx().stream));
+    if ((rc = fir_rows_run(h, n, nrow, pitch, xp, yp))) return rc;
+    size_t osz = esz;
+    if (wide) {   // widen on the device (the staged input is done with in stream order)
+        if ((rc = widen_launch(yp, (int64_t)(total / 4), xp, ctx().stream))) return rc;
+        yp = xp;
+        osz = 2 * esz;
+    }
+    SK_HIP(hipMemcpy2DAsync(y, (size_t)n * osz, yp, (size_t)pitch * osz, (size_t)n * osz, (size_t)nrow, hipMemcpyDeviceToHost, ctx().stream));
+    return sync_checked();
+}
+
+int skdsp_fir_filter_rows_dev(skdsp_handle hh, const void *x_dev, int64_t n, int64_t nrow, int64_t x_stride, int64_t y_stride, void *y_dev)
+{
+    API_BEGIN;
+    FirHandle *h = as_handle<FirHandle>(hh, H_FIR);
+    SK_CHECK(h, SKDSP_ERR_BADARG, "fir_filter_rows: not a FIR handle");
+    SK_CHECK(n >= 0 && nrow >= 0 && nrow < ((int64_t)1 << 31), SKDSP_ERR_BADARG, "fir_filter_rows: bad arguments");
+    if (n == 0 || nrow == 0) return SKDSP_OK;
+    SK_CHECK(x_stride >= n && y_stride >= n, SKDSP_ERR_BADARG, "fir_filter_rows: row stride below the row length");
+    std::lock_guard<std::mutex> lk(h->mu);
+    const size_t esz = dtype_size(h->dtype);
+    const int64_t pitch = fir_rows_pitch(h, n);
+    const size_t total = (size_t)nrow * (size_t)pitch * esz;
+    void *base = nullptr, *yp = nullptr;
+    int rc = ws_reserve(0, kHeadroomBytes + total + 256, &base);
+    if (rc) return rc;
+    void *xp = (char *)base + kHeadroomBytes;
+    if ((rc = ws_reserve(1, total + 256, &yp))) return rc;
+    SK_HIP(hipMemcpy2DAsync(xp, (size_t)pitch * esz, x_dev, (size_t)x_stride * esz, (size_t)n * esz, (size_t)nrow, hipMemcpyDeviceToDevice, ctx().stream));
+    if ((rc = fir_rows_run(h, n, nrow, pitch, xp, yp))) return rc;
+    SK_HIP(hipMemcpy2DAsync(y_dev, (size_t)y_stride * esz, yp, (size_t)pitch * esz, (size_t)n * esz, (size_t)nrow, hipMemcpyDeviceToDevice, ctx().stream));
+    return SKDSP_OK;
 }
 
 int skdsp_fir_filter(skdsp_handle h, const void *x, int64_t n, void *y) { return fir_host_call(h, x, n, 1, 1, 0, y); }

@@ -27,6 +27,7 @@ SYMBOLS = [
     "skdsp_host_alloc", "skdsp_host_free", "skdsp_malloc", "skdsp_free", "skdsp_memcpy_h2d", "skdsp_memcpy_d2h", "skdsp_memcpy_d2d", "skdsp_memset",
     "skdsp_sync", "skdsp_timer_start", "skdsp_timer_stop", "skdsp_fill_noise_dev",
     "skdsp_fir_create", "skdsp_fir_set_algo", "skdsp_fir_get_algo", "skdsp_fir_filter", "skdsp_fir_filter_dev",
+    "skdsp_fir_filter_rows", "skdsp_fir_filter_rows_dev",
     "skdsp_fir_up", "skdsp_fir_up_dev", "skdsp_fir_dn", "skdsp_fir_dn_dev", "skdsp_fir_updn", "skdsp_fir_updn_dev",
     "skdsp_sos_create", "skdsp_tf_create", "skdsp_tf2sos", "skdsp_iir_filter", "skdsp_iir_filter_dev", "skdsp_iir_up",
     "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev", "skdsp_iir_state_len", "skdsp_iir_filter_state_dev",
@@ -86,6 +87,8 @@ def load():
         L.skdsp_fir_get_algo.argtypes = [vp, i64, ctypes.POINTER(ci)]
         L.skdsp_fir_filter.argtypes = [vp, vp, i64, vp]
         L.skdsp_fir_filter_dev.argtypes = [vp, vp, i64, i64, vp]
+        L.skdsp_fir_filter_rows.argtypes = [vp, vp, i64, i64, vp]
+        L.skdsp_fir_filter_rows_dev.argtypes = [vp, vp, i64, i64, i64, i64, vp]
         L.skdsp_fir_up.argtypes = [vp, vp, i64, ci, vp]
         L.skdsp_fir_up_dev.argtypes = [vp, vp, i64, i64, ci, vp]
         L.skdsp_fir_dn.argtypes = [vp, vp, i64, ci, vp]
@@ -336,16 +339,22 @@ class PinnedPool:
     A copy back into a fresh np.empty array pays for the population of its pages and their first device access
     (31 ms per 512 MiB instead of 12, and another 26 ms when NumPy unmaps it again: tools/host_pipe_time.py); a
     page-locked block receives the DMA at the link rate and is handed to the next call of the same size when its
-    array is garbage collected.  The arrays are ordinary writable ndarrays (their .base chain ends in the block).
-    max_bytes bounds what the pool keeps for reuse (blocks in use by live arrays are not counted); 0 switches it off."""
+    array is garbage collected.  The arrays are ordinary writable ndarrays whose .base chain ends in the block: they do
+    NOT own their memory (ndarray.resize refuses them; np.copy gives an owning array).
+    max_bytes bounds what the pool keeps for reuse; max_live_bytes bounds the page-locked memory in the hands of live
+    result arrays plus the pool (beyond it results are ordinary np.empty arrays); 0 switches the pool off.
+    The lock is re-entrant and nothing is allocated while it is held: a block's finaliser (_give_back) can run inside
+    any allocation -- including one made by this class -- when the cyclic collector fires."""
 
     GRANULE = 2 << 20
 
-    def __init__(self, max_bytes=4 << 30, min_bytes=32 << 20):
+    def __init__(self, max_bytes=4 << 30, min_bytes=32 << 20, max_live_bytes=None):
         self.max_bytes, self.min_bytes = int(max_bytes), int(min_bytes)
+        self.max_live_bytes = int(max_live_bytes) if max_live_bytes is not None else 4 * self.max_bytes
         self._free = {}      # rounded size -> [ptr]
         self._kept = 0
-        self._lock = threading.Lock()
+        self._live = 0       # bytes of blocks currently wrapped by result arrays
+        self._lock = threading.RLock()
 
     def empty(self, count, dtype):
         dtype = np.dtype(dtype)
@@ -353,36 +362,62 @@ class PinnedPool:
         if self.max_bytes <= 0 or nbytes < self.min_bytes:
             return np.empty(count, dtype=dtype)
         size = -(-nbytes // self.GRANULE) * self.GRANULE
+        ptr = None
         with self._lock:
             lst = self._free.get(size)
-            ptr = lst.pop() if lst else None
-            if ptr is not None:
+            if lst:
+                ptr = lst.pop()
                 self._kept -= size
+                self._live += size
+            elif self._live + self._kept + size > self.max_live_bytes:
+                size = 0   # cap on page-locked host memory reached
+            else:
+                self._live += size   # reserved before the allocation below (which runs outside the lock)
+        if size == 0:
+            return np.empty(count, dtype=dtype)
         if ptr is None:
             p = ctypes.c_void_p(0)
             try:
                 check(load().skdsp_host_alloc(ctypes.byref(p), size))
             except Exception:
+                with self._lock:
+                    self._live -= size
                 return np.empty(count, dtype=dtype)   # no page-locked memory left: an ordinary array
             ptr = p.value
         block = _PinnedBlock(self, ptr, size)
         return np.asarray(block)[:nbytes].view(dtype)
 
     def _give_back(self, ptr, size):
+        keep = False
         with self._lock:
-            if self._kept + size <= self.max_bytes:
-                self._free.setdefault(size, []).append(ptr)
+            self._live -= size
+            lst = self._free.get(size)
+            if self._kept + size <= self.max_bytes and lst is not None:
+                lst.append(ptr)          # (list.append of an int allocates nothing the collector tracks)
                 self._kept += size
-                return
+                keep = True
+        if keep:
+            return
+        if self._kept + size <= self.max_bytes:
+            fresh = [ptr]                # first block of this size: the list is built OUTSIDE the lock
+            with self._lock:
+                if self._kept + size <= self.max_bytes:
+                    cur = self._free.get(size)
+                    if cur is None:
+                        self._free[size] = fresh
+                    else:
+                        cur.append(ptr)
+                    self._kept += size
+                    return
         load().skdsp_host_free(ctypes.c_void_p(ptr))
 
     def trim(self):
         """Release every block the pool holds for reuse."""
         with self._lock:
-            ptrs = [p for lst in self._free.values() for p in lst]
-            self._free, self._kept = {}, 0
-        for p in ptrs:
-            load().skdsp_host_free(ctypes.c_void_p(p))
+            old, self._free, self._kept = self._free, {}, 0
+        for lst in old.values():
+            for p in lst:
+                load().skdsp_host_free(ctypes.c_void_p(p))
 
 
 result_pool = PinnedPool(int(os.environ.get("SKDSP_PINNED_POOL_BYTES", str(4 << 30))))
@@ -467,6 +502,16 @@ class FirKernel(_HostCalls):
         n = xd.n if n is None else n
         check(load().skdsp_fir_updn_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, n_hist, int(L), int(M),
                                          ctypes.c_void_p(yd.ptr)))
+
+    def filter_rows(self, x2, wide=False):
+        """x2: C-contiguous (rows, n): every row filtered from rest in ONE call (one pitched copy each way, one launch)."""
+        rows, n = x2.shape
+        y = self._host(x2.size, x2.dtype, wide, lambda y: check(load().skdsp_fir_filter_rows(ctypes.c_void_p(self.h), _ptr(x2), n, rows, _ptr(y))))
+        return y.reshape(rows, n)
+
+    def filter_rows_dev(self, xd, yd, n, rows, x_stride=None, y_stride=None):
+        check(load().skdsp_fir_filter_rows_dev(ctypes.c_void_p(self.h), ctypes.c_void_p(xd.ptr), n, rows, n if x_stride is None else x_stride,
+                                                n if y_stride is None else y_stride, ctypes.c_void_p(yd.ptr)))
 
     def filter_shard_dev(self, xd, yd, n=None):
         n = xd.n if n is None else n

@@ -113,7 +113,13 @@ def mpsk_bb(n_symb, ns, mod, pulse='rect', alpha=0.25, m=6):
 def rz_bits(n_bits, ns, pulse='rect', alpha=0.25, m=6):
     """Return-to-zero 0/1 waveform from random bits (digitalcom.py:998-1048): (x, b / ns, data)."""
     data = np.random.randint(0, 2, n_bits)
-    b = _pulse(pulse, ns, alpha, m, err='pulse type must be rec, rc, or src')
+    try:
+        b = _pulse(pulse, ns, alpha, m, err='pulse type must be rec, rc, or src')
+    except ValueError as e:
+        # the reference only warns here (digitalcom.py:1045-1046) and then fails on its unassigned `b` (:1047)
+        import warnings
+        warnings.warn(str(e))
+        raise UnboundLocalError("local variable 'b' referenced before assignment")
     x = pulse_shape(data, b, ns) if n_bits else np.zeros(0)
     return x, b / float(ns), data
 
@@ -135,20 +141,45 @@ def gmsk_bb(n_bits, ns, msk=0, bt=0.35):
 
 
 def time_delay(x, d, n=4):
-    """Farrow-structure time delay (digitalcom.py:1089-1160) for a CONSTANT delay d (the branch that is one lfilter call,
-    :1110-1131): cubic Lagrange taps behind fix(d) whole samples, filtered on the GPU.  A delay that varies per sample
-    is the reference's per-sample Python loop and is not on the accelerated path."""
+    """Farrow-structure time delay (digitalcom.py:1089-1160).  A Python float / int d is the reference's constant-delay
+    branch (:1110-1131): cubic Lagrange taps behind fix(d) whole samples, ONE lfilter call -- filtered on the GPU.
+    Anything else is the time-varying branch (:1132-1160, d[k] per sample): a 4-tap gather with polynomial weights,
+    y[k] = ((v3 mu + v2) mu + v1) mu + v0,  v_j = W_j . x[k-Nd_k+1 .. k-Nd_k-2],  mu = 1 - frac(d[k]),
+    evaluated for all k at once on the host (the reference loops over k in Python; there is no filter call to
+    accelerate: every output has its own taps)."""
     from . import multirate_helper as mrh
-    if np.ndim(d) != 0 and len(np.atleast_1d(d)) != 1:
-        raise NotImplementedError("time_delay: only a constant delay (scalar d) runs on the GPU path")
-    d = float(np.atleast_1d(d)[0])
-    if int(np.fix(d)) < 1 or int(np.fix(d)) > n - 2:
+    if type(d) == float or type(d) == int:   # (the reference's own test, :1110)
+        if int(np.fix(d)) < 1 or int(np.fix(d)) > n - 2:
+            raise ValueError("time_delay: the integer part of d must lie in [1, n - 2]")
+        frac = d - np.fix(d)
+        nd = int(np.fix(d))
+        b = np.zeros(nd + 4)
+        b[nd] = -(frac - 1) * (frac - 2) * (frac - 3) / 6.
+        b[nd + 1] = frac * (frac - 2) * (frac - 3) / 2.
+        b[nd + 2] = -frac * (frac - 1) * (frac - 3) / 2.
+        b[nd + 3] = frac * (frac - 1) * (frac - 2) / 6.
+        return mrh.multirate_FIR(b).filter(np.asarray(x))
+    x = np.asarray(x)
+    d = np.asarray(d, dtype=np.float64)
+    if d.ndim == 0:                           # a NumPy scalar: the reference would index it and fail; treat it as constant per sample
+        d = np.full(len(x), float(d))
+    if len(d) < len(x):
+        raise IndexError("index %d is out of bounds for axis 0 with size %d" % (len(d), len(d)))   # what d[k] raises in the reference
+    d = d[:len(x)]
+    if len(x) and (np.fix(np.min(d)) < 1 or np.fix(np.max(d)) > n - 2):
         raise ValueError("time_delay: the integer part of d must lie in [1, n - 2]")
-    frac = d - np.fix(d)
-    nd = int(np.fix(d))
-    b = np.zeros(nd + 4)
-    b[nd] = -(frac - 1) * (frac - 2) * (frac - 3) / 6.
-    b[nd + 1] = frac * (frac - 2) * (frac - 3) / 2.
-    b[nd + 2] = -frac * (frac - 1) * (frac - 3) / 2.
-    b[nd + 3] = frac * (frac - 1) * (frac - 2) / 6.
-    return mrh.multirate_FIR(b).filter(np.asarray(x))
+    nd = np.fix(d).astype(np.int64)
+    mu = 1.0 - (d - np.fix(d))
+    k = np.arange(len(x))
+    xr = np.real(x).astype(np.float64) if np.iscomplexobj(x) else x.astype(np.float64)   # y = np.zeros(len(x)): real (:1139)
+    taps = np.zeros((4, len(x)))
+    for i in range(4):                        # X[Nd-1+i] = x[k - (Nd-1) - i], zero before the start
+        idx = k - (nd - 1) - i
+        ok = idx >= 0
+        taps[i, ok] = xr[idx[ok]]
+    w3 = np.array([1. / 6, -1. / 2, 1. / 2, -1. / 6])
+    w2 = np.array([0, 1. / 2, -1., 1. / 2])
+    w1 = np.array([-1. / 6, 1., -1. / 2, -1. / 3])
+    w0 = np.array([0, 0, 1., 0])
+    v3, v2, v1, v0 = w3 @ taps, w2 @ taps, w1 @ taps, w0 @ taps
+    return ((v3 * mu + v2) * mu + v1) * mu + v0

@@ -54,15 +54,6 @@ def _wide():
     return bool(config.strict_dtype)
 
 
-def _rows(fn, xg):
-    """Apply a 1-D kernel call along the last axis (lfilter/sosfilt semantics for N-D)."""
-    if xg.ndim == 1:
-        return fn(xg)
-    flat = xg.reshape(-1, xg.shape[-1])
-    out = [fn(np.ascontiguousarray(r)) for r in flat]
-    return np.stack(out).reshape(xg.shape[:-1] + (out[0].shape[-1],))
-
-
 def _fingerprint(*arrays):
     """Cheap identity of the coefficient arrays an object currently holds (the reference reads its public
     attributes on every call, so obj.b = new_taps must take effect on the next call)."""
@@ -110,11 +101,21 @@ class multirate_FIR(object):
     # --- reference surface --------------------------------------------------
     def filter(self, x):
         """y = lfilter(b, [1], x)  (multirate_helper.py:104-109)"""
+        return self._filter(x, bool(config.strict_dtype))
+
+    def _filter(self, x, strict):
+        """filter() with the result-dtype policy as an argument (callers inside the package that need the reference's
+        dtypes whatever the global switch says pass strict=True instead of flipping config.strict_dtype around the call:
+        that was not thread-safe)."""
         xg, ref_dt = _signal(x, self._bc)
         if xg.size == 0:
             raise ValueError("v cannot be empty")
         k = self._kern.get(xg.dtype)
-        return _finish(_rows(lambda r: k.filter(r, wide=_wide()), xg), ref_dt)
+        if xg.ndim > 1:   # N-D: every row of the last axis in one call (rows laid end to end behind Ntaps-1 zeros)
+            y = k.filter_rows(xg.reshape(-1, xg.shape[-1]), wide=strict).reshape(xg.shape)
+        else:
+            y = k.filter(xg, wide=strict)
+        return y.astype(ref_dt, copy=False) if strict else y
 
     def up(self, x, L_change=12):
         """y = lfilter(b, [1], L*upsample(x, L))  (multirate_helper.py:112-118), polyphase on the GPU."""

@@ -118,12 +118,7 @@ def _transform_domain_fir(x, h, N, mode, name):
     x = np.asarray(x)
     if len(x) == 0:
         return (np.zeros(0), np.zeros((0, 0))) if mode == 1 else np.zeros(0)
-    saved = config.strict_dtype
-    config.strict_dtype = True
-    try:
-        y = mrh.multirate_FIR(np.asarray(h)).filter(x)
-    finally:
-        config.strict_dtype = saved
+    y = mrh.multirate_FIR(np.asarray(h))._filter(x, True)   # the reference's float64 / complex128 whatever config.strict_dtype says
     y = np.ascontiguousarray(np.real(y), dtype=np.float64)
     if mode == 1:
         return y, _frame_matrix(x, np.asarray(h), int(N), name)

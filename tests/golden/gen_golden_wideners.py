@@ -62,6 +62,14 @@ xt = rng.standard_normal(2000)
 out["td_x"] = xt
 out["td_y"] = dc.time_delay(xt, 1.37, 4)
 out["td_y2"] = dc.time_delay(xt, 2.0, 6)
+# the time-varying branch (digitalcom.py:1132-1160): a delay per sample, swept and jittered across [1, n-2]
+td_d = 2.0 + 0.95 * np.sin(np.arange(2000) * 0.013) ** 2 + 0.04 * rng.random(2000)
+td_d[::11] = 1.0
+out["td_d"] = td_d
+out["td_y3"] = dc.time_delay(xt, td_d, 4)
+td_d6 = 1.0 + 3.99 * rng.random(2000)
+out["td_d6"] = td_d6
+out["td_y4"] = dc.time_delay(xt, td_d6, 6)
 
 np.savez_compressed(os.path.join(HERE, "g14_wideners.npz"), **out)
 print("wrote g14_wideners.npz:", {k: np.asarray(v).shape for k, v in out.items()})

@@ -189,3 +189,55 @@ def test_parallel_form_coherent_inputs(kind):
         ref = signal.sosfilt(sos, x.astype(np.float64))
         scale = max(np.max(np.abs(ref)), 1e-3 * np.max(np.abs(x)))   # (the band-pass removes DC: judge against the input scale there)
         assert np.max(np.abs(y - ref)) <= 5e-7 * scale, (name, kind, np.max(np.abs(y - ref)) / scale)
+
+
+# ---- N-D FIR rows in one call (the FIR half of the same reference behaviour: lfilter along the last axis) --------------
+@pytest.mark.parametrize("ntaps,shape,dt", [(127, (4096, 16384), np.float32), (1024, (6, 3, 20000), np.complex64), (33, (5, 70), np.float64),
+                                            (1024, (3, 9000), np.complex128), (300, (17, 5000), np.float32), (5000, (3, 12000), np.float32)])
+def test_fir_nd_rows_in_one_call(ntaps, shape, dt):
+    """multirate_FIR.filter on an N-D array == lfilter(b, [1], x) along the last axis (multirate_helper.py:108): every row
+    from rest, rows laid end to end behind Ntaps-1 zeros and filtered as one launch."""
+    from scipy import signal
+    rng = np.random.default_rng(3)
+    b = signal.firwin(ntaps, 0.2)
+    x = rng.standard_normal(shape)
+    if np.dtype(dt).kind == "c":
+        x = x + 1j * rng.standard_normal(shape)
+    x = x.astype(dt)
+    old = sk.config.strict_dtype
+    sk.config.strict_dtype = False
+    try:
+        y = mrh.multirate_FIR(b).filter(x)
+    finally:
+        sk.config.strict_dtype = old
+    assert y.shape == x.shape
+    flat_y = y.reshape(-1, shape[-1])
+    flat_x = x.reshape(-1, shape[-1])
+    rows = sorted({0, 1, flat_y.shape[0] // 2, flat_y.shape[0] - 1})
+    tol = TOL32 if dt in (np.float32, np.complex64) else TOL64
+    wide = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    for r in rows:
+        assert_close(flat_y[r], signal.lfilter(b, [1], flat_x[r].astype(wide)), tol, "row %d" % r)
+    # the reference's own dtype convention on the default path
+    y2 = mrh.multirate_FIR(b).filter(x[..., :64] if x.ndim == 2 else x[0, :, :64])
+    assert y2.dtype == wide
+
+
+def test_fir_rows_dev_strided():
+    from scipy import signal
+    b = signal.firwin(200, 0.3)
+    n, rows, pitch = 10_000, 7, 10_240
+    rng = np.random.default_rng(4)
+    x = np.zeros((rows, pitch), np.complex64)
+    x[:, :n] = rng.standard_normal((rows, n)) + 1j * rng.standard_normal((rows, n))
+    k = _ffi.FirKernel(b, _ffi.C64)
+    xd = _ffi.DeviceArray.from_host(x.ravel())
+    yd = _ffi.DeviceArray.from_host(np.full(rows * pitch, 3.0 + 0j, np.complex64))
+    try:
+        k.filter_rows_dev(xd, yd, n, rows, pitch, pitch)
+        y = yd.to_host().reshape(rows, pitch)
+        assert np.all(y[:, n:] == 3.0)
+        assert_close(y[:, :n], signal.lfilter(b, [1], x[:, :n].astype(np.complex128), axis=-1), TOL32, "strided FIR rows")
+    finally:
+        xd.free()
+        yd.free()

@@ -764,6 +764,7 @@ def _g11():
 def test_interp24_deci24_match_reference():
     from sk_dsp_comm_amd import sigsys, config
     g = _g11()
+    old = config.strict_dtype
     config.strict_dtype = True
     try:
         y = sigsys.interp24(g["i24_x"])
@@ -775,7 +776,7 @@ def test_interp24_deci24_match_reference():
         y32 = sigsys.interp24(g["i24_x"].astype(np.float32))  # float32 signal: float32 I/O kernels
         assert y32.dtype == np.float64 and max(rel_err(y32, g["i24_y"])) <= 2e-6
     finally:
-        config.strict_dtype = False
+        config.strict_dtype = old
 
 
 @pytest.mark.gpu
@@ -1598,8 +1599,11 @@ def test_wideners_match_reference():
     assert_close(y, g["msk_y"], 1e-9, "msk")
     assert_close(dcm.time_delay(g["td_x"], 1.37, 4), g["td_y"], 1e-12, "time_delay")
     assert_close(dcm.time_delay(g["td_x"], 2.0, 6), g["td_y2"], 1e-12, "time_delay integer")
-    with pytest.raises(NotImplementedError):
-        dcm.time_delay(g["td_x"], np.full(len(g["td_x"]), 1.5))
+    # a delay per sample: the reference's time-varying Farrow loop (digitalcom.py:1132-1160)
+    assert_close(dcm.time_delay(g["td_x"], g["td_d"], 4), g["td_y3"], 1e-13, "time_delay d[k]")
+    assert_close(dcm.time_delay(g["td_x"], g["td_d6"], 6), g["td_y4"], 1e-13, "time_delay d[k], n = 6")
+    with pytest.raises(ValueError):
+        dcm.time_delay(g["td_x"], np.full(len(g["td_x"]), 3.5), 4)
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.complex64])
