@@ -216,16 +216,18 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
         w.kern = "ols64_tile_kernel (float64 overlap-save, 4096-point tiles)"
         w.wl = "multirate_FIR.filter: 1024-tap lowpass, complex128 (the reference's own arithmetic), %s samples" % lg
         w.metric = "complex128 MSamples/s (FIR-1024 tap, %s samples)" % lg
-    elif name in ("iir8", "iir8tp", "iir8cas", "iirlp8"):
+    elif name in ("iir8", "iir8tp", "iir8cas", "iirlp8", "iir8c64"):
         if name == "iirlp8":   # rate_change(12)'s own design (multirate_helper.py:62): butter(8, 0.9 / 12), as biquads
             sos = _ffi.tf2sos(*_butter8_rate_change12())
         else:
             sos = elliptic_bpf_sos()
         w.sos, w.dtype, w.arith = sos, np.float32, "f32 I/O, f64 state"
+        if name == "iir8c64":   # the same cascade on a complex baseband signal: re and im streams interleaved on alternate lanes
+            w.dtype, w.arith = np.complex64, "c64 I/O, f64 state"
         w.xd = _ffi.DeviceArray(n, w.dtype).fill_noise(2026, first_index=rank * n)
         w.yd = _ffi.DeviceArray(n, w.dtype)
         if world == 1:
-            k = _ffi.IirKernel(_ffi.F32, sos=sos)
+            k = _ffi.IirKernel(_ffi.code_of(w.dtype), sos=sos)
             if name == "iir8tp":   # config 4 through K1 + carries + K3 (what round 1 ran), for comparison
                 def step():
                     with _ffi.option("iir_par", 0), _ffi.option("iir_two_pass", 1):
@@ -243,16 +245,18 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
             w.step = lambda: iir.filter_local_dev(w.xd, w.yd, n)
         if name == "iir8":
             w.shard = ("iir", sos, 2026)
-        w.alg_bytes = 8.0 * n
-        w.compute = ("FP64 vector (v_fma_f64)", 78.6, 72.0 * n)   # 9 flop per biquad per sample
+        cplx = 2 if name == "iir8c64" else 1
+        w.alg_bytes = 8.0 * n * cplx
+        w.compute = ("FP64 vector (v_fma_f64)", 78.6, 72.0 * n * cplx)   # 9 flop per biquad per (real) sample
         w.kern = {"iir8": "iir_par_kernel (parallel-form single-pass scan, one segment per wave)",
                   "iir8cas": "iir_fused_kernel (cascade-form single-pass scan, chunk scan on the matrix pipe; forced)",
                   "iir8tp": "iir_k1r_kernel + iir_carry_kernel + iir_chunk_kernel (two-pass scan, forced)",
-                  "iirlp8": "iir_par_kernel (parallel-form single-pass scan)"}[name]
+                  "iirlp8": "iir_par_kernel (parallel-form single-pass scan)",
+                  "iir8c64": "iir_par_kernel<complex> (parallel-form single-pass scan, re / im on alternate lanes)"}[name]
         what = "order-8 Butterworth lowpass of rate_change(12), 4 biquads" if name == "iirlp8" else "8-biquad elliptic bandpass"
-        w.wl = "multirate_IIR.filter: %s, float32, %s samples, exact affine scan%s" % (
-            what, lg, " (two-pass scan forced)" if name == "iir8tp" else " (cascade-form single pass forced)" if name == "iir8cas" else "")
-        w.metric = "float32 MSamples/s (%s, %s samples)" % ("SOS IIR, " + what, lg)
+        w.wl = "multirate_IIR.filter: %s, %s, %s samples, exact affine scan%s" % (
+            what, "complex64" if name == "iir8c64" else "float32", lg, " (two-pass scan forced)" if name == "iir8tp" else " (cascade-form single pass forced)" if name == "iir8cas" else "")
+        w.metric = "%s MSamples/s (%s, %s samples)" % ("complex64" if name == "iir8c64" else "float32", "SOS IIR, " + what, lg)
         if name == "iirlp8":
             w.compute = ("FP64 vector (v_fma_f64)", 78.6, 36.0 * n)
     else:
@@ -357,7 +361,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--settle-seconds", type=float, default=0.5,
                     help="untimed passes before the warm-up steps until the GPU clock has left its idle state")
-    ap.add_argument("--workload", default="fir1024", choices=["fir1024", "updn43", "iir8", "fir127", "iir8tp", "iir8cas", "iirlp8", "fir1024c128"])
+    ap.add_argument("--workload", default="fir1024", choices=["fir1024", "updn43", "iir8", "fir127", "iir8tp", "iir8cas", "iirlp8", "iir8c64", "fir1024c128"])
     ap.add_argument("--log2n", type=int, default=26, help="weak scaling: samples per GPU = 2^log2n")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--total-log2n", type=int, default=30, help="strong scaling: 2^total samples shared by all GPUs")
@@ -464,7 +468,7 @@ def main():
     if world == 1 and args.workload == "fir1024" and not args.no_other_configs and args.scaling == "weak":
         free_workload(w)
         others = {}
-        for name in ("updn43", "iir8", "fir127", "iir8tp", "iir8cas", "iirlp8", "fir1024c128"):
+        for name in ("updn43", "iir8", "fir127", "iir8tp", "iir8cas", "iirlp8", "iir8c64", "fir1024c128"):
             try:
                 o = make_workload(name, 1 << 26, 0, 1, tr, _ffi, sharding)
                 Ko = args.other_steps if name != "fir1024c128" else max(args.other_steps // 5, 5)
@@ -556,7 +560,8 @@ def cpu_baseline_port(args, w):
     cores_avail = os.cpu_count()
     if w.name.startswith("iir"):
         x = w.xd.to_host(0, min(w.n, 1 << 26))
-        m, dt = _sized_sample(lambda k: orc.sos_filter_f32in_timed(w.sos, x[:k]), 1 << 18, x.size, args.cpu_seconds)
+        fn = orc.sos_filter if np.iscomplexobj(x) else orc.sos_filter_f32in_timed
+        m, dt = _sized_sample(lambda k: fn(w.sos, x[:k]), 1 << 18, x.size, args.cpu_seconds)
         what = "sequential DF2T in float64 (sosfilt restated in C)"
     elif w.name == "updn43":
         x = w.xd.to_host(0, 1 << 20)

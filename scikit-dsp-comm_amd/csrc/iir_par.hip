@@ -92,7 +92,7 @@ __device__ __forceinline__ void blocks_acc(const double *__restrict__ P, const d
 
 typedef double v2d_t __attribute__((ext_vector_type(2)));
 
-template <int NSEC, typename IO, bool DEC>
+template <int NSEC, typename IO, bool DEC, bool CPLX>
 __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
                                                                  const double *__restrict__ lvl, const double *__restrict__ psi)
 {
@@ -102,11 +102,18 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     using St = Stage<IO>;
     constexpr int kRowBytes = St::pitch * (int)sizeof(IO);
     constexpr int kWaveStage = 64 * kRowBytes;                    // 9216 (float) / 17408 (double) bytes: also holds the 8 KiB scan exchange
-    static_assert(kWaveStage >= 64 * 16 * 8, "scan exchange must fit the wave's stage image");
+    static_assert(kWaveStage >= 64 * 16 * 8 + kParMaxK * 64 * 4, "scan exchange + look-back words must fit the wave's stage image");
     __shared__ __attribute__((aligned(16))) char lds_raw[4 * kWaveStage];
     __shared__ double gl[(T / 4) * 64];
-    __shared__ __attribute__((aligned(16))) unsigned cwsh[4][kParMaxK * 32];
     __shared__ int base_sh;
+    // CPLX: an interleaved complex signal.  Lane L owns component L & 1 (re / im) of complex chunk L >> 1: T complex samples
+    // per chunk, 32 chunks per wave segment.  The two components are independent real signals through the same real
+    // filter, so everything between the staging image and the recurrence is the real kernel with "the chunk to my left"
+    // two lanes away; only the staging (de-interleave on the way in, re-interleave on the way out) and the look-back
+    // (two end states per segment) differ.
+    constexpr int LS = CPLX ? 2 : 1;            // lanes per chunk
+    constexpr int CH = 64 / LS;                 // chunks per wave segment
+    constexpr int GR = 32 * LS;                 // look-back granules per segment
 
     // (the wave index through readfirstlane: segment, row and every base address are then wave-uniform SGPR values)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,31 +135,72 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     IO *y = reinterpret_cast<IO *>(a.y) + (size_t)row * a.y_stride;
     IO *stage = reinterpret_cast<IO *>(lds_raw + wave * kWaveStage);
     double *E = reinterpret_cast<double *>(lds_raw + wave * kWaveStage);   // scan exchange [section][lane][2] (aliases the image)
-    const int64_t row0 = (int64_t)seg * 64;   // first chunk of the segment
-    const bool interior = a.aligned && (row0 + 64) * T <= a.n;
+    const int64_t row0 = (int64_t)seg * CH;   // first chunk of the segment
+    const bool interior = a.aligned && (row0 + CH) * T <= a.n;   // (a.n: samples per row -- complex samples for CPLX)
 
     typedef float pre_t __attribute__((ext_vector_type(4)));
     pre_t pre[NP][St::per_thread];
     // (uniform segment base + one 32-bit lane offset + constants: hipcc then addresses every access of the segment as
     // SGPR base + VGPR offset + immediate instead of keeping a 64-bit address pair per access alive)
-    const IO *xseg = x + row0 * T;
-    IO *yseg = y + row0 * T;
-    const unsigned loff = (unsigned)((lane / St::segs) * T + (lane % St::segs) * St::elems);
-    constexpr unsigned kRowStep = (64 / St::segs) * T;   // elements between a lane's consecutive staged segments
+    const IO *xseg = x + row0 * T * LS;          // (IO scalars: an interleaved complex sample is two)
+    IO *yseg = y + row0 * T * LS;
+    // a 16-byte unit of a chunk's piece: St::segs units per real chunk piece, 2 x St::segs per complex one (re/im interleaved)
+    constexpr int USEG = St::segs * LS;
+    const unsigned loff = (unsigned)((lane / USEG) * T * LS + (lane % USEG) * St::elems);
+    constexpr unsigned kRowStep = (64 / USEG) * T * LS;   // IO scalars between a lane's consecutive staged units
     auto load_piece = [&](int p) {  // interior segments only
 #pragma unroll
         for (int i = 0; i < St::per_thread; ++i)
-            pre[p][i] = __builtin_nontemporal_load(reinterpret_cast<const pre_t *>(xseg + (loff + i * kRowStep + p * kPiece)));
+            pre[p][i] = __builtin_nontemporal_load(reinterpret_cast<const pre_t *>(xseg + (loff + i * kRowStep + p * kPiece * LS)));
+    };
+    // image position of staged unit (i, lane): real: 16 bytes of row idx / segs; complex: the unit holds elems / 2 complex
+    // samples of chunk idx / USEG -- their re parts go to row 2 chunk, their im parts to row 2 chunk + 1
+    auto image_put = [&](int i, const pre_t &val) __attribute__((always_inline)) {
+        const int idx = i * 64 + lane;
+        if constexpr (!CPLX) {
+            const int r = idx / St::segs, sg = idx % St::segs;
+            *reinterpret_cast<pre_t *>(stage + r * St::pitch + sg * St::elems) = val;
+        } else {
+            const int ch = idx / USEG, u = idx % USEG;
+            const IO *e = reinterpret_cast<const IO *>(&val);
+            IO *re = stage + (2 * ch) * St::pitch + u * (St::elems / 2), *im = re + St::pitch;
+#pragma unroll
+            for (int k = 0; k < St::elems / 2; ++k) {
+                re[k] = e[2 * k];
+                im[k] = e[2 * k + 1];
+            }
+        }
+    };
+    auto image_get = [&](int i) __attribute__((always_inline)) -> pre_t {
+        const int idx = i * 64 + lane;
+        if constexpr (!CPLX) {
+            const int r = idx / St::segs, sg = idx % St::segs;
+            return *reinterpret_cast<const pre_t *>(stage + r * St::pitch + sg * St::elems);
+        } else {
+            const int ch = idx / USEG, u = idx % USEG;
+            const IO *re = stage + (2 * ch) * St::pitch + u * (St::elems / 2), *im = re + St::pitch;
+            pre_t val;
+            IO *e = reinterpret_cast<IO *>(&val);
+#pragma unroll
+            for (int k = 0; k < St::elems / 2; ++k) {
+                e[2 * k] = re[k];
+                e[2 * k + 1] = im[k];
+            }
+            return val;
+        }
     };
     auto stage_slow = [&](int p) {  // zero beyond the signal
 #pragma unroll 1
         for (int i = 0; i < St::per_thread; ++i) {
             const int idx = i * 64 + lane;
-            const int r = idx / St::segs, sg = idx % St::segs;
-            const int64_t g = (row0 + r) * T + (int64_t)p * kPiece + (int64_t)sg * St::elems;
-            IO *dst = stage + r * St::pitch + sg * St::elems;
+            const int r = idx / USEG, sg = idx % USEG;
+            // g: index of the unit's first sample (a complex sample for CPLX) in the row
+            const int64_t g = (row0 + r) * T + (int64_t)p * kPiece + (int64_t)sg * (St::elems / LS);
+            pre_t val;
+            IO *e4 = reinterpret_cast<IO *>(&val);
 #pragma unroll
-            for (int e = 0; e < St::elems; ++e) dst[e] = (g + e < a.n) ? x[g + e] : IO(0);
+            for (int e = 0; e < St::elems; ++e) e4[e] = (g + e / LS < a.n) ? x[g * LS + e] : IO(0);
+            image_put(i, val);
         }
     };
 
@@ -174,11 +222,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     for (int p = 0; p < NP; ++p) {
         if (interior) {
 #pragma unroll
-            for (int i = 0; i < St::per_thread; ++i) {
-                const int idx = i * 64 + lane;
-                const int r = idx / St::segs, sg = idx % St::segs;
-                *reinterpret_cast<pre_t *>(stage + r * St::pitch + sg * St::elems) = pre[p][i];
-            }
+            for (int i = 0; i < St::per_thread; ++i) image_put(i, pre[p][i]);
         } else {
             stage_slow(p);
         }
@@ -219,7 +263,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     if (a.dbg & 4) a.n_lv = 0;
 #pragma unroll 1
     for (int l = 0; l < a.n_lv; ++l) {
-        const int s = 1 << l;
+        const int s = LS << l;
         const int src = lane >= s ? lane - s : lane;
         double left[D];
 #pragma unroll
@@ -237,26 +281,28 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     double z[D];
 #pragma unroll
     for (int k = 0; k < NSEC; ++k) {
-        const v2d_t t = *reinterpret_cast<const v2d_t *>(E + (k * 64 + (lane ? lane - 1 : 0)) * 2);
-        z[2 * k] = lane ? t[0] : 0.0;
-        z[2 * k + 1] = lane ? t[1] : 0.0;
+        const v2d_t t = *reinterpret_cast<const v2d_t *>(E + (k * 64 + (lane >= LS ? lane - LS : 0)) * 2);
+        z[2 * k] = lane >= LS ? t[0] : 0.0;
+        z[2 * k + 1] = lane >= LS ? t[1] : 0.0;
     }
 
-    // ---- L: publish the segment's end state from rest, fetch the K predecessors' ----------------------------------------
-    unsigned *cw = cwsh[wave];
-    if (lane < 2 * D) {
-        const int d = lane >> 1;
-        const unsigned half = reinterpret_cast<const unsigned *>(E)[((((d >> 1) * 64) + 63) * 2 + (d & 1)) * 2 + (lane & 1)];
-        __hip_atomic_store(a.lb + (size_t)tk * 32 + lane, ((unsigned long long)a.epoch << 32) | half, __ATOMIC_RELAXED,
+    // ---- L: publish the segment's end state(s) from rest, fetch the K predecessors' ------------------------------------
+    // (CPLX: two states per segment -- lanes 62 / 63 hold the re / im stream's; granule g belongs to stream g >> 5)
+    unsigned *cw = reinterpret_cast<unsigned *>(lds_raw + wave * kWaveStage + 64 * 16 * 8);   // behind the scan exchange, inside the (idle) image
+    if (lane < GR && (lane & 31) < 2 * D) {
+        const int d = (lane & 31) >> 1, src_lane = CPLX ? 62 + (lane >> 5) : 63;
+        const unsigned half = reinterpret_cast<const unsigned *>(E)[((((d >> 1) * 64) + src_lane) * 2 + (d & 1)) * 2 + (lane & 1)];
+        __hip_atomic_store(a.lb + (size_t)tk * GR + lane, ((unsigned long long)a.epoch << 32) | half, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
     if (seg > 0 && !(a.dbg & 4)) {
 #pragma unroll 1
-        for (int k0 = 0; k0 < a.K; k0 += 2) {
-            const int back = k0 + (lane >> 5) + 1;   // this lane's predecessor distance
+        for (int k0 = 0; k0 < a.K; k0 += 64 / GR) {
+            const int back = k0 + (CPLX ? 0 : (lane >> 5)) + 1;   // this lane's predecessor distance
+            const int gi = CPLX ? lane : (lane & 31);            // its granule
             unsigned got = 0;
-            if (back <= a.K && back <= seg && (lane & 31) < 2 * D) {
-                const unsigned long long *srcp = a.lb + (size_t)(tk - back) * 32 + (lane & 31);
+            if (back <= a.K && back <= seg && (gi & 31) < 2 * D) {
+                const unsigned long long *srcp = a.lb + (size_t)(tk - back) * GR + gi;
                 unsigned long long g = 0;
                 int spins = 0;
                 for (;;) {
@@ -271,13 +317,14 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
                 }
                 got = (unsigned)g;
             }
-            if (back <= kParMaxK) cw[(back - 1) * 32 + (lane & 31)] = got;
+            if (back <= kParMaxK) cw[(back - 1) * GR + gi] = got;
         }
         wave_lds_sync();
 
         // ---- C: z_j += Phi^j c,  c = sum_m Psi^m P_(s-1-m) ---------------------------------------------------------------
         double u[D];
-        const double *cwd = reinterpret_cast<const double *>(cw);
+        const double *cwd = reinterpret_cast<const double *>(cw) + (CPLX ? (lane & 1) * 16 : 0);   // (this lane's stream)
+        const int cj = lane / LS;   // chunk index inside the segment
 #pragma unroll
         for (int k = 0; k < NSEC; ++k) {
             const v2d_t t = *reinterpret_cast<const v2d_t *>(cwd + 2 * k);
@@ -289,7 +336,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
             double pm[D];
 #pragma unroll
             for (int k = 0; k < NSEC; ++k) {
-                const v2d_t t = *reinterpret_cast<const v2d_t *>(cwd + m * 16 + 2 * k);
+                const v2d_t t = *reinterpret_cast<const v2d_t *>(cwd + m * (GR / 2) + 2 * k);
                 pm[2 * k] = t[0];
                 pm[2 * k + 1] = t[1];
             }
@@ -297,7 +344,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         }
 #pragma unroll 1
         for (int l = 0; l < a.n_lv; ++l) {
-            if ((lane >> l) & 1) {
+            if ((cj >> l) & 1) {
                 double t2[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) t2[d] = 0.0;
@@ -306,7 +353,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
                 for (int d = 0; d < D; ++d) u[d] = t2[d];
             }
         }
-        if ((lane >> a.n_lv) == 0) {   // (Phi^j c is negligible for j >= 2^n_lv)
+        if ((cj >> a.n_lv) == 0) {   // (Phi^j c is negligible for j >= 2^n_lv)
 #pragma unroll
             for (int d = 0; d < D; ++d) z[d] += u[d];
         }
@@ -350,12 +397,8 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         if (!DEC && interior) {
             if (!(a.dbg & 8))
 #pragma unroll
-            for (int i = 0; i < St::per_thread; ++i) {
-                const int idx = i * 64 + lane;
-                const int r = idx / St::segs, sg = idx % St::segs;
-                const pre_t val = *reinterpret_cast<const pre_t *>(stage + r * St::pitch + sg * St::elems);
-                __builtin_nontemporal_store(val, reinterpret_cast<pre_t *>(yseg + (loff + i * kRowStep + p * kPiece)));
-            }
+            for (int i = 0; i < St::per_thread; ++i)
+                __builtin_nontemporal_store(image_get(i), reinterpret_cast<pre_t *>(yseg + (loff + i * kRowStep + p * kPiece * LS)));
             continue;
         }
         int64_t dq_run = 0;
@@ -363,11 +406,11 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 #pragma unroll 1
         for (int i = 0; i < St::per_thread; ++i) {
             const int idx = i * 64 + lane;
-            const int r = idx / St::segs, sg = idx % St::segs;
-            const int64_t g = (row0 + r) * T + (int64_t)p * kPiece + (int64_t)sg * St::elems;
-            const pre_t val = *reinterpret_cast<const pre_t *>(stage + r * St::pitch + sg * St::elems);
+            const int r = idx / USEG, sg = idx % USEG;
+            const int64_t g = (row0 + r) * T + (int64_t)p * kPiece + (int64_t)sg * (St::elems / LS);   // first sample of the unit
+            const pre_t val = image_get(i);
             const IO *tmp = reinterpret_cast<const IO *>(&val);
-            if (DEC) {
+            if (DEC && !CPLX) {
                 // decimating store (as in iir_fused_kernel): segment i of this lane starts a fixed number of samples after
                 // segment i - 1, so its (quotient, remainder) by dec follow from the first by adding (dec_dq, dec_dr)
                 if (i == 0) {
@@ -396,7 +439,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
             } else if (g < a.n) {
 #pragma unroll
                 for (int e = 0; e < St::elems; ++e)
-                    if (g + e < a.n) y[g + e] = tmp[e];
+                    if (g + e / LS < a.n) y[g * LS + e] = tmp[e];
             }
         }
     }
@@ -417,7 +460,7 @@ struct ParPlan {
     long double a1[8], a2[8], r0[8], r1[8], c0 = 0.0L;
     double na1[8], na2[8], al[8], be[8], gamma = 0.0;
     double kappa = 0.0, ir_err = 0.0;
-    ParTables tab[2];            // [0] float32 signals (T = 128), [1] float64 signals (T = 64)
+    ParTables tab[4];            // [0] float32 (T = 128), [1] float64 (T = 64), [2] complex64, [3] complex128 (32 chunks per segment)
     unsigned long long *lbg_dev = nullptr;
     size_t lbg_cap = 0;
     unsigned long long *ticket_dev = nullptr;
@@ -552,8 +595,9 @@ M2 m2mul(const M2 &x, const M2 &y)
 }
 long double m2max(const M2 &x) { return std::max(std::max(fabsl(x.m[0]), fabsl(x.m[1])), std::max(fabsl(x.m[2]), fabsl(x.m[3]))); }
 
-int par_tables(ParPlan &P, ParTables &tb, int T, long double negl, hipStream_t s)
+int par_tables(ParPlan &P, ParTables &tb, int T, int chunks, long double negl, hipStream_t s)
 {
+    const int LV = chunks == 64 ? 6 : 5;   // scan levels inside a wave segment of `chunks` chunks
     const int N = P.nsec;
     tb.T = T;
     std::vector<double> lvl((size_t)6 * N * 4), psi((size_t)(kParMaxK - 1) * N * 4), gt((size_t)T * 16, 0.0);
@@ -566,14 +610,14 @@ int par_tables(ParPlan &P, ParTables &tb, int T, long double negl, hipStream_t s
             sq = m2mul(sq, sq);
         }
         M2 pw = Phi;
-        for (int l = 0; l <= 6; ++l) {
+        for (int l = 0; l <= LV; ++l) {
             lvmax[l] = std::max(lvmax[l], m2max(pw));
             if (!std::isfinite((double)m2max(pw))) return 1;
-            if (l < 6)
+            if (l < LV)
                 for (int i = 0; i < 4; ++i) lvl[((size_t)l * N + k) * 4 + i] = (double)pw.m[i];
-            if (l < 6) pw = m2mul(pw, pw);
+            if (l < LV) pw = m2mul(pw, pw);
         }
-        const M2 Psi = pw;   // Phi^64
+        const M2 Psi = pw;   // Phi^chunks: the transition over one wave segment
         M2 pk = Psi;
         for (int m = 1; m <= kParMaxK; ++m) {
             psimax[m] = std::max(psimax[m], m2max(pk));
@@ -593,14 +637,14 @@ int par_tables(ParPlan &P, ParTables &tb, int T, long double negl, hipStream_t s
             g0 = g2;
         }
     }
-    tb.n_lv = 6;
-    for (int l = 6; l >= 0; --l)
+    tb.n_lv = LV;
+    for (int l = LV; l >= 0; --l)
         if (lvmax[l] < negl) tb.n_lv = std::min(tb.n_lv, l);
     tb.K = 0;
     for (int m = 1; m <= kParMaxK; ++m)
         if (psimax[m] < negl) { tb.K = m; break; }
     if (tb.K == 0) return 1;   // remembers more than kParMaxK segments
-    if (tb.n_lv < 6) tb.K = 1;
+    if (tb.n_lv < LV) tb.K = 1;
     SK_HIP(hipMalloc((void **)&tb.gt_dev, gt.size() * 8));
     SK_HIP(hipMalloc((void **)&tb.lvl_dev, lvl.size() * 8));
     SK_HIP(hipMalloc((void **)&tb.psi_dev, psi.size() * 8));
@@ -633,12 +677,12 @@ int iir_par_expand_host(const double *coef, int nsec, double *out, int *accepted
     return SKDSP_OK;
 }
 
-template <typename IO>
+template <typename IO, bool CPLX>
 static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
                       void *y, hipStream_t s, int dec)
 {
     const int T = tb.T;
-    const int64_t S = (int64_t)64 * T;
+    const int64_t S = (int64_t)(CPLX ? 32 : 64) * T;   // samples per wave segment
     const int64_t nseg = (n + S - 1) / S;
     SK_CHECK(nseg * nrow < (1 << 30), SKDSP_ERR_BADARG, "iir: too many segments");
     const int total = (int)(nseg * nrow);
@@ -647,7 +691,7 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
         SK_HIP(hipMemsetAsync(p->ticket_dev, 0, 8 * kParTickets, s));
         p->ticket_count = 0;
     }
-    const size_t need = (size_t)total * 32 * 8;
+    const size_t need = (size_t)total * (CPLX ? 64 : 32) * 8;
     if (need > p->lbg_cap) {
         if (p->lbg_dev) {
             SK_HIP(hipStreamSynchronize(s));
@@ -685,11 +729,11 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
         ParCoef<N> cf;                                                                                                  \
         for (int k = 0; k < N; ++k) { cf.na1[k] = p->na1[k]; cf.na2[k] = p->na2[k]; cf.al[k] = p->al[k]; cf.be[k] = p->be[k]; } \
         cf.gamma = p->gamma;                                                                                            \
-        if (a.dec > 1)                                                                                                  \
-            hipLaunchKernelGGL((iir_par_kernel<N, IO, true>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,               \
+        if (a.dec > 1 && !CPLX)                                                                                         \
+            hipLaunchKernelGGL((iir_par_kernel<N, IO, true && !CPLX, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf, \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);      \
         else                                                                                                            \
-            hipLaunchKernelGGL((iir_par_kernel<N, IO, false>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,              \
+            hipLaunchKernelGGL((iir_par_kernel<N, IO, false, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,        \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);      \
         break;                                                                                                          \
     }
@@ -706,8 +750,10 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
 }
 
 // returns 1 when the parallel form does not apply to this handle / call (nothing was launched)
-int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y, hipStream_t s, int dec)
+int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y, hipStream_t s, int dec,
+                   int interleaved)
 {
+    if (interleaved && (dec > 1 || nrow != 1)) return 1;
     if (h->order != 2 || h->nsec < 1 || h->nsec > 8) return 1;
     if (!h->par) {
         h->par = new ParPlan();
@@ -717,16 +763,18 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     ParPlan *p = h->par;
     if (p->state != 1) return 1;
     const bool dbl = dtype_double(h->dtype);
-    ParTables &tb = p->tab[dbl ? 1 : 0];
+    ParTables &tb = p->tab[(dbl ? 1 : 0) + (interleaved ? 2 : 0)];
     if (tb.T == 0) {
         // negligibility as in iir_scan.hip: 1e-30 for float64 signals, 1e-18 for float32 signals (a tenth of an ulp of the
         // float64 state the dropped term would be added to)
-        const int rc = par_tables(*p, tb, dbl ? SK_PAR_T32 / 2 : SK_PAR_T32, dbl ? 1e-30L : 1e-18L, s);
+        const int rc = par_tables(*p, tb, dbl ? SK_PAR_T32 / 2 : SK_PAR_T32, interleaved ? 32 : 64, dbl ? 1e-30L : 1e-18L, s);
         if (rc < 0) return rc;
     }
     if (tb.K == 0) return 1;
-    return dbl ? launch_par<double>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec)
-               : launch_par<float>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec);
+    if (interleaved)
+        return dbl ? launch_par<double, true>(h, p, tb, x, n, 1, 0, 0, y, s, 1) : launch_par<float, true>(h, p, tb, x, n, 1, 0, 0, y, s, 1);
+    return dbl ? launch_par<double, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec)
+               : launch_par<float, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec);
 }
 
 }  // namespace skdsp

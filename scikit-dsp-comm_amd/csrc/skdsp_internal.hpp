@@ -211,7 +211,7 @@ void iir_free(IirPlan *p);
 // Parallel-form single-pass scan (iir_par.hip): real signals, <= 8 biquads with simple poles, zero initial state, no state
 // output; nrow rows x_stride / y_stride elements apart in one launch.  Returns 1 when it does not apply (nothing launched).
 int iir_par_launch(IirHandle *h, const void *x_dev, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y_dev, hipStream_t s,
-                   int dec = 1);
+                   int dec = 1, int interleaved = 0);   // interleaved = 1: x / y interleaved complex, n complex samples, one row
 int iir_par_expand_host(const double *coef, int nsec, double *out, int *accepted);   // host-only (tests): [c0, (a1,a2,r0,r1) x nsec, kappa, ir_err]
 void iir_par_free(ParPlan *p);
 bool iir_shape_supported(int nsec, int order);

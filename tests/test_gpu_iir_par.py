@@ -241,3 +241,42 @@ def test_fir_rows_dev_strided():
     finally:
         xd.free()
         yd.free()
+
+
+# ---- interleaved complex signals: lanes alternate between the re and the im stream ------------------------------------
+@pytest.mark.parametrize("dt,n", [(np.complex64, 3_000_017), (np.complex64, 4096 * 3), (np.complex64, 4096 * 40 + 1), (np.complex64, 1031),
+                                  (np.complex128, 1_100_003), (np.complex128, 2048 * 5)])
+@pytest.mark.parametrize("filt", ["ellip8", "butter8rc12", "butter5", "biquad", "butter3", "narrow8"])
+def test_parallel_form_complex_vs_cascade_kernels_and_scipy(dt, n, filt):
+    from scipy import signal
+    sos = designs()[filt]
+    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+    xd = _ffi.DeviceArray(n, dt).fill_noise(41)
+    y1, y2 = _ffi.DeviceArray(n, dt), _ffi.DeviceArray(n, dt)
+    tol = TOL32 if dt == np.complex64 else TOL64
+    try:
+        with _ffi.option("iir_par", 1):
+            k.filter_dev(xd, y1)
+        with _ffi.option("iir_par", 0):
+            k.filter_dev(xd, y2)
+        w = min(n, 1 << 19)
+        for s0 in sorted({0, max(0, n // 2 - 12345), n - w}):
+            m = min(w, n - s0)
+            assert_close(y1.to_host(s0, m), y2.to_host(s0, m), tol, "parallel form vs cascade kernels @%d" % s0)
+        m = min(n, 150_000)
+        ref = signal.sosfilt(sos, xd.to_host(0, m).astype(np.complex128))
+        assert_close(y1.to_host(0, m), ref, tol, "head vs sosfilt")
+        if n > 400_000:
+            lead = 150_000
+            lo = n - m - lead
+            ref2 = signal.sosfilt(sos, xd.to_host(lo, n - lo).astype(np.complex128))
+            assert_close(y1.to_host(n - m, m), ref2[-m:], tol, "tail vs sosfilt")
+        first = y1.to_host(n - w, w)
+        with _ffi.option("iir_par", 1):
+            for _ in range(3):
+                k.filter_dev(xd, y1)
+        assert np.array_equal(y1.to_host(n - w, w), first)
+    finally:
+        xd.free()
+        y1.free()
+        y2.free()
