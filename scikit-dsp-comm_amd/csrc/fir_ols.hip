@@ -147,25 +147,27 @@ __device__ __forceinline__ void load_tile(const OlsArgs &A, int64_t tile, int t,
     }
 }
 
-__device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t, const cf *v)
+template <bool DEC> __device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t, const cf *v)
 {
     const int64_t out0 = tile * A.V;
     const bool full = A.aligned && out0 + A.V <= A.n;
 #if SKDSP_OLS_NOMEM
     if (A.n != -12345) return;
 #endif
-    if (A.dec > 1) {
+    if (DEC) {
         // decimating store: the full-rate convolution is computed (it is memory-bound, and cheaper than
         // Ntaps/dec direct taps per kept sample once Ntaps/dec exceeds a few dozen), 1/dec of it leaves
         const unsigned M = (unsigned)A.dec;
         const int64_t q0 = out0 / A.dec;                 // uniform
         const unsigned r0 = (unsigned)(out0 - q0 * A.dec);
+        int a0 = A.a0;   // (opaque copy: nothing of this path is hoisted out of the tile loop)
+        asm volatile("" : "+s"(a0));
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            if (a < A.a0) continue;
+            if (a < a0) continue;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const unsigned gl = r0 + 512u * (unsigned)(a - A.a0) + 2u * (unsigned)t + (unsigned)e;
+                const unsigned gl = r0 + 512u * (unsigned)(a - a0) + 2u * (unsigned)t + (unsigned)e;
                 const unsigned q = gl / M;
                 if (q * M == gl && out0 + (int64_t)(gl - r0) < A.n_keep) A.y[q0 + q] = v[2 * a + e];
             }
@@ -179,24 +181,41 @@ __device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t
         int tt = t;
         asm volatile("" : "+v"(tt));
         float4 *yp = reinterpret_cast<float4 *>(A.y + out0 + 2 * tt);
+        // one copy of the 16 - a0 stores per possible a0 (compile-time offsets and no predicates): with a run-time a0 hipcc
+        // hoisted sixteen (64-bit exec mask, 64-bit offset) pairs out of the tile loop -- 96 SGPRs, parked in VGPR lanes
+        // and fetched back with 139 v_readlane per tile
+        auto stores = [&](auto a0c) __attribute__((always_inline)) {
+            constexpr int A0 = decltype(a0c)::value;
 #pragma unroll
-        for (int a = 0; a < 16; ++a)
+            for (int a = A0; a < 16; ++a) {
 #if SKDSP_OLS_NT_ST
-            if (a >= A.a0) {
                 v4f_t nv;
                 nv.x = v[2 * a].x; nv.y = v[2 * a].y; nv.z = v[2 * a + 1].x; nv.w = v[2 * a + 1].y;
-                __builtin_nontemporal_store(nv, reinterpret_cast<v4f_t *>(yp) + (a - A.a0) * 256);
-            }
+                __builtin_nontemporal_store(nv, reinterpret_cast<v4f_t *>(yp) + (a - A0) * 256);
 #else
-            if (a >= A.a0) yp[(a - A.a0) * 256] = pack(v[2 * a], v[2 * a + 1]);
+                yp[(a - A0) * 256] = pack(v[2 * a], v[2 * a + 1]);
 #endif
+            }
+        };
+        switch (A.a0) {
+            case 1: stores(std::integral_constant<int, 1>{}); break;
+            case 2: stores(std::integral_constant<int, 2>{}); break;
+            case 3: stores(std::integral_constant<int, 3>{}); break;
+            case 4: stores(std::integral_constant<int, 4>{}); break;
+            case 5: stores(std::integral_constant<int, 5>{}); break;
+            case 6: stores(std::integral_constant<int, 6>{}); break;
+            case 7: stores(std::integral_constant<int, 7>{}); break;
+            default: stores(std::integral_constant<int, 8>{}); break;
+        }
     } else {
+        int a0 = A.a0;   // opaque copy: keeps the sixteen (mask, offset) pairs of this once-per-launch path out of the tile loop's prologue
+        asm volatile("" : "+s"(a0));
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            if (a < A.a0) continue;
+            if (a < a0) continue;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int64_t g = out0 + 512 * (a - A.a0) + 2 * t + e;
+                const int64_t g = out0 + 512 * (a - a0) + 2 * t + e;
                 if (g < A.n) A.y[g] = v[2 * a + e];
             }
         }
@@ -219,41 +238,46 @@ __device__ __forceinline__ void load_tile_real(const OlsArgs &A, int64_t pair, i
         asm volatile("" : "+v"(tt));
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
+            // v[2a] = the (column 0, column 1) pair of tile A, v[2a+1] of tile B: exactly what fwd_pass1_real takes
+            // (structure of arrays; ols_core.hpp) -- the loaded registers are used where they land
             const v2f_t ra = __builtin_nontemporal_load(reinterpret_cast<const v2f_t *>(xr + inA) + (unsigned)(a * 256 + tt));
             const v2f_t rb = __builtin_nontemporal_load(reinterpret_cast<const v2f_t *>(xr + inB) + (unsigned)(a * 256 + tt));
-            v[2 * a] = make_float2(ra.x, rb.x);
-            v[2 * a + 1] = make_float2(ra.y, rb.y);
+            v[2 * a] = make_float2(ra.x, ra.y);
+            v[2 * a + 1] = make_float2(rb.x, rb.y);
         }
     } else {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
+            float ra[2], rb[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int64_t ga = inA + 512 * a + 2 * t + e, gb = ga + A.V;
-                float re = 0.f, im = 0.f;
-                if (ga >= -A.n_hist && ga < A.n) re = xr[ga];
-                if (gb >= -A.n_hist && gb < A.n) im = xr[gb];
-                v[2 * a + e] = make_float2(re, im);
+                ra[e] = (ga >= -A.n_hist && ga < A.n) ? xr[ga] : 0.f;
+                rb[e] = (gb >= -A.n_hist && gb < A.n) ? xr[gb] : 0.f;
             }
+            v[2 * a] = make_float2(ra[0], ra[1]);
+            v[2 * a + 1] = make_float2(rb[0], rb[1]);
         }
     }
 }
 
-__device__ __forceinline__ void store_tile_real(const OlsArgs &A, int64_t pair, int t, const cf *v)
+template <bool DEC> __device__ __forceinline__ void store_tile_real(const OlsArgs &A, int64_t pair, int t, const cf *v)
 {
     float *yr = reinterpret_cast<float *>(A.y);
     const int64_t outA = (2 * pair) * A.V, outB = outA + A.V;
     const bool full = A.aligned && outB + A.V <= A.n;
-    if (A.dec > 1) {  // decimating store, see store_tile
+    if (DEC) {  // decimating store, see store_tile
         const unsigned M = (unsigned)A.dec;
         const int64_t qa = outA / A.dec, qb = outB / A.dec;
         const unsigned ra0 = (unsigned)(outA - qa * A.dec), rb0 = (unsigned)(outB - qb * A.dec);
+        int a0 = A.a0;   // (opaque copy: see store_tile)
+        asm volatile("" : "+s"(a0));
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            if (a < A.a0) continue;
+            if (a < a0) continue;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const unsigned loc = 512u * (unsigned)(a - A.a0) + 2u * (unsigned)t + (unsigned)e;
+                const unsigned loc = 512u * (unsigned)(a - a0) + 2u * (unsigned)t + (unsigned)e;
                 const unsigned ga = ra0 + loc, gb = rb0 + loc;
                 const unsigned ka = ga / M, kb = gb / M;
                 if (ka * M == ga && outA + (int64_t)loc < A.n_keep) yr[qa + ka] = v[2 * a + e].x;
@@ -265,22 +289,40 @@ __device__ __forceinline__ void store_tile_real(const OlsArgs &A, int64_t pair, 
     if (full) {
         int tt = t;  // (opaque copy: keeps the 28 store addresses from being hoisted out of the tile loop and spilled)
         asm volatile("" : "+v"(tt));
+        auto stores = [&](auto a0c) __attribute__((always_inline)) {   // (one copy per a0: see store_tile)
+            constexpr int A0 = decltype(a0c)::value;
 #pragma unroll
-        for (int a = 0; a < 16; ++a)
-            if (a >= A.a0) {
+            for (int a = A0; a < 16; ++a) {
+                // v[2a] = (A, B) of column 0, v[2a+1] = (A, B) of column 1: ONE register swap turns the two pairs into
+                // (A col 0, A col 1) and (B col 0, B col 1), the 8-byte store operands
+                float a0 = v[2 * a].x, b0 = v[2 * a].y, a1 = v[2 * a + 1].x, b1 = v[2 * a + 1].y;
+                asm("v_swap_b32 %0, %1" : "+v"(b0), "+v"(a1));
                 v2f_t ra, rb;
-                ra.x = v[2 * a].x; ra.y = v[2 * a + 1].x;
-                rb.x = v[2 * a].y; rb.y = v[2 * a + 1].y;
-                __builtin_nontemporal_store(ra, reinterpret_cast<v2f_t *>(yr + outA + 2 * tt) + (a - A.a0) * 256);
-                __builtin_nontemporal_store(rb, reinterpret_cast<v2f_t *>(yr + outB + 2 * tt) + (a - A.a0) * 256);
+                ra.x = a0; ra.y = b0;   // (b0 now holds A of column 1)
+                rb.x = a1; rb.y = b1;   // (a1 now holds B of column 0)
+                __builtin_nontemporal_store(ra, reinterpret_cast<v2f_t *>(yr + outA + 2 * tt) + (a - A0) * 256);
+                __builtin_nontemporal_store(rb, reinterpret_cast<v2f_t *>(yr + outB + 2 * tt) + (a - A0) * 256);
             }
+        };
+        switch (A.a0) {
+            case 1: stores(std::integral_constant<int, 1>{}); break;
+            case 2: stores(std::integral_constant<int, 2>{}); break;
+            case 3: stores(std::integral_constant<int, 3>{}); break;
+            case 4: stores(std::integral_constant<int, 4>{}); break;
+            case 5: stores(std::integral_constant<int, 5>{}); break;
+            case 6: stores(std::integral_constant<int, 6>{}); break;
+            case 7: stores(std::integral_constant<int, 7>{}); break;
+            default: stores(std::integral_constant<int, 8>{}); break;
+        }
     } else {
+        int a0 = A.a0;   // (opaque copy: see store_tile)
+        asm volatile("" : "+s"(a0));
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            if (a < A.a0) continue;
+            if (a < a0) continue;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int64_t ga = outA + 512 * (a - A.a0) + 2 * t + e, gb = ga + A.V;
+                const int64_t ga = outA + 512 * (a - a0) + 2 * t + e, gb = ga + A.V;
                 if (ga < A.n) yr[ga] = v[2 * a + e].x;
                 if (gb < A.n) yr[gb] = v[2 * a + e].y;
             }
@@ -292,9 +334,9 @@ template <bool REAL> __device__ __forceinline__ void load_any(const OlsArgs &A, 
 {
     if (REAL) load_tile_real(A, tile, t, v); else load_tile(A, tile, t, v);
 }
-template <bool REAL> __device__ __forceinline__ void store_any(const OlsArgs &A, int64_t tile, int t, const cf *v)
+template <bool REAL, bool DEC> __device__ __forceinline__ void store_any(const OlsArgs &A, int64_t tile, int t, const cf *v)
 {
-    if (REAL) store_tile_real(A, tile, t, v); else store_tile(A, tile, t, v);
+    if (REAL) store_tile_real<DEC>(A, tile, t, v); else store_tile<DEC>(A, tile, t, v);
 }
 
 // Persistent: gridDim.x = 2 workgroups per CU, each walks tiles blockIdx.x, +gridDim.x, ...
@@ -304,7 +346,8 @@ template <bool REAL> __device__ __forceinline__ void store_any(const OlsArgs &A,
 // tile-invariant inter-pass twiddles never touch the VM path (T1 as 15 register-resident
 // powers of W_4096^t, T2 as two 4 KiB LDS tables): vmcnt retires in order, so any table
 // load issued after a prefetch would force the prefetch to land first.
-template <bool TRACE, bool REAL>
+// DEC: the decimating store (multirate_FIR.dn) is its own instantiation, so that the plain filter carries none of its code
+template <bool TRACE, bool REAL, bool DEC>
 __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 {
     __shared__ float4 lds[kLdsUnits + 2 * kT2Units];
@@ -398,13 +441,13 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
             const int64_t next = tile + gridDim.x;
             cf nx[32];
             if (next < A.ntiles) load_any<REAL>(A, phys(next), t, nx);
-            store_any<REAL>(A, phys(tile), t, v);
+            store_any<REAL, DEC>(A, phys(tile), t, v);
 #pragma unroll
             for (int i = 0; i < 32; ++i) v[i] = nx[i];
             continue;
         }
 #endif
-        fwd_pass1(t, v, tw, lds);
+        if (REAL) fwd_pass1_real(t, v, tw, lds); else fwd_pass1(t, v, tw, lds);
         SK_STAMP(2);
         __syncthreads();
         SK_STAMP(3);
@@ -453,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 #elif SKDSP_OLS_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
-        store_any<REAL>(A, phys(tile), t, v);
+        store_any<REAL, DEC>(A, phys(tile), t, v);
 #if SKDSP_OLS_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
 #elif SKDSP_OLS_PRIO == 2
@@ -580,7 +623,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
         SK_HIP(hipMalloc((void **)&d, nw * 8));
         SK_HIP(hipMemsetAsync(d, 0, nw * 8, s));
         A.trace = d;
-        hipLaunchKernelGGL((ols_tile_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        hipLaunchKernelGGL((ols_tile_kernel<true, false, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
         std::vector<unsigned long long> hbuf(nw);
         SK_HIP(hipMemcpyAsync(hbuf.data(), d, nw * 8, hipMemcpyDeviceToHost, s));
         SK_HIP(hipStreamSynchronize(s));
@@ -594,8 +637,13 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
         return SKDSP_OK;
     }
 #endif
-    if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
-    else hipLaunchKernelGGL((ols_tile_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    if (A.dec > 1) {
+        if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((ols_tile_kernel<false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    } else {
+        if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((ols_tile_kernel<false, false, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    }
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
 }

@@ -142,13 +142,63 @@ template <bool INV> SK_HD cf madd_mi(cf p, cf d)
 }
 SK_HD cf cneg(cf a) { return make_float2(-a.x, -a.y); }
 #endif
+// ----------------------------------------------------------------------------
+// Two columns at once.  A thread owns the columns e = 0 / e = 1 of every row; `cf2` holds one complex value of EACH in
+// structure-of-arrays form: re = (re of column 0, re of column 1), im likewise.  The butterflies are the same packed
+// instructions as on (re, im) pairs -- an add is two v_pk_add_f32 for two columns, a constant twiddle four v_pk_* for two
+// columns -- so a DFT costs what two single-column DFTs cost.  Why it exists: a float32 signal rides two REAL tiles
+// A / B per complex tile (re = A, im = B), and an 8-byte load of A delivers exactly one `re` pair, of B one `im` pair:
+// the loaded registers ARE the cf2 operands, with no 2 x 2 register transposition behind the loads (which hipcc placed
+// right behind the prefetch and waited for: the float32 tile ran without a prefetch).  The per-column twiddle multiply
+// at the end of pass 1 reads its column through op_sel and writes an ordinary (re, im) pair, so the way back is free.
+// ----------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+struct cf2 { v2f re, im; };
+SK_HD cf2 make_cf2(cf re_pair, cf im_pair) { return cf2{V(re_pair), V(im_pair)}; }
+SK_HD cf2 cadd(cf2 a, cf2 b) { return cf2{a.re + b.re, a.im + b.im}; }
+SK_HD cf2 csub(cf2 a, cf2 b) { return cf2{a.re - b.re, a.im - b.im}; }
+SK_HD cf2 cneg(cf2 a) { return cf2{-a.re, -a.im}; }
+template <bool INV> SK_HD cf2 madd_mi(cf2 p, cf2 d) { return INV ? cf2{p.re - d.im, p.im + d.re} : cf2{p.re + d.im, p.im - d.re}; }
+template <bool INV> SK_HD cf2 cmul_k(cf2 a, float c, float s)
+{
+    return INV ? cf2{a.re * c - a.im * s, a.im * c + a.re * s} : cf2{a.re * c + a.im * s, a.im * c - a.re * s};
+}
+SK_HD cf column(cf2 a, int e) { return e ? make_float2(a.re.y, a.im.y) : make_float2(a.re.x, a.im.x); }
+// column COL of a, times w: an ordinary (re, im) pair out
+template <int COL> SK_HD cf soa_cmul(cf2 a, cf w)
+{
+    v2f r;
+    if (COL == 0)
+        asm("v_pk_mul_f32 %0, %1, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]"
+            : "=&v"(r) : "v"(a.re), "v"(a.im), "v"(V(w)));
+    else
+        asm("v_pk_mul_f32 %0, %1, %3 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+            : "=&v"(r) : "v"(a.re), "v"(a.im), "v"(V(w)));
+    return C(r);
+}
+#else
+struct cf2 { float re[2], im[2]; };
+SK_HD cf2 make_cf2(cf re_pair, cf im_pair) { return cf2{{re_pair.x, re_pair.y}, {im_pair.x, im_pair.y}}; }
+SK_HD cf2 cadd(cf2 a, cf2 b) { return cf2{{a.re[0] + b.re[0], a.re[1] + b.re[1]}, {a.im[0] + b.im[0], a.im[1] + b.im[1]}}; }
+SK_HD cf2 csub(cf2 a, cf2 b) { return cf2{{a.re[0] - b.re[0], a.re[1] - b.re[1]}, {a.im[0] - b.im[0], a.im[1] - b.im[1]}}; }
+SK_HD cf2 cneg(cf2 a) { return cf2{{-a.re[0], -a.re[1]}, {-a.im[0], -a.im[1]}}; }
+SK_HD cf column(cf2 a, int e) { return make_float2(a.re[e], a.im[e]); }
+SK_HD cf2 from_columns(cf c0, cf c1) { return cf2{{c0.x, c1.x}, {c0.y, c1.y}}; }
+template <bool INV> SK_HD cf2 madd_mi(cf2 p, cf2 d) { return from_columns(madd_mi<INV>(column(p, 0), column(d, 0)), madd_mi<INV>(column(p, 1), column(d, 1))); }
+template <bool INV> SK_HD cf2 cmul_k(cf2 a, float c, float s) { return from_columns(cmul_k<INV>(column(a, 0), c, s), cmul_k<INV>(column(a, 1), c, s)); }
+template <int COL> SK_HD cf soa_cmul(cf2 a, cf w) { return cmul(column(a, COL), w); }
+#endif
+
 // p - (-i) d forward == p + (+i) d
-template <bool INV> SK_HD cf msub_mi(cf p, cf d) { return madd_mi<!INV>(p, d); }
+template <bool INV, class E> SK_HD E msub_mi(E p, E d) { return madd_mi<!INV>(p, d); }
 // a * (-i) forward, a * (+i) inverse
 template <bool INV> SK_HD cf mul_mi(cf a) { return madd_mi<INV>(make_float2(0.f, 0.f), a); }
+template <bool INV> SK_HD cf2 mul_mi(cf2 a) { return madd_mi<INV>(make_cf2(make_float2(0.f, 0.f), make_float2(0.f, 0.f)), a); }
 
 // a * W_N^K  (forward, W = exp(-2 pi i / N)) or a * conj(W_N^K) (INV); K compile-time
-template <int N, int K, bool INV> SK_HD cf twmul(cf a)
+template <int N, int K, bool INV, class E> SK_HD E twmul(E a)
 {
     constexpr int k32 = ((K % N) * (32 / N)) & 31;
     constexpr float Ct[32] = SK_C32;
@@ -161,7 +211,7 @@ template <int N, int K, bool INV> SK_HD cf twmul(cf a)
 }
 
 // Xa = E + W_N^K O,  Xb = E - W_N^K O   (the -i / +i cases fold into the add)
-template <int N, int K, bool INV> SK_HD void bfly_tw(cf E, cf O, cf &Xa, cf &Xb)
+template <int N, int K, bool INV, class T> SK_HD void bfly_tw(T E, T O, T &Xa, T &Xb)
 {
     constexpr int k32 = ((K % N) * (32 / N)) & 31;
     if constexpr (k32 == 8) {
@@ -171,7 +221,7 @@ template <int N, int K, bool INV> SK_HD void bfly_tw(cf E, cf O, cf &Xa, cf &Xb)
         Xa = msub_mi<INV>(E, O);
         Xb = madd_mi<INV>(E, O);
     } else {
-        const cf t = twmul<N, K, INV>(O);
+        const T t = twmul<N, K, INV>(O);
         Xa = cadd(E, t);
         Xb = csub(E, t);
     }
@@ -189,8 +239,8 @@ template <int I, int E, class F> SK_HD void static_for(F &&f)
 // Out-of-place N-point DFT of x[0], x[S], x[2S], ... into X[0..N) (natural order).
 // INV = unnormalised inverse.  N in {1,2,4,8,16,32}.  Everything is unrolled at
 // compile time, so x/X live in registers.
-template <int N, int S, bool INV> struct Dft {
-    static SK_HD void run(const cf *x, cf *X)
+template <class T, int N, int S, bool INV> struct DftT {
+    static SK_HD void run(const T *x, T *X)
     {
         if constexpr (N == 1) {
             X[0] = x[0];
@@ -198,35 +248,35 @@ template <int N, int S, bool INV> struct Dft {
             X[0] = cadd(x[0], x[S]);
             X[1] = csub(x[0], x[S]);
         } else if constexpr (N == 4) {
-            const cf s02 = cadd(x[0], x[2 * S]), d02 = csub(x[0], x[2 * S]);
-            const cf s13 = cadd(x[S], x[3 * S]), d13 = csub(x[S], x[3 * S]);
+            const T s02 = cadd(x[0], x[2 * S]), d02 = csub(x[0], x[2 * S]);
+            const T s13 = cadd(x[S], x[3 * S]), d13 = csub(x[S], x[3 * S]);
             X[0] = cadd(s02, s13);
             X[2] = csub(s02, s13);
             X[1] = madd_mi<INV>(d02, d13);
             X[3] = msub_mi<INV>(d02, d13);
         } else if constexpr (N == 8) {
-            cf E[4], O[4];
-            Dft<4, 2 * S, INV>::run(x, E);
-            Dft<4, 2 * S, INV>::run(x + S, O);
+            T E[4], O[4];
+            DftT<T, 4, 2 * S, INV>::run(x, E);
+            DftT<T, 4, 2 * S, INV>::run(x + S, O);
             static_for<0, 4>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 bfly_tw<8, k, INV>(E[k], O[k], X[k], X[k + 4]);
             });
         } else {
             constexpr int M = N / 4;
-            cf S0[M], S1[M], S2[M], S3[M];
-            Dft<M, 4 * S, INV>::run(x, S0);
-            Dft<M, 4 * S, INV>::run(x + S, S1);
-            Dft<M, 4 * S, INV>::run(x + 2 * S, S2);
-            Dft<M, 4 * S, INV>::run(x + 3 * S, S3);
+            T S0[M], S1[M], S2[M], S3[M];
+            DftT<T, M, 4 * S, INV>::run(x, S0);
+            DftT<T, M, 4 * S, INV>::run(x + S, S1);
+            DftT<T, M, 4 * S, INV>::run(x + 2 * S, S2);
+            DftT<T, M, 4 * S, INV>::run(x + 3 * S, S3);
             static_for<0, M>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                const cf t0 = S0[k];
-                const cf t1 = twmul<N, k, INV>(S1[k]);
-                const cf t2 = twmul<N, 2 * k, INV>(S2[k]);
-                const cf t3 = twmul<N, 3 * k, INV>(S3[k]);
-                const cf s02 = cadd(t0, t2), d02 = csub(t0, t2);
-                const cf s13 = cadd(t1, t3), d13 = csub(t1, t3);
+                const T t0 = S0[k];
+                const T t1 = twmul<N, k, INV>(S1[k]);
+                const T t2 = twmul<N, 2 * k, INV>(S2[k]);
+                const T t3 = twmul<N, 3 * k, INV>(S3[k]);
+                const T s02 = cadd(t0, t2), d02 = csub(t0, t2);
+                const T s13 = cadd(t1, t3), d13 = csub(t1, t3);
                 X[k] = cadd(s02, s13);
                 X[k + 2 * M] = csub(s02, s13);
                 X[k + M] = madd_mi<INV>(d02, d13);
@@ -235,6 +285,7 @@ template <int N, int S, bool INV> struct Dft {
         }
     }
 };
+template <int N, int S, bool INV> using Dft = DftT<cf, N, S, INV>;
 
 // ----------------------------------------------------------------------------
 // LDS addressing (float4 units)
@@ -255,8 +306,13 @@ template <int K, bool INV> SK_HD cf mul_w8192(cf a)
     // cos/sin(2 pi k / 8192), k = 0..15
     constexpr float C[16] = {1.0f, 0.99999970586288223f, 0.99999882345170188f, 0.99999735276697821f, 0.99999529380957619f, 0.99999264658070719f, 0.9999894110819284f, 0.9999855873151432f, 0.99998117528260111f, 0.99997617498689761f, 0.99997058643097414f, 0.99996440961811828f, 0.9999576445519639f, 0.99995029123649048f, 0.99994234967602391f, 0.999933819875236f};
     constexpr float S[16] = {0.0f, 0.00076699031874270449f, 0.0015339801862847655f, 0.002300969151425805f, 0.0030679567629659761f, 0.0038349425697062275f, 0.0046019261204485705f, 0.0053689069639963425f, 0.0061358846491544753f, 0.0069028587247297558f, 0.007669828739531097f, 0.0084367942423697988f, 0.0092037547820598194f, 0.0099707099074180308f, 0.010737659167264491f, 0.011504602110422714f};
+    // plain scalar arithmetic on purpose: the 15 (cos, sin) pairs then travel as 32-bit LITERALS of v_mul_f32 / v_fmamk_f32
+    // (4 instructions per product) instead of as 30 more loop-invariant SGPRs next to the DFT twiddles -- with them the
+    // kernel needed ~130 SGPRs, hipcc parked the surplus in VGPR lanes and paid two v_readlane per use of ANY spilled
+    // constant (208 per tile).
     if constexpr (K == 0) return a;
-    else return cmul_k<INV>(a, C[K], S[K]);
+    else if constexpr (INV) return make_float2(a.x * C[K] - a.y * S[K], a.y * C[K] + a.x * S[K]);
+    else return make_float2(a.x * C[K] + a.y * S[K], a.y * C[K] - a.x * S[K]);
 }
 
 // pass 1 + twiddle + exchange-1 write.  thread t = 16 b + q.
@@ -276,6 +332,24 @@ SK_HD void fwd_pass1(int t, const cf *v, const cf *tw, float4 *lds)
     static_for<1, 16>([&](auto kc) {
         constexpr int k1 = decltype(kc)::value;
         lds[lds_unit(k1, b, q)] = pack(cmul(o0[k1], tw[k1]), cmul(mul_w8192<k1, false>(o1[k1]), tw[k1]));
+    });
+}
+
+// The same for a float32 signal riding two real tiles A / B (re = A, im = B): v[2a] = (A[512a+2t], A[512a+2t+1]) and
+// v[2a+1] = (B[512a+2t], B[512a+2t+1]) exactly as the 8-byte loads deliver them -- the (column 0, column 1) pairs of the
+// real and of the imaginary parts, i.e. cf2 operands.  Both columns go through ONE two-column DFT16; the twiddle
+// multiply picks its column through op_sel and leaves (re, im) pairs for the exchange image.
+SK_HD void fwd_pass1_real(int t, const cf *v, const cf *tw, float4 *lds)
+{
+    cf2 in[16], o[16];
+    SK_UNROLL
+    for (int a = 0; a < 16; ++a) in[a] = make_cf2(v[2 * a], v[2 * a + 1]);
+    DftT<cf2, 16, 1, false>::run(in, o);
+    const int b = t >> 4, q = t & 15;
+    lds[lds_unit(0, b, q)] = pack(column(o[0], 0), column(o[0], 1));
+    static_for<1, 16>([&](auto kc) {
+        constexpr int k1 = decltype(kc)::value;
+        lds[lds_unit(k1, b, q)] = pack(soa_cmul<0>(o[k1], tw[k1]), mul_w8192<k1, false>(soa_cmul<1>(o[k1], tw[k1])));
     });
 }
 
