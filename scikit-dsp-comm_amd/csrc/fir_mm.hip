@@ -134,19 +134,29 @@ __global__ __launch_bounds__(256) void fir_mm_kernel(const X *__restrict__ x, co
     for (int tile = wave; tile < ntiles; tile += 4) {
         // W[u][N]: window index of (column N, lag u) = q_ds * Nloc + (K - 1) - u
         const int eb = a.q_ds * (tile * 16 + ncol) + (K - 1) - klane;
-        // four interleaved accumulator sets: independent MFMA chains, and partial sums of K/4 terms each
-        // (a single f32 chain over all lags sits at 5e-7 of the float64 result for ~150 lags)
-        V ar[4], ai[4];
+        // NA interleaved accumulator sets: independent MFMA chains, and partial sums of K / NA terms each, added as a tree
+        // (a single f32 chain over all lags sits at 5e-7 of the float64 result for ~150 lags on NOISE; on coherent inputs
+        // -- DC through all-positive taps -- every addition of a chain rounds the same way and the error grows with the
+        // chain length: 8 sets instead of 4 for the float32 engines halve it; the float64 engine keeps 4)
+        constexpr int NA = sizeof(S) == 4 ? 8 : 4;
+        V ar[NA], ai[NA];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ar[c] = ai[c] = V{0, 0, 0, 0};
+        for (int c = 0; c < NA; ++c) ar[c] = ai[c] = V{0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < K4B; ++ks) {
             const X b = win[mm_phys(eb - 4 * ks)];
-            ar[ks & 3] = mm_mfma(areg[ks], mm_re(b), ar[ks & 3]);
-            if constexpr (CPLX) ai[ks & 3] = mm_mfma(areg[ks], mm_im(b), ai[ks & 3]);
+            ar[ks % NA] = mm_mfma(areg[ks], mm_re(b), ar[ks % NA]);
+            if constexpr (CPLX) ai[ks % NA] = mm_mfma(areg[ks], mm_im(b), ai[ks % NA]);
         }
-        const V ar0 = (ar[0] + ar[1]) + (ar[2] + ar[3]);
-        const V ai0 = (ai[0] + ai[1]) + (ai[2] + ai[3]);
+#pragma unroll
+        for (int w = NA / 2; w >= 1; w /= 2)
+#pragma unroll
+            for (int c = 0; c < w; ++c) {
+                ar[c] = ar[c] + ar[c + w];
+                ai[c] = ai[c] + ai[c + w];
+            }
+        const V ar0 = ar[0];
+        const V ai0 = ai[0];
         // rows 4 (lane >> 4) + i of column N: outputs m = RS N + row
         const int64_t N = S0 + tile * 16 + ncol;
         const int row0 = 4 * klane;

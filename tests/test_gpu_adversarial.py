@@ -33,7 +33,9 @@ from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 
-TOL32 = 1e-6
+TOL32 = 1e-6         # the north star's bound
+TOL32_PASS = 6e-7    # what the engines the library PICKS hold on coherent pass-band inputs (measured worst: 5.3e-7, the
+                     # 8192-point float32 FFT of the overlap-save tile): pinned here so that the margin cannot erode unseen
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -89,11 +91,11 @@ def signal_of(kind, n, cplx, f0=0.0123, first=0):
     return x.astype(np.complex64 if cplx else np.float32)
 
 
-def check(y, ref, what):
-    """pass-band bound: 1e-6 on max-abs error / max-abs reference and on relative L2"""
+def check(y, ref, what, tol=TOL32_PASS):
+    """pass-band bound on max-abs error / max-abs reference and on relative L2: 6e-7 (the north star asks 1e-6)"""
     e_max, e_l2 = rel_err(y, ref)
     _REPORT.append({"case": what, "max_over_peak": e_max, "rel_l2": e_l2})
-    assert e_max <= TOL32 and e_l2 <= TOL32, "%s: max/peak %.3g, rel-L2 %.3g > 1e-6" % (what, e_max, e_l2)
+    assert e_max <= tol and e_l2 <= tol, "%s: max/peak %.3g, rel-L2 %.3g > %.1g" % (what, e_max, e_l2, tol)
     return e_max, e_l2
 
 
@@ -127,7 +129,10 @@ def test_filter_coherent_inputs(engine, algo, cplx, taps, kind):
     if stop:
         check_forward(y, orc.fir_filter(b, x), b, x, what)
     else:
-        check(y, orc.fir_filter(b, x), what)
+        # the direct form FORCED onto a 4097-tap filter (AUTO takes overlap-save from 82 / 146 taps on) is one float32
+        # chain of 128 products per partial sum in the sliding-window kernel: 8e-7 on DC, the only case above 6e-7
+        forced_long = engine == "direct" and len(b) > 2000
+        check(y, orc.fir_filter(b, x), what, TOL32 if forced_long else TOL32_PASS)
 
 
 @pytest.mark.parametrize("kind", ["dc", "tone", "tone_m100dB", "stop"])
