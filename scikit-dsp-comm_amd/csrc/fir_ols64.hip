@@ -148,7 +148,8 @@ struct Ols64Args {
     int64_t n_keep;
 };
 
-template <bool REAL>
+// DEC: the decimating store (multirate_FIR.dn) is its own instantiation: the plain filter carries none of its code
+template <bool REAL, bool DEC>
 __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args A)
 {
     __shared__ cdd img[16 * kPitch64];
@@ -300,34 +301,67 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
         dft16_g(v);   // v[a] = y[256 a + t]
         asm volatile("" : "+v"(ts));
         // ---- store the last V points ----
-        if (REAL) {
-            const int64_t outA = (2 * tile) * A.V, outB = outA + A.V;
+        // whole tile(s) inside the signal, no decimation: one copy of the 16 - a0 unguarded stores per possible a0
+        // (compile-time offsets, no predicates -- as in fir_ols.hip: a run-time a0 made hipcc keep sixteen (exec mask, 64-bit
+        // offset) pairs alive across the tile loop, and with them it spilled 72 VGPRs in the complex kernel: 0.691 -> 0.578 ms)
+        const int64_t out0 = (REAL ? 2 * tile : tile) * A.V;
+        const bool full = !DEC && out0 + (REAL ? 2 : 1) * (int64_t)A.V <= A.n;
+        typedef double v2d_t __attribute__((ext_vector_type(2)));
+        if (full) {
+            auto stores = [&](auto a0c) __attribute__((always_inline)) {
+                constexpr int A0 = decltype(a0c)::value;
 #pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                if (a < A.a0) continue;
-                const int64_t loc = 256 * (a - A.a0) + ts;
-                const int64_t ga = outA + loc, gb = outB + loc;
-                if (A.dec > 1) {
-                    if (ga < A.n_keep && ga % A.dec == 0) A.y[ga / A.dec] = v[a].x;
-                    if (gb < A.n_keep && gb % A.dec == 0) A.y[gb / A.dec] = v[a].y;
-                } else {
-                    if (ga < A.n) __builtin_nontemporal_store(v[a].x, A.y + ga);
-                    if (gb < A.n) __builtin_nontemporal_store(v[a].y, A.y + gb);
+                for (int a = A0; a < 16; ++a) {
+                    if (REAL) {
+                        __builtin_nontemporal_store(v[a].x, A.y + out0 + 256 * (a - A0) + ts);
+                        __builtin_nontemporal_store(v[a].y, A.y + out0 + A.V + 256 * (a - A0) + ts);
+                    } else {
+                        v2d_t q;
+                        q.x = v[a].x; q.y = v[a].y;
+                        __builtin_nontemporal_store(q, reinterpret_cast<v2d_t *>(A.y) + out0 + 256 * (a - A0) + ts);
+                    }
                 }
+            };
+            switch (A.a0) {
+                case 1: stores(std::integral_constant<int, 1>{}); break;
+                case 2: stores(std::integral_constant<int, 2>{}); break;
+                case 3: stores(std::integral_constant<int, 3>{}); break;
+                case 4: stores(std::integral_constant<int, 4>{}); break;
+                case 5: stores(std::integral_constant<int, 5>{}); break;
+                case 6: stores(std::integral_constant<int, 6>{}); break;
+                case 7: stores(std::integral_constant<int, 7>{}); break;
+                default: stores(std::integral_constant<int, 8>{}); break;
             }
         } else {
-            const int64_t out0 = tile * A.V;
-            typedef double v2d_t __attribute__((ext_vector_type(2)));
+            int a0 = A.a0;   // (opaque copy: nothing of this path is hoisted out of the tile loop)
+            asm volatile("" : "+s"(a0));
+            if (REAL) {
+                const int64_t outA = out0, outB = outA + A.V;
 #pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                if (a < A.a0) continue;
-                const int64_t g = out0 + 256 * (a - A.a0) + ts;
-                v2d_t q;
-                q.x = v[a].x; q.y = v[a].y;
-                if (A.dec > 1) {
-                    if (g < A.n_keep && g % A.dec == 0) reinterpret_cast<v2d_t *>(A.y)[g / A.dec] = q;
-                } else if (g < A.n) {
-                    __builtin_nontemporal_store(q, reinterpret_cast<v2d_t *>(A.y) + g);
+                for (int a = 0; a < 16; ++a) {
+                    if (a < a0) continue;
+                    const int64_t loc = 256 * (a - a0) + ts;
+                    const int64_t ga = outA + loc, gb = outB + loc;
+                    if (DEC) {
+                        if (ga < A.n_keep && ga % A.dec == 0) A.y[ga / A.dec] = v[a].x;
+                        if (gb < A.n_keep && gb % A.dec == 0) A.y[gb / A.dec] = v[a].y;
+                    } else {
+                        if (ga < A.n) __builtin_nontemporal_store(v[a].x, A.y + ga);
+                        if (gb < A.n) __builtin_nontemporal_store(v[a].y, A.y + gb);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    if (a < a0) continue;
+                    const int64_t g = out0 + 256 * (a - a0) + ts;
+                    v2d_t q;
+                    q.x = v[a].x; q.y = v[a].y;
+                    if (DEC) {
+                        if (g < A.n_keep && g % A.dec == 0) reinterpret_cast<v2d_t *>(A.y)[g / A.dec] = q;
+                    } else if (g < A.n) {
+                        __builtin_nontemporal_store(q, reinterpret_cast<v2d_t *>(A.y) + g);
+                    }
                 }
             }
         }
@@ -419,8 +453,13 @@ int fir_ols64_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, voi
     A.n_keep = n;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     if (grid > ntiles) grid = ntiles;
-    if (real) hipLaunchKernelGGL(ols64_tile_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, A);
-    else hipLaunchKernelGGL(ols64_tile_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, A);
+    if (A.dec > 1) {
+        if (real) hipLaunchKernelGGL((ols64_tile_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((ols64_tile_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    } else {
+        if (real) hipLaunchKernelGGL((ols64_tile_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((ols64_tile_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    }
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
 }
