@@ -168,37 +168,42 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
 #pragma unroll
         for (int k3 = 0; k3 < (HREG ? 16 : 1); ++k3) hh[k3] = A.Hp[k3 * 256 + t];
     }
-#define SK_OLS64_H(k3) (HREG ? hh[HREG ? (k3) : 0] : A.Hp[(k3) * 256 + th])
 
     // x[in0 + 256 a + t] -> dst[a] (complex), or (xA, xB) of two real tiles; zero outside [-n_hist, n)
     auto load_tile = [&](int64_t tile, int tl, cdd *dst) __attribute__((always_inline)) {
         if (REAL) {
             const int64_t inA = (2 * tile) * A.V - A.ov, inB = inA + A.V;
             const bool interior = inA >= -A.n_hist && inB + kN64 <= A.n;
+            if (interior) {   // uniform base + 32-bit lane offset: SGPR-base addressing, no 64-bit address pair per access
+                const double *pa = A.x + inA, *pb = A.x + inB;
 #pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                const int64_t ga = inA + 256 * a + tl, gb = ga + A.V;
-                double re = 0.0, im = 0.0;
-                if (interior) {
-                    re = __builtin_nontemporal_load(A.x + ga);
-                    im = __builtin_nontemporal_load(A.x + gb);
-                } else {
+                for (int a = 0; a < 16; ++a)
+                    dst[a] = make_double2(__builtin_nontemporal_load(pa + (unsigned)(256 * a + tl)), __builtin_nontemporal_load(pb + (unsigned)(256 * a + tl)));
+            } else {
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    const int64_t ga = inA + 256 * a + tl, gb = ga + A.V;
+                    double re = 0.0, im = 0.0;
                     if (ga >= -A.n_hist && ga < A.n) re = A.x[ga];
                     if (gb >= -A.n_hist && gb < A.n) im = A.x[gb];
+                    dst[a] = make_double2(re, im);
                 }
-                dst[a] = make_double2(re, im);
             }
         } else {
             const int64_t in0 = tile * A.V - A.ov;
             const bool interior = in0 >= -A.n_hist && in0 + kN64 <= A.n;
             typedef double v2d_t __attribute__((ext_vector_type(2)));
+            if (interior) {
+                const v2d_t *px = reinterpret_cast<const v2d_t *>(A.x) + in0;
 #pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                const int64_t g = in0 + 256 * a + tl;
-                if (interior) {
-                    const v2d_t q = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(A.x) + g);
+                for (int a = 0; a < 16; ++a) {
+                    const v2d_t q = __builtin_nontemporal_load(px + (unsigned)(256 * a + tl));
                     dst[a] = make_double2(q.x, q.y);
-                } else {
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    const int64_t g = in0 + 256 * a + tl;
                     dst[a] = (g >= -A.n_hist && g < A.n) ? make_double2(A.x[2 * g], A.x[2 * g + 1]) : make_double2(0.0, 0.0);
                 }
             }
@@ -264,12 +269,27 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
             }
         }
         // ---- pass 3: thread (k1 = hi4, k2 = lo4): DFT16 over c; multiply by H ----
+        // (H streamed from L2 -- the two-real-tiles kernel -- is requested HERE, a whole DFT16 ahead of its use: requested at
+        // the multiply, behind the opaque copy of the thread index, every tile waited out an L2 round trip)
+        constexpr bool EARLY = !HREG && !DEC;   // (the decimating-store instantiation has no registers to spare for it)
+        if (EARLY) asm volatile("" : "+v"(th));
+        cdd hs[HREG ? 1 : 16];
+        if (EARLY) {
+#pragma unroll
+            for (int k3 = 0; k3 < 16; ++k3) hs[HREG ? 0 : k3] = A.Hp[k3 * 256 + th];
+        }
 #pragma unroll
         for (int c = 0; c < 16; ++c) v[c] = img[hi4 * kPitch64 + lo4 * 17 + c];
         dft16_f(v);   // Z[k3] at v[P16(k3)]
-        asm volatile("" : "+v"(th));
+        if (!EARLY) {
+            asm volatile("" : "+v"(th));
+            if (!HREG) {
 #pragma unroll
-        for (int k3 = 0; k3 < 16; ++k3) v[P16(k3)] = cmul(v[P16(k3)], SK_OLS64_H(k3));
+                for (int k3 = 0; k3 < 16; ++k3) hs[HREG ? 0 : k3] = A.Hp[k3 * 256 + th];
+            }
+        }
+#pragma unroll
+        for (int k3 = 0; k3 < 16; ++k3) v[P16(k3)] = cmul(v[P16(k3)], HREG ? hh[HREG ? k3 : 0] : hs[HREG ? 0 : k3]);
         // ---- inverse pass 3: over k3 -> c (takes the spectrum where it lies); the conj twiddle W_256^(c k2) is applied by the reader ----
         dft16_g(v);   // v[c] for thread (k1, k2)
 #pragma unroll
@@ -313,12 +333,12 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
 #pragma unroll
                 for (int a = A0; a < 16; ++a) {
                     if (REAL) {
-                        __builtin_nontemporal_store(v[a].x, A.y + out0 + 256 * (a - A0) + ts);
-                        __builtin_nontemporal_store(v[a].y, A.y + out0 + A.V + 256 * (a - A0) + ts);
+                        __builtin_nontemporal_store(v[a].x, (A.y + out0) + (unsigned)(256 * (a - A0) + ts));
+                        __builtin_nontemporal_store(v[a].y, (A.y + out0 + A.V) + (unsigned)(256 * (a - A0) + ts));
                     } else {
                         v2d_t q;
                         q.x = v[a].x; q.y = v[a].y;
-                        __builtin_nontemporal_store(q, reinterpret_cast<v2d_t *>(A.y) + out0 + 256 * (a - A0) + ts);
+                        __builtin_nontemporal_store(q, (reinterpret_cast<v2d_t *>(A.y) + out0) + (unsigned)(256 * (a - A0) + ts));
                     }
                 }
             };
