@@ -22,5 +22,5 @@ for dt, ntaps, M in ((np.complex64, 1024, 1), (np.float32, 1024, 1), (np.float32
     ms = timeit((lambda: k.filter_dev(xd, yd)) if M == 1 else (lambda: k.dn_dev(xd, yd, M)))
     esz = np.dtype(dt).itemsize
     bytes_ = esz * n + esz * (n // M)
-    print("%s %-9s %4d taps M=%d: %.4f ms  %.2f TB/s  %.1f %% of 8 TB/s" % (tag, np.dtype(dt).name, ntaps, M, ms, bytes_ / ms / 1e9, bytes_ / ms / 1e9 / 80), flush=True)
+    print("%s %-9s %4d taps M=%d: %.4f ms  %.2f TB/s  %.1f %% of 8 TB/s" % (tag, np.dtype(dt).name, ntaps, M, ms, bytes_ / ms / 1e9, bytes_ / ms / 1e6 / 80), flush=True)
     xd.free(); yd.free()
