@@ -195,9 +195,10 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
             const bool interior = in0 >= -A.n_hist && in0 + kN64 <= A.n;
             typedef double v2d_t __attribute__((ext_vector_type(2)));
             if (interior) {
-                // PLAIN loads here (the two-real-tiles kernel keeps nontemporal ones): neighbouring tiles share OV of their 4096
-                // points (a quarter at 1024 taps) and run on the same XCD at the same time -- a nontemporal request does not
-                // leave its line in that XCD's L2 for the neighbour (PMC: 1.25 x the input bytes read from HBM): 0.587 -> 0.549 ms
+                // PLAIN loads here (the two-real-tiles kernel keeps nontemporal ones; A/B on the same box, alternating): complex128
+                // 0.587 -> 0.549 ms, float64 0.320 -> 0.325 ms.  (Neighbouring tiles share OV of their 4096 points -- a quarter at
+                // 1024 taps -- and run on the same XCD at the same time; the FETCH_SIZE counter did NOT drop with the change, so
+                // whatever helps is not fewer fabric reads.)
                 const v2d_t *px = reinterpret_cast<const v2d_t *>(A.x) + in0;
 #pragma unroll
                 for (int a = 0; a < 16; ++a) {

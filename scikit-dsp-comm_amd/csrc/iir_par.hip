@@ -43,7 +43,10 @@
 
 namespace skdsp {
 
-constexpr int kParMaxK = 4;   // look-back depth served (segments the filter may remember)
+constexpr int kParMaxK = 8;   // look-back depth served (segments the filter may remember): 8 for float64 signals, 4 for float32 ones
+// (half the samples per segment and a 1e-30 instead of a 1e-18 threshold make a float64 segment "shorter" for the same filter; the look-back
+// words of K segments live behind the scan exchange inside the wave's stage image, which is twice as large for float64)
+constexpr int par_max_k(bool dbl) { return dbl ? 8 : 4; }
 constexpr int kParTickets = 16;   // segment dispensers per launch
 #ifndef SK_PAR_T32
 #define SK_PAR_T32 128   // samples per lane (float32 signals); float64 signals: half
@@ -102,7 +105,8 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     using St = Stage<IO>;
     constexpr int kRowBytes = St::pitch * (int)sizeof(IO);
     constexpr int kWaveStage = 64 * kRowBytes;                    // 9216 (float) / 17408 (double) bytes: also holds the 8 KiB scan exchange
-    static_assert(kWaveStage >= 64 * 16 * 8 + kParMaxK * 64 * 4, "scan exchange + look-back words must fit the wave's stage image");
+    constexpr int KMAX = par_max_k(sizeof(IO) == 8);
+    static_assert(kWaveStage >= 64 * 16 * 8 + KMAX * 64 * 4, "scan exchange + look-back words must fit the wave's stage image");
     __shared__ __attribute__((aligned(16))) char lds_raw[4 * kWaveStage];
     __shared__ double gl[(T / 4) * 64];
     __shared__ int base_sh;
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
                 }
                 got = (unsigned)g;
             }
-            if (back <= kParMaxK) cw[(back - 1) * GR + gi] = got;
+            if (back <= KMAX) cw[(back - 1) * GR + gi] = got;
         }
         wave_lds_sync();
 
@@ -451,7 +455,7 @@ struct ParTables {
     int n_lv = 0, K = 0;         // K = 0: the filter remembers more than kParMaxK segments of this length (not served)
     double *gt_dev = nullptr;    // G in MFMA A-operand order [T / 4][64]
     double *lvl_dev = nullptr;   // Phi^(2^l), l = 0..5: [6][nsec][4]
-    double *psi_dev = nullptr;   // Psi^m, m = 1..kParMaxK-1, Psi = Phi^64: [3][nsec][4]
+    double *psi_dev = nullptr;   // Psi^m, m = 1..kParMaxK-1, Psi = Phi^(chunks per segment): [kParMaxK - 1][nsec][4]
 };
 
 struct ParPlan {
@@ -595,7 +599,7 @@ M2 m2mul(const M2 &x, const M2 &y)
 }
 long double m2max(const M2 &x) { return std::max(std::max(fabsl(x.m[0]), fabsl(x.m[1])), std::max(fabsl(x.m[2]), fabsl(x.m[3]))); }
 
-int par_tables(ParPlan &P, ParTables &tb, int T, int chunks, long double negl, hipStream_t s)
+int par_tables(ParPlan &P, ParTables &tb, int T, int chunks, long double negl, int kmax, hipStream_t s)
 {
     const int LV = chunks == 64 ? 6 : 5;   // scan levels inside a wave segment of `chunks` chunks
     const int N = P.nsec;
@@ -641,7 +645,7 @@ int par_tables(ParPlan &P, ParTables &tb, int T, int chunks, long double negl, h
     for (int l = LV; l >= 0; --l)
         if (lvmax[l] < negl) tb.n_lv = std::min(tb.n_lv, l);
     tb.K = 0;
-    for (int m = 1; m <= kParMaxK; ++m)
+    for (int m = 1; m <= kmax; ++m)
         if (psimax[m] < negl) { tb.K = m; break; }
     if (tb.K == 0) return 1;   // remembers more than kParMaxK segments
     if (tb.n_lv < LV) tb.K = 1;
@@ -767,7 +771,7 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     if (tb.T == 0) {
         // negligibility as in iir_scan.hip: 1e-30 for float64 signals, 1e-18 for float32 signals (a tenth of an ulp of the
         // float64 state the dropped term would be added to)
-        const int rc = par_tables(*p, tb, dbl ? SK_PAR_T32 / 2 : SK_PAR_T32, interleaved ? 32 : 64, dbl ? 1e-30L : 1e-18L, s);
+        const int rc = par_tables(*p, tb, dbl ? SK_PAR_T32 / 2 : SK_PAR_T32, interleaved ? 32 : 64, dbl ? 1e-30L : 1e-18L, par_max_k(dbl), s);
         if (rc < 0) return rc;
     }
     if (tb.K == 0) return 1;

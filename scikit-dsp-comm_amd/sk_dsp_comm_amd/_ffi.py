@@ -276,6 +276,18 @@ class DeviceArray:
         check(load().skdsp_memcpy_d2h(_ptr(out), ctypes.c_void_p(self.ptr + start * esz), out.nbytes))
         return out
 
+    def window(self, start, count):
+        """A non-owning view of samples [start, start + count) (kernels that write a slice of a larger device buffer)."""
+        if start < 0 or start + count > self.n:
+            raise ValueError("window outside the device array")
+        v = object.__new__(DeviceArray)
+        v.n, v.code, v.dtype, v.headroom, v._pad = int(count), self.code, self.dtype, 0, 0
+        v._base = None
+        v.ptr = self.ptr + int(start) * self.dtype.itemsize
+        v._fin = lambda: None
+        v._owner = self   # keeps the allocation alive
+        return v
+
     def fill_noise(self, seed, first_index=0):
         check(load().skdsp_fill_noise_dev(ctypes.c_void_p(self.ptr), self.n, self.code, int(seed), int(first_index)))
         return self

@@ -280,3 +280,51 @@ def test_parallel_form_complex_vs_cascade_kernels_and_scipy(dt, n, filt):
         xd.free()
         y1.free()
         y2.free()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
+def test_parallel_form_unaligned_and_tiny(dt):
+    """Device pointers that are only element-aligned (a window starting at an odd sample: every segment takes the guarded
+    staging path) and very short signals (one partly filled segment)."""
+    from scipy import signal
+    sos = designs()["cheby6"]
+    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+    wide = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    tol = TOL32 if dt in (np.float32, np.complex64) else TOL64
+    n = 70_001
+    xd = _ffi.DeviceArray(n + 8, dt).fill_noise(5)
+    yd = _ffi.DeviceArray(n + 8, dt)
+    try:
+        for off in (1, 3):
+            xv, yv = xd.window(off, n), yd.window(off, n)
+            k.filter_dev(xv, yv)
+            ref = signal.sosfilt(sos, xv.to_host().astype(wide))
+            assert_close(yv.to_host(), ref, tol, "offset %d" % off)
+        for m in (1, 2, 63, 129):
+            xv, yv = xd.window(0, m), yd.window(0, m)
+            k.filter_dev(xv, yv)
+            assert_close(yv.to_host(), signal.sosfilt(sos, xv.to_host().astype(wide)), tol, "n = %d" % m)
+    finally:
+        xd.free()
+        yd.free()
+
+
+def test_rows_edge_shapes():
+    """Rows shorter than the filter, a single row, a single column."""
+    from scipy import signal
+    b = signal.firwin(300, 0.2)
+    sos = designs()["butter5"]
+    rng = np.random.default_rng(8)
+    for shape in ((5, 17), (1, 4000), (4000, 1), (2, 299)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        yf = mrh.multirate_FIR(b).filter(x)
+        yi = mrh.multirate_IIR(sos).filter(x)
+        assert yf.shape == x.shape and yi.shape == x.shape
+        ref_f = signal.lfilter(b, [1], x.astype(np.float64), axis=-1)
+        if shape[-1] < 50:
+            # rows that end inside the filter's first, tiny taps: the OUTPUT is 1e-4 of the input, and float32 filtering holds
+            # 1e-6 of the input-sized partial sums (DESIGN.md 2a: the forward-error bound), not of such an output
+            assert np.max(np.abs(yf - ref_f)) <= TOL32 * np.sum(np.abs(b)) * np.max(np.abs(x)), shape
+        else:
+            assert_close(yf, ref_f, TOL32, "fir %s" % (shape,))
+        assert_close(yi, signal.sosfilt(sos, x.astype(np.float64), axis=-1), TOL32, "iir %s" % (shape,))

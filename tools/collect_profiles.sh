@@ -8,7 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$R
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 fir1024c128; do
+for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python $ROOT/bench.py --workload $w --no-cpu-baseline --no-other-configs > /dev/null 2>&1
   cp $OUT/trace_$w/*/*kernel_stats.csv $OUT/kernel_stats_$w.csv
   rm -rf $OUT/trace_$w
@@ -28,8 +28,12 @@ for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 fir1024c128; do
 done
 cd $ROOT
 python bench.py > $OUT/bench_fir1024.json 2>$OUT/bench_fir1024.err
-for w in updn43 iir8 fir127 iir8tp iir8cas iirlp8 fir1024c128; do
+for w in updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; do
   python bench.py --workload $w --no-other-configs > $OUT/bench_$w.json 2>/dev/null
 done
 python bench.py --scaling strong --total-log2n 30 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_fir1024_2p30_one_gpu.json 2>/dev/null
+python tools/ab_iir_par.py 26 > $OUT/ab_iir_par.txt 2>&1
+python tools/time_fir_shapes.py > $OUT/fir_shapes.txt 2>&1
+python tools/time_fir_c128.py > $OUT/fir_f64.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_dp_pipes.hip -o /tmp/ubench_dp_pipes 2>/dev/null && /tmp/ubench_dp_pipes > $OUT/ubench_dp_pipes.txt 2>&1
 ls -la $OUT
