@@ -571,6 +571,8 @@ def _sized_sample(run, first, n_max, seconds):
     run(first)
     dt = max(time.perf_counter() - t0, 1e-6)
     m = int(min(n_max, max(first, first * seconds / dt)))
+    if m >= 0.75 * n_max:
+        m = n_max        # close enough to the whole workload: run all of it, so that the figure is not a partial-sample one
     t0 = time.perf_counter()
     run(m)
     return m, time.perf_counter() - t0
