@@ -334,6 +334,71 @@ def timed_steps(w, K, W, settle_s, tr, _ffi):
     return tr.allreduce_max(t1 - t0), tr.allreduce_max(ev_ms), (t1 - t0, ev_ms)
 
 
+def _smi_sample():
+    """(board power W, power cap W, shader clock MHz) from one rocm-smi call; None where it could not be read."""
+    import re, subprocess
+    try:
+        txt = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower", "--showclocks"], capture_output=True, text=True, timeout=30).stdout
+    except Exception:
+        return None, None, None
+    def grab(pat):
+        m = re.search(pat, txt)
+        return float(m.group(1)) if m else None
+    return (grab(r"Current Socket Graphics Package Power \(W\):\s*([0-9.]+)") or grab(r"Average Graphics Package Power \(W\):\s*([0-9.]+)"),
+            grab(r"Max Graphics Package Power \(W\):\s*([0-9.]+)"), grab(r"sclk clock level:[^(]*\(([0-9.]+)Mhz\)"))
+
+
+def board_state_of(w, seconds, _ffi):
+    """Board power and shader clock (rocm-smi, a second thread) while the same step runs back to back for `seconds`,
+    right after the timed region.  The streaming kernels here run AT the board power cap: the shader clock, and with it the
+    time per step, is what the firmware leaves under that cap, which is why instruction-level changes that do not save
+    energy do not move these numbers."""
+    import threading
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            samples.append(_smi_sample())
+            stop.wait(0.2)
+    th = threading.Thread(target=sampler)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        w.step()
+    _ffi.sync()
+    th.start()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(100):
+            w.step()
+        _ffi.sync()
+    stop.set()
+    th.join()
+    pw = sorted(v[0] for v in samples if v[0] is not None)
+    ck = sorted(v[2] for v in samples if v[2] is not None)
+    cap = [v[1] for v in samples if v[1] is not None]
+    if not pw:
+        return {"skipped": "rocm-smi gave no reading on this box"}
+    return {"power_w": pw[len(pw) // 2], "power_cap_w": cap[0] if cap else None, "sclk_mhz": ck[len(ck) // 2] if ck else None,
+            "sclk_max_mhz": 2400, "samples": len(pw),
+            "what": "median rocm-smi reading while this step runs back to back for %.1f s after the timed region" % seconds}
+
+
+def device_copy_of(w, _ffi, reps=40):
+    """What this board streams when it does nothing else: hipMemcpyAsync device-to-device of as many bytes as the workload reads,
+    counted like the roofline counts (bytes read + bytes written), timed with HIP events on the same stream."""
+    import ctypes
+    nbytes = int(min(w.xd.n * w.xd.dtype.itemsize, w.yd.n * w.yd.dtype.itemsize))
+    cp = _ffi.load().skdsp_memcpy_d2d
+    dst, src = ctypes.c_void_p(w.yd.ptr), ctypes.c_void_p(w.xd.ptr)
+    for _ in range(10):
+        _ffi.check(cp(dst, src, nbytes))
+    _ffi.sync()
+    _ffi.timer_start()
+    for _ in range(reps):
+        _ffi.check(cp(dst, src, nbytes))
+    ms = _ffi.timer_stop() / reps
+    return {"GBps": 2 * nbytes / ms / 1e6, "ms": ms, "bytes_copied": nbytes, "what": "hipMemcpyAsync device-to-device, read + written bytes"}
+
+
 def roofline_of(w, ev_ms, K, log2n_for_traffic):
     t_kernel = ev_ms * 1e-3 / K  # average launch (+ halo) duration from HIP events
     achieved = w.alg_bytes / t_kernel / 1e9
@@ -388,6 +453,7 @@ def main():
     ap.add_argument("--other-steps", type=int, default=100)
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="target CPU time of each baseline sample")
     ap.add_argument("--launch-timeout", type=float, default=1500.0)
+    ap.add_argument("--board-seconds", type=float, default=1.5, help="0: skip the power / clock reading and the device-copy reference")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -411,6 +477,15 @@ def main():
 
     w = make_workload(args.workload, n, rank, world, tr, _ffi, sharding)
     elapsed, ev_ms, mine = timed_steps(w, K, W, args.settle_seconds, tr, _ffi)
+
+    board = copy_ref = None
+    if world == 1 and args.board_seconds > 0:   # (before anything else touches the outputs: the parity check reads them first)
+        try:
+            board = board_state_of(w, args.board_seconds, _ffi)
+        except Exception as e:
+            board = {"skipped": "%s: %s" % (type(e).__name__, e)}
+        w.step()
+        _ffi.sync()
 
     per_rank = None
     if world > 1:
@@ -468,6 +543,8 @@ def main():
         dp = dp_pipe_of(w, ev_ms, K, info["compute_units"])
         if dp is not None:
             out["fp64_pipe"] = dp
+        if board is not None:
+            out["board"] = board
         if per_rank is not None:
             out["per_rank"] = per_rank
         if check is not None:
@@ -477,6 +554,14 @@ def main():
             out["parity_what"] = ("every rank: first 2048 outputs of its shard (they consume the %s from rank r-1) and one interior "
                                   "window vs the CPU oracle on inputs regenerated by global index; max over ranks; tolerance %g"
                                   % ("Ntaps-1 halo" if w.shard[0] == "fir" else "handed-over filter state", PARITY_TOL))
+
+    if rank == 0 and world == 1 and args.board_seconds > 0:   # (after the parity check: the copy overwrites the outputs)
+        try:
+            copy_ref = device_copy_of(w, _ffi)
+            out["device_copy"] = copy_ref
+            out["roofline"]["frac_of_device_copy"] = out["roofline"]["achieved"] / copy_ref["GBps"]
+        except Exception as e:
+            out["device_copy"] = {"skipped": "%s: %s" % (type(e).__name__, e)}
 
     # ------------------------------------------- CPU baselines (rank 0 of a 1-GPU run only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -505,6 +590,9 @@ def main():
                 dp = dp_pipe_of(o, ev, Ko, info["compute_units"])
                 if dp is not None:
                     others[name]["fp64_pipe"] = dp
+                if args.board_seconds > 0:
+                    b = board_state_of(o, min(args.board_seconds, 1.0), _ffi)
+                    others[name]["board"] = {k: b.get(k) for k in ("power_w", "sclk_mhz")} if "power_w" in b else b
                 free_workload(o)
             except Exception as e:  # a broken side config must not take the headline line with it
                 others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -520,7 +608,7 @@ def main():
 # kernel sources whose change makes a committed PMC measurement stale (workload -> files under scikit-dsp-comm_amd/csrc)
 TRAFFIC_SOURCES = {
     "fir1024": ["fir_ols.hip", "ols_core.hpp"], "fir127": ["fir_bx.hip"], "updn43": ["fir_bx.hip"],
-    "fir1024c128": ["fir_ols64.hip"], "iir8": ["iir_par.hip"], "iirlp8": ["iir_par.hip"],
+    "fir1024c128": ["fir_ols64.hip"], "iir8": ["iir_par.hip"], "iirlp8": ["iir_par.hip"], "iir8c64": ["iir_par.hip"],
     "iir8cas": ["iir_fused.hip", "iir_common.hpp"], "iir8tp": ["iir_scan.hip", "iir_common.hpp"],
 }
 

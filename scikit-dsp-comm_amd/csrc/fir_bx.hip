@@ -31,7 +31,7 @@
 #define SK_BX_NT_ST 1  // nontemporal output stores: 0.317 -> 0.312 ms (config 3), 0.1365 -> 0.1243 ms (127-tap float32); nontemporal window LOADS cost 25 %: neighbours share halos through the cache
 #endif
 #ifndef SK_BX_PRIO
-#define SK_BX_PRIO 1  // raised wave priority while stores and the window prefetch are issued: config 3 0.3214 -> 0.3154 ms
+#define SK_BX_PRIO 1  // raised wave priority while stores and the window prefetch are issued: config 3 0.3214 -> 0.3154 ms (priority over the whole split / store / load phase, none at all, or the two workgroups of a CU taking turns: the same within 0.5 %)
 #endif
 #ifndef SK_BX_NT_LD
 #define SK_BX_NT_LD 0
@@ -62,17 +62,45 @@ struct BxArgs {
     // s col mod 16 shifted by one): 2-way conflicts on a third of the reads, 42 % of the LDS cycles of L/M = 4/3
     // (s = 3).  With every second column both row sets hit the eight EVEN (odd) residues exactly once: none.
     int eo;
+#ifdef SK_BX_TRACE_BUILD  // developer build (tools/bx_trace.py): [workgroup][iteration < 64][wave][10]: 9 s_memtime stamps (the ninth: prefetched window arrived) + (XCC_ID << 32 | HW_ID) of one launch
+    unsigned long long *trace;
+#endif
 };
 
-// (a, b) -> three packed bf16 pairs, a in the low half: a = a1 + a2 + a3 exactly (24 = 3 x 8 mantissa bits)
+// (a, b) -> three packed bf16 pairs, a in the low half: a = a1 + a2 + a3 exactly (24 = 3 x 8 mantissa bits).
+// The residuals are formed with SCALAR subtractions on purpose (SK_BX_PK_SPLIT=1: the packed form, half the instructions):
+// v_pk_add_f32 runs on the datapath the matrix pipe uses, so while the other workgroup of the CU is in its MFMA phase a packed
+// split does not advance at all (tools/bx_trace.py: the split of one workgroup ended ~240 clocks after the partner's last MFMA,
+// every window, which is what locked the two workgroups of a CU in phase).
+#ifndef SK_BX_PK_SPLIT
+#define SK_BX_PK_SPLIT 0
+#endif
 __device__ __forceinline__ void bx_split2(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3)
 {
+#if SK_BX_PK_SPLIT
     v2f_bx v = {a, b};
     p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, v2bf_bx));
     v2f_bx r = {a - __uint_as_float(p1 << 16), b - __uint_as_float(p1 & 0xffff0000u)};
     p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, v2bf_bx));
     v2f_bx r2 = {r.x - __uint_as_float(p2 << 16), r.y - __uint_as_float(p2 & 0xffff0000u)};
     p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, v2bf_bx));
+#else
+    auto cvt = [](float lo, float hi) -> unsigned {
+        unsigned p;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(lo), "v"(hi));
+        return p;
+    };
+    auto sub = [](float x, unsigned piece) -> float {   // (an asm statement: hipcc's SLP vectoriser would pair two of these into v_pk_add_f32)
+        float r;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(piece));
+        return r;
+    };
+    p1 = cvt(a, b);
+    const float ra = sub(a, p1 << 16), rb = sub(b, p1 & 0xffff0000u);
+    p2 = cvt(ra, rb);
+    const float sa = sub(ra, p2 << 16), sb = sub(rb, p2 & 0xffff0000u);
+    p3 = cvt(sa, sb);
+#endif
 }
 
 __device__ __forceinline__ v4f_bx bx_mfma(uint4 a, uint4 b, v4f_bx c)
@@ -189,13 +217,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (fast) store_window();
     else stage_window_slow(wdx);
     __syncthreads();
-    {
-        const int64_t wnext = wdx + gridDim.x;
-        fast = wnext < nwin && interior(wnext);
-        if (fast) load_window(wnext);
-    }
+    int64_t wnext = wdx + gridDim.x;
+    fast = wnext < nwin && interior(wnext);
+    if (fast) load_window(wnext);
+#ifdef SK_BX_TRACE_BUILD
+    unsigned long long stamp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int it = 0;
+#define BX_STAMP(k) stamp[k] = __builtin_readcyclecounter();
+#else
+#define BX_STAMP(k)
+#endif
 #pragma unroll 1
-    for (; wdx < nwin; wdx += gridDim.x) {
+    for (; wdx < nwin;) {
+        BX_STAMP(0)
         const int64_t S0 = wdx * a.NS;  // first column of this window
         v4f_bx big[RT][C], small[RT][C];
         // column (within the window) of tile ct, tile row r
@@ -260,20 +294,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float *yb = y + m_base * C;
             const int64_t left = a.n_out - m_base;
             const int rem = left > (int64_t)0x7fffffff ? 0x7fffffff : (left < 0 ? 0 : (int)left);
+            // (scalar adds through asm: hipcc pairs them into v_pk_add_f32, which waits for the matrix pipe -- see bx_split2)
+            auto sum = [](float u, float w) -> float {
+                float r;
+                asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(w));
+                return r;
+            };
             auto put = [&](int rt, int i, int off) __attribute__((always_inline)) {
 #if SK_BX_NT_ST
                 if (CPLX) {
-                    v2f_bx o = {big[rt][0][i] + small[rt][0][i], big[rt][C - 1][i] + small[rt][C - 1][i]};
+                    v2f_bx o = {sum(big[rt][0][i], small[rt][0][i]), sum(big[rt][C - 1][i], small[rt][C - 1][i])};
                     __builtin_nontemporal_store(o, reinterpret_cast<v2f_bx *>(yb + 2 * off));
                 } else {
-                    __builtin_nontemporal_store(big[rt][0][i] + small[rt][0][i], yb + off);
+                    __builtin_nontemporal_store(sum(big[rt][0][i], small[rt][0][i]), yb + off);
                 }
 #else
                 if (CPLX)
                     *reinterpret_cast<float2 *>(yb + 2 * off) =
-                        make_float2(big[rt][0][i] + small[rt][0][i], big[rt][C - 1][i] + small[rt][C - 1][i]);
+                        make_float2(sum(big[rt][0][i], small[rt][0][i]), sum(big[rt][C - 1][i], small[rt][C - 1][i]));
                 else
-                    yb[off] = big[rt][0][i] + small[rt][0][i];
+                    yb[off] = sum(big[rt][0][i], small[rt][0][i]);
 #endif
             };
 #ifdef SK_BX_NOSTORE
@@ -307,14 +347,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __builtin_amdgcn_s_setprio(0);
 #endif
         }
+        BX_STAMP(1)
         const bool has_last = ct < ntiles;
         if (has_last) mma_tile(ct);
+        BX_STAMP(2)
         __syncthreads();  // everyone is done reading the planes
-        const int64_t wnext = wdx + gridDim.x;
+        BX_STAMP(3)
         if (wnext < nwin) {
-            if (fast) store_window();
-            else stage_window_slow(wnext);
+            if (fast) {
+#ifdef SK_BX_TRACE_BUILD
+#pragma unroll
+                for (int h = 0; h < UPT; ++h)
+#pragma unroll
+                    for (int w = 0; w < F4; ++w) asm volatile("" : "+v"(pre[h][w].x), "+v"(pre[h][w].y), "+v"(pre[h][w].z), "+v"(pre[h][w].w));
+                BX_STAMP(8)
+#endif
+                store_window();
+            } else {
+                stage_window_slow(wnext);
+            }
         }
+        BX_STAMP(4)
 #if SK_BX_PRIO
         __builtin_amdgcn_s_setprio(3);
 #endif
@@ -322,7 +375,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #if SK_BX_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+        BX_STAMP(5)
         __syncthreads();  // the planes hold window w+1
+        BX_STAMP(6)
         const int64_t wnext2 = wnext + gridDim.x;
         fast = wnext2 < nwin && interior(wnext2);
 #if SK_BX_PRIO
@@ -332,7 +387,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #if SK_BX_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+#ifdef SK_BX_TRACE_BUILD
+        BX_STAMP(7)
+        if (a.trace && lane == 0 && it < 64) {
+            unsigned long long *t = a.trace + (((size_t)blockIdx.x * 64 + it) * 4 + wave) * 10;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) t[k] = stamp[k];
+            t[9] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
+        ++it;
+#endif
+        wdx = wnext;
+        wnext = wnext2;
     }
+#undef BX_STAMP
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -497,10 +565,30 @@ int fir_bx_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L,
     const int64_t ncols = (n_out + a.RS - 1) / a.RS;
     const int64_t nwin = (ncols + a.NS - 1) / a.NS;
     const unsigned grid = (unsigned)std::min<int64_t>(nwin, (int64_t)2 * ctx().num_cus);  // persistent: two per CU
+#ifdef SK_BX_TRACE_BUILD
+    a.trace = nullptr;
+    const char *trace_path = getenv("SKDSP_BX_TRACE");
+    if (trace_path) {
+        SK_HIP(hipMalloc((void **)&a.trace, (size_t)grid * 64 * 4 * 10 * 8));
+        SK_HIP(hipMemsetAsync(a.trace, 0, (size_t)grid * 64 * 4 * 10 * 8, s));
+    }
+#endif
     const bool ok = cplx ? bx_dispatch<true>(t->KB, t->RT, grid, lds, s, x, t->At, a, y)
                          : bx_dispatch<false>(t->KB, t->RT, grid, lds, s, x, t->At, a, y);
     SK_CHECK(ok, SKDSP_ERR_UNSUPPORTED, "fir_bx: no kernel for %d blocks x %d row tiles", t->KB, t->RT);
     SK_HIP(hipGetLastError());
+#ifdef SK_BX_TRACE_BUILD
+    if (trace_path) {
+        std::vector<unsigned long long> hbuf((size_t)grid * 64 * 4 * 10);
+        SK_HIP(hipMemcpyAsync(hbuf.data(), a.trace, hbuf.size() * 8, hipMemcpyDeviceToHost, s));
+        SK_HIP(hipStreamSynchronize(s));
+        SK_HIP(hipFree(a.trace));
+        if (FILE *f = fopen(trace_path, "wb")) {
+            fwrite(hbuf.data(), 8, hbuf.size(), f);
+            fclose(f);
+        }
+    }
+#endif
     return SKDSP_OK;
 }
 

@@ -9,19 +9,19 @@ OUT=$ROOT/gpurun_out/profiles_$R
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python $ROOT/bench.py --workload $w --no-cpu-baseline --no-other-configs > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python $ROOT/bench.py --workload $w --no-cpu-baseline --no-other-configs --board-seconds 0 > /dev/null 2>&1
   cp $OUT/trace_$w/*/*kernel_stats.csv $OUT/kernel_stats_$w.csv
   rm -rf $OUT/trace_$w
 done
 # PMC passes, each counter group in its own run (never combined with other trace domains)
-for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 fir1024c128; do
+for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; do
   sets=("FETCH_SIZE" "WRITE_SIZE")
   [ $w = fir1024 ] && sets+=("SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES")
   # the issue / wait picture of config 4, before (cascade form) and after (parallel form)
   case $w in iir8|iir8cas) sets+=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS");; esac
   for set in "${sets[@]}"; do
     tag=$(echo $set | cut -d' ' -f1)
-    rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$tag -- python $ROOT/bench.py --workload $w --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$tag -- python $ROOT/bench.py --workload $w --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs --board-seconds 0 > /dev/null 2>&1
     cp $OUT/pmc_$tag/*/*counter_collection.csv $OUT/pmc_${w}_$tag.csv 2>/dev/null
     rm -rf $OUT/pmc_$tag
   done
@@ -32,6 +32,7 @@ for w in updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; do
   python bench.py --workload $w --no-other-configs > $OUT/bench_$w.json 2>/dev/null
 done
 python bench.py --scaling strong --total-log2n 30 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_fir1024_2p30_one_gpu.json 2>/dev/null
+python tools/power_probe.py idle copy fir1024 updn43 iir8 iir8cas fir127 > $OUT/power_probe.txt 2>&1
 python tools/ab_iir_par.py 26 > $OUT/ab_iir_par.txt 2>&1
 python tools/time_fir_shapes.py > $OUT/fir_shapes.txt 2>&1
 python tools/time_fir_c128.py > $OUT/fir_f64.txt 2>&1

@@ -32,6 +32,7 @@ WORK = {  # workload -> (substring of every kernel of a step, substring of the k
     "iir8cas": ("skdsp::iir_fused", "skdsp::iir_fused", 8 * 2 ** 26),   # ... forced through the cascade-form single pass (round 2's default)
     "fir1024c128": ("ols64_tile_kernel", "ols64_tile_kernel", 32 * 2 ** 26),
     "iir8tp": ("skdsp::iir_", "float, true", 8 * 2 ** 26),  # ... forced through K1 (matrix pipe) + carries + K3 (the WRITE = true instantiation runs once per step)
+    "iir8c64": ("skdsp::iir_par", "skdsp::iir_par", 16 * 2 ** 26),   # config 4's filter on an interleaved complex64 signal
     "iirlp8": ("skdsp::iir_par", "skdsp::iir_par", 8 * 2 ** 26),   # rate_change(12)'s lowpass, parallel-form single-pass scan
 }
 for w, (pat, marker, alg) in WORK.items():
