@@ -102,6 +102,12 @@ int skdsp_fir_get_algo(skdsp_handle h, int64_t n, int *algo_used);
 /* .filter(x): signal.lfilter(b,[1],x), multirate_helper.py:104-109.  y has n samples. */
 int skdsp_fir_filter(skdsp_handle h, const void *x, int64_t n, void *y);
 int skdsp_fir_filter_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev);
+/* The same call spread over the GPUs of one process (SURVEY 8(b) / BASELINE config 5 without a launcher): the host vector is cut into
+ * contiguous sample blocks, one range of chunks per slot bound by skdsp_init_devices, each chunk staged with the Ntaps-1 samples in
+ * front of it -- the halo comes from the caller's array, so the GPUs exchange nothing.  ngpu: slots to use, 0 = all bound
+ * (skdsp_fir_filter uses all of them as well; this entry lets a caller choose).  Device-resident shards with an RCCL halo
+ * between processes: skdsp_fir_filter_shard_dev below. */
+int skdsp_fir_filter_sharded(skdsp_handle h, const void *x, int64_t n, void *y, int ngpu);
 /* N-D inputs: lfilter filters along the last axis in ONE call (multirate_helper.py:108).  nrow rows of n samples, each
  * filtered from rest: one pitched copy in, one launch over the rows laid end to end with Ntaps-1 zeros between them,
  * one pitched copy out (host form: rows contiguous; device form: x_stride / y_stride elements between rows, >= n). */

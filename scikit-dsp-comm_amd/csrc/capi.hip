@@ -598,11 +598,14 @@ static int run_pipeline(const ChunkPlan &p, int64_t k0, int64_t k1, const char *
 
 // Deal the chunks of a plan to every bound slot (contiguous ranges); make_self(slot) gives the per-slot kernel argument
 // (the handle's clone on that slot).  One worker thread per extra slot; the caller's thread serves its own slot.
+static thread_local int tl_slot_limit = 0;   // > 0: this call uses at most that many slots (skdsp_fir_filter_sharded)
+
 static int run_on_slots(const ChunkPlan &p, const char *x, char *y, chunk_kernel_fn kern, void *(*make_self)(void *, int), void *base_self,
                         bool allow_multi)
 {
     const int home = ctx().slot;
     int nslots = allow_multi && opt().host_multi_slot ? slot_count() : 1;
+    if (tl_slot_limit > 0 && nslots > tl_slot_limit) nslots = tl_slot_limit;
     if (nslots > p.nchunks) nslots = (int)p.nchunks;
     if (nslots <= 1) return run_pipeline(p, 0, p.nchunks, x, y, kern, make_self(base_self, home));
     std::vector<void *> selfs((size_t)nslots, nullptr);
@@ -1325,6 +1328,19 @@ int skdsp_fir_filter_rows_dev(skdsp_handle hh, const void *x_dev, int64_t n, int
 }
 
 int skdsp_fir_filter(skdsp_handle h, const void *x, int64_t n, void *y) { return fir_host_call(h, x, n, 1, 1, 0, y); }
+
+int skdsp_fir_filter_sharded(skdsp_handle h, const void *x, int64_t n, void *y, int ngpu)
+{
+    {
+        API_BEGIN;
+        SK_CHECK(ngpu >= 0 && ngpu <= slot_count(), SKDSP_ERR_BADARG, "fir_filter_sharded: ngpu = %d, %d slots bound (skdsp_init_devices)", ngpu,
+                 slot_count());
+    }
+    tl_slot_limit = ngpu;
+    const int rc = fir_host_call(h, x, n, 1, 1, 0, y);
+    tl_slot_limit = 0;
+    return rc;
+}
 int skdsp_fir_up(skdsp_handle h, const void *x, int64_t n, int L, void *y) { return fir_host_call(h, x, n, L, 1, 1, y); }
 int skdsp_fir_dn(skdsp_handle h, const void *x, int64_t n, int M, void *y) { return fir_host_call(h, x, n, 1, M, 1, y); }
 int skdsp_fir_updn(skdsp_handle h, const void *x, int64_t n, int L, int M, void *y) { return fir_host_call(h, x, n, L, M, 1, y); }

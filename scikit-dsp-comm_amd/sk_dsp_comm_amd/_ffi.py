@@ -27,7 +27,7 @@ SYMBOLS = [
     "skdsp_host_alloc", "skdsp_host_free", "skdsp_malloc", "skdsp_free", "skdsp_memcpy_h2d", "skdsp_memcpy_d2h", "skdsp_memcpy_d2d", "skdsp_memset",
     "skdsp_sync", "skdsp_timer_start", "skdsp_timer_stop", "skdsp_fill_noise_dev",
     "skdsp_fir_create", "skdsp_fir_set_algo", "skdsp_fir_get_algo", "skdsp_fir_filter", "skdsp_fir_filter_dev",
-    "skdsp_fir_filter_rows", "skdsp_fir_filter_rows_dev",
+    "skdsp_fir_filter_rows", "skdsp_fir_filter_rows_dev", "skdsp_fir_filter_sharded",
     "skdsp_fir_up", "skdsp_fir_up_dev", "skdsp_fir_dn", "skdsp_fir_dn_dev", "skdsp_fir_updn", "skdsp_fir_updn_dev",
     "skdsp_sos_create", "skdsp_tf_create", "skdsp_tf2sos", "skdsp_iir_filter", "skdsp_iir_filter_dev", "skdsp_iir_up",
     "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev", "skdsp_iir_state_len", "skdsp_iir_filter_state_dev",
@@ -86,6 +86,7 @@ def load():
         L.skdsp_fir_set_algo.argtypes = [vp, ci]
         L.skdsp_fir_get_algo.argtypes = [vp, i64, ctypes.POINTER(ci)]
         L.skdsp_fir_filter.argtypes = [vp, vp, i64, vp]
+        L.skdsp_fir_filter_sharded.argtypes = [vp, vp, i64, vp, ci]
         L.skdsp_fir_filter_dev.argtypes = [vp, vp, i64, i64, vp]
         L.skdsp_fir_filter_rows.argtypes = [vp, vp, i64, i64, vp]
         L.skdsp_fir_filter_rows_dev.argtypes = [vp, vp, i64, i64, i64, i64, vp]
@@ -487,6 +488,11 @@ class FirKernel(_HostCalls):
     # host vectors ------------------------------------------------------
     def filter(self, x, wide=False):
         return self._host(x.size, x.dtype, wide, lambda y: check(load().skdsp_fir_filter(ctypes.c_void_p(self.h), _ptr(x), x.size, _ptr(y))))
+
+    def filter_sharded(self, x, ngpu=0, wide=False):
+        """.filter(x) over the first ngpu slots bound by init_devices (0: all): contiguous sample blocks, halos from the host array."""
+        return self._host(x.size, x.dtype, wide,
+                          lambda y: check(load().skdsp_fir_filter_sharded(ctypes.c_void_p(self.h), _ptr(x), x.size, _ptr(y), int(ngpu))))
 
     def up(self, x, L, wide=False):
         return self._host(x.size * L, x.dtype, wide, lambda y: check(load().skdsp_fir_up(ctypes.c_void_p(self.h), _ptr(x), x.size, int(L), _ptr(y))))

@@ -98,6 +98,17 @@ assert np.max(np.abs(y1 - y)) / np.max(np.abs(y)) < 1e-6
 yd = f.dn(x, 12); yu = f.up(x[:200000], 12)
 _ffi.set_option('host_multi_slot', 1)
 assert np.array_equal(f.dn(x, 12), yd) and np.array_equal(f.up(x[:200000], 12), yu)
+# skdsp_fir_filter_sharded: the caller chooses how many of the bound slots take part (0 = all); asking for more is an argument error
+k = _ffi.FirKernel(b, _ffi.C64)
+y0 = k.filter(x)
+for ng in (0, 1, 2, 3):
+    ys = k.filter_sharded(x, ng)
+    assert np.max(np.abs(ys - y0)) / np.max(np.abs(y0)) < 1e-6, ng
+try:
+    k.filter_sharded(x, 4)
+    raise SystemExit('ngpu above the bound slots was accepted')
+except ValueError:
+    pass
 print('SLOTS_OK')
 """ % (ROOT, ROOT)
     out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
