@@ -51,6 +51,12 @@ constexpr int kParTickets = 16;   // segment dispensers per launch
 #ifndef SK_PAR_T32
 #define SK_PAR_T32 128   // samples per lane (float32 signals); float64 signals: half
 #endif
+#ifndef SK_PAR_PRIO
+#define SK_PAR_PRIO 3
+#endif
+#ifndef SK_PAR_PRIO_ST
+#define SK_PAR_PRIO_ST 1
+#endif
 #ifndef SK_PAR_OCC
 #define SK_PAR_OCC 2     // waves per SIMD the register budget is set for
 #endif
@@ -79,6 +85,9 @@ struct ParArgs {
     int dec;                     // > 1: only y[k * dec] is stored (at y[k])
     int dec_dq, dec_dr;          // (rows between a lane's staged segments x T) div / mod dec
     int64_t n_keep;              // (n / dec) * dec
+#ifdef SK_PAR_TRACE_BUILD        // developer build (tools/par_trace.py): [segment ticket][16]: 12 s_memtime stamps, HW_ID, XCC_ID
+    unsigned long long *trace;
+#endif
     int dbg;                     // developer timing switches (option iir_par_dbg; wrong results): 1 no MFMAs, 2 no recurrence, 4 no scan / look-back, 8 no stores, 16 no loads
 };
 
@@ -121,19 +130,42 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 
     // (the wave index through readfirstlane: segment, row and every base address are then wave-uniform SGPR values)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SK_PAR_TRACE_BUILD
+    unsigned long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PAR_STAMP(k) stamp[k] = __builtin_readcyclecounter();
+#else
+#define PAR_STAMP(k)
+#endif
+    PAR_STAMP(0)
+    // Everything in front of the recurrence runs at raised priority -- where the recurrence is what the launch waits for.  The
+    // recurrence of the wave that shares this SIMD is a dense v_fma_f64 stream and, being the older wave, wins every issue arbitration: a younger wave's G x products (the same FP64 datapath),
+    // its scan and its correction then crawl (tools/par_trace.py: 29 k clocks for 128 MFMAs that take 8 k) and are still unfinished when
+    // the older wave's recurrence ends -- the pipe idles until they are.  With priority the preparation is over early and the next
+    // recurrence starts the moment the pipe is free.  Config 4: 0.161 -> 0.150 ms float32, 0.322 -> 0.303 ms complex64 (same box, alternating);
+    // float64 signals and cascades of fewer than 6 biquads are bound by their memory walk and LOSE 2-6 % with it (the stores of
+    // the older wave then wait behind the younger wave's loads), so the switch follows the FP64 work per byte.
+    constexpr bool PRIO = SK_PAR_PRIO != 0 && sizeof(IO) == 4 && NSEC >= 6;
+    if (PRIO) __builtin_amdgcn_s_setprio(SK_PAR_PRIO);
     // kParTickets dispensers, one per workgroup residue (a single word serialises the 2048 draws of a 2^26-sample launch in
     // the L2 atomic unit: 22 us of an otherwise empty launch): workgroup b draws q from dispenser b mod kParTickets and serves
     // wave segments 4 (kParTickets q + b mod kParTickets) ...; every dispenser hands out exactly the numbers of its residue
     // class, so the launch covers every segment once, and the smallest segment not yet drawn is drawn by the next workgroup
     // of its class that starts -- which needs only that running workgroups finish, and those wait for smaller segments only
-    if (tid == 0) {
-        const unsigned res = blockIdx.x % kParTickets;
-        base_sh = 4 * (int)((unsigned)(atomicAdd(a.ticket + res, 1ull) - a.ticket_base) * kParTickets + res);
-    }
-    for (int i = tid; i < (T / 4) * 64; i += kIirThreads) gl[i] = gtab[i];
+    // (the table is requested first and the ticket behind it, so that the two round trips overlap: thread 0 used to wait for its ticket
+    // before it asked for its share of the table, and the barrier for thread 0)
+    constexpr int kTabPer = (T / 4) * 64 / kIirThreads;
+    double tab[kTabPer];
+#pragma unroll
+    for (int i = 0; i < kTabPer; ++i) tab[i] = gtab[tid + i * kIirThreads];
+    unsigned long long drawn = 0;
+    if (tid == 0) drawn = atomicAdd(a.ticket + blockIdx.x % kParTickets, 1ull);
+#pragma unroll
+    for (int i = 0; i < kTabPer; ++i) gl[tid + i * kIirThreads] = tab[i];
+    if (tid == 0) base_sh = 4 * (int)((unsigned)(drawn - a.ticket_base) * kParTickets + blockIdx.x % kParTickets);
     __syncthreads();   // the only workgroup barrier
     const int tk = __builtin_amdgcn_readfirstlane(base_sh) + wave;
     if (tk >= a.total) return;
+    PAR_STAMP(1)
     const int row = a.nseg == a.total ? 0 : __builtin_amdgcn_readfirstlane(tk / a.nseg), seg = tk - row * a.nseg;
     const IO *x = reinterpret_cast<const IO *>(a.x) + (size_t)row * a.x_stride;
     IO *y = reinterpret_cast<IO *>(a.y) + (size_t)row * a.y_stride;
@@ -222,6 +254,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 #pragma unroll
         for (int p = 0; p < NP; ++p) load_piece(p);
     }
+    PAR_STAMP(2)
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         if (interior) {
@@ -244,6 +277,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         wave_lds_sync();
     }
 
+    PAR_STAMP(3)
     // chunk end states from the accumulator layout (column = lane & 15, state row = (lane >> 4) + 4 reg) to one lane per chunk
     double v[D];
 #pragma unroll
@@ -282,6 +316,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         for (int k = 0; k < NSEC; ++k) *reinterpret_cast<v2d_t *>(E + (k * 64 + lane) * 2) = v2d_t{v[2 * k], v[2 * k + 1]};
         wave_lds_sync();
     }
+    PAR_STAMP(4)
     double z[D];
 #pragma unroll
     for (int k = 0; k < NSEC; ++k) {
@@ -324,6 +359,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
             if (back <= KMAX) cw[(back - 1) * GR + gi] = got;
         }
         wave_lds_sync();
+        PAR_STAMP(5)
 
         // ---- C: z_j += Phi^j c,  c = sum_m Psi^m P_(s-1-m) ---------------------------------------------------------------
         double u[D];
@@ -363,6 +399,8 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         }
     }
     wave_lds_sync();  // the image is free again
+    PAR_STAMP(6)
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
 
     // ---- B: the recurrence over the register-resident chunk; outputs leave through the LDS image ------------------------
     // (the output taps live in VGPRs: 33 double coefficients next to the addresses do not fit a wave's 102 SGPRs, and
@@ -394,6 +432,10 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
             }
             xq[(p * kPiece + k) / St::elems][(p * kPiece + k) % St::elems] = (IO)yv;
         }
+#ifdef SK_PAR_TRACE_BUILD
+        if (p < 4) { stamp[7 + (p < 4 ? p : 3)] = __builtin_readcyclecounter(); }
+#endif
+        if (PRIO && SK_PAR_PRIO_ST) __builtin_amdgcn_s_setprio(SK_PAR_PRIO);   // (the piece's way out through the image: -2.7 %)
         wave_lds_sync();  // the wave's rows are free (its previous piece's stores have read them)
 #pragma unroll
         for (int sgi = 0; sgi < St::segs; ++sgi) *reinterpret_cast<xv_t *>(myrow + sgi * St::elems) = xq[p * St::segs + sgi];
@@ -403,6 +445,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 #pragma unroll
             for (int i = 0; i < St::per_thread; ++i)
                 __builtin_nontemporal_store(image_get(i), reinterpret_cast<pre_t *>(yseg + (loff + i * kRowStep + p * kPiece * LS)));
+            if (PRIO && SK_PAR_PRIO_ST) __builtin_amdgcn_s_setprio(0);
             continue;
         }
         int64_t dq_run = 0;
@@ -447,6 +490,18 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
             }
         }
     }
+#ifdef SK_PAR_TRACE_BUILD
+    PAR_STAMP(11)
+    if (a.trace && lane == 0) {
+        unsigned long long *t = a.trace + (size_t)tk * 16;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) t[k] = stamp[k];
+        t[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        t[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        t[14] = blockIdx.x;
+    }
+#endif
+#undef PAR_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------------- host side
@@ -718,6 +773,14 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
     a.aligned = ((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (nrow == 1 || ((x_stride * sizeof(IO)) % 16 == 0 && (y_stride * sizeof(IO)) % 16 == 0))) ? 1 : 0;
     a.dec = dec > 1 ? dec : 1;
     a.dbg = opt().iir_par_dbg;
+#ifdef SK_PAR_TRACE_BUILD
+    a.trace = nullptr;
+    const char *trace_path = getenv("SKDSP_PAR_TRACE");
+    if (trace_path) {
+        SK_HIP(hipMalloc((void **)&a.trace, (size_t)total * 16 * 8));
+        SK_HIP(hipMemsetAsync(a.trace, 0, (size_t)total * 16 * 8, s));
+    }
+#endif
     a.n_keep = (n / a.dec) * a.dec;
     {
         const int64_t step = (int64_t)(64 / Stage<IO>::segs) * T;   // samples between a lane's staged segments
@@ -750,6 +813,18 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
     }
 #undef SK_PAR
     SK_HIP(hipGetLastError());
+#ifdef SK_PAR_TRACE_BUILD
+    if (trace_path) {
+        std::vector<unsigned long long> hbuf((size_t)total * 16);
+        SK_HIP(hipMemcpyAsync(hbuf.data(), a.trace, hbuf.size() * 8, hipMemcpyDeviceToHost, s));
+        SK_HIP(hipStreamSynchronize(s));
+        SK_HIP(hipFree(a.trace));
+        if (FILE *f = fopen(trace_path, "wb")) {
+            fwrite(hbuf.data(), 8, hbuf.size(), f);
+            fclose(f);
+        }
+    }
+#endif
     return SKDSP_OK;
 }
 

@@ -32,7 +32,7 @@ for w in updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; do
   python bench.py --workload $w --no-other-configs > $OUT/bench_$w.json 2>/dev/null
 done
 python bench.py --scaling strong --total-log2n 30 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_fir1024_2p30_one_gpu.json 2>/dev/null
-python tools/power_probe.py idle copy fir1024 updn43 iir8 iir8cas fir127 > $OUT/power_probe.txt 2>&1
+python tools/power_probe.py idle copy fir1024 fir1024f32 fir1024f64 fir1024c128 updn43 fir127 iir8 iir8cas iir8c64 iirlp8 > $OUT/power_probe.txt 2>&1
 python tools/ab_iir_par.py 26 > $OUT/ab_iir_par.txt 2>&1
 python tools/time_fir_shapes.py > $OUT/fir_shapes.txt 2>&1
 python tools/time_fir_c128.py > $OUT/fir_f64.txt 2>&1

@@ -1,5 +1,5 @@
 """Developer aid: board power and shader clock while one workload runs back to back (is a kernel held by the power cap?):
-   python tools/power_probe.py [fir1024 updn43 iir8 iir8cas fir127 copy idle]
+   python tools/power_probe.py [idle copy fir1024 fir1024f32 fir1024f64 fir1024c128 updn43 fir127 iir8 iir8cas iir8c64 iirlp8]
 Samples `rocm-smi --showpower --showclocks --showperflevel` about twice a second from a second thread while the main thread keeps the queue full."""
 import ctypes, os, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,7 @@ def smi():
     keep = [l.strip() for l in out.splitlines() if ("Power" in l or "sclk" in l or "mclk" in l or "fclk" in l)]
     return " | ".join(keep)
 
-def run(name, seconds=5.0):
+def run(name, seconds=3.0):
     n = 1 << 26
     if name == "idle":
         step = None
@@ -31,15 +31,25 @@ def run(name, seconds=5.0):
         k = _ffi.FirKernel(bench.firwin_lowpass(512, 0.225), _ffi.C64)
         xd = _ffi.DeviceArray(n, np.complex64).fill_noise(1); yd = _ffi.DeviceArray(n * 4 // 3, np.complex64)
         step = lambda: k.updn_dev(xd, yd, 4, 3)
+    elif name in ("fir1024f32", "fir1024f64", "fir1024c128"):
+        dt = {"fir1024f32": np.float32, "fir1024f64": np.float64, "fir1024c128": np.complex128}[name]
+        k = _ffi.FirKernel(bench.firwin_lowpass(1024, 0.2), _ffi.code_of(dt))
+        xd = _ffi.DeviceArray(n, dt, headroom=1024).fill_noise(1); yd = _ffi.DeviceArray(n, dt)
+        step = lambda: k.filter_dev(xd, yd)
     elif name == "fir127":
         k = _ffi.FirKernel(bench.firwin_lowpass(127, 0.2), _ffi.F32)
         xd = _ffi.DeviceArray(n, np.float32, headroom=1024).fill_noise(1); yd = _ffi.DeviceArray(n, np.float32)
         step = lambda: k.filter_dev(xd, yd)
-    elif name in ("iir8", "iir8cas"):
-        sos = np.load(os.path.join(ROOT, "tests", "golden", "g7_iir_sos.npz"))["sos8"]
+    elif name in ("iir8", "iir8cas", "iir8c64", "iirlp8"):
+        if name == "iirlp8":
+            from scipy import signal
+            sos = signal.butter(8, 0.9 / 12, output="sos")
+        else:
+            sos = np.load(os.path.join(ROOT, "tests", "golden", "g7_iir_sos.npz"))["sos8"]
         _ffi.set_option("iir_par", 0 if name == "iir8cas" else 1)
-        k = _ffi.IirKernel(_ffi.F32, sos=sos)
-        xd = _ffi.DeviceArray(n, np.float32).fill_noise(7); yd = _ffi.DeviceArray(n, np.float32)
+        dt = np.complex64 if name == "iir8c64" else np.float32
+        k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+        xd = _ffi.DeviceArray(n, dt).fill_noise(7); yd = _ffi.DeviceArray(n, dt)
         step = lambda: k.filter_dev(xd, yd)
     else:
         raise SystemExit("unknown workload " + name)
