@@ -441,10 +441,18 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         for (int sgi = 0; sgi < St::segs; ++sgi) *reinterpret_cast<xv_t *>(myrow + sgi * St::elems) = xq[p * St::segs + sgi];
         wave_lds_sync();
         if (!DEC && interior) {
-            if (!(a.dbg & 8))
+            if (!(a.dbg & 8)) {
+                // (all reads of the image first, into the registers the piece has just left: issued one behind the other they cost
+                // one LDS round trip; hipcc otherwise cycles two staging vectors through four read -> wait -> store rounds)
+                pre_t outq[St::per_thread];
 #pragma unroll
-            for (int i = 0; i < St::per_thread; ++i)
-                __builtin_nontemporal_store(image_get(i), reinterpret_cast<pre_t *>(yseg + (loff + i * kRowStep + p * kPiece * LS)));
+                for (int i = 0; i < St::per_thread; ++i) outq[i] = image_get(i);
+#pragma unroll
+                for (int i = 0; i < St::per_thread; ++i) asm volatile("" : "+v"(outq[i]));
+#pragma unroll
+                for (int i = 0; i < St::per_thread; ++i)
+                    __builtin_nontemporal_store(outq[i], reinterpret_cast<pre_t *>(yseg + (loff + i * kRowStep + p * kPiece * LS)));
+            }
             if (PRIO && SK_PAR_PRIO_ST) __builtin_amdgcn_s_setprio(0);
             continue;
         }
