@@ -135,3 +135,22 @@ def test_sos_state_matrix_matches_sosfilt():
     z = np.random.default_rng(3).standard_normal((sos.shape[0], 2))
     _, zf = signal.sosfilt(sos, np.zeros(5), zi=z)
     assert np.allclose(np.linalg.matrix_power(A, 5) @ z.ravel(), zf.ravel(), rtol=1e-13, atol=1e-15)
+
+
+def test_bench_reads_board_power_and_clock_from_rocm_smi(monkeypatch):
+    """bench.py's board leg parses `rocm-smi --showpower --showmaxpower --showclocks`; the text below is what the tool prints on an MI355X box
+    (profiles/r03/power_probe.txt).  A box without the tool yields (None, None, None) and the leg reports itself as skipped."""
+    import types
+    import bench
+    text = ("============================ ROCm System Management Interface ============================\n"
+            "GPU[0]\t\t: fclk clock level: 0: (1250Mhz)\nGPU[0]\t\t: mclk clock level: 0: (2000Mhz)\n"
+            "GPU[0]\t\t: sclk clock level: 1: (2121Mhz)\nGPU[0]\t\t: socclk clock level: S: (38Mhz)\n"
+            "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0\n"
+            "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1394.0\n")
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(stdout=text))
+    assert bench._smi_sample() == (1394.0, 1400.0, 2121.0)
+
+    def missing(*a, **k):
+        raise FileNotFoundError("rocm-smi")
+    monkeypatch.setattr(subprocess, "run", missing)
+    assert bench._smi_sample() == (None, None, None)
