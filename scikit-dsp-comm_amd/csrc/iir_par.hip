@@ -138,12 +138,13 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 #endif
     PAR_STAMP(0)
     // Everything in front of the recurrence runs at raised priority -- where the recurrence is what the launch waits for.  The
-    // recurrence of the wave that shares this SIMD is a dense v_fma_f64 stream and, being the older wave, wins every issue arbitration: a younger wave's G x products (the same FP64 datapath),
-    // its scan and its correction then crawl (tools/par_trace.py: 29 k clocks for 128 MFMAs that take 8 k) and are still unfinished when
-    // the older wave's recurrence ends -- the pipe idles until they are.  With priority the preparation is over early and the next
-    // recurrence starts the moment the pipe is free.  Config 4: 0.161 -> 0.150 ms float32, 0.322 -> 0.303 ms complex64 (same box, alternating);
-    // float64 signals and cascades of fewer than 6 biquads are bound by their memory walk and LOSE 2-6 % with it (the stores of
-    // the older wave then wait behind the younger wave's loads), so the switch follows the FP64 work per byte.
+    // recurrence of the wave that shares this SIMD is a dense v_fma_f64 stream and, being the older wave, wins every issue
+    // arbitration: a younger wave's G x products (the same FP64 datapath), its scan and its correction then crawl
+    // (tools/par_trace.py: 29 k clocks for 128 MFMAs that take 8 k) and are still unfinished when the older wave's recurrence ends --
+    // the pipe idles until they are.  With priority the preparation is over early and the next recurrence starts the moment the
+    // pipe is free.  Config 4: 0.161 -> 0.150 ms float32, 0.322 -> 0.303 ms complex64 (same box, alternating); float64 signals and
+    // cascades of fewer than 6 biquads are bound by their memory walk and LOSE 2-6 % with it (the stores of the older wave then
+    // wait behind the younger wave's loads), so the switch follows the FP64 work per byte.
     constexpr bool PRIO = SK_PAR_PRIO != 0 && sizeof(IO) == 4 && NSEC >= 6;
     if (PRIO) __builtin_amdgcn_s_setprio(SK_PAR_PRIO);
     // kParTickets dispensers, one per workgroup residue (a single word serialises the 2048 draws of a 2^26-sample launch in
