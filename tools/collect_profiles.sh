@@ -1,20 +1,22 @@
 #!/bin/bash
 # Collect the per-round profile artefacts on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r01'
+#   gpurun --timeout 600 -- 'bash tools/collect_profiles.sh r03 pmc iir8 iirlp8'    (only the PMC passes of the workloads named, added to an existing collection)
 # Writes gpurun_out/profiles_<round>/ ; copy what should be judged into profiles/<round>/.
 set -u
 R=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$R
-rm -rf $OUT && mkdir -p $OUT
+PMC_ONLY=""
+if [ "${2:-}" = pmc ]; then shift 2; PMC_ONLY="$*"; mkdir -p $OUT; else rm -rf $OUT && mkdir -p $OUT; fi
 cd /tmp && export TMPDIR=/tmp
-for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; do
+[ -z "$PMC_ONLY" ] && for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python $ROOT/bench.py --workload $w --no-cpu-baseline --no-other-configs --board-seconds 0 > /dev/null 2>&1
   cp $OUT/trace_$w/*/*kernel_stats.csv $OUT/kernel_stats_$w.csv
   rm -rf $OUT/trace_$w
 done
 # PMC passes, each counter group in its own run (never combined with other trace domains)
-for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; do
+for w in ${PMC_ONLY:-fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128}; do
   sets=("FETCH_SIZE" "WRITE_SIZE")
   [ $w = fir1024 ] && sets+=("SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES")
   # the issue / wait picture of config 4, before (cascade form) and after (parallel form)
@@ -27,6 +29,7 @@ for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; d
   done
 done
 cd $ROOT
+[ -n "$PMC_ONLY" ] && { ls -la $OUT | tail -5; exit 0; }
 python bench.py > $OUT/bench_fir1024.json 2>$OUT/bench_fir1024.err
 for w in updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; do
   python bench.py --workload $w --no-other-configs > $OUT/bench_$w.json 2>/dev/null
