@@ -85,6 +85,11 @@ struct ParArgs {
     int dec;                     // > 1: only y[k * dec] is stored (at y[k])
     int dec_dq, dec_dr;          // (rows between a lane's staged segments x T) div / mod dec
     int64_t n_keep;              // (n / dec) * dec
+    // up > 1 (real signals, one row): x holds n_in = n / up samples and the kernel filters up * upsample(x, up) -- the zero-stuffed
+    // signal exists only in the wave's staging image (multirate_IIR.up / rate_change.up: multirate_helper.py:69-75, 177-184)
+    int up;
+    unsigned up_magic;           // ceil(2^32 / up): (v * up_magic) >> 32 = v / up for the v < 2^15 met here
+    int64_t n_in;
 #ifdef SK_PAR_TRACE_BUILD        // developer build (tools/par_trace.py): [segment ticket][16]: 12 s_memtime stamps, HW_ID, XCC_ID
     unsigned long long *trace;
 #endif
@@ -241,6 +246,32 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         }
     };
 
+    // .up: output-rate unit (i, lane) of piece p from the input-rate signal: sample m of the row is up * x[m / up] where up divides m
+    const int64_t m0 = row0 * T;                                 // output-rate index of the segment's first sample (wave-uniform)
+    const int64_t up_q0 = a.up > 1 ? m0 / a.up : 0;
+    const unsigned up_r0 = a.up > 1 ? (unsigned)(m0 - up_q0 * a.up) : 0u;
+    auto stage_up = [&](int p) {
+#pragma unroll 1
+        for (int i = 0; i < St::per_thread; ++i) {
+            const int idx = i * 64 + lane;
+            const int r = idx / USEG, sg = idx % USEG;
+            const unsigned v = up_r0 + (unsigned)(r * T + p * kPiece + sg * St::elems);   // < up + 64 T
+            const unsigned q = (unsigned)(((unsigned long long)v * a.up_magic) >> 32);
+            const unsigned rem = v - q * (unsigned)a.up;
+            pre_t val;
+            IO *e4 = reinterpret_cast<IO *>(&val);
+#pragma unroll
+            for (int e = 0; e < St::elems; ++e) {
+                const unsigned t = rem + e;                       // < up + elems: a multiple of up iff it is 0, up, 2 up or 3 up
+                const unsigned k = (t >= (unsigned)a.up) + (t >= 2u * a.up) + (t >= 3u * a.up);
+                const int64_t qi = up_q0 + q + k;
+                e4[e] = (t == k * (unsigned)a.up && qi < a.n_in) ? (IO)((IO)a.up * x[qi]) : IO(0);
+            }
+            image_put(i, val);
+        }
+    };
+    const bool ld_fast = interior && a.up == 1;
+
     // ---- A: stream the segment in; chunk rows to registers; V = G x on the matrix pipe --------------------------------
     // (the chunk as 16-byte vectors: as a scalar array hipcc's SROA left half of it in scratch memory)
     typedef IO xv_t __attribute__((ext_vector_type(St::elems)));
@@ -251,16 +282,18 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     const int c = lane & 15, j = lane >> 4;
     IO *myrow = stage + lane * St::pitch;
     // (every piece of the segment is requested up front: the landing registers are the ones the chunk will occupy anyway)
-    if (interior && !(a.dbg & 16)) {
+    if (ld_fast && !(a.dbg & 16)) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) load_piece(p);
     }
     PAR_STAMP(2)
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        if (interior) {
+        if (ld_fast) {
 #pragma unroll
             for (int i = 0; i < St::per_thread; ++i) image_put(i, pre[p][i]);
+        } else if (!CPLX && a.up > 1) {
+            stage_up(p);
         } else {
             stage_slow(p);
         }
@@ -747,7 +780,7 @@ int iir_par_expand_host(const double *coef, int nsec, double *out, int *accepted
 
 template <typename IO, bool CPLX>
 static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
-                      void *y, hipStream_t s, int dec)
+                      void *y, hipStream_t s, int dec, int up = 1)
 {
     const int T = tb.T;
     const int64_t S = (int64_t)(CPLX ? 32 : 64) * T;   // samples per wave segment
@@ -781,6 +814,9 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
     SK_CHECK(a.err, SKDSP_ERR_HIP, "iir: no host-mapped error word");
     a.aligned = ((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (nrow == 1 || ((x_stride * sizeof(IO)) % 16 == 0 && (y_stride * sizeof(IO)) % 16 == 0))) ? 1 : 0;
     a.dec = dec > 1 ? dec : 1;
+    a.up = up > 1 ? up : 1;
+    a.up_magic = a.up > 1 ? (unsigned)((((unsigned long long)1 << 32) + a.up - 1) / a.up) : 0u;
+    a.n_in = a.up > 1 ? n / a.up : n;
     a.dbg = opt().iir_par_dbg;
 #ifdef SK_PAR_TRACE_BUILD
     a.trace = nullptr;
@@ -839,9 +875,11 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
 
 // returns 1 when the parallel form does not apply to this handle / call (nothing was launched)
 int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y, hipStream_t s, int dec,
-                   int interleaved)
+                   int interleaved, int up)
 {
     if (interleaved && (dec > 1 || nrow != 1)) return 1;
+    // .up: x holds n / up samples; one real row, no decimation; the exact-division trick of the staging covers up <= 4096
+    if (up > 1 && (interleaved || dec > 1 || nrow != 1 || up > 4096 || n % up != 0)) return 1;
     if (h->order != 2 || h->nsec < 1 || h->nsec > 8) return 1;
     if (!h->par) {
         h->par = new ParPlan();
@@ -861,8 +899,8 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     if (tb.K == 0) return 1;
     if (interleaved)
         return dbl ? launch_par<double, true>(h, p, tb, x, n, 1, 0, 0, y, s, 1) : launch_par<float, true>(h, p, tb, x, n, 1, 0, 0, y, s, 1);
-    return dbl ? launch_par<double, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec)
-               : launch_par<float, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec);
+    return dbl ? launch_par<double, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up)
+               : launch_par<float, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up);
 }
 
 }  // namespace skdsp

@@ -50,6 +50,7 @@ struct Options {
     int k1r_wgs = 2;
     int iir_two_pass = 0;     // 1: K1 + carries + K3 even where the single-pass scan applies; -1: single pass wherever it applies
     int iir_par = 1;          // 0: never the parallel-form scan (iir_par.hip); the cascade kernels everywhere
+    int iir_up_fused = 1;     // 0: multirate_IIR.up / rate_change.up write the zero-stuffed signal first (A/B switch)
     int iir_par_dbg = 0;      // developer timing switches of iir_par_kernel (ParArgs::dbg; wrong results)
     int shard_no_overlap = 0; // sharded FIR: halo exchange in front of the whole filter instead of beside the interior tiles
     int shard_reserve = 8;
@@ -211,7 +212,8 @@ void iir_free(IirPlan *p);
 // Parallel-form single-pass scan (iir_par.hip): real signals, <= 8 biquads with simple poles, zero initial state, no state
 // output; nrow rows x_stride / y_stride elements apart in one launch.  Returns 1 when it does not apply (nothing launched).
 int iir_par_launch(IirHandle *h, const void *x_dev, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y_dev, hipStream_t s,
-                   int dec = 1, int interleaved = 0);   // interleaved = 1: x / y interleaved complex, n complex samples, one row
+                   int dec = 1, int interleaved = 0,    // interleaved = 1: x / y interleaved complex, n complex samples, one row
+                   int up = 1);                         // up > 1: x holds n / up samples, the launch filters up * upsample(x, up) (n outputs)
 int iir_par_expand_host(const double *coef, int nsec, double *out, int *accepted);   // host-only (tests): [c0, (a1,a2,r0,r1) x nsec, kappa, ir_err]
 void iir_par_free(ParPlan *p);
 bool iir_shape_supported(int nsec, int order);
