@@ -699,6 +699,10 @@ static int iir_up_any(IirHandle *h, const void *x_dev, int64_t n, int L, void *y
         if ((rc = upsample_launch(x_dev, n, L, h->dtype, (double)L, y_dev, s))) return rc;
         return iir_any_dev(h, y_dev, nl, y_dev);
     }
+    if (L > 1 && opt().iir_par && opt().iir_up_fused && h->order == 2 && !opt().iir_planar) {   // (interleaved in, interleaved out)
+        rc = iir_par_launch(h, x_dev, nl, 1, 0, 0, y_dev, s, 1, 1, L);
+        if (rc != 1) return rc;
+    }
     const size_t rsz = dtype_double(h->dtype) ? 8 : 4;
     const int64_t stride = (int64_t)round_up((size_t)nl, 64);
     void *planes = nullptr;

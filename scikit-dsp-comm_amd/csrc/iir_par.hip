@@ -85,7 +85,7 @@ struct ParArgs {
     int dec;                     // > 1: only y[k * dec] is stored (at y[k])
     int dec_dq, dec_dr;          // (rows between a lane's staged segments x T) div / mod dec
     int64_t n_keep;              // (n / dec) * dec
-    // up > 1 (real signals, one row): x holds n_in = n / up samples and the kernel filters up * upsample(x, up) -- the zero-stuffed
+    // up > 1 (one row): x holds n_in = n / up samples and the kernel filters up * upsample(x, up) -- the zero-stuffed
     // signal exists only in the wave's staging image (multirate_IIR.up / rate_change.up: multirate_helper.py:69-75, 177-184)
     int up;
     unsigned up_magic;           // ceil(2^32 / up): (v * up_magic) >> 32 = v / up for the v < 2^15 met here
@@ -255,17 +255,18 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         for (int i = 0; i < St::per_thread; ++i) {
             const int idx = i * 64 + lane;
             const int r = idx / USEG, sg = idx % USEG;
-            const unsigned v = up_r0 + (unsigned)(r * T + p * kPiece + sg * St::elems);   // < up + 64 T
+            // v: the unit's first sample (a complex sample for CPLX) counted from the last multiple of up in front of the segment
+            const unsigned v = up_r0 + (unsigned)(r * T + p * kPiece + sg * (St::elems / LS));   // < up + 64 T
             const unsigned q = (unsigned)(((unsigned long long)v * a.up_magic) >> 32);
             const unsigned rem = v - q * (unsigned)a.up;
             pre_t val;
             IO *e4 = reinterpret_cast<IO *>(&val);
 #pragma unroll
             for (int e = 0; e < St::elems; ++e) {
-                const unsigned t = rem + e;                       // < up + elems: a multiple of up iff it is 0, up, 2 up or 3 up
+                const unsigned t = rem + e / LS;                  // < up + elems: a multiple of up iff it is 0, up, 2 up or 3 up
                 const unsigned k = (t >= (unsigned)a.up) + (t >= 2u * a.up) + (t >= 3u * a.up);
                 const int64_t qi = up_q0 + q + k;
-                e4[e] = (t == k * (unsigned)a.up && qi < a.n_in) ? (IO)((IO)a.up * x[qi]) : IO(0);
+                e4[e] = (t == k * (unsigned)a.up && qi < a.n_in) ? (IO)((IO)a.up * x[qi * LS + e % LS]) : IO(0);
             }
             image_put(i, val);
         }
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         if (ld_fast) {
 #pragma unroll
             for (int i = 0; i < St::per_thread; ++i) image_put(i, pre[p][i]);
-        } else if (!CPLX && a.up > 1) {
+        } else if (a.up > 1) {
             stage_up(p);
         } else {
             stage_slow(p);
@@ -878,8 +879,8 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
                    int interleaved, int up)
 {
     if (interleaved && (dec > 1 || nrow != 1)) return 1;
-    // .up: x holds n / up samples; one real row, no decimation; the exact-division trick of the staging covers up <= 4096
-    if (up > 1 && (interleaved || dec > 1 || nrow != 1 || up > 4096 || n % up != 0)) return 1;
+    // .up: x holds n / up samples; one row, no decimation; the exact-division trick of the staging covers up <= 4096
+    if (up > 1 && (dec > 1 || nrow != 1 || up > 4096 || n % up != 0)) return 1;
     if (h->order != 2 || h->nsec < 1 || h->nsec > 8) return 1;
     if (!h->par) {
         h->par = new ParPlan();
@@ -898,7 +899,7 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     }
     if (tb.K == 0) return 1;
     if (interleaved)
-        return dbl ? launch_par<double, true>(h, p, tb, x, n, 1, 0, 0, y, s, 1) : launch_par<float, true>(h, p, tb, x, n, 1, 0, 0, y, s, 1);
+        return dbl ? launch_par<double, true>(h, p, tb, x, n, 1, 0, 0, y, s, 1, up) : launch_par<float, true>(h, p, tb, x, n, 1, 0, 0, y, s, 1, up);
     return dbl ? launch_par<double, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up)
                : launch_par<float, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up);
 }

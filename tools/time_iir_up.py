@@ -1,4 +1,4 @@
-"""Time multirate_IIR.up / rate_change.up on device vectors (float32): python tools/time_iir_up.py [<option> <value>]
+"""Time multirate_IIR.up / rate_change.up on device vectors (float32, complex64): python tools/time_iir_up.py [<option> <value>]
    algorithmic bytes = 4 B x (n_in + n_in L): the input read once, the output written once."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ cases = [("rate_change(12).up: butter(8, 0.075)", signal.butter(8, 0.9 / 12, out
          ("multirate_IIR(ellip bandpass, 8 biquads).up(x, 4)", sos8, 4, 1 << 24),
          ("multirate_IIR(ellip bandpass, 8 biquads).up(x, 2)", sos8, 2, 1 << 25)]
 for name, sos, L, n in cases:
-    for dt in (np.float32,):
+    for dt in (np.float32, np.complex64):
         k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
         xd = _ffi.DeviceArray(n, dt).fill_noise(5); yd = _ffi.DeviceArray(n * L, dt)
         for _ in range(20): k.up_dev(xd, yd, L)
@@ -25,7 +25,7 @@ for name, sos, L, n in cases:
         for _ in range(50): k.up_dev(xd, yd, L)
         ms = _ffi.timer_stop() / 50
         x = xd.to_host(0, 40000)
-        up = np.zeros(40000 * L); up[::L] = L * x.astype(np.float64)
+        up = np.zeros(40000 * L, dtype=np.complex128 if np.dtype(dt).kind == 'c' else np.float64); up[::L] = L * x.astype(up.dtype)
         ref = signal.sosfilt(sos, up)
         e = float(np.max(np.abs(yd.to_host(0, 40000 * L) - ref)) / np.max(np.abs(ref)))
         print("%-52s %s n_in 2^%d: %.4f ms  %.2f TB/s algorithmic  err %.1e" % (name, np.dtype(dt).name, n.bit_length() - 1, ms, np.dtype(dt).itemsize * n * (1 + L) / ms / 1e9, e), flush=True)
