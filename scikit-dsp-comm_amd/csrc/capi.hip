@@ -111,7 +111,7 @@ const OptEntry kOptTable[] = {
     {"sw_no_tile", &Options::sw_no_tile}, {"sw_no_lpt", &Options::sw_no_lpt}, {"mm_ns", &Options::mm_ns},
     {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
-    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_up_fused", &Options::iir_up_fused}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
+    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_up_fused", &Options::iir_up_fused}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
     {"shard_reserve", &Options::shard_reserve}, {"shard_two_launches", &Options::shard_two_launches},
     {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
     {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline}, {"host_multi_slot", &Options::host_multi_slot},

@@ -85,6 +85,10 @@ struct ParArgs {
     int dec;                     // > 1: only y[k * dec] is stored (at y[k])
     int dec_dq, dec_dr;          // (rows between a lane's staged segments x T) div / mod dec
     int64_t n_keep;              // (n / dec) * dec
+    // dec_compact: the kept outputs of a whole segment are gathered in the wave's (idle) stage image and leave as one contiguous run of
+    // y (dec >= the samples of a 16-byte unit, and n_seg / dec of them fit the image); else the image-and-pick path below
+    int dec_compact;
+    unsigned dec_magic;          // ceil(2^32 / dec)
     // up > 1 (one row): x holds n_in = n / up samples and the kernel filters up * upsample(x, up) -- the zero-stuffed
     // signal exists only in the wave's staging image (multirate_IIR.up / rate_change.up: multirate_helper.py:69-75, 177-184)
     int up;
@@ -447,6 +451,23 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         be[s] = cf.be[s];
         asm volatile("" : "+v"(be[s]));
     }
+    // .dn, compact form: this lane's sample stream (T samples of chunk cj, component lane % LS) walks the positions
+    // v = R0 + cj T + c of the segment, R0 = (first sample of the segment) mod dec; sample v is kept iff dec divides v, as
+    // output Q0 + v / dec of the row.  (dq, dt) = (v / dec, v mod dec) of the next 16-byte unit, advanced by its size per unit.
+    const bool compact = DEC && a.dec_compact;
+    int64_t dec_q0 = 0;
+    unsigned dec_r0 = 0, dq = 0, dt = 0;
+    if (compact) {
+        dec_q0 = m0 / a.dec;
+        dec_r0 = (unsigned)(m0 - dec_q0 * a.dec);
+        const unsigned v0 = dec_r0 + (unsigned)((lane / LS) * T);
+        dq = (unsigned)(((unsigned long long)v0 * a.dec_magic) >> 32);
+        dt = v0 - dq * (unsigned)a.dec;
+    }
+    const unsigned dec_ob = dec_r0 != 0 ? 1u : 0u;     // first output of the segment, relative to dec_q0
+    const int64_t n_out = a.n_keep / a.dec;
+    const int64_t olim64 = n_out - dec_q0;
+    const unsigned olim = olim64 <= 0 ? 0u : (olim64 > 0x7fffffff ? 0x7fffffffu : (unsigned)olim64);   // outputs of this row from dec_q0 on
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         if (!(a.dbg & 2))
@@ -470,6 +491,24 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 #ifdef SK_PAR_TRACE_BUILD
         if (p < 4) { stamp[7 + (p < 4 ? p : 3)] = __builtin_readcyclecounter(); }
 #endif
+        if (compact) {
+#pragma unroll
+            for (int sgi = 0; sgi < St::segs; ++sgi) {
+                const xv_t u = xq[p * St::segs + sgi];
+                const unsigned e0 = dt == 0 ? 0u : (unsigned)a.dec - dt;    // the unit's kept sample, if < elems (dec >= elems: at most one)
+                IO pick = u[0];
+#pragma unroll
+                for (int e = 1; e < St::elems; ++e) pick = (e0 == (unsigned)e) ? u[e] : pick;
+                const unsigned oq = dq + (dt != 0);                          // its output, relative to dec_q0
+                if (e0 < (unsigned)St::elems && oq < olim) {
+                    const unsigned slot = (oq - dec_ob) * LS + (unsigned)(lane % LS);
+                    stage[slot + (slot >> 5)] = pick;                        // (one pad per 32: the lanes' runs start T / dec slots apart)
+                }
+                dt += St::elems;
+                if (dt >= (unsigned)a.dec) { dt -= (unsigned)a.dec; dq += 1; }
+            }
+            continue;
+        }
         if (PRIO && SK_PAR_PRIO_ST) __builtin_amdgcn_s_setprio(SK_PAR_PRIO);   // (the piece's way out through the image: -2.7 %)
         wave_lds_sync();  // the wave's rows are free (its previous piece's stores have read them)
 #pragma unroll
@@ -532,6 +571,17 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
                     if (g + e / LS < a.n) y[g * LS + e] = tmp[e];
             }
         }
+    }
+    if (compact) {
+        // the segment's kept outputs: one contiguous run of the row, y[dec_q0 + dec_ob ...)
+        wave_lds_sync();
+        const int64_t ob = dec_q0 + dec_ob;
+        int64_t oe = dec_q0 + (int64_t)((dec_r0 + (unsigned)(CH * T) + (unsigned)a.dec - 1) / (unsigned)a.dec);
+        if (oe > n_out) oe = n_out;
+        const int cnt = oe > ob ? (int)(oe - ob) * LS : 0;
+        IO *yo = y + ob * LS;
+#pragma unroll 1
+        for (int i = lane; i < cnt; i += 64) __builtin_nontemporal_store(stage[i + (i >> 5)], yo + i);
     }
 #ifdef SK_PAR_TRACE_BUILD
     PAR_STAMP(11)
@@ -779,6 +829,15 @@ int iir_par_expand_host(const double *coef, int nsec, double *out, int *accepted
     return SKDSP_OK;
 }
 
+// .dn: can a segment's kept outputs be gathered in the wave's stage image (see ParArgs::dec_compact)?
+template <typename IO, bool CPLX> static bool par_dec_compact(int dec, int64_t seg_samples)
+{
+    constexpr int elems = 16 / (int)sizeof(IO), ls = CPLX ? 2 : 1;
+    const int64_t slots = (seg_samples / dec + 2) * ls;
+    const int64_t bytes = (slots + slots / 32 + 2) * (int64_t)sizeof(IO);
+    return dec >= elems && bytes <= (int64_t)64 * Stage<IO>::pitch * (int64_t)sizeof(IO) && opt().iir_dn_compact;
+}
+
 template <typename IO, bool CPLX>
 static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
                       void *y, hipStream_t s, int dec, int up = 1)
@@ -815,6 +874,8 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
     SK_CHECK(a.err, SKDSP_ERR_HIP, "iir: no host-mapped error word");
     a.aligned = ((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (nrow == 1 || ((x_stride * sizeof(IO)) % 16 == 0 && (y_stride * sizeof(IO)) % 16 == 0))) ? 1 : 0;
     a.dec = dec > 1 ? dec : 1;
+    a.dec_magic = a.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + a.dec - 1) / a.dec) : 0u;
+    a.dec_compact = a.dec > 1 && par_dec_compact<IO, CPLX>(a.dec, S) ? 1 : 0;
     a.up = up > 1 ? up : 1;
     a.up_magic = a.up > 1 ? (unsigned)((((unsigned long long)1 << 32) + a.up - 1) / a.up) : 0u;
     a.n_in = a.up > 1 ? n / a.up : n;
@@ -842,8 +903,8 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
         ParCoef<N> cf;                                                                                                  \
         for (int k = 0; k < N; ++k) { cf.na1[k] = p->na1[k]; cf.na2[k] = p->na2[k]; cf.al[k] = p->al[k]; cf.be[k] = p->be[k]; } \
         cf.gamma = p->gamma;                                                                                            \
-        if (a.dec > 1 && !CPLX)                                                                                         \
-            hipLaunchKernelGGL((iir_par_kernel<N, IO, true && !CPLX, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf, \
+        if (a.dec > 1)                                                                                                  \
+            hipLaunchKernelGGL((iir_par_kernel<N, IO, true, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,         \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);      \
         else                                                                                                            \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, false, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,        \
@@ -878,7 +939,7 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
 int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y, hipStream_t s, int dec,
                    int interleaved, int up)
 {
-    if (interleaved && (dec > 1 || nrow != 1)) return 1;
+    if (interleaved && nrow != 1) return 1;
     // .up: x holds n / up samples; one row, no decimation; the exact-division trick of the staging covers up <= 4096
     if (up > 1 && (dec > 1 || nrow != 1 || up > 4096 || n % up != 0)) return 1;
     if (h->order != 2 || h->nsec < 1 || h->nsec > 8) return 1;
@@ -898,8 +959,10 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
         if (rc < 0) return rc;
     }
     if (tb.K == 0) return 1;
+    // (interleaved signals have no decimating store here but the compact one)
+    if (interleaved && dec > 1 && !(dbl ? par_dec_compact<double, true>(dec, (int64_t)32 * tb.T) : par_dec_compact<float, true>(dec, (int64_t)32 * tb.T))) return 1;
     if (interleaved)
-        return dbl ? launch_par<double, true>(h, p, tb, x, n, 1, 0, 0, y, s, 1, up) : launch_par<float, true>(h, p, tb, x, n, 1, 0, 0, y, s, 1, up);
+        return dbl ? launch_par<double, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up) : launch_par<float, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up);
     return dbl ? launch_par<double, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up)
                : launch_par<float, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up);
 }

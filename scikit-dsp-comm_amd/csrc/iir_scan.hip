@@ -1220,9 +1220,10 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     // Parallel form (iir_par.hip): the same transfer function as independent two-state branches, every wave its own segment.
     // No state crosses these calls (scipy's zi / zf live in the cascade's coordinates: such calls keep the kernels below).
     if (zi_host == nullptr && zf_host == nullptr && opt().iir_par > 0 && h->order == 2 && h->nsec <= 8 &&
-        (interleaved ? dec <= 1 : (dec <= 1 || nbatch == 1))) {
-        // (interleaved complex: re and im are two independent real signals on one memory stream: lanes alternate between them)
-        const int r = interleaved ? iir_par_launch(h, x, n, 1, 0, 0, y, s, 1, 1)
+        (interleaved || dec <= 1 || nbatch == 1)) {
+        // (interleaved complex: re and im are two independent real signals on one memory stream: lanes alternate between them;
+        // with dec > 1 only where a segment's kept outputs fit the wave's stage image -- else 1 comes back)
+        const int r = interleaved ? iir_par_launch(h, x, n, 1, 0, 0, y, s, dec, 1)
                                   : iir_par_launch(h, x, n, nbatch, batch_stride, batch_stride, y, s, dec);
         if (r != 1) return r;   // (1 = not applicable: poles shared between sections, slow decay, ...)
     }

@@ -108,24 +108,44 @@ def test_parallel_form_is_what_config4_runs():
         y2.free()
 
 
-@pytest.mark.parametrize("M", [2, 3, 4, 12, 5000])
-@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("M", [2, 3, 4, 5, 12, 13, 64, 127, 4096, 5000])
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
 def test_parallel_form_decimating_store(dt, M):
-    """.dn: only every M-th output is stored (multirate_helper.py:186-192: downsample(sosfilt(sos, x), M))."""
+    """.dn: only every M-th output is stored (multirate_helper.py:186-192: downsample(sosfilt(sos, x), M)).  Where M is at least the
+    samples of a 16-byte unit and a segment's kept outputs fit the wave's stage image they are gathered there and leave as one
+    contiguous run (option iir_dn_compact); the other store picks them out of the transposed image.  Both against the reference
+    arithmetic, and against each other bit for bit; sizes that end inside a segment, a chunk and a unit."""
     from scipy import signal
-    sos = designs()["ellip8"]
-    n = 1_300_007
-    k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
-    xd = _ffi.DeviceArray(n, dt).fill_noise(9)
-    yd = _ffi.DeviceArray(n // M + 8, dt)
-    try:
-        k.dn_dev(xd, yd, M)
-        got = yd.to_host(0, n // M)
-        ref = signal.sosfilt(sos, xd.to_host().astype(np.float64))[::M][:n // M]
-        assert_close(got, ref, TOL32 if dt == np.float32 else TOL64, "dn M=%d" % M)
-    finally:
-        xd.free()
-        yd.free()
+    cplx = np.dtype(dt).kind == "c"
+    single = np.dtype(dt).itemsize // (2 if cplx else 1) == 4
+    for name in ("ellip8", "butter3"):
+        sos = designs()[name]
+        for n in (1_300_007, 8192 * 5, 8192 * 2 + 129, 4099, M, M - 1, 1):
+            if n < 1:
+                continue
+            k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+            xd = _ffi.DeviceArray(n, dt).fill_noise(9 + M)
+            yd = _ffi.DeviceArray(n // M + 8, dt)
+            try:
+                x = xd.to_host()
+                ref = signal.sosfilt(sos, x.astype(np.complex128 if cplx else np.float64))[::M][:n // M]
+                got = []
+                for compact in (1, 0):
+                    with _ffi.option("iir_dn_compact", compact):
+                        yd.write(np.full(n // M + 8, 7.0, dtype=dt))
+                        k.dn_dev(xd, yd, M)
+                        got.append(yd.to_host(0, n // M))
+                        assert np.all(yd.to_host(n // M, 8) == 7.0), "wrote beyond floor(n / M) outputs (M=%d n=%d compact=%d)" % (M, n, compact)
+                if n // M:
+                    if n >= 4099:
+                        assert_close(got[0], ref, TOL32 if single else TOL64, "%s dn M=%d n=%d" % (name, M, n))
+                    if not cplx:
+                        assert np.array_equal(got[0], got[1]), (name, M, n)
+                    else:
+                        assert max(rel_err(got[0], got[1])) <= (2e-7 if single else 1e-13), (name, M, n)
+            finally:
+                xd.free()
+                yd.free()
 
 
 @pytest.mark.parametrize("L", [2, 3, 4, 5, 12, 13, 64, 100, 4096])
