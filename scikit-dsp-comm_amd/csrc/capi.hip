@@ -256,6 +256,7 @@ static bool fir_needs_parts(const FirHandle *h, int L = 1)
     return per_phase > (dtype_double(h->dtype) ? 2049 : 4097);
 }
 static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev);
+static int fir_filter_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev);
 static int ols_launch_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, int dec = 1);
 // y[j] = L sum_t b[(j M mod L) + L t] x[(j M div L) - t] with b cut into segments of `seg` taps, seg a multiple of lcm(L, M):
 // segment s delays the up-rate signal by s seg samples = s seg / L input samples = s seg / M outputs, so it is the same
@@ -332,7 +333,16 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
     if (dtype_double(h->dtype)) {  // float64: the decimating overlap-save store beats Ntaps / M direct FP64 taps per kept sample early
         if (M > 1 && pick_fir_algo(h, n) == SKDSP_FIR_OLS && !opt().dn_no_ols && h->ntaps / M >= 24)
             return fir_ols64_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
-        return fir_direct_launch(h, x_dev, n, n_hist, 1, M, n / M, y_dev, ctx().stream);
+        int rc = fir_direct_launch(h, x_dev, n, n_hist, 1, M, n / M, y_dev, ctx().stream);
+        if (rc == SKDSP_ERR_UNSUPPORTED && M > 1) {   // (a stride the polyphase kernels' LDS window does not hold: see below)
+            if (fir_ols64_supported(h) && !opt().dn_no_ols) return fir_ols64_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
+            void *full = nullptr;
+            const int64_t nk = (n / M) * M;
+            if ((rc = ws_reserve(2, (size_t)nk * dtype_size(h->dtype) + 256, &full))) return rc;
+            if ((rc = fir_filter_any(h, x_dev, nk, n_hist, full))) return rc;
+            return downsample_launch(full, nk, M, 0, h->dtype, y_dev, ctx().stream);
+        }
+        return rc;
     }
     bool ols = M > 1 && fir_ols_supported(h) && pick_fir_algo(h, n) == SKDSP_FIR_OLS && !opt().dn_no_ols;
     if (ols) {
@@ -341,7 +351,18 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
         else ols = h->ntaps / M >= (h->dtype == SKDSP_C64 ? 24 : 64);  // the two-real-tiles store pays two divides per sample
     }
     if (ols) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
-    return fir_direct_launch(h, x_dev, n, n_hist, 1, M, n / M, y_dev, ctx().stream);
+    int rc = fir_direct_launch(h, x_dev, n, n_hist, 1, M, n / M, y_dev, ctx().stream);
+    if (rc == SKDSP_ERR_UNSUPPORTED && M > 1) {
+        // a stride the polyphase kernels' LDS window does not hold (a few hundred taps and M in the thousands): the decimating
+        // overlap-save store takes any M; without that engine, the full-rate filter and a strided copy
+        if (fir_ols_supported(h) && !opt().dn_no_ols) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
+        void *full = nullptr;
+        const int64_t nk = (n / M) * M;
+        if ((rc = ws_reserve(2, (size_t)nk * dtype_size(h->dtype) + 256, &full))) return rc;
+        if ((rc = fir_filter_any(h, x_dev, nk, n_hist, full))) return rc;
+        return downsample_launch(full, nk, M, 0, h->dtype, y_dev, ctx().stream);
+    }
+    return rc;
 }
 
 // .up / fused L over M: one polyphase launch, or tap segments when a phase holds more taps than a launch takes

@@ -64,6 +64,7 @@ struct OlsArgs {
     int aligned;    // x and y element-aligned (8 bytes complex64, 4 bytes float32)
     int64_t ntiles;
     int dec;        // > 1: keep every dec-th output only (multirate_FIR.dn): y[g / dec] = out[g] for g % dec == 0
+    unsigned dec_magic;   // ceil(2^32 / dec): (g * dec_magic) >> 32 = g / dec for the tile-local g < 2^15 met in the store
     int64_t n_keep; // dec * floor(n / dec)
     // Sharded filter (dist.hip): the Ntaps-1 samples in front of x arrive over xGMI on another stream while this launch
     // already runs.  Only tile 0 reads them, so tile 0 is walked LAST and whoever owns it waits for halo_flag >= halo_seq
@@ -147,7 +148,9 @@ __device__ __forceinline__ void load_tile(const OlsArgs &A, int64_t tile, int t,
     }
 }
 
-template <bool DEC> __device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t, const cf *v)
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+
+template <bool DEC> __device__ __forceinline__ void store_tile(const OlsArgs &A, int64_t tile, int t, const cf *v, float4 *lds)
 {
     const int64_t out0 = tile * A.V;
     const bool full = A.aligned && out0 + A.V <= A.n;
@@ -156,21 +159,37 @@ template <bool DEC> __device__ __forceinline__ void store_tile(const OlsArgs &A,
 #endif
     if (DEC) {
         // decimating store: the full-rate convolution is computed (it is memory-bound, and cheaper than
-        // Ntaps/dec direct taps per kept sample once Ntaps/dec exceeds a few dozen), 1/dec of it leaves
+        // Ntaps/dec direct taps per kept sample once Ntaps/dec exceeds a few dozen), 1/dec of it leaves.  The tile's kept outputs are
+        // ONE run of y: every thread drops its kept samples into the (idle) FFT image at their output positions -- one multiply-high
+        // per sample finds them -- and the workgroup then writes the run with consecutive 2 KiB stores.  (Before: a 32-bit division
+        // and a predicated 8-byte store per sample, a quarter of the lanes of every store instruction active at dec = 4.)
         const unsigned M = (unsigned)A.dec;
         const int64_t q0 = out0 / A.dec;                 // uniform
         const unsigned r0 = (unsigned)(out0 - q0 * A.dec);
+        const unsigned ob = r0 != 0 ? 1u : 0u;           // the tile's first output, relative to q0
+        cf *buf = reinterpret_cast<cf *>(lds);
         int a0 = A.a0;   // (opaque copy: nothing of this path is hoisted out of the tile loop)
         asm volatile("" : "+s"(a0));
+        __syncthreads();   // every wave has read its share of the image
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             if (a < a0) continue;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const unsigned gl = r0 + 512u * (unsigned)(a - a0) + 2u * (unsigned)t + (unsigned)e;
-                const unsigned q = gl / M;
-                if (q * M == gl && out0 + (int64_t)(gl - r0) < A.n_keep) A.y[q0 + q] = v[2 * a + e];
+                const unsigned q = (unsigned)(((unsigned long long)gl * A.dec_magic) >> 32);
+                if (q * M == gl) buf[q - ob] = v[2 * a + e];
             }
+        }
+        __syncthreads();
+        int64_t oe = q0 + (int64_t)((r0 + (unsigned)A.V + M - 1) / M);
+        const int64_t n_out = A.n_keep / A.dec;
+        if (oe > n_out) oe = n_out;
+        const int cnt = (int)(oe - (q0 + ob));
+        cf *yo = A.y + q0 + ob;
+        for (int i = t; i < cnt; i += 256) {
+            const v2f_t o = {buf[i].x, buf[i].y};
+            __builtin_nontemporal_store(o, reinterpret_cast<v2f_t *>(yo + i));
         }
         return;
     }
@@ -226,7 +245,6 @@ template <bool DEC> __device__ __forceinline__ void store_tile(const OlsArgs &A,
 // A real-tap FIR commutes with taking real/imaginary parts, so real tile 2p goes in as
 // the real part and real tile 2p+1 as the imaginary part of complex tile p; the FFT work
 // per real sample halves and the same kernel body serves both dtypes.
-typedef float v2f_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void load_tile_real(const OlsArgs &A, int64_t pair, int t, cf *v)
 {
@@ -261,29 +279,38 @@ __device__ __forceinline__ void load_tile_real(const OlsArgs &A, int64_t pair, i
     }
 }
 
-template <bool DEC> __device__ __forceinline__ void store_tile_real(const OlsArgs &A, int64_t pair, int t, const cf *v)
+template <bool DEC> __device__ __forceinline__ void store_tile_real(const OlsArgs &A, int64_t pair, int t, const cf *v, float4 *lds)
 {
     float *yr = reinterpret_cast<float *>(A.y);
     const int64_t outA = (2 * pair) * A.V, outB = outA + A.V;
     const bool full = A.aligned && outB + A.V <= A.n;
-    if (DEC) {  // decimating store, see store_tile
+    if (DEC) {  // decimating store, see store_tile: the pair's two tiles are one run of 2 V outputs
         const unsigned M = (unsigned)A.dec;
-        const int64_t qa = outA / A.dec, qb = outB / A.dec;
-        const unsigned ra0 = (unsigned)(outA - qa * A.dec), rb0 = (unsigned)(outB - qb * A.dec);
+        const int64_t q0 = outA / A.dec;
+        const unsigned r0 = (unsigned)(outA - q0 * A.dec);
+        const unsigned ob = r0 != 0 ? 1u : 0u;
+        float *buf = reinterpret_cast<float *>(lds);
         int a0 = A.a0;   // (opaque copy: see store_tile)
         asm volatile("" : "+s"(a0));
+        __syncthreads();
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             if (a < a0) continue;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const unsigned loc = 512u * (unsigned)(a - a0) + 2u * (unsigned)t + (unsigned)e;
-                const unsigned ga = ra0 + loc, gb = rb0 + loc;
-                const unsigned ka = ga / M, kb = gb / M;
-                if (ka * M == ga && outA + (int64_t)loc < A.n_keep) yr[qa + ka] = v[2 * a + e].x;
-                if (kb * M == gb && outB + (int64_t)loc < A.n_keep) yr[qb + kb] = v[2 * a + e].y;
+                const unsigned ga = r0 + 512u * (unsigned)(a - a0) + 2u * (unsigned)t + (unsigned)e, gb = ga + (unsigned)A.V;
+                const unsigned ka = (unsigned)(((unsigned long long)ga * A.dec_magic) >> 32), kb = (unsigned)(((unsigned long long)gb * A.dec_magic) >> 32);
+                if (ka * M == ga) buf[ka - ob] = v[2 * a + e].x;
+                if (kb * M == gb) buf[kb - ob] = v[2 * a + e].y;
             }
         }
+        __syncthreads();
+        int64_t oe = q0 + (int64_t)((r0 + 2u * (unsigned)A.V + M - 1) / M);
+        const int64_t n_out = A.n_keep / A.dec;
+        if (oe > n_out) oe = n_out;
+        const int cnt = (int)(oe - (q0 + ob));
+        float *yo = yr + q0 + ob;
+        for (int i = t; i < cnt; i += 256) __builtin_nontemporal_store(buf[i], yo + i);
         return;
     }
     if (full) {
@@ -334,9 +361,9 @@ template <bool REAL> __device__ __forceinline__ void load_any(const OlsArgs &A, 
 {
     if (REAL) load_tile_real(A, tile, t, v); else load_tile(A, tile, t, v);
 }
-template <bool REAL, bool DEC> __device__ __forceinline__ void store_any(const OlsArgs &A, int64_t tile, int t, const cf *v)
+template <bool REAL, bool DEC> __device__ __forceinline__ void store_any(const OlsArgs &A, int64_t tile, int t, const cf *v, float4 *lds)
 {
-    if (REAL) store_tile_real<DEC>(A, tile, t, v); else store_tile<DEC>(A, tile, t, v);
+    if (REAL) store_tile_real<DEC>(A, tile, t, v, lds); else store_tile<DEC>(A, tile, t, v, lds);
 }
 
 // Persistent: gridDim.x = 2 workgroups per CU, each walks tiles blockIdx.x, +gridDim.x, ...
@@ -441,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
             const int64_t next = tile + gridDim.x;
             cf nx[32];
             if (next < A.ntiles) load_any<REAL>(A, phys(next), t, nx);
-            store_any<REAL, DEC>(A, phys(tile), t, v);
+            store_any<REAL, DEC>(A, phys(tile), t, v, lds);
 #pragma unroll
             for (int i = 0; i < 32; ++i) v[i] = nx[i];
             continue;
@@ -496,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 #elif SKDSP_OLS_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
-        store_any<REAL, DEC>(A, phys(tile), t, v);
+        store_any<REAL, DEC>(A, phys(tile), t, v, lds);
 #if SKDSP_OLS_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
 #elif SKDSP_OLS_PRIO == 2
@@ -606,6 +633,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols: too many tiles");
     A.ntiles = ntiles;
     A.dec = dec > 1 ? dec : 1;
+    A.dec_magic = A.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + A.dec - 1) / A.dec) : 0u;
     A.n_keep = n;
     A.halo_flag = halo_flag; A.halo_seq = halo_seq; A.halo_err = halo_err;
     SK_CHECK(!(halo_flag && real), SKDSP_ERR_UNSUPPORTED, "fir_ols: halo flag wait is for complex64 shards");

@@ -146,6 +146,7 @@ struct Ols64Args {
     int ov, V, a0;    // a0 = ov / 256: first stored 256-block
     int64_t ntiles;
     int dec;
+    unsigned dec_magic;   // ceil(2^32 / dec): (g * dec_magic) >> 32 = g / dec for the tile-local g < 2^14 of the decimating store
     int64_t n_keep;
 };
 
@@ -332,7 +333,50 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
         const int64_t out0 = (REAL ? 2 * tile : tile) * A.V;
         const bool full = !DEC && out0 + (REAL ? 2 : 1) * (int64_t)A.V <= A.n;
         typedef double v2d_t __attribute__((ext_vector_type(2)));
-        if (full) {
+        if (DEC) {
+            // decimating store (multirate_FIR.dn): the tile's (the pair's) kept outputs are ONE run of y.  Every thread drops its kept samples
+            // into the idle image at their output positions -- one multiply-high per sample finds them -- and the workgroup writes the run
+            // with consecutive stores.  (Before: a 64-bit remainder, a 64-bit quotient and a predicated store per sample.)
+            const unsigned M = (unsigned)A.dec;
+            const int64_t q0 = out0 / A.dec;                 // uniform
+            const unsigned r0 = (unsigned)(out0 - q0 * A.dec);
+            const unsigned ob = r0 != 0 ? 1u : 0u;           // the run's first output, relative to q0
+            int a0 = A.a0;   // (opaque copy: nothing of this path is hoisted out of the tile loop)
+            asm volatile("" : "+s"(a0));
+            __syncthreads();   // every wave has read its share of the image
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                if (a < a0) continue;
+                const unsigned ga = r0 + 256u * (unsigned)(a - a0) + (unsigned)ts;
+                const unsigned ka = (unsigned)(((unsigned long long)ga * A.dec_magic) >> 32);
+                if (REAL) {
+                    double *buf = reinterpret_cast<double *>(img);
+                    const unsigned gb = ga + (unsigned)A.V;
+                    const unsigned kb = (unsigned)(((unsigned long long)gb * A.dec_magic) >> 32);
+                    if (ka * M == ga) buf[ka - ob] = v[a].x;
+                    if (kb * M == gb) buf[kb - ob] = v[a].y;
+                } else if (ka * M == ga) {
+                    img[ka - ob] = v[a];
+                }
+            }
+            __syncthreads();
+            int64_t oe = q0 + (int64_t)((r0 + (REAL ? 2u : 1u) * (unsigned)A.V + M - 1) / M);
+            const int64_t n_out = A.n_keep / A.dec;
+            if (oe > n_out) oe = n_out;
+            const int cnt = (int)(oe - (q0 + ob));
+            if (REAL) {
+                const double *buf = reinterpret_cast<const double *>(img);
+                double *yo = A.y + q0 + ob;
+                for (int i = ts; i < cnt; i += 256) __builtin_nontemporal_store(buf[i], yo + i);
+            } else {
+                v2d_t *yo = reinterpret_cast<v2d_t *>(A.y) + q0 + ob;
+                for (int i = ts; i < cnt; i += 256) {
+                    v2d_t q;
+                    q.x = img[i].x; q.y = img[i].y;
+                    __builtin_nontemporal_store(q, yo + i);
+                }
+            }
+        } else if (full) {
             auto stores = [&](auto a0c) __attribute__((always_inline)) {
                 constexpr int A0 = decltype(a0c)::value;
 #pragma unroll
@@ -475,6 +519,7 @@ int fir_ols64_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, voi
     if (real) ntiles = (ntiles + 1) / 2;
     A.ntiles = ntiles;
     A.dec = dec > 1 ? dec : 1;
+    A.dec_magic = A.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + A.dec - 1) / A.dec) : 0u;
     A.n_keep = n;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     if (grid > ntiles) grid = ntiles;

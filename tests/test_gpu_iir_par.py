@@ -239,6 +239,45 @@ def test_parallel_form_coherent_inputs(kind):
         assert np.max(np.abs(y - ref)) <= 5e-7 * scale, (name, kind, np.max(np.abs(y - ref)) / scale)
 
 
+@pytest.mark.parametrize("M", [2, 3, 4, 5, 12, 13, 64, 1000, 4096])
+@pytest.mark.parametrize("dt,ntaps", [(np.complex64, 512), (np.float32, 1024), (np.float32, 300), (np.complex64, 2049), (np.float64, 1024), (np.complex128, 700)])
+def test_fir_overlap_save_decimating_store(dt, ntaps, M):
+    """multirate_FIR.dn through the overlap-save engine (multirate_helper.py:121-127: downsample(lfilter(b, [1], x), M)): every tile's kept
+    outputs are gathered in the FFT image and leave as one run.  Against the oracle on windows of the result, for lengths that end inside
+    a tile, and nothing may be written beyond floor(n / M) outputs."""
+    import bench
+    b = bench.firwin_lowpass(ntaps, 0.8 / M if M <= 64 else 0.05)
+    cplx = np.dtype(dt).kind == "c"
+    for n in (3_000_017, 7169 * 3 + 5, 8192, M * 7 + M - 1, M, 1):
+        k = _ffi.FirKernel(b, _ffi.code_of(dt))
+        k.set_algo(_ffi.FIR_OLS)
+        xd = _ffi.DeviceArray(n, dt).fill_noise(M + ntaps)
+        yd = _ffi.DeviceArray(n // M + 8, dt)
+        try:
+            yd.write(np.full(n // M + 8, 7.0, dtype=dt))
+            k.dn_dev(xd, yd, M)
+            got = yd.to_host(0, n // M)
+            assert np.all(yd.to_host(n // M, 8) == 7.0), "wrote beyond floor(n / M) outputs (M=%d n=%d)" % (M, n)
+            x = xd.to_host().astype(np.complex128 if cplx else np.float64)
+            if n // M == 0:
+                continue
+            tol = 1e-6 if np.dtype(dt).itemsize // (2 if cplx else 1) == 4 else 1e-12
+            if n <= 40_000:
+                ref = orc.fir_filter(b, x)[::M][:n // M]
+                assert_close(got, ref, tol * max(1.0, np.sum(np.abs(b)) * np.max(np.abs(x)) / np.max(np.abs(ref))), "dn M=%d n=%d" % (M, n))
+            else:
+                for o0 in (0, (n // M) // 2, n // M - 300):
+                    cnt = min(300, n // M - o0)
+                    lo = max(o0 * M - (ntaps - 1), 0)
+                    seg = orc.fir_filter(b, x[lo:(o0 + cnt) * M])[o0 * M - lo:]
+                    ref = seg[::M][:cnt]
+                    # (float32 contract: 1e-6 of the output's peak; a window inside the start-up transient is far below it)
+                    assert np.max(np.abs(got[o0:o0 + cnt] - ref)) <= tol * np.max(np.abs(got)), (M, n, o0)
+        finally:
+            xd.free()
+            yd.free()
+
+
 # ---- N-D FIR rows in one call (the FIR half of the same reference behaviour: lfilter along the last axis) --------------
 @pytest.mark.parametrize("ntaps,shape,dt", [(127, (4096, 16384), np.float32), (1024, (6, 3, 20000), np.complex64), (33, (5, 70), np.float64),
                                             (1024, (3, 9000), np.complex128), (300, (17, 5000), np.float32), (5000, (3, 12000), np.float32)])
