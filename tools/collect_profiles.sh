@@ -38,6 +38,8 @@ python bench.py --scaling strong --total-log2n 30 --steps 50 --warmup 10 --no-cp
 python tools/power_probe.py idle copy fir1024 fir1024f32 fir1024f64 fir1024c128 updn43 fir127 iir8 iir8cas iir8c64 iirlp8 > $OUT/power_probe.txt 2>&1
 python tools/ab_iir_par.py 26 > $OUT/ab_iir_par.txt 2>&1
 python tools/time_fir_shapes.py > $OUT/fir_shapes.txt 2>&1
+python tools/time_iir_up.py > $OUT/iir_up.txt 2>&1
+python tools/time_iir_dn.py > $OUT/iir_dn.txt 2>&1
 python tools/time_fir_c128.py > $OUT/fir_f64.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_dp_pipes.hip -o /tmp/ubench_dp_pipes 2>/dev/null && /tmp/ubench_dp_pipes > $OUT/ubench_dp_pipes.txt 2>&1
 ls -la $OUT
