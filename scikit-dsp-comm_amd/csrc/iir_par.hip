@@ -88,6 +88,9 @@ struct ParArgs {
     // dec_compact: the kept outputs of a whole segment are gathered in the wave's (idle) stage image and leave as one contiguous run of
     // y (dec >= the samples of a 16-byte unit, and n_seg / dec of them fit the image); else the image-and-pick path below
     int dec_compact;
+    // dec_rounds > 1 (float32 / complex64 with dec = 2, 3: a segment keeps more than the image holds, and a 16-byte unit up to two samples):
+    // the gathering happens behind the recurrence, dec_rounds ranges of chunks one after the other, each range a run of its own
+    int dec_rounds;
     unsigned dec_magic;          // ceil(2^32 / dec)
     // up > 1 (one row): x holds n_in = n / up samples and the kernel filters up * upsample(x, up) -- the zero-stuffed
     // signal exists only in the wave's staging image (multirate_IIR.up / rate_change.up: multirate_helper.py:69-75, 177-184)
@@ -113,10 +116,14 @@ __device__ __forceinline__ void blocks_acc(const double *__restrict__ P, const d
 
 typedef double v2d_t __attribute__((ext_vector_type(2)));
 
-template <int NSEC, typename IO, bool DEC, bool CPLX>
+// DECM: 0 every output is stored; 1 .dn (the kept outputs gathered per piece, or picked out of the image); 2 .dn with dec = 2, 3 on 4-sample
+// units (gathered behind the recurrence in ranges of chunks) -- an instantiation of its own: inside the others its 64 predicated LDS
+// writes cost the 8-biquad kernels 450 spilled SGPRs and 2 % on every other M
+template <int NSEC, typename IO, int DECM, bool CPLX>
 __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
                                                                  const double *__restrict__ lvl, const double *__restrict__ psi)
 {
+    constexpr bool DEC = DECM != 0;
     constexpr int D = 2 * NSEC;
     constexpr int T = SK_PAR_T32 * 4 / (int)sizeof(IO);
     constexpr int NP = T / kPiece;
@@ -455,9 +462,10 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     // v = R0 + cj T + c of the segment, R0 = (first sample of the segment) mod dec; sample v is kept iff dec divides v, as
     // output Q0 + v / dec of the row.  (dq, dt) = (v / dec, v mod dec) of the next 16-byte unit, advanced by its size per unit.
     const bool compact = DEC && a.dec_compact;
+    constexpr bool rounds = DECM == 2;
     int64_t dec_q0 = 0;
     unsigned dec_r0 = 0, dq = 0, dt = 0;
-    if (compact) {
+    if (compact || rounds) {
         dec_q0 = m0 / a.dec;
         dec_r0 = (unsigned)(m0 - dec_q0 * a.dec);
         const unsigned v0 = dec_r0 + (unsigned)((lane / LS) * T);
@@ -509,6 +517,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
             }
             continue;
         }
+        if (rounds) continue;   // (the outputs stay in the registers of the chunk until the gathering below)
         if (PRIO && SK_PAR_PRIO_ST) __builtin_amdgcn_s_setprio(SK_PAR_PRIO);   // (the piece's way out through the image: -2.7 %)
         wave_lds_sync();  // the wave's rows are free (its previous piece's stores have read them)
 #pragma unroll
@@ -570,6 +579,51 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
                 for (int e = 0; e < St::elems; ++e)
                     if (g + e / LS < a.n) y[g * LS + e] = tmp[e];
             }
+        }
+    }
+    if constexpr (rounds) {
+        // dec = 2, 3 on 4-sample units: the chunks of the segment in a.dec_rounds ranges; a range's kept outputs are a run of the row
+        const unsigned M = (unsigned)a.dec;
+        const int per = CH / a.dec_rounds;                              // chunks per range
+        const int cj = lane / LS;
+        const unsigned v0 = dec_r0 + (unsigned)(cj * T);
+        const unsigned dq0 = (unsigned)(((unsigned long long)v0 * a.dec_magic) >> 32), dt0 = v0 - dq0 * M;
+#pragma unroll 1
+        for (int rd = 0; rd < a.dec_rounds; ++rd) {
+            const unsigned vb = dec_r0 + (unsigned)(rd * per * T);       // the range's first sample
+            const unsigned ob_r = (vb + M - 1) / M;                        // its first output, relative to dec_q0
+            if (cj / per == rd) {
+                unsigned q = dq0, t = dt0;
+#pragma unroll
+                for (int ui = 0; ui < T / St::elems; ++ui) {
+                    const xv_t u = xq[ui];
+                    // the unit's kept samples: e0 = (-t) mod M and, if it still lies inside the unit, e0 + M
+                    const unsigned e0 = t == 0 ? 0u : M - t, e1 = e0 + M;
+                    IO p0 = u[0], p1 = u[St::elems - 1];
+#pragma unroll
+                    for (int e = 1; e < St::elems; ++e) {
+                        p0 = (e0 == (unsigned)e) ? u[e] : p0;
+                        p1 = (e1 == (unsigned)e) ? u[e] : p1;
+                    }
+                    const unsigned o0 = q + (t != 0);                      // output of the sample at e0, relative to dec_q0
+                    const unsigned slot = (o0 - ob_r) * LS + (unsigned)(lane % LS);
+                    if (e0 < (unsigned)St::elems && o0 < olim) stage[slot + (slot >> 5)] = p0;
+                    if (e1 < (unsigned)St::elems && o0 + 1 < olim) stage[slot + LS + ((slot + LS) >> 5)] = p1;
+                    t += St::elems;
+                    const unsigned kk = (t >= M) + (t >= 2 * M);
+                    t -= kk * M;
+                    q += kk;
+                }
+            }
+            wave_lds_sync();
+            const unsigned ve = dec_r0 + (unsigned)((rd + 1) * per * T);
+            unsigned oe_r = (ve + M - 1) / M;
+            if (oe_r > olim) oe_r = olim;
+            const int cnt = oe_r > ob_r ? (int)(oe_r - ob_r) * LS : 0;
+            IO *yo = y + (dec_q0 + ob_r) * LS;
+#pragma unroll 1
+            for (int i = lane; i < cnt; i += 64) __builtin_nontemporal_store(stage[i + (i >> 5)], yo + i);
+            wave_lds_sync();
         }
     }
     if (compact) {
@@ -838,6 +892,12 @@ template <typename IO, bool CPLX> static bool par_dec_compact(int dec, int64_t s
     return dec >= elems && bytes <= (int64_t)64 * Stage<IO>::pitch * (int64_t)sizeof(IO) && opt().iir_dn_compact;
 }
 
+// .dn with dec below the samples of a 16-byte unit (float32 / complex64, dec = 2, 3): gathered in two ranges of chunks behind the recurrence
+template <typename IO, bool CPLX> static bool par_dec_rounds(int dec)
+{
+    return sizeof(IO) == 4 && (dec == 2 || dec == 3) && opt().iir_dn_compact;
+}
+
 template <typename IO, bool CPLX>
 static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
                       void *y, hipStream_t s, int dec, int up = 1)
@@ -876,6 +936,7 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
     a.dec = dec > 1 ? dec : 1;
     a.dec_magic = a.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + a.dec - 1) / a.dec) : 0u;
     a.dec_compact = a.dec > 1 && par_dec_compact<IO, CPLX>(a.dec, S) ? 1 : 0;
+    a.dec_rounds = !a.dec_compact && par_dec_rounds<IO, CPLX>(a.dec) ? 2 : 1;
     a.up = up > 1 ? up : 1;
     a.up_magic = a.up > 1 ? (unsigned)((((unsigned long long)1 << 32) + a.up - 1) / a.up) : 0u;
     a.n_in = a.up > 1 ? n / a.up : n;
@@ -903,11 +964,15 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
         ParCoef<N> cf;                                                                                                  \
         for (int k = 0; k < N; ++k) { cf.na1[k] = p->na1[k]; cf.na2[k] = p->na2[k]; cf.al[k] = p->al[k]; cf.be[k] = p->be[k]; } \
         cf.gamma = p->gamma;                                                                                            \
-        if (a.dec > 1)                                                                                                  \
-            hipLaunchKernelGGL((iir_par_kernel<N, IO, true, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,         \
+        if (a.dec > 1 && a.dec_rounds > 1) {                                                                            \
+            if constexpr (sizeof(IO) == 4)                                                                              \
+                hipLaunchKernelGGL((iir_par_kernel<N, IO, 2, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,        \
+                                   (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);  \
+        } else if (a.dec > 1)                                                                                           \
+            hipLaunchKernelGGL((iir_par_kernel<N, IO, 1, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,            \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);      \
         else                                                                                                            \
-            hipLaunchKernelGGL((iir_par_kernel<N, IO, false, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,        \
+            hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,            \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);      \
         break;                                                                                                          \
     }
@@ -960,7 +1025,8 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     }
     if (tb.K == 0) return 1;
     // (interleaved signals have no decimating store here but the compact one)
-    if (interleaved && dec > 1 && !(dbl ? par_dec_compact<double, true>(dec, (int64_t)32 * tb.T) : par_dec_compact<float, true>(dec, (int64_t)32 * tb.T))) return 1;
+    if (interleaved && dec > 1 && !(dbl ? par_dec_compact<double, true>(dec, (int64_t)32 * tb.T)
+                                        : (par_dec_compact<float, true>(dec, (int64_t)32 * tb.T) || par_dec_rounds<float, true>(dec)))) return 1;
     if (interleaved)
         return dbl ? launch_par<double, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up) : launch_par<float, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up);
     return dbl ? launch_par<double, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up)

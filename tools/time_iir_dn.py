@@ -10,7 +10,7 @@ if len(sys.argv) > 2:
     _ffi.set_option(sys.argv[1], int(sys.argv[2])); print(sys.argv[1], sys.argv[2])
 sos8 = np.load(os.path.join(ROOT, "tests", "golden", "g7_iir_sos.npz"))["sos8"]
 n = 1 << 26
-for name, sos, M in (("butter8 rc12", signal.butter(8, 0.075, output="sos"), 12), ("ellip8", sos8, 3), ("butter8 rc4", signal.butter(8, 0.225, output="sos"), 4)):
+for name, sos, M in (("butter8 rc12", signal.butter(8, 0.075, output="sos"), 12), ("ellip8", sos8, 3), ("ellip8", sos8, 2), ("ellip8", sos8, 4), ("butter8 rc2", signal.butter(8, 0.45, output="sos"), 2), ("butter8 rc4", signal.butter(8, 0.225, output="sos"), 4)):
     for dt in (np.float32, np.complex64, np.float64, np.complex128):
         k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
         xd = _ffi.DeviceArray(n, dt).fill_noise(5); yd = _ffi.DeviceArray(n // M + 16, dt)
