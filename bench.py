@@ -396,7 +396,25 @@ def device_copy_of(w, _ffi, reps=40):
     for _ in range(reps):
         _ffi.check(cp(dst, src, nbytes))
     ms = _ffi.timer_stop() / reps
-    return {"GBps": 2 * nbytes / ms / 1e6, "ms": ms, "bytes_copied": nbytes, "what": "hipMemcpyAsync device-to-device, read + written bytes"}
+    out = {"GBps": 2 * nbytes / ms / 1e6, "ms": ms, "bytes_copied": nbytes, "what": "hipMemcpyAsync device-to-device, read + written bytes"}
+    # the library's own stride-1 copy (sigsys.downsample(x, 1): one 16-byte load and store per lane) over the same bytes: a second
+    # reference, because hipMemcpyAsync is not the fastest copy this board does
+    try:
+        dn = _ffi.load().skdsp_downsample_dev
+        n_el = nbytes // w.xd.dtype.itemsize
+        for _ in range(10):
+            _ffi.check(dn(src, n_el, 1, 0, w.xd.code, dst))
+        _ffi.sync()
+        _ffi.timer_start()
+        for _ in range(reps):
+            _ffi.check(dn(src, n_el, 1, 0, w.xd.code, dst))
+        ms2 = _ffi.timer_stop() / reps
+        out["own_copy_GBps"] = 2 * nbytes / ms2 / 1e6
+        out["own_copy_what"] = "skdsp_downsample_dev(x, n, M=1): this library's stride-1 copy kernel over the same bytes"
+    except Exception as e:
+        out["own_copy_GBps"] = None
+        out["own_copy_what"] = "%s: %s" % (type(e).__name__, e)
+    return out
 
 
 def roofline_of(w, ev_ms, K, log2n_for_traffic):
@@ -560,6 +578,8 @@ def main():
             copy_ref = device_copy_of(w, _ffi)
             out["device_copy"] = copy_ref
             out["roofline"]["frac_of_device_copy"] = out["roofline"]["achieved"] / copy_ref["GBps"]
+            if copy_ref.get("own_copy_GBps"):
+                out["roofline"]["frac_of_fastest_copy"] = out["roofline"]["achieved"] / max(copy_ref["GBps"], copy_ref["own_copy_GBps"])
         except Exception as e:
             out["device_copy"] = {"skipped": "%s: %s" % (type(e).__name__, e)}
 
