@@ -1,0 +1,140 @@
+"""Randomised differential test of the reference surface (multirate_FIR / multirate_IIR / rate_change .filter/.up/.dn, upsample, downsample)
+against scipy.signal on the host: random dtypes, lengths (around tile / segment / chunk boundaries), factors, tap counts and designs,
+fixed seeds.  Complements the structured parity tests: its job is the combination nobody thought of."""
+import os
+
+import numpy as np
+import pytest
+from scipy import signal
+
+from sk_dsp_comm_amd import _ffi, multirate_helper as mrh, sigsys as ss
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+NSEED = int(os.environ.get("SKDSP_FUZZ_SEEDS", "12"))   # (more seeds for a one-off hunt: SKDSP_FUZZ_SEEDS=200)
+LENGTHS = [1, 2, 3, 7, 63, 64, 65, 127, 128, 129, 255, 257, 1023, 1024, 1025, 4095, 4097, 7168, 7169, 7170, 8191, 8192, 8193,
+           16384 + 5, 3 * 8192 - 1, 65536 + 17, 250_003]
+DTYPES = [np.float32, np.complex64, np.float64, np.complex128]
+
+
+def _signal(rng, n, dt):
+    x = rng.standard_normal(n)
+    if np.dtype(dt).kind == "c":
+        x = x + 1j * rng.standard_normal(n)
+    return x.astype(dt)
+
+
+def _tol(dt, ref, gain=1.0):
+    single = np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4
+    return (1e-6 if single else 1e-10) * gain
+
+
+def _check(y, ref, dt, what, bound):
+    """1e-6 (1e-10) of the output's peak -- or, for outputs far below the input (stop bands, start-up), of the forward bound"""
+    assert y.shape == ref.shape, (what, y.shape, ref.shape)
+    if ref.size == 0:
+        return
+    scale = max(float(np.max(np.abs(ref))), 1e-2 * bound)
+    err = float(np.max(np.abs(y - ref)))
+    assert err <= _tol(dt, ref) * scale * 2, "%s: err %.3g, scale %.3g" % (what, err, scale)
+
+
+@pytest.mark.parametrize("seed", range(NSEED))
+def test_fuzz_fir(seed):
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(14):
+        dt = DTYPES[rng.integers(len(DTYPES))]
+        n = int(LENGTHS[rng.integers(len(LENGTHS))])
+        ntaps = int(rng.choice([1, 2, 5, 31, 64, 127, 128, 200, 511, 512, 1024, 1500, 4097]))
+        b = signal.firwin(ntaps, float(rng.uniform(0.05, 0.8))) if ntaps > 1 else np.array([float(rng.uniform(0.5, 2.0))])
+        if rng.random() < 0.2:
+            b = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+        op = rng.choice(["filter", "up", "dn"])
+        f = int(rng.choice([1, 2, 3, 4, 5, 12, 17]))
+        x = _signal(rng, n, dt)
+        xw = x.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64)
+        fir = mrh.multirate_FIR(b)
+        bound = float(np.sum(np.abs(b)) * np.max(np.abs(x)))
+        what = "%s %s n=%d taps=%d f=%d" % (op, np.dtype(dt).name, n, ntaps, f)
+        if op == "filter":
+            _check(fir.filter(x), signal.lfilter(b, [1], xw), dt, what, bound)
+        elif op == "up":
+            if n * f > 3_000_000:
+                continue
+            up = np.zeros(n * f, dtype=xw.dtype)
+            up[::f] = f * xw
+            _check(fir.up(x, f), signal.lfilter(b, [1], up), dt, what, bound * f)
+        else:
+            _check(np.asarray(fir.dn(x, f)), signal.lfilter(b, [1], xw)[::f][:n // f], dt, what, bound)
+
+
+@pytest.mark.parametrize("seed", range(NSEED))
+def test_fuzz_iir(seed):
+    rng = np.random.default_rng(2000 + seed)
+    for _ in range(14):
+        dt = DTYPES[rng.integers(len(DTYPES))]
+        n = int(LENGTHS[rng.integers(len(LENGTHS))])
+        order = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 12, 16]))
+        kind = rng.choice(["butter", "cheby1", "ellip"])
+        wn = float(rng.uniform(0.03, 0.6))
+        if kind == "butter":
+            sos = signal.butter(order, wn, output="sos")
+        elif kind == "cheby1":
+            sos = signal.cheby1(order, 0.5, wn, output="sos")
+        else:
+            sos = signal.ellip(min(order, 8), 0.5, 60, wn, output="sos")
+        op = rng.choice(["filter", "up", "dn"])
+        f = int(rng.choice([1, 2, 3, 4, 5, 12, 17]))
+        x = _signal(rng, n, dt)
+        xw = x.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64)
+        iir = mrh.multirate_IIR(sos)
+        # forward bound of the cascade: the l1 norm of its impulse response (numerically) x max|x|
+        h = signal.sosfilt(sos, np.r_[1.0, np.zeros(4095)])
+        bound = float(np.sum(np.abs(h)) * np.max(np.abs(x)))
+        what = "%s %s n=%d %s(%d, %.3f) f=%d" % (op, np.dtype(dt).name, n, kind, order, wn, f)
+        if op == "filter":
+            _check(iir.filter(x), signal.sosfilt(sos, xw), dt, what, bound)
+        elif op == "up":
+            if n * f > 3_000_000:
+                continue
+            up = np.zeros(n * f, dtype=xw.dtype)
+            up[::f] = f * xw
+            _check(iir.up(x, f), signal.sosfilt(sos, up), dt, what, bound * f)
+        else:
+            _check(np.asarray(iir.dn(x, f)), signal.sosfilt(sos, xw)[::f][:n // f], dt, what, bound)
+
+
+@pytest.mark.parametrize("seed", range(max(NSEED // 3, 1)))
+def test_fuzz_rate_change_and_resamplers(seed):
+    rng = np.random.default_rng(3000 + seed)
+    for _ in range(10):
+        dt = DTYPES[rng.integers(len(DTYPES))]
+        n = int(LENGTHS[rng.integers(len(LENGTHS))])
+        M = int(rng.choice([2, 3, 4, 6, 12]))
+        x = _signal(rng, n, dt)
+        xw = x.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64)
+        rc = mrh.rate_change(M, 0.9, int(rng.choice([4, 6, 8])), str(rng.choice(["butter", "cheby1"])))
+        h = signal.lfilter(rc.b, rc.a, np.r_[1.0, np.zeros(8191)])
+        bound = float(np.sum(np.abs(h)) * np.max(np.abs(x)))
+        single = np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4
+        # (the reference runs (b, a) as ONE transposed section in float64: its own roundoff on these narrow designs is ~1e-9)
+        if n * M <= 3_000_000:
+            up = np.zeros(n * M, dtype=xw.dtype)
+            up[::M] = M * xw
+            ref = signal.lfilter(rc.b, rc.a, up)
+            y = rc.up(x)
+            assert np.max(np.abs(y - ref)) <= (2e-6 if single else 1e-7) * max(np.max(np.abs(ref)), 1e-2 * bound * M), ("rc.up", np.dtype(dt).name, n, M)
+        ref = signal.lfilter(rc.b, rc.a, xw)[::M][:n // M]
+        y = np.asarray(rc.dn(x))
+        assert y.shape == ref.shape
+        if ref.size:
+            assert np.max(np.abs(y - ref)) <= (2e-6 if single else 1e-7) * max(np.max(np.abs(ref)), 1e-2 * bound), ("rc.dn", np.dtype(dt).name, n, M)
+        L = int(rng.choice([1, 2, 3, 7]))
+        u = ss.upsample(x, L)
+        ru = np.zeros(n * L, dtype=u.dtype)
+        ru[::L] = x
+        assert np.array_equal(u, ru)
+        p = int(rng.integers(0, M))
+        if n >= M:
+            assert np.array_equal(np.asarray(ss.downsample(x, M, p)), x[p::M][:n // M])
