@@ -138,3 +138,42 @@ def test_fuzz_rate_change_and_resamplers(seed):
         p = int(rng.integers(0, M))
         if n >= M:
             assert np.array_equal(np.asarray(ss.downsample(x, M, p)), x[p::M][:n // M])
+
+
+@pytest.mark.parametrize("seed", range(max(NSEED // 2, 1)))
+def test_fuzz_nd_and_streaming(seed):
+    """N-D arrays filter along the last axis in one call (lfilter / sosfilt semantics); a signal cut at random points and run through
+    filter_stream block by block reproduces the one-shot result."""
+    rng = np.random.default_rng(4000 + seed)
+    for _ in range(6):
+        dt = DTYPES[rng.integers(len(DTYPES))]
+        single = np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4
+        wide = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+        # ---- N-D
+        shape = tuple(int(v) for v in rng.choice([1, 2, 3, 5, 17], size=int(rng.integers(1, 3)))) + (int(rng.choice([1, 5, 100, 4099, 8192, 20_001])),)
+        x = _signal(rng, int(np.prod(shape)), dt).reshape(shape)
+        ntaps = int(rng.choice([3, 64, 127, 300, 1024]))
+        b = signal.firwin(ntaps, 0.3)
+        sos = signal.butter(int(rng.choice([2, 5, 8])), float(rng.uniform(0.05, 0.5)), output="sos")
+        for name, y, ref, bound in (("fir", mrh.multirate_FIR(b).filter(x), signal.lfilter(b, [1], x.astype(wide)), np.sum(np.abs(b))),
+                                    ("iir", mrh.multirate_IIR(sos).filter(x), signal.sosfilt(sos, x.astype(wide)),
+                                     np.sum(np.abs(signal.sosfilt(sos, np.r_[1.0, np.zeros(4095)]))))):
+            _check(y, ref, dt, "%s N-D %s %s" % (name, shape, np.dtype(dt).name), float(bound * np.max(np.abs(x))))
+        # ---- streaming
+        n = int(rng.choice([10, 1000, 9000, 70_001]))
+        x = _signal(rng, n, dt)
+        cuts = sorted(set(int(c) for c in rng.integers(0, n + 1, size=int(rng.integers(1, 5)))) | {0, n})
+        fir, iir = mrh.multirate_FIR(b), mrh.multirate_IIR(sos)
+        yf, yi, zf, zi = [], [], None, None
+        for a0, a1 in zip(cuts[:-1], cuts[1:]):
+            blk = x[a0:a1]
+            if blk.size == 0:
+                continue
+            o, zf = fir.filter_stream(blk, zi=zf)
+            yf.append(o)
+            o, zi = iir.filter_stream(blk, zi=zi)
+            yi.append(o)
+        tol = 2e-6 if single else 1e-10
+        for name, got, ref in (("fir", np.concatenate(yf), signal.lfilter(b, [1], x.astype(wide))), ("iir", np.concatenate(yi), signal.sosfilt(sos, x.astype(wide)))):
+            assert got.shape == ref.shape
+            assert np.max(np.abs(got - ref)) <= tol * max(np.max(np.abs(ref)), 1e-2 * np.max(np.abs(x))), ("%s stream" % name, np.dtype(dt).name, n, cuts)
