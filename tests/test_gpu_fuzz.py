@@ -177,3 +177,62 @@ def test_fuzz_nd_and_streaming(seed):
         for name, got, ref in (("fir", np.concatenate(yf), signal.lfilter(b, [1], x.astype(wide))), ("iir", np.concatenate(yi), signal.sosfilt(sos, x.astype(wide)))):
             assert got.shape == ref.shape
             assert np.max(np.abs(got - ref)) <= tol * max(np.max(np.abs(ref)), 1e-2 * np.max(np.abs(x))), ("%s stream" % name, np.dtype(dt).name, n, cuts)
+
+
+@pytest.mark.parametrize("seed", range(max(NSEED // 2, 1)))
+def test_fuzz_device_views_at_odd_offsets(seed):
+    """The *_dev entry points on windows of larger device buffers: element-aligned but not 16-byte-aligned inputs and outputs (the vector
+    load / store fast paths must step aside), guard words on both sides of every output must survive."""
+    rng = np.random.default_rng(5000 + seed)
+    for _ in range(8):
+        dt = DTYPES[rng.integers(len(DTYPES))]
+        cplx = np.dtype(dt).kind == "c"
+        single = np.dtype(dt).itemsize // (2 if cplx else 1) == 4
+        wide = np.complex128 if cplx else np.float64
+        n = int(rng.choice([1, 5, 129, 4100, 8192, 8192 * 3 + 7, 70_003]))
+        op = str(rng.choice(["filter", "up", "dn"]))
+        f = 1 if op == "filter" else int(rng.choice([2, 3, 4, 5, 12]))
+        n_out = n if op == "filter" else (n * f if op == "up" else n // f)
+        if n_out == 0 or n_out > 2_000_000:
+            continue
+        ox, oy = int(rng.integers(0, 9)), int(rng.integers(1, 9))
+        x = _signal(rng, n, dt)
+        xbuf = _ffi.DeviceArray(n + 16, dt)
+        ybuf = _ffi.DeviceArray(n_out + 32, dt)
+        try:
+            xbuf.write(np.concatenate([np.zeros(ox, dt), x, np.zeros(16 - ox, dt)]))
+            ybuf.write(np.full(n_out + 32, 7.0, dtype=dt))
+            xv, yv = xbuf.window(ox, n), ybuf.window(oy, n_out)
+            if rng.random() < 0.5:
+                ntaps = int(rng.choice([5, 127, 300, 1024]))
+                b = signal.firwin(ntaps, 0.25)
+                k = _ffi.FirKernel(b, _ffi.code_of(dt))
+                full = signal.lfilter(b, [1], x.astype(wide)) if op != "up" else None
+                bound = np.sum(np.abs(b))
+                name = "fir %d taps" % ntaps
+                lf = lambda v: signal.lfilter(b, [1], v)
+            else:
+                sos = signal.butter(int(rng.choice([2, 5, 8])), float(rng.uniform(0.05, 0.5)), output="sos")
+                k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
+                bound = np.sum(np.abs(signal.sosfilt(sos, np.r_[1.0, np.zeros(4095)])))
+                name = "iir %d sections" % len(sos)
+                lf = lambda v: signal.sosfilt(sos, v)
+            if op == "filter":
+                k.filter_dev(xv, yv)
+                ref = lf(x.astype(wide))
+            elif op == "up":
+                k.up_dev(xv, yv, f)
+                up = np.zeros(n * f, dtype=wide)
+                up[::f] = f * x.astype(wide)
+                ref = lf(up)
+                bound = bound * f
+            else:
+                k.dn_dev(xv, yv, f)
+                ref = lf(x.astype(wide))[::f][:n_out]
+            got = ybuf.to_host()
+            what = "%s %s %s n=%d f=%d offsets %d/%d" % (name, op, np.dtype(dt).name, n, f, ox, oy)
+            assert np.all(got[:oy] == 7.0) and np.all(got[oy + n_out:] == 7.0), "guard words overwritten: " + what
+            _check(got[oy:oy + n_out], ref, dt, what, float(bound * np.max(np.abs(x))))
+        finally:
+            xbuf.free()
+            ybuf.free()
