@@ -1,5 +1,5 @@
 """Developer aid: board power and shader clock while one workload runs back to back (is a kernel held by the power cap?):
-   python tools/power_probe.py [idle copy fir1024 fir1024f32 fir1024f64 fir1024c128 updn43 fir127 iir8 iir8cas iir8c64 iirlp8]
+   python tools/power_probe.py [option=value ...] [idle copy fir1024 fir1024f32 fir1024f64 fir1024c128 updn43 fir127 iir8 iir8cas iir8c64 iirlp8]
 Samples `rocm-smi --showpower --showclocks --showperflevel` about twice a second from a second thread while the main thread keeps the queue full."""
 import ctypes, os, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -75,5 +75,10 @@ def run(name, seconds=3.0):
     sys.stdout.flush()
 
 _ffi.init(0)
+opts = [a for a in sys.argv[1:] if "=" in a]      # library options for the whole run: name=value
+for o in opts:
+    _ffi.set_option(o.split("=")[0], int(o.split("=")[1]))
+    print("option", o)
+sys.argv = [a for a in sys.argv if "=" not in a]
 for w in (sys.argv[1:] or ["idle", "fir1024", "updn43", "iir8", "fir127"]):
     run(w)
