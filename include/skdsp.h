@@ -125,7 +125,9 @@ int skdsp_fir_updn(skdsp_handle h, const void *x, int64_t n, int L, int M, void 
 int skdsp_fir_updn_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev);
 
 /* ---- IIR: multirate_IIR (multirate_helper.py:159-192), rate_change (:54-83) - */
-/* sos: nsec x 6 float64, sos[:,3]==1 (scipy.signal.sosfilt contract). */
+/* sos: nsec x 6 float64, sos[:,3]==1 (scipy.signal.sosfilt contract); any number of sections up to 4096, as sosfilt takes them
+ * (more than 8 run as consecutive groups of at most 8 on the device; a float32 cascade whose intermediate signals do not survive
+ * float32 storage between two groups runs in float64 inside). */
 int skdsp_sos_create(const double *sos, int nsec, int dtype, skdsp_handle *out);
 /* transfer function (b,a) for signal.lfilter(b,a,.), multirate_helper.py:74,81;
  * a[0]-normalised.  scipy runs (b,a) as one DF2T section of order N; the scan kernel

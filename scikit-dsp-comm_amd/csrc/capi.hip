@@ -111,7 +111,7 @@ const OptEntry kOptTable[] = {
     {"sw_no_tile", &Options::sw_no_tile}, {"sw_no_lpt", &Options::sw_no_lpt}, {"mm_ns", &Options::mm_ns},
     {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
-    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_up_fused", &Options::iir_up_fused}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
+    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
     {"shard_reserve", &Options::shard_reserve}, {"shard_two_launches", &Options::shard_two_launches},
     {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
     {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline}, {"host_multi_slot", &Options::host_multi_slot},
@@ -1380,14 +1380,82 @@ static int iir_create_common(int nsec, int order, const std::vector<double> &coe
 {
     SK_CHECK(out, SKDSP_ERR_BADARG, "iir_create: null out");
     SK_CHECK(dtype_valid(dtype), SKDSP_ERR_BADARG, "iir_create: bad dtype %d", dtype);
-    SK_CHECK(iir_shape_supported(nsec, order), SKDSP_ERR_UNSUPPORTED,
-             "iir_create: %d sections of order %d not supported (SOS: 1..12 sections; (b,a): order 1..12)", nsec, order);
+    SK_CHECK(order == 2 && nsec >= 1 && nsec <= 4096, SKDSP_ERR_UNSUPPORTED,
+             "iir_create: %d sections of order %d not supported (second-order sections, 1 .. 4096 of them)", nsec, order);
     std::unique_ptr<IirHandle> h(new IirHandle());
     h->kind = H_IIR;
     h->dtype = dtype;
     h->nsec = nsec;
     h->order = order;
     h->coef = coef;
+    if (nsec > 12 || (nsec > 8 && opt().iir_split)) {
+        // groups of at most 8 sections, as even as possible (10 -> 5 + 5): each a handle of its own, made from the CALLER's factorisation.
+        // Between two groups the signal is stored in the handle's precision.  For float32 handles that rounding (6e-8 of the
+        // INTERMEDIATE's peak, then amplified by the rest of the cascade) must stay below the float32 contract on the output: with
+        // A = l1 norm of the impulse response up to a boundary, B = from it on, T = of the whole cascade, the boundary costs at most
+        // 6e-8 A B / T of the output's scale.  A Butterworth cascade has A B / T ~ 2; an order-17 Chebyshev in scipy's section order
+        // 170 (measured: 1e-5).  Such cascades keep the largest groups the cascade kernels take (12: no boundary at all up to 12 sections).
+        int per = 8;
+        if (!dtype_double(dtype)) {
+            const int NH = 16384;
+            auto run = [&](int s0, int s1, std::vector<double> &v) {   // v <- sections [s0, s1) applied to v (DF2T, from rest)
+                for (int sct = s0; sct < s1; ++sct) {
+                    const double *c = coef.data() + 5 * sct;
+                    double z0 = 0.0, z1 = 0.0;
+                    for (int i = 0; i < NH; ++i) {
+                        const double xin = v[i], yo = c[0] * xin + z0;
+                        z0 = c[1] * xin - c[3] * yo + z1;
+                        z1 = c[2] * xin - c[4] * yo;
+                        v[i] = yo;
+                    }
+                }
+            };
+            auto l1 = [&](const std::vector<double> &v) { double a = 0.0; for (double q : v) a += std::fabs(q); return a; };
+            std::vector<double> imp(NH, 0.0);
+            imp[0] = 1.0;
+            std::vector<double> whole = imp;
+            run(0, nsec, whole);
+            const double T = l1(whole);
+            const int ng8 = (nsec + 7) / 8;
+            double worst = 0.0;
+            std::vector<double> head = imp;
+            for (int g = 0, s0 = 0; g + 1 < ng8; ++g) {
+                const int cnt = nsec / ng8 + (g < nsec % ng8 ? 1 : 0);
+                run(s0, s0 + cnt, head);
+                s0 += cnt;
+                std::vector<double> tail = imp;
+                run(s0, nsec, tail);
+                worst = std::max(worst, l1(head) * l1(tail) / std::max(T, 1e-300));
+            }
+            if (!(worst <= 16.0)) {
+                if (nsec <= 12) goto single_group;      // one launch sequence of the cascade kernels: float64 between ALL sections
+                // too many sections for that, and no float32 boundary is safe: the same cascade in float64 (widen, filter, narrow)
+                skdsp_handle th = nullptr;
+                const int rc = iir_create_common(nsec, 2, coef, dtype == SKDSP_C64 ? SKDSP_C128 : SKDSP_F64, &th);
+                if (rc) return rc;
+                h->twin64 = static_cast<IirHandle *>(th);
+                h->twin64->slot = ctx().slot;
+                *out = h.release();
+                return SKDSP_OK;
+            }
+        }
+        const int ng = (nsec + per - 1) / per;
+        for (int g = 0, s0 = 0; g < ng; ++g) {
+            const int cnt = nsec / ng + (g < nsec % ng ? 1 : 0);
+            std::vector<double> part(coef.begin() + (size_t)5 * s0, coef.begin() + (size_t)5 * (s0 + cnt));
+            skdsp_handle gh = nullptr;
+            const int rc = iir_create_common(cnt, 2, part, dtype, &gh);
+            if (rc) return rc;
+            IirHandle *gp = static_cast<IirHandle *>(gh);
+            gp->group_first = s0;
+            gp->slot = ctx().slot;
+            h->groups.push_back(gp);
+            s0 += cnt;
+        }
+        *out = h.release();
+        return SKDSP_OK;
+    }
+single_group:
     if (order == 2 && nsec >= 2 && !opt().iir_no_unit) {
         // unit-tail re-factorisation (see IirHandle): H_0' = H_0 * prod_{j>=1} b0_j,  H_k' = H_k / b0_k
         bool ok = true;
@@ -1497,6 +1565,22 @@ static int iir_rows_dev(IirHandle *h, const void *x_dev, int64_t n, int64_t nrow
     SK_CHECK(x_stride >= n && y_stride >= n, SKDSP_ERR_BADARG, "iir_filter_rows: row stride below the row length");
     SK_CHECK(nrow < (1 << 24), SKDSP_ERR_BADARG, "iir_filter_rows: too many rows");
     const size_t esz = dtype_size(h->dtype);
+    if (!h->groups.empty() && !dtype_complex(h->dtype) && opt().iir_par > 0) {
+        // groups of sections (more than 8 biquads): every group over all rows in one launch where its parallel form applies, in place behind the first
+        for (size_t gi = 0; gi < h->groups.size(); ++gi) {
+            IirHandle *g = h->groups[gi];
+            const void *src = gi == 0 ? x_dev : y_dev;
+            const int64_t ss = gi == 0 ? x_stride : y_stride;
+            int rc = iir_par_launch(g, src, n, (int)nrow, ss, y_stride, y_dev, ctx().stream);
+            if (rc == 1) {
+                for (int64_t r = 0; r < nrow; ++r)
+                    if ((rc = iir_any_dev(g, (const char *)src + (size_t)r * ss * esz, n, (char *)y_dev + (size_t)r * y_stride * esz))) return rc;
+            } else if (rc) {
+                return rc;
+            }
+        }
+        return SKDSP_OK;
+    }
     if (!dtype_complex(h->dtype) && opt().iir_par > 0) {
         const int r = iir_par_launch(h, x_dev, n, (int)nrow, x_stride, y_stride, y_dev, ctx().stream);
         if (r != 1) return r;

@@ -925,13 +925,18 @@ __global__ __launch_bounds__(1024) void iir_wg_scan_kernel(const double *__restr
 #if SK_SCAN_PART != 2
 bool iir_shape_supported(int nsec, int order)
 {
-    return order == 2 && nsec >= 1 && nsec <= 12;
+    return order == 2 && nsec >= 1 && nsec <= 12;   // (one group: longer cascades are split by the handle)
 }
 
 IirHandle::~IirHandle()
 {
     if (plan) iir_free(plan);
     if (par) iir_par_free(par);
+    for (IirHandle *g : groups) delete g;
+    if (group_tmp) (void)hipFree(group_tmp);
+    delete twin64;
+    if (twin_in) (void)hipFree(twin_in);
+    if (twin_out) (void)hipFree(twin_out);
 }
 
 void iir_free(IirPlan *p)
@@ -1214,6 +1219,77 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
         if (zf_host) {
             if (zi_host) memcpy(zf_host, zi_host, (size_t)nbatch * h->nsec * h->order * 8);
             else memset(zf_host, 0, (size_t)nbatch * h->nsec * h->order * 8);
+        }
+        return SKDSP_OK;
+    }
+    if (h->twin64) {
+        // the float64 detour (see IirHandle::twin64): planar float32 in, planar float32 out
+        if (interleaved) return 1;
+        const int64_t tot = nbatch > 1 ? batch_stride * nbatch : n;
+        auto grow = [&](void *&p, size_t &have, size_t need) -> int {
+            if (need <= have) return SKDSP_OK;
+            if (p) {
+                SK_HIP(hipStreamSynchronize(s));
+                SK_HIP(hipFree(p));
+                p = nullptr; have = 0;
+            }
+            SK_HIP(hipMalloc(&p, need));
+            have = need;
+            return SKDSP_OK;
+        };
+        int rc = grow(h->twin_in, h->twin_in_bytes, (size_t)tot * 8 + 256);
+        if (rc) return rc;
+        if ((rc = convert_launch(x, h->twin_in, tot, true, s))) return rc;
+        void *o64 = h->twin_in;
+        int64_t out_tot = tot;
+        if (dec > 1) {   // (one real row: the kept outputs go to a buffer of their own)
+            out_tot = n / dec;
+            if ((rc = grow(h->twin_out, h->twin_out_bytes, (size_t)out_tot * 8 + 256))) return rc;
+            o64 = h->twin_out;
+        }
+        if ((rc = iir_launch_planar(h->twin64, h->twin_in, n, nbatch, batch_stride, o64, s, zi_host, zf_host, 0, dec))) return rc;
+        return convert_launch(o64, y, out_tot, false, s);
+    }
+    if (!h->groups.empty()) {
+        // consecutive groups of sections, each through this function: group 0 reads x, the others filter y in place; a decimating call keeps
+        // the full-rate signal of all groups but the last in a buffer of the handle; the states are per section, so a group takes its slice
+        if (interleaved) return 1;   // (the caller's planar form splits; an interleaved group chain could stop half-way through "not applicable")
+        const int D = h->nsec * 2;
+        const size_t esz = dtype_double(h->dtype) ? 8 : 4;
+        void *mid = y;
+        if (dec > 1) {
+            const size_t need = (size_t)(nbatch > 1 ? batch_stride * nbatch : n) * esz + 256;
+            if (need > h->group_tmp_bytes) {
+                if (h->group_tmp) {
+                    SK_HIP(hipStreamSynchronize(s));
+                    SK_HIP(hipFree(h->group_tmp));
+                    h->group_tmp = nullptr; h->group_tmp_bytes = 0;
+                }
+                SK_HIP(hipMalloc(&h->group_tmp, need));
+                h->group_tmp_bytes = need;
+            }
+            mid = h->group_tmp;
+        }
+        std::vector<double> zi_g, zf_g;
+        for (size_t gi = 0; gi < h->groups.size(); ++gi) {
+            IirHandle *g = h->groups[gi];
+            const bool last = gi + 1 == h->groups.size();
+            const int Dg = g->nsec * 2;
+            const double *zi_p = nullptr;
+            double *zf_p = nullptr;
+            if (zi_host) {
+                zi_g.resize((size_t)nbatch * Dg);
+                for (int b = 0; b < nbatch; ++b) memcpy(zi_g.data() + (size_t)b * Dg, zi_host + (size_t)b * D + 2 * g->group_first, (size_t)Dg * 8);
+                zi_p = zi_g.data();
+            }
+            if (zf_host) {
+                zf_g.assign((size_t)nbatch * Dg, 0.0);
+                zf_p = zf_g.data();
+            }
+            const int rc = iir_launch_planar(g, gi == 0 ? x : mid, n, nbatch, batch_stride, last ? y : mid, s, zi_p, zf_p, 0, last ? dec : 1);
+            if (rc) return rc;
+            if (zf_host)
+                for (int b = 0; b < nbatch; ++b) memcpy(zf_host + (size_t)b * D + 2 * g->group_first, zf_g.data() + (size_t)b * Dg, (size_t)Dg * 8);
         }
         return SKDSP_OK;
     }

@@ -269,6 +269,24 @@ int accumulate_launch(void *y, const void *t, int64_t nscalars, bool dbl, hipStr
     return SKDSP_OK;
 }
 
+// element-wise float32 <-> float64 between device vectors of any (element) alignment: the float64 detour of float32 cascades whose
+// sections cannot be grouped in float32 (iir_scan.hip)
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void convert_kernel(const S *__restrict__ src, D *__restrict__ dst, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (D)src[i];
+}
+
+int convert_launch(const void *src, void *dst, int64_t nscalars, bool to_double, hipStream_t s)
+{
+    if (nscalars <= 0) return SKDSP_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((nscalars + 255) / 256, 8192);
+    if (to_double) hipLaunchKernelGGL((convert_kernel<float, double>), dim3(blocks), dim3(256), 0, s, (const float *)src, (double *)dst, nscalars);
+    else hipLaunchKernelGGL((convert_kernel<double, float>), dim3(blocks), dim3(256), 0, s, (const double *)src, (float *)dst, nscalars);
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
 int widen_launch(const void *src, int64_t nscalars, void *dst, hipStream_t s)
 {
     if (nscalars <= 0) return SKDSP_OK;

@@ -49,6 +49,7 @@ struct Options {
     int iir_no_k1r = 0;
     int k1r_wgs = 2;
     int iir_two_pass = 0;     // 1: K1 + carries + K3 even where the single-pass scan applies; -1: single pass wherever it applies
+    int iir_split = 1;        // 0: cascades of 9 .. 12 biquads stay one launch sequence of the cascade kernels (no groups; more than 12 always split)
     int iir_par = 1;          // 0: never the parallel-form scan (iir_par.hip); the cascade kernels everywhere
     int iir_dn_compact = 1;   // 0: the parallel-form .dn keeps the image-and-pick store for every M (A/B switch)
     int iir_up_fused = 1;     // 0: multirate_IIR.up / rate_change.up write the zero-stuffed signal first (A/B switch)
@@ -201,6 +202,19 @@ struct IirHandle : HandleBase {
     std::vector<double> state_scale;
     IirPlan *plan = nullptr;
     struct ParPlan *par = nullptr;   // partial-fraction form of the same transfer function (iir_par.hip), made on first use
+    // Cascades of more than 8 biquads run as consecutive groups of at most 8 (the kernels' register budgets; 8 is what the parallel form
+    // takes): group g filters the output of group g - 1 in place, each with its own plans; the caller's per-section states are sliced.
+    // scipy.signal.sosfilt takes any number of sections, and so does this.
+    std::vector<IirHandle *> groups;
+    // float32 handles whose sections cannot be grouped in float32 (the rounding of the signal between two groups, amplified by the rest
+    // of the cascade, would break the float32 contract: capi.hip) and are too many for one launch sequence: the same cascade as a float64
+    // handle; the signal is widened, filtered and narrowed on the device
+    IirHandle *twin64 = nullptr;
+    void *twin_in = nullptr, *twin_out = nullptr;
+    size_t twin_in_bytes = 0, twin_out_bytes = 0;
+    int group_first = 0;             // (a group: its first section in the parent's numbering)
+    void *group_tmp = nullptr;       // full-rate intermediate of a decimating call
+    size_t group_tmp_bytes = 0;
     ~IirHandle();
 };
 // x/y: real planar arrays in the handle's precision; complex callers pass nbatch=2 planes
@@ -227,6 +241,7 @@ int downsample_launch(const void *x_dev, int64_t n, int M, int p, int dtype, voi
 int deinterleave_launch(const void *x_dev, int64_t n, int dtype_complex_in, void *re_dev, void *im_dev, hipStream_t s);
 int interleave_launch(const void *re_dev, const void *im_dev, int64_t n, int dtype_complex_out, void *y_dev, hipStream_t s);
 int widen_launch(const void *src_dev, int64_t nscalars, void *dst_dev, hipStream_t s);  // float32 -> float64
+int convert_launch(const void *src_dev, void *dst_dev, int64_t nscalars, bool to_double, hipStream_t s);   // element-wise float32 <-> float64, any alignment
 int accumulate_launch(void *y_dev, const void *t_dev, int64_t nscalars, bool dbl, hipStream_t s);  // y += t
 int fill_noise_launch(void *x_dev, int64_t n, int dtype, uint64_t seed, int64_t first, hipStream_t s);
 

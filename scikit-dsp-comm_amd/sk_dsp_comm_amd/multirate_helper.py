@@ -25,7 +25,7 @@ from . import sigsys as ssd
 
 log = getLogger(__name__)
 
-_MAX_SOS = 12  # sections per device cascade; longer designs are split into chained cascades
+_MAX_SOS = 4096  # sections per device cascade (the library runs more than 8 as consecutive groups on the device); beyond: chained cascades
 
 
 def _signal(x, coef_complex=False):

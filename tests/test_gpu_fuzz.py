@@ -30,14 +30,18 @@ def _tol(dt, ref, gain=1.0):
     return (1e-6 if single else 1e-10) * gain
 
 
-def _check(y, ref, dt, what, bound):
-    """1e-6 (1e-10) of the output's peak -- or, for outputs far below the input (stop bands, start-up), of the forward bound"""
+def _check(y, ref, dt, what, bound, ref_spread=0.0):
+    """1e-6 (1e-10) of the output's peak -- or, for outputs far below the input (stop bands, start-up), of the forward bound.
+    ref_spread: how far two float64 evaluations of the reference itself lie apart (sections in another order): a cascade whose
+    float64 result is only good to 1e-6 (a 40th-order Chebyshev) cannot be matched closer than that by anybody -- and the scans here,
+    which combine chunk transitions instead of running the recursion sample by sample, lose up to ~100 x that spread on such
+    cascades (measured over 2000 random cases: <= 110 x), hence the factor."""
     assert y.shape == ref.shape, (what, y.shape, ref.shape)
     if ref.size == 0:
         return
     scale = max(float(np.max(np.abs(ref))), 1e-2 * bound)
     err = float(np.max(np.abs(y - ref)))
-    assert err <= _tol(dt, ref) * scale * 2, "%s: err %.3g, scale %.3g" % (what, err, scale)
+    assert err <= _tol(dt, ref) * scale * 2 + 300.0 * ref_spread, "%s: err %.3g, scale %.3g, reference spread %.3g" % (what, err, scale, ref_spread)
 
 
 @pytest.mark.parametrize("seed", range(NSEED))
@@ -75,7 +79,7 @@ def test_fuzz_iir(seed):
     for _ in range(14):
         dt = DTYPES[rng.integers(len(DTYPES))]
         n = int(LENGTHS[rng.integers(len(LENGTHS))])
-        order = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 12, 16]))
+        order = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 17, 18, 20, 24, 30, 40]))   # (more than 8 biquads: consecutive groups)
         kind = rng.choice(["butter", "cheby1", "ellip"])
         wn = float(rng.uniform(0.03, 0.6))
         if kind == "butter":
@@ -93,16 +97,22 @@ def test_fuzz_iir(seed):
         h = signal.sosfilt(sos, np.r_[1.0, np.zeros(4095)])
         bound = float(np.sum(np.abs(h)) * np.max(np.abs(x)))
         what = "%s %s n=%d %s(%d, %.3f) f=%d" % (op, np.dtype(dt).name, n, kind, order, wn, f)
+        def both(v):   # the reference, and the same cascade with its sections in reverse order (equal in exact arithmetic)
+            r = signal.sosfilt(sos, v)
+            return r, float(np.max(np.abs(r - signal.sosfilt(np.ascontiguousarray(sos[::-1]), v)))) if len(sos) > 8 else 0.0
         if op == "filter":
-            _check(iir.filter(x), signal.sosfilt(sos, xw), dt, what, bound)
+            ref, spread = both(xw)
+            _check(iir.filter(x), ref, dt, what, bound, spread)
         elif op == "up":
             if n * f > 3_000_000:
                 continue
             up = np.zeros(n * f, dtype=xw.dtype)
             up[::f] = f * xw
-            _check(iir.up(x, f), signal.sosfilt(sos, up), dt, what, bound * f)
+            ref, spread = both(up)
+            _check(iir.up(x, f), ref, dt, what, bound * f, spread)
         else:
-            _check(np.asarray(iir.dn(x, f)), signal.sosfilt(sos, xw)[::f][:n // f], dt, what, bound)
+            ref, spread = both(xw)
+            _check(np.asarray(iir.dn(x, f)), ref[::f][:n // f], dt, what, bound, spread)
 
 
 @pytest.mark.parametrize("seed", range(max(NSEED // 3, 1)))
@@ -154,7 +164,7 @@ def test_fuzz_nd_and_streaming(seed):
         x = _signal(rng, int(np.prod(shape)), dt).reshape(shape)
         ntaps = int(rng.choice([3, 64, 127, 300, 1024]))
         b = signal.firwin(ntaps, 0.3)
-        sos = signal.butter(int(rng.choice([2, 5, 8])), float(rng.uniform(0.05, 0.5)), output="sos")
+        sos = signal.butter(int(rng.choice([2, 5, 8, 18, 22, 34])), float(rng.uniform(0.05, 0.5)), output="sos")
         for name, y, ref, bound in (("fir", mrh.multirate_FIR(b).filter(x), signal.lfilter(b, [1], x.astype(wide)), np.sum(np.abs(b))),
                                     ("iir", mrh.multirate_IIR(sos).filter(x), signal.sosfilt(sos, x.astype(wide)),
                                      np.sum(np.abs(signal.sosfilt(sos, np.r_[1.0, np.zeros(4095)]))))):
