@@ -246,3 +246,58 @@ def test_fuzz_device_views_at_odd_offsets(seed):
         finally:
             xbuf.free()
             ybuf.free()
+
+
+@pytest.mark.parametrize("seed", range(max(NSEED // 2, 1)))
+def test_fuzz_fir_wide(seed):
+    """The FIR corners the first FIR fuzz leaves out: complex taps, tap counts beyond one launch (tap segments), the fused L / M resampler,
+    the transform-domain wrappers os_filter / oa_filter (sigsys.py:482-598), the three-stage interp24 / deci24 chains (sigsys.py:2945-3028)."""
+    rng = np.random.default_rng(6000 + seed)
+    for _ in range(6):
+        dt = DTYPES[rng.integers(len(DTYPES))]
+        cplx = np.dtype(dt).kind == "c"
+        wide = np.complex128 if cplx else np.float64
+        n = int(LENGTHS[rng.integers(len(LENGTHS))])
+        x = _signal(rng, n, dt)
+        xw = x.astype(wide)
+        # complex taps / very long filters
+        ntaps = int(rng.choice([7, 90, 700, 4097, 6000, 9001]))
+        b = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+        if rng.random() < 0.5:
+            b = b + 1j * rng.standard_normal(ntaps) / np.sqrt(ntaps)
+        bound = float(np.sum(np.abs(b)) * np.max(np.abs(x)))
+        ref = signal.lfilter(b, [1], xw.astype(np.complex128) if np.iscomplexobj(b) else xw)
+        y = mrh.multirate_FIR(b).filter(x)
+        _check(np.asarray(y), ref, dt, "filter %s n=%d taps=%d complex taps %s" % (np.dtype(dt).name, n, ntaps, np.iscomplexobj(b)), bound)
+        # fused L / M through the C entry (downsample(up(x, L), M))
+        L, M = int(rng.choice([2, 3, 4, 5, 7])), int(rng.choice([2, 3, 5, 9]))
+        bt = signal.firwin(int(rng.choice([32, 129, 512])), 0.9 / max(L, M))
+        if n * L <= 3_000_000 and (n * L) // M > 0:
+            up = np.zeros(n * L, dtype=wide)
+            up[::L] = L * xw
+            ref = signal.lfilter(bt, [1], up)[::M][:(n * L) // M]
+            y = _ffi.FirKernel(bt, _ffi.code_of(dt)).updn(x, L, M)
+            _check(y, ref, dt, "updn %s n=%d %d/%d" % (np.dtype(dt).name, n, L, M), float(np.sum(np.abs(bt)) * L * np.max(np.abs(x))))
+        # os_filter / oa_filter: both return real(lfilter(h, 1, x)) (the reference pads P-1 zeros in front for overlap-save and slices them off)
+        if not cplx:
+            P = int(rng.choice([8, 33, 100]))
+            h = signal.firwin(P, 0.3)
+            N = int(rng.choice([128, 256, 1024]))
+            if n > P:
+                refw = signal.lfilter(h, [1], xw)
+                single = np.dtype(dt).itemsize == 4
+                for name, fn in (("os", ss.os_filter), ("oa", ss.oa_filter)):
+                    y = np.asarray(fn(x, h, N))
+                    assert y.shape == refw.shape and np.max(np.abs(y - refw)) <= (2e-6 if single else 1e-10) * max(np.max(np.abs(refw)), 1e-2 * np.max(np.abs(x))), (name, n, P, N)
+        # interp24 / deci24 on short real signals
+        if not cplx and n <= 4097:
+            xs = xw[:min(n, 700)]
+            y = ss.interp24(xs.astype(dt))
+            r = xs
+            for Lk in (2, 3, 4):
+                bb, aa = signal.butter(10, 1.0 / Lk)
+                u = np.zeros(len(r) * Lk)
+                u[::Lk] = Lk * r
+                r = signal.lfilter(bb, aa, u)
+            single = np.dtype(dt).itemsize == 4
+            assert np.max(np.abs(y - r)) <= (3e-6 if single else 1e-7) * max(np.max(np.abs(r)), 1e-3), ("interp24", len(xs))
