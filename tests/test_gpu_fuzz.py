@@ -310,3 +310,37 @@ def test_fuzz_fir_wide(seed):
                 r = signal.lfilter(bb, aa, u)
             single = np.dtype(dt).itemsize == 4
             assert np.max(np.abs(y - r)) <= (3e-6 if single else 1e-7) * max(np.max(np.abs(r)), 1e-3), ("interp24", len(xs))
+
+
+@pytest.mark.parametrize("seed", range(max(NSEED // 2, 1)))
+def test_fuzz_host_chunk_pipeline(seed):
+    """Host-array calls on vectors cut into small chunks (option host_chunk_log2 = 10 .. 14): every chunk is staged with the history it
+    needs (FIR: Ntaps-1 samples, whole output periods for L / M; IIR: the section states from the chunk before) -- the results must not
+    depend on where the cuts fall."""
+    rng = np.random.default_rng(7000 + seed)
+    for _ in range(5):
+        dt = DTYPES[rng.integers(len(DTYPES))]
+        cplx = np.dtype(dt).kind == "c"
+        wide = np.complex128 if cplx else np.float64
+        lg = int(rng.integers(10, 15))
+        n = int(rng.integers(1, 40)) * (1 << lg) // 8 + int(rng.integers(0, 50))
+        x = _signal(rng, n, dt)
+        xw = x.astype(wide)
+        ntaps = int(rng.choice([3, 64, 200, 1024, 1500]))
+        b = signal.firwin(ntaps, 0.3)
+        sos = signal.butter(int(rng.choice([2, 5, 8, 11])), float(rng.uniform(0.05, 0.5)), output="sos")
+        f = int(rng.choice([2, 3, 4, 5, 12]))
+        hb = float(np.sum(np.abs(b)) * np.max(np.abs(x)))
+        hs = float(np.sum(np.abs(signal.sosfilt(sos, np.r_[1.0, np.zeros(4095)]))) * np.max(np.abs(x)))
+        with _ffi.option("host_chunk_log2", lg):
+            fir, iir = mrh.multirate_FIR(b), mrh.multirate_IIR(sos)
+            tag = "%s n=%d chunk 2^%d taps=%d f=%d" % (np.dtype(dt).name, n, lg, ntaps, f)
+            _check(fir.filter(x), signal.lfilter(b, [1], xw), dt, "fir.filter " + tag, hb)
+            _check(iir.filter(x), signal.sosfilt(sos, xw), dt, "iir.filter " + tag, hs)
+            _check(np.asarray(fir.dn(x, f)), signal.lfilter(b, [1], xw)[::f][:n // f], dt, "fir.dn " + tag, hb)
+            _check(np.asarray(iir.dn(x, f)), signal.sosfilt(sos, xw)[::f][:n // f], dt, "iir.dn " + tag, hs)
+            if n * f <= 1_500_000:
+                up = np.zeros(n * f, dtype=wide)
+                up[::f] = f * xw
+                _check(fir.up(x, f), signal.lfilter(b, [1], up), dt, "fir.up " + tag, hb * f)
+                _check(iir.up(x, f), signal.sosfilt(sos, up), dt, "iir.up " + tag, hs * f)
