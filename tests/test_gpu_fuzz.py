@@ -344,3 +344,51 @@ def test_fuzz_host_chunk_pipeline(seed):
                 up[::f] = f * xw
                 _check(fir.up(x, f), signal.lfilter(b, [1], up), dt, "fir.up " + tag, hb * f)
                 _check(iir.up(x, f), signal.sosfilt(sos, up), dt, "iir.up " + tag, hs * f)
+
+
+def test_fuzz_multi_slot_host_calls():
+    """Three slots on the one GPU of the box (skdsp_init_devices([0, 0, 0]): three streams, workspaces, handle clones and worker threads): the
+    host-array FIR calls deal their chunks to all of them.  Random lengths, chunk sizes, factors and dtypes against scipy, in a process of its
+    own (slots are bound once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+import numpy as np
+from scipy import signal
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'scikit-dsp-comm_amd'))
+from sk_dsp_comm_amd import _ffi, multirate_helper as mrh
+assert _ffi.init_devices([0, 0, 0]) == 3
+rng = np.random.default_rng(77)
+bad = []
+for case in range(40):
+    dt = [np.float32, np.complex64, np.float64, np.complex128][rng.integers(4)]
+    cplx = np.dtype(dt).kind == 'c'
+    wide = np.complex128 if cplx else np.float64
+    single = np.dtype(dt).itemsize // (2 if cplx else 1) == 4
+    lg = int(rng.integers(10, 15))
+    n = int(rng.integers(2, 60)) * (1 << lg) // 4 + int(rng.integers(0, 50))
+    x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+    x = x.astype(dt)
+    ntaps = int(rng.choice([5, 127, 700, 1024]))
+    b = signal.firwin(ntaps, 0.3)
+    f = int(rng.choice([2, 3, 4, 12]))
+    _ffi.set_option('host_chunk_log2', lg)
+    fir = mrh.multirate_FIR(b)
+    full = signal.lfilter(b, [1], x.astype(wide))
+    tol = (2e-6 if single else 1e-10) * max(np.max(np.abs(full)), 1e-2 * np.max(np.abs(x)))
+    k = _ffi.FirKernel(b, _ffi.code_of(dt))
+    got = {'filter': fir.filter(x), 'dn': np.asarray(fir.dn(x, f)), 'sharded2': k.filter_sharded(x, 2), 'sharded3': k.filter_sharded(x, 0)}
+    ref = {'filter': full, 'dn': full[::f][:n // f], 'sharded2': full, 'sharded3': full}
+    if n * f <= 1_000_000:
+        up = np.zeros(n * f, dtype=wide); up[::f] = f * x.astype(wide)
+        got['up'] = fir.up(x, f); ref['up'] = signal.lfilter(b, [1], up)
+    for name in got:
+        if got[name].shape != ref[name].shape or np.max(np.abs(got[name] - ref[name])) > tol * (f if name == 'up' else 1):
+            bad.append((case, name, np.dtype(dt).name, n, lg, ntaps, f))
+print('MULTI_SLOT_FUZZ', 'OK' if not bad else bad)
+""" % (root, root)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert b"MULTI_SLOT_FUZZ OK" in out.stdout, out.stdout.decode()[-3000:]
