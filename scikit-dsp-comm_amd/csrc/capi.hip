@@ -111,7 +111,7 @@ const OptEntry kOptTable[] = {
     {"sw_no_tile", &Options::sw_no_tile}, {"sw_no_lpt", &Options::sw_no_lpt}, {"mm_ns", &Options::mm_ns},
     {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
-    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
+    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
     {"shard_reserve", &Options::shard_reserve}, {"shard_two_launches", &Options::shard_two_launches},
     {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
     {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline}, {"host_multi_slot", &Options::host_multi_slot},
@@ -366,9 +366,46 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
 }
 
 // .up / fused L over M: one polyphase launch, or tap segments when a phase holds more taps than a launch takes
+// multirate_FIR.up: polyphase kernels or the overlap-save walk over (tile, phase) pairs (fir_ols.hip)?  Both are timed models of this
+// board at 2^26 outputs (tools/time_fir_up.py; ms), scaled to the call: the polyphase kernels cost per tap of a phase -- little where the
+// matrix-pipe kernel covers the shape, 3-4x that where it does not -- the walk costs per (tile, phase) pair whatever the phase length,
+// plus what its stride-L stores cost, and runs in rounds of one pair per resident workgroup.
+static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
+{
+    const int T = (h->ntaps + L - 1) / L;
+    const int floor_t = opt().fir_up_ols_min;   // < 0: wherever supported from -floor_t taps per phase on, no cost model (tests, A/B timing)
+    if (floor_t == 0 || T < std::abs(floor_t) || n < 8192 || !fir_ols_up_supported(h, L)) return false;
+    if (floor_t < 0) return true;
+    if ((opt().fir_algo != SKDSP_FIR_AUTO ? opt().fir_algo : h->algo) == SKDSP_FIR_DIRECT) return false;
+    if (fir_needs_parts(h, L)) return true;   // (longer than one polyphase launch takes)
+    const bool cplx = h->dtype == SKDSP_C64, bx = fir_bx_blocks(h, L, M) > 0;
+    const double Lf = (double)L;
+    double ols = cplx ? 0.27 + 0.022 * std::min(Lf, 20.0) : 0.13 + 0.018 * std::min(Lf, 28.0);
+    double poly = cplx ? (bx ? 0.06 + 0.0011 * T : 0.02 + 0.0037 * T) : (bx ? 0.055 + 0.0005 * T : 0.03 + 0.0018 * T);
+    if (L > 16 && !bx) poly *= 1.0 + Lf / 12.0;   // (one tap table per phase: the polyphase kernels lose their reuse)
+    const int V = 8192 - ((T - 1 + 511) / 512) * 512;
+    const double slots = 2.0 * ctx().num_cus;
+    const double pairs = (double)((n + V - 1) / V) * (cplx ? 1.0 : 0.5) * Lf;
+    ols *= std::ceil(pairs / slots) * slots * (double)V * (cplx ? 1.0 : 2.0) / 67108864.0;
+    poly *= (double)n * Lf / 67108864.0;
+    if (M > 1) {   // L / M: the polyphase kernels compute the kept outputs only; the walk computes all, then a strided copy
+        poly /= (double)M;
+        ols += (cplx ? 0.10 : 0.06) * (double)n * Lf / 67108864.0;
+    }
+    return ols < poly;
+}
+
 static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev)
 {
     if (L == 1) return fir_dn_any(h, x_dev, n, n_hist, M, y_dev);
+    if (M == 1 && fir_up_prefers_ols(h, L, n)) return fir_ols_up_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream);
+    if (M > 1 && fir_up_prefers_ols(h, L, n, M)) {   // long phases: all n L outputs by the walk, every M-th of them kept
+        void *full = nullptr;
+        int rc = ws_reserve(2, (size_t)n * L * dtype_size(h->dtype) + 256, &full);
+        if (rc) return rc;
+        if ((rc = fir_ols_up_launch(h, x_dev, n, n_hist, L, full, ctx().stream))) return rc;
+        return downsample_launch(full, n * L, M, 0, h->dtype, y_dev, ctx().stream);
+    }
     if (fir_needs_parts(h, L)) return fir_parts_run(h, x_dev, n, n_hist, L, M, y_dev);
     return fir_direct_launch(h, x_dev, n, n_hist, L, M, (n * L) / M, y_dev, ctx().stream);
 }

@@ -563,6 +563,7 @@ FirHandle::~FirHandle()
     for (auto &t : mm) if (t.At) (void)hipFree(t.At);
     for (auto &t : bx) if (t.At) (void)hipFree(t.At);
     if (ols) fir_ols_free(ols);
+    for (auto &u : ols_up) fir_ols_free(u.plan);
     if (ols64) fir_ols64_free(ols64);
     for (FirHandle *p : parts) delete p;
 }

@@ -65,6 +65,9 @@ struct OlsArgs {
     int64_t ntiles;
     int dec;        // > 1: keep every dec-th output only (multirate_FIR.dn): y[g / dec] = out[g] for g % dec == 0
     unsigned dec_magic;   // ceil(2^32 / dec): (g * dec_magic) >> 32 = g / dec for the tile-local g < 2^15 met in the store
+    // up > 1 (multirate_FIR.up with long phases): the walk runs over (tile, phase) pairs -- index w stands for input tile w / up filtered
+    // with the taps of phase w % up (Hp holds up tables of 4096 float4), and output i of that pair lands at y[i * up + phase]
+    int up;
     int64_t n_keep; // dec * floor(n / dec)
     // Sharded filter (dist.hip): the Ntaps-1 samples in front of x arrive over xGMI on another stream while this launch
     // already runs.  Only tile 0 reads them, so tile 0 is walked LAST and whoever owns it waits for halo_flag >= halo_seq
@@ -366,6 +369,85 @@ template <bool REAL, bool DEC> __device__ __forceinline__ void store_any(const O
     if (REAL) store_tile_real<DEC>(A, tile, t, v, lds); else store_tile<DEC>(A, tile, t, v, lds);
 }
 
+// ---- multirate_FIR.up: output i of (tile, phase) goes to y[i * up + phase] -------------------------------------------
+// Every phase touches every 128-byte line of the tile's output run, whatever the lanes do; what can be chosen is how many lines ONE
+// store instruction touches.  A thread holds outputs 2t and 2t+1 of each 512-block, so storing them as they lie makes an instruction
+// span 128 outputs with every other one written.  One v_permlane32_swap per register first hands the odd outputs of lanes 0..31 to
+// lanes 32..63 and the even outputs of lanes 32..63 to lanes 0..31: each instruction then writes 64 CONSECUTIVE outputs of the
+// phase (half the lines per instruction, both for 8-byte and 4-byte samples).
+__device__ __forceinline__ void lanes_swap_halves(float &e0, float &e1)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(e0), __float_as_uint(e1), false, false);
+    e0 = __uint_as_float(r[0]);   // lanes 0..31: own even output; lanes 32..63: odd output of lane - 32
+    e1 = __uint_as_float(r[1]);   // lanes 0..31: even output of lane + 32; lanes 32..63: own odd output
+}
+// position (inside a 512-block) of the first of this lane's two outputs after the swap; the second lies 64 further
+__device__ __forceinline__ int up_lane_pos(int t)
+{
+    const int lane = t & 63;
+    return 128 * (t >> 6) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);
+}
+
+// (addresses: a uniform 64-bit base per 512-block plus a 32-bit per-lane byte offset -- the scalar-base form of the store instruction;
+// per-lane 64-bit addresses for the 32 stores were all formed ahead of the first store and cost 14-62 spilled registers)
+__device__ __forceinline__ void store_tile_up(const OlsArgs &A, int64_t tile, int ph, int t, const cf *v)
+{
+    int a0 = A.a0;
+    asm volatile("" : "+s"(a0));
+    int tt = t;   // (opaque copy: the offsets are rebuilt per tile instead of living in registers across the tile loop)
+    asm volatile("" : "+v"(tt));
+    const int pos = up_lane_pos(tt);   // this lane's first output inside a 512-block (the second: + 64)
+    const int64_t out0 = tile * A.V;
+    char *ub = reinterpret_cast<char *>(A.y + out0 * A.up + ph);   // uniform
+    const int64_t left = A.n - out0;
+    const int lim = (left > (1 << 20) ? (1 << 20) : (int)left) - pos;   // outputs i < lim (relative to this lane's first) exist
+    const bool whole = left >= A.V;   // (uniform: every tile but the last)
+    const unsigned b0 = (unsigned)pos * (unsigned)A.up * 8u, b1 = b0 + 64u * (unsigned)A.up * 8u;
+    const size_t step = (size_t)512 * A.up * 8;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        if (a < a0) continue;
+        cf e0 = v[2 * a], e1 = v[2 * a + 1];
+        lanes_swap_halves(e0.x, e1.x);
+        lanes_swap_halves(e0.y, e1.y);
+        const int i = 512 * (a - a0);
+        char *ua = ub + (size_t)(a - a0) * step;
+        if (whole || i < lim) *reinterpret_cast<cf *>(ua + b0) = e0;
+        if (whole || i + 64 < lim) *reinterpret_cast<cf *>(ua + b1) = e1;
+    }
+}
+
+__device__ __forceinline__ void store_tile_real_up(const OlsArgs &A, int64_t pair, int ph, int t, const cf *v)
+{
+    int a0 = A.a0;
+    asm volatile("" : "+s"(a0));
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    const int pos = up_lane_pos(tt);
+    const int64_t outA = (2 * pair) * A.V;
+    char *ua0 = reinterpret_cast<char *>(reinterpret_cast<float *>(A.y) + outA * A.up + ph);   // uniform
+    char *ub0 = ua0 + (size_t)A.V * A.up * 4;   // the pair's second tile
+    const int64_t left = A.n - outA;
+    const int lim = (left > (1 << 20) ? (1 << 20) : (int)left) - pos;
+    const int limb = lim - A.V;
+    const bool whole = left >= 2 * (int64_t)A.V;
+    const unsigned b0 = (unsigned)pos * (unsigned)A.up * 4u, b1 = b0 + 64u * (unsigned)A.up * 4u;
+    const size_t step = (size_t)512 * A.up * 4;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        if (a < a0) continue;
+        cf e0 = v[2 * a], e1 = v[2 * a + 1];
+        lanes_swap_halves(e0.x, e1.x);
+        lanes_swap_halves(e0.y, e1.y);
+        const int i = 512 * (a - a0);
+        char *ua = ua0 + (size_t)(a - a0) * step, *ub = ub0 + (size_t)(a - a0) * step;
+        if (whole || i < lim) *reinterpret_cast<float *>(ua + b0) = e0.x;
+        if (whole || i + 64 < lim) *reinterpret_cast<float *>(ua + b1) = e1.x;
+        if (whole || i < limb) *reinterpret_cast<float *>(ub + b0) = e0.y;
+        if (whole || i + 64 < limb) *reinterpret_cast<float *>(ub + b1) = e1.y;
+    }
+}
+
 // Persistent: gridDim.x = 2 workgroups per CU, each walks tiles blockIdx.x, +gridDim.x, ...
 // Per tile the only vector-memory traffic is [H: 16 loads at tile start, consumed after
 // the forward FFT] [next tile's x: 16 loads issued after the H multiply, consumed at the
@@ -374,7 +456,10 @@ template <bool REAL, bool DEC> __device__ __forceinline__ void store_any(const O
 // powers of W_4096^t, T2 as two 4 KiB LDS tables): vmcnt retires in order, so any table
 // load issued after a prefetch would force the prefetch to land first.
 // DEC: the decimating store (multirate_FIR.dn) is its own instantiation, so that the plain filter carries none of its code
-template <bool TRACE, bool REAL, bool DEC>
+// UP: multirate_FIR.up for phases too long for the polyphase kernels (see OlsArgs::up): the same walk over (tile, phase) pairs, H of the
+// pair's phase fetched per pair, outputs stored with stride up.  Neighbouring walk indices are the phases of one input tile: they run on
+// one XCD at one time, so the tile is fetched from HBM once and the strided stores of its phases meet in that XCD's L2.
+template <bool TRACE, bool REAL, bool DEC, bool UP = false>
 __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 {
     __shared__ float4 lds[kLdsUnits + 2 * kT2Units];
@@ -421,7 +506,6 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
     // vector-memory pipe (~10 B/clk) had to move, and that pipe is what bounds the kernel.
 #if SKDSP_OLS_HREG
     float4 hh[16];
-    load_H(t, A.Hp, hh);
 #endif
     // XCD-aware walk: workgroup w runs on XCD w % 8, so give each XCD a contiguous run of tiles per
     // round -- neighbouring tiles share Ntaps-1 input samples, which then hit that XCD's L2 instead of
@@ -430,7 +514,15 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
                                                                  : (int64_t)blockIdx.x;
     // (sharded launches walk tile 0 last: walk index w stands for tile w + 1, the last index for tile 0)
     const bool t0_last = A.halo_flag != nullptr;
-    auto phys = [&](int64_t w) -> int64_t { return t0_last ? (w + 1 < A.ntiles ? w + 1 : 0) : w; };
+    // .up: pair w = (input tile w / up, phase w % up); w < 2^31 (checked at launch), so 32-bit divisions
+    auto phys = [&](int64_t w) -> int64_t {
+        if (UP) return (int64_t)((unsigned)w / (unsigned)A.up);
+        return t0_last ? (w + 1 < A.ntiles ? w + 1 : 0) : w;
+    };
+    auto phase_of = [&](int64_t w) -> int { return (int)((unsigned)w % (unsigned)A.up); };
+#if SKDSP_OLS_HREG
+    if (!UP) load_H(t, A.Hp, hh);
+#endif
     cf v[32];
 #if SKDSP_OLS_PREFETCH
     if (tile < A.ntiles) {
@@ -451,6 +543,17 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 #if !SKDSP_OLS_PREFETCH
         if (t0_last && phys(tile) == 0) wait_halo(A);
         load_any<REAL>(A, phys(tile), t, v);
+#endif
+#if SKDSP_OLS_HREG
+        if (UP) {   // this pair's phase (streamed per pair: 64 KiB from L2.  One phase per workgroup with H held in registers like
+                    // .filter -- a grid that is a multiple of up -- compiled to 14 spilled registers whose reloads wait for the previous
+                    // pair's strided stores: 0.66 vs 0.52 ms at L = 12, never faster)
+            int tt = t;
+            asm volatile("" : "+v"(tt));
+            const volatile float4 *hp = reinterpret_cast<const volatile float4 *>(A.Hp) + (size_t)phase_of(tile) * 4096;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) hh[j] = vld(hp + (unsigned)(j * 256 + tt));
+        }
 #endif
 #if !SKDSP_OLS_HREG
         float4 hh[16];
@@ -523,7 +626,11 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 #elif SKDSP_OLS_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
-        store_any<REAL, DEC>(A, phys(tile), t, v, lds);
+        if (UP) {
+            if (REAL) store_tile_real_up(A, phys(tile), phase_of(tile), t, v); else store_tile_up(A, phys(tile), phase_of(tile), t, v);
+        } else {
+            store_any<REAL, DEC>(A, phys(tile), t, v, lds);
+        }
 #if SKDSP_OLS_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
 #elif SKDSP_OLS_PRIO == 2
@@ -548,33 +655,55 @@ bool fir_ols_supported(const FirHandle *h)
     return h->dtype == SKDSP_C64 || (h->dtype == SKDSP_F32 && !h->taps_complex);
 }
 
-static int ensure_plan(FirHandle *h)
+// Tables of one plan: `up` phase filters (phase p: taps gain * b[p + up t], t < T) as `up` consecutive Hp tables; up = 1 is the filter itself.
+static int build_plan(const FirHandle *h, int up, OlsPlan **out)
 {
-    if (h->ols) return SKDSP_OK;
+    const int comp = h->taps_complex ? 2 : 1;
+    const int T = (h->ntaps + up - 1) / up;
     OlsPlan *p = new OlsPlan();
-    p->ntaps = h->ntaps;
-    p->ov = ((h->ntaps - 1 + 511) / 512) * 512;
+    p->ntaps = T;
+    p->ov = ((T - 1 + 511) / 512) * 512;
     if (p->ov == 0) p->ov = 512;
     p->V = kN - p->ov;
-    std::vector<float4> T1, T2, Hp;
+    std::vector<float4> T1, T2, Hp, Hall;
     make_T1(T1);
     make_T2(T2);
-    make_Hp(h->taps_host.data(), h->ntaps, h->taps_complex ? 2 : 1, Hp);
+    if (up == 1) {
+        make_Hp(h->taps_host.data(), h->ntaps, comp, Hall);
+    } else {
+        std::vector<double> ph((size_t)T * comp);
+        for (int q = 0; q < up; ++q) {
+            std::fill(ph.begin(), ph.end(), 0.0);
+            for (int t = 0; t < T; ++t) {
+                const int k = q + up * t;
+                if (k >= h->ntaps) break;
+                for (int c = 0; c < comp; ++c) ph[(size_t)t * comp + c] = (double)up * h->taps_host[(size_t)k * comp + c];  // (the gain L of multirate_FIR.up)
+            }
+            make_Hp(ph.data(), T, comp, Hp);
+            Hall.insert(Hall.end(), Hp.begin(), Hp.end());
+        }
+    }
     hipError_t e;
     if ((e = hipMalloc((void **)&p->T1, T1.size() * sizeof(float4))) != hipSuccess ||
         (e = hipMalloc((void **)&p->T2, T2.size() * sizeof(float4))) != hipSuccess ||
-        (e = hipMalloc((void **)&p->Hp, Hp.size() * sizeof(float4))) != hipSuccess) {
+        (e = hipMalloc((void **)&p->Hp, Hall.size() * sizeof(float4))) != hipSuccess) {
         fir_ols_free(p);
         return hip_fail(e, "hipMalloc(ols tables)", __FILE__, __LINE__);
     }
     if ((e = hipMemcpy(p->T1, T1.data(), T1.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(p->T2, T2.data(), T2.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(p->Hp, Hp.data(), Hp.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess) {
+        (e = hipMemcpy(p->Hp, Hall.data(), Hall.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess) {
         fir_ols_free(p);
         return hip_fail(e, "hipMemcpy(ols tables)", __FILE__, __LINE__);
     }
-    h->ols = p;
+    *out = p;
     return SKDSP_OK;
+}
+
+static int ensure_plan(FirHandle *h)
+{
+    if (h->ols) return SKDSP_OK;
+    return build_plan(h, 1, &h->ols);
 }
 
 void fir_ols_free(OlsPlan *p)
@@ -635,6 +764,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.dec = dec > 1 ? dec : 1;
     A.dec_magic = A.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + A.dec - 1) / A.dec) : 0u;
     A.n_keep = n;
+    A.up = 1;
     A.halo_flag = halo_flag; A.halo_seq = halo_seq; A.halo_err = halo_err;
     SK_CHECK(!(halo_flag && real), SKDSP_ERR_UNSUPPORTED, "fir_ols: halo flag wait is for complex64 shards");
     int64_t grid = 2 * (int64_t)ctx().num_cus;  // 2 resident workgroups per CU (76 KiB LDS each)
@@ -672,6 +802,58 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
         if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
         else hipLaunchKernelGGL((ols_tile_kernel<false, false, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
     }
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+// ---- multirate_FIR.up with long phases ---------------------------------------------------------------------------
+// y[i L + p] = L sum_t b[p + L t] x[i - t]: L filters of ceil(Ntaps / L) taps over the SAME input, outputs interleaved.  The polyphase
+// kernels (fir_direct / fir_bx) spend Ntaps / L multiply-adds per output; from ~100 taps per phase on, the overlap-save walk over (tile,
+// phase) pairs is cheaper: every pair costs what one tile of .filter costs, whatever the phase length.
+bool fir_ols_up_supported(const FirHandle *h, int L)
+{
+    if (L < 2 || L > 64) return false;
+    const int T = (h->ntaps + L - 1) / L;
+    if (T < 2 || T - 1 > 4096) return false;
+    return h->dtype == SKDSP_C64 || (h->dtype == SKDSP_F32 && !h->taps_complex);
+}
+
+int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s)
+{
+    if (n <= 0) return SKDSP_OK;
+    SK_CHECK(fir_ols_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols_up: needs complex64 (or float32 with real taps), 2 <= L <= 64, 2..4097 taps per phase");
+    OlsPlan *p = nullptr;
+    for (auto &u : h->ols_up)
+        if (u.L == L) p = u.plan;
+    if (!p) {
+        int rc = build_plan(h, L, &p);
+        if (rc) return rc;
+        h->ols_up.push_back(FirHandle::OlsUp{L, p});
+    }
+    OlsArgs A;
+    A.x = (const cf *)x;
+    A.y = (cf *)y;
+    A.n = n;
+    A.n_hist = n_hist;
+    A.T1 = p->T1; A.T2 = p->T2; A.Hp = p->Hp;
+    A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512;
+    const bool real = h->dtype == SKDSP_F32;
+    A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & (real ? 3 : 7)) == 0;
+    int64_t ntiles = (n + p->V - 1) / p->V;
+    if (real) ntiles = (ntiles + 1) / 2;
+    ntiles *= L;
+    SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols_up: too many tiles");
+    A.ntiles = ntiles;
+    A.dec = 1; A.dec_magic = 0u; A.n_keep = n;
+    A.up = L;
+    A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr;
+    A.trace = nullptr;
+    int64_t grid = 2 * (int64_t)ctx().num_cus;
+    const int reserve_wgs = opt().ols_reserve;
+    if (reserve_wgs > 0 && grid > 8 * (int64_t)reserve_wgs) grid -= reserve_wgs;
+    if (grid > ntiles) grid = ntiles;
+    if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL((ols_tile_kernel<false, false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
 }

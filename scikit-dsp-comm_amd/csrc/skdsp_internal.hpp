@@ -52,6 +52,8 @@ struct Options {
     int iir_split = 1;        // 0: cascades of 9 .. 12 biquads stay one launch sequence of the cascade kernels (no groups; more than 12 always split)
     int iir_par = 1;          // 0: never the parallel-form scan (iir_par.hip); the cascade kernels everywhere
     int iir_dn_compact = 1;   // 0: the parallel-form .dn keeps the image-and-pick store for every M (A/B switch)
+    int fir_up_ols_min = 64;  // multirate_FIR.up: phases of at least this many taps MAY go through the overlap-save walk (the cost model
+                              // of fir_up_prefers_ols decides); 0: never; -k: always from k taps per phase on (A/B switch)
     int iir_up_fused = 1;     // 0: multirate_IIR.up / rate_change.up write the zero-stuffed signal first (A/B switch)
     int iir_par_dbg = 0;      // developer timing switches of iir_par_kernel (ParArgs::dbg; wrong results)
     int shard_no_overlap = 0; // sharded FIR: halo exchange in front of the whole filter instead of beside the interior tiles
@@ -149,6 +151,8 @@ struct FirHandle : HandleBase {
     struct BxTab { int L, M, Lp, q, DS, RS, RT, U0, KB; void *At; };
     std::vector<BxTab> bx;
     OlsPlan *ols = nullptr;
+    struct OlsUp { int L; OlsPlan *plan; };   // overlap-save plans of multirate_FIR.up, keyed by L (fir_ols_up_launch)
+    std::vector<OlsUp> ols_up;
     Ols64Plan *ols64 = nullptr;
     // Filters longer than one kernel launch takes (fir_part_len) run as partial FIRs over consecutive tap segments,
     // each applied to the correspondingly delayed input and summed (capi.hip): parts[s] holds taps [s seg, (s+1) seg).
@@ -182,6 +186,9 @@ int fir_ols_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, v
                    const unsigned *halo_flag = nullptr, unsigned halo_seq = 0, unsigned *halo_err = nullptr);
 int fir_ols_publish_halo(unsigned *flag, unsigned seq, hipStream_t s);  // one-thread kernel: *flag = seq (agent-scope release)
 void fir_ols_free(OlsPlan *p);
+// multirate_FIR.up as an overlap-save walk over (tile, phase) pairs: complex64, float32 with real taps; 2..4097 taps per phase
+bool fir_ols_up_supported(const FirHandle *h, int L);
+int fir_ols_up_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s);
 // FFT overlap-save in float64 (fir_ols64.hip): complex128, and float64 with real taps; 2..2049 taps
 bool fir_ols64_supported(const FirHandle *h);
 int fir_ols64_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, hipStream_t s, int dec = 1);

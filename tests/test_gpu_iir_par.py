@@ -278,6 +278,93 @@ def test_fir_overlap_save_decimating_store(dt, ntaps, M):
             yd.free()
 
 
+@pytest.mark.parametrize("L", [2, 3, 4, 7, 12, 64])
+@pytest.mark.parametrize("dt,ntaps", [(np.complex64, 1024), (np.float32, 1024), (np.float32, 777), (np.complex64, 4099), (np.complex64, 9001)])
+def test_fir_overlap_save_up(dt, ntaps, L):
+    """multirate_FIR.up with long phases (multirate_helper.py:113-119: lfilter(b, [1], L * upsample(x, L))) as an overlap-save walk over (tile,
+    phase) pairs.  Against the oracle on windows of the result and against the polyphase kernels; lengths that end inside a tile; complex
+    taps; a streamed continuation (n_hist); nothing written beyond n * L outputs."""
+    import bench
+    if (ntaps + L - 1) // L < 12:
+        pytest.skip("phases this short never take the overlap-save walk")
+    b = bench.firwin_lowpass(ntaps, 0.8 / L)
+    cplx = np.dtype(dt).kind == "c"
+    if cplx and ntaps == 4099:
+        b = b * np.exp(0.07j * np.arange(ntaps))   # complex taps
+    hist = (ntaps - 1 + L - 1) // L
+    for n in (700_001, 7169 * 2 + 5, 16384, 20_000):
+        k = _ffi.FirKernel(b, _ffi.code_of(dt))
+        xd = _ffi.DeviceArray(n, dt).fill_noise(L + ntaps)
+        yd = _ffi.DeviceArray(n * L + 8, dt)
+        y2 = _ffi.DeviceArray(n * L + 8, dt)
+        try:
+            yd.write(np.full(n * L + 8, 7.0, dtype=dt))
+            with _ffi.option("fir_up_ols_min", -12):
+                k.up_dev(xd, yd, L)
+            with _ffi.option("fir_up_ols_min", 0):
+                k.up_dev(xd, y2, L)
+            got = yd.to_host(0, n * L)
+            assert np.all(yd.to_host(n * L, 8) == 7.0), "wrote beyond n * L outputs (L=%d n=%d)" % (L, n)
+            other = y2.to_host(0, n * L)
+            peak = np.max(np.abs(other))
+            assert np.max(np.abs(got - other)) <= 2e-6 * peak, ("polyphase kernels", L, n, np.max(np.abs(got - other)) / peak)
+            x = xd.to_host().astype(np.complex128 if cplx else np.float64)
+            for o0 in (0, (n * L) // 2 + 1, n * L - 400):
+                cnt = min(400, n * L - o0)
+                i0 = max(o0 // L - hist - 1, 0)
+                i1 = (o0 + cnt + L - 1) // L
+                up = np.zeros((i1 - i0) * L, dtype=x.dtype)
+                up[::L] = L * x[i0:i1]
+                ref = orc.fir_filter(b, up)[o0 - i0 * L:][:cnt]
+                assert np.max(np.abs(got[o0:o0 + cnt] - ref)) <= 1e-6 * peak, (L, n, o0)
+            # streamed continuation: the second half with the first half's tail as history == the one-shot result
+            h0 = n // 2
+            if h0 > hist:
+                yd.write(np.full(n * L + 8, 7.0, dtype=dt))
+                with _ffi.option("fir_up_ols_min", -12):
+                    k.up_dev(xd.window(h0, n - h0), yd, L, n_hist=hist)
+                cont = yd.to_host(0, (n - h0) * L)
+                assert np.max(np.abs(cont - got[h0 * L:])) <= 2e-6 * peak, ("continuation", L, n)
+        finally:
+            xd.free()
+            yd.free()
+            y2.free()
+
+
+@pytest.mark.parametrize("L,M", [(4, 3), (3, 2), (7, 5), (2, 3), (12, 5)])
+@pytest.mark.parametrize("dt,ntaps", [(np.complex64, 2048), (np.float32, 3001)])
+def test_fir_overlap_save_up_then_every_mth(dt, ntaps, L, M):
+    """L / M rate change with long phases: the overlap-save .up into scratch, every M-th output kept -- the same numbers as the
+    polyphase kernels (which compute the kept outputs only), floor(n L / M) outputs and none beyond."""
+    import bench
+    b = bench.firwin_lowpass(ntaps, 0.8 / max(L, M))
+    for n in (300_001, 16384):
+        n_out = (n * L) // M
+        k = _ffi.FirKernel(b, _ffi.code_of(dt))
+        xd = _ffi.DeviceArray(n, dt).fill_noise(L * M)
+        yd, y2 = _ffi.DeviceArray(n_out + 8, dt), _ffi.DeviceArray(n_out + 8, dt)
+        try:
+            yd.write(np.full(n_out + 8, 7.0, dtype=dt))
+            with _ffi.option("fir_up_ols_min", -12):
+                k.updn_dev(xd, yd, L, M)
+            with _ffi.option("fir_up_ols_min", 0):
+                k.updn_dev(xd, y2, L, M)
+            got, other = yd.to_host(0, n_out), y2.to_host(0, n_out)
+            assert np.all(yd.to_host(n_out, 8) == 7.0), (L, M, n)
+            peak = np.max(np.abs(other))
+            assert np.max(np.abs(got - other)) <= 2e-6 * peak, (L, M, n, np.max(np.abs(got - other)) / peak)
+            x = xd.to_host(0, 4000).astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64)
+            up = np.zeros(4000 * L, dtype=x.dtype)
+            up[::L] = L * x
+            ref = orc.fir_filter(b, up)[::M]
+            m = min(len(ref), n_out)
+            assert np.max(np.abs(got[:m] - ref[:m])) <= 1e-6 * peak, (L, M, n)
+        finally:
+            xd.free()
+            yd.free()
+            y2.free()
+
+
 # ---- N-D FIR rows in one call (the FIR half of the same reference behaviour: lfilter along the last axis) --------------
 @pytest.mark.parametrize("ntaps,shape,dt", [(127, (4096, 16384), np.float32), (1024, (6, 3, 20000), np.complex64), (33, (5, 70), np.float64),
                                             (1024, (3, 9000), np.complex128), (300, (17, 5000), np.float32), (5000, (3, 12000), np.float32)])

@@ -1,0 +1,33 @@
+"""Developer timing: multirate_FIR.up through the overlap-save walk over (tile, phase) pairs against the polyphase kernels
+(option fir_up_ols_min), device-resident signals, 2^NOUT_LOG2 outputs (default 26).
+Run on the GPU box: python tools/time_fir_up.py [LxT ...]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scikit-dsp-comm_amd"))
+import numpy as np
+import bench
+from sk_dsp_comm_amd import _ffi
+
+_ffi.init(0)
+shapes = [(L, T) for L in (2, 3, 4, 8, 12) for T in (48, 64, 96, 128, 192, 256, 512, 1024)] + [(5, 256), (11, 256), (64, 64)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+for dt in (np.complex64, np.float32):
+    for L, T in shapes:
+        ntaps = L * T
+        n = (1 << int(os.environ.get("NOUT_LOG2", "26"))) // L
+        k = _ffi.FirKernel(bench.firwin_lowpass(ntaps, 0.8 / L), _ffi.code_of(dt))
+        xd = _ffi.DeviceArray(n, dt).fill_noise(1); yd = _ffi.DeviceArray(n * L, dt)
+        ms = []
+        for thr in (0, -2, 64):
+            with _ffi.option("fir_up_ols_min", thr):
+                for _ in range(3): k.up_dev(xd, yd, L)
+                _ffi.sync(); _ffi.timer_start()
+                for _ in range(10): k.up_dev(xd, yd, L)
+                ms.append(_ffi.timer_stop() / 10)
+        isz = np.dtype(dt).itemsize
+        best = min(ms[0], ms[1])
+        print("%-10s up L=%2d %5d taps (%4d per phase) n_in %9d: polyphase %.4f ms  overlap-save %.4f ms  default %.4f ms (%.2f TB/s algorithmic)%s"
+              % (np.dtype(dt).name, L, ntaps, T, n, ms[0], ms[1], ms[2], isz * n * (1 + L) / ms[2] / 1e9,
+                 "" if ms[2] <= 1.08 * best else "   <-- default is not the faster path"), flush=True)
+        xd.free(); yd.free()
