@@ -374,12 +374,29 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
 {
     const int T = (h->ntaps + L - 1) / L;
     const int floor_t = opt().fir_up_ols_min;   // < 0: wherever supported from -floor_t taps per phase on, no cost model (tests, A/B timing)
-    if (floor_t == 0 || T < std::abs(floor_t) || n < 8192 || !fir_ols_up_supported(h, L)) return false;
+    const bool dbl = dtype_double(h->dtype);
+    if (floor_t == 0 || T < std::abs(floor_t) || n < 8192 || !(dbl ? fir_ols64_up_supported(h, L) : fir_ols_up_supported(h, L))) return false;
     if (floor_t < 0) return true;
     if ((opt().fir_algo != SKDSP_FIR_AUTO ? opt().fir_algo : h->algo) == SKDSP_FIR_DIRECT) return false;
     if (fir_needs_parts(h, L)) return true;   // (longer than one polyphase launch takes)
-    const bool cplx = h->dtype == SKDSP_C64, bx = fir_bx_blocks(h, L, M) > 0;
     const double Lf = (double)L;
+    if (dbl) {   // FP64 direct taps against the float64 walk (4096-point tiles)
+        const bool c128 = h->dtype == SKDSP_C128;
+        double ols = c128 ? 0.70 + 0.03 * std::min(Lf, 12.0) : 0.29 + 0.02 * std::min(Lf, 12.0);
+        double poly = c128 ? 0.5 + 0.0055 * T : (T <= 128 ? 0.17 + 0.0018 * T : 0.1 + 0.0028 * T);
+        if (L > 16 && !c128) poly *= 1.0 + Lf / 12.0;
+        const int V = 4096 - ((T - 1 + 255) / 256) * 256;
+        const double slots = 2.0 * ctx().num_cus;
+        const double pairs = (double)((n + V - 1) / V) * (c128 ? 1.0 : 0.5) * Lf;
+        ols *= std::ceil(pairs / slots) * slots * (double)V * (c128 ? 1.0 : 2.0) / 67108864.0;
+        poly *= (double)n * Lf / 67108864.0;
+        if (M > 1) {
+            poly /= (double)M;
+            ols += (c128 ? 0.20 : 0.10) * (double)n * Lf / 67108864.0;
+        }
+        return ols < poly;
+    }
+    const bool cplx = h->dtype == SKDSP_C64, bx = fir_bx_blocks(h, L, M) > 0;
     double ols = cplx ? 0.27 + 0.022 * std::min(Lf, 20.0) : 0.13 + 0.018 * std::min(Lf, 28.0);
     double poly = cplx ? (bx ? 0.06 + 0.0011 * T : 0.02 + 0.0037 * T) : (bx ? 0.055 + 0.0005 * T : 0.03 + 0.0018 * T);
     if (L > 16 && !bx) poly *= 1.0 + Lf / 12.0;   // (one tap table per phase: the polyphase kernels lose their reuse)
@@ -398,12 +415,16 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
 static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev)
 {
     if (L == 1) return fir_dn_any(h, x_dev, n, n_hist, M, y_dev);
-    if (M == 1 && fir_up_prefers_ols(h, L, n)) return fir_ols_up_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream);
+    auto walk = [&](void *out) {
+        return dtype_double(h->dtype) ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream)
+                                      : fir_ols_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream);
+    };
+    if (M == 1 && fir_up_prefers_ols(h, L, n)) return walk(y_dev);
     if (M > 1 && fir_up_prefers_ols(h, L, n, M)) {   // long phases: all n L outputs by the walk, every M-th of them kept
         void *full = nullptr;
         int rc = ws_reserve(2, (size_t)n * L * dtype_size(h->dtype) + 256, &full);
         if (rc) return rc;
-        if ((rc = fir_ols_up_launch(h, x_dev, n, n_hist, L, full, ctx().stream))) return rc;
+        if ((rc = walk(full))) return rc;
         return downsample_launch(full, n * L, M, 0, h->dtype, y_dev, ctx().stream);
     }
     if (fir_needs_parts(h, L)) return fir_parts_run(h, x_dev, n, n_hist, L, M, y_dev);

@@ -565,6 +565,7 @@ FirHandle::~FirHandle()
     if (ols) fir_ols_free(ols);
     for (auto &u : ols_up) fir_ols_free(u.plan);
     if (ols64) fir_ols64_free(ols64);
+    for (auto &u : ols64_up) fir_ols64_free(u.plan);
     for (FirHandle *p : parts) delete p;
 }
 

@@ -148,10 +148,15 @@ struct Ols64Args {
     int dec;
     unsigned dec_magic;   // ceil(2^32 / dec): (g * dec_magic) >> 32 = g / dec for the tile-local g < 2^14 of the decimating store
     int64_t n_keep;
+    // up > 1 (multirate_FIR.up with long phases, as in fir_ols.hip): the walk runs over (tile, phase) pairs -- index w is input tile
+    // w / up filtered with phase w % up (Hp: up tables of 4096 bins), output i of the pair lands at y[i * up + phase]
+    int up;
 };
 
 // DEC: the decimating store (multirate_FIR.dn) is its own instantiation: the plain filter carries none of its code
-template <bool REAL, bool DEC>
+// UP: multirate_FIR.up over (tile, phase) pairs; H of the pair's phase streamed from L2, stores with stride up (a thread's outputs are
+//     lane-consecutive here, so every store instruction writes 64 consecutive outputs of the phase as it is)
+template <bool REAL, bool DEC, bool UP = false>
 __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args A)
 {
     __shared__ cdd img[16 * kPitch64];
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
     const cdd w2 = A.W2[lo4];      // W_256^c             (pass 2: thread (k1, c))
     // This thread's 16 bins of H: in registers for the whole launch in the complex kernel (0.691 vs 0.738 ms at 2^26), streamed
     // from L2 per tile in the two-real-tiles kernel (registers there: 0.487 vs 0.401 ms -- its loads and stores need more of them)
-    constexpr bool HREG = SK_OLS64_HREG < 0 ? !REAL : SK_OLS64_HREG != 0;
+    constexpr bool HREG = !UP && (SK_OLS64_HREG < 0 ? !REAL : SK_OLS64_HREG != 0);
     cdd hh[HREG ? 16 : 1];
     if (HREG) {
 #pragma unroll
@@ -217,20 +222,25 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
     };
     int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
     for (; tile < A.ntiles; tile += gridDim.x) {
+        // .up: pair index -> (input tile, phase); < 2^31 pairs (checked at launch)
+        const int64_t tin = UP ? (int64_t)((unsigned)tile / (unsigned)A.up) : tile;
+        const int ph = UP ? (int)((unsigned)tile % (unsigned)A.up) : 0;
+        const cdd *Hq = UP ? A.Hp + (size_t)ph * kN64 : A.Hp;
         cdd v[16];
         // opaque copies of the thread index: stop LICM from hoisting the 16 + 16 + 16 loop-invariant 64-bit addresses of the
         // loads, the H bins and the stores out of the tile loop (they were spilled and reloaded in front of every access)
         int tl = t, th = t, ts = t;
         asm volatile("" : "+v"(tl));
-        load_tile(tile, tl, v);
+        load_tile(tin, tl, v);
 #if SK_OLS64_L2_TOUCH
         // Two-real-tiles kernel: the next pair's 512 cache lines are pulled towards the L2 while this one is transformed: one
         // 4-byte load per line, two per thread, straight into a scratch corner of the LDS (global_load_lds_dword: no
         // destination VGPR -- a register prefetch of the 16 values spilled in every form tried, and so did two live "touch"
         // registers).  float64, 1024 taps, 2^26: 0.3895 -> 0.3596 ms.  The complex kernel loses with it (0.691 -> 0.809 ms).
         if (REAL) {
-            const int64_t nt = tile + gridDim.x;
-            if (nt < A.ntiles) {
+            const int64_t nw = tile + gridDim.x;
+            const int64_t nt = UP ? (int64_t)((unsigned)nw / (unsigned)A.up) : nw;
+            if (nw < A.ntiles) {
                 const char *xb = reinterpret_cast<const char *>(A.x);
                 int64_t o0 = -1, o1 = -1;   // byte offsets of this lane's two lines
                 if (REAL) {
@@ -277,12 +287,12 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
         // ---- pass 3: thread (k1 = hi4, k2 = lo4): DFT16 over c; multiply by H ----
         // (H streamed from L2 -- the two-real-tiles kernel -- is requested HERE, a whole DFT16 ahead of its use: requested at
         // the multiply, behind the opaque copy of the thread index, every tile waited out an L2 round trip)
-        constexpr bool EARLY = !HREG && !DEC;   // (the decimating-store instantiation has no registers to spare for it)
+        constexpr bool EARLY = !HREG && !DEC && !(UP && !REAL);   // (the decimating-store and the complex .up instantiations have no registers to spare for it)
         if (EARLY) asm volatile("" : "+v"(th));
         cdd hs[HREG ? 1 : 16];
         if (EARLY) {
 #pragma unroll
-            for (int k3 = 0; k3 < 16; ++k3) hs[HREG ? 0 : k3] = A.Hp[k3 * 256 + th];
+            for (int k3 = 0; k3 < 16; ++k3) hs[HREG ? 0 : k3] = Hq[k3 * 256 + th];
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) v[c] = img[hi4 * kPitch64 + lo4 * 17 + c];
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
             asm volatile("" : "+v"(th));
             if (!HREG) {
 #pragma unroll
-                for (int k3 = 0; k3 < 16; ++k3) hs[HREG ? 0 : k3] = A.Hp[k3 * 256 + th];
+                for (int k3 = 0; k3 < 16; ++k3) hs[HREG ? 0 : k3] = Hq[k3 * 256 + th];
             }
         }
 #pragma unroll
@@ -330,10 +340,35 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
         // whole tile(s) inside the signal, no decimation: one copy of the 16 - a0 unguarded stores per possible a0
         // (compile-time offsets, no predicates -- as in fir_ols.hip: a run-time a0 made hipcc keep sixteen (exec mask, 64-bit
         // offset) pairs alive across the tile loop, and with them it spilled 72 VGPRs in the complex kernel: 0.691 -> 0.578 ms)
-        const int64_t out0 = (REAL ? 2 * tile : tile) * A.V;
-        const bool full = !DEC && out0 + (REAL ? 2 : 1) * (int64_t)A.V <= A.n;
+        const int64_t out0 = (REAL ? 2 * tin : tin) * A.V;
+        const bool full = !DEC && !UP && out0 + (REAL ? 2 : 1) * (int64_t)A.V <= A.n;
         typedef double v2d_t __attribute__((ext_vector_type(2)));
-        if (DEC) {
+        if (UP) {
+            // y[(out0 + i) up + ph]: a uniform 64-bit base per 256-block plus a 32-bit per-lane byte offset (scalar-base stores)
+            int a0 = A.a0;
+            asm volatile("" : "+s"(a0));
+            constexpr int ESZ = REAL ? 8 : 16;
+            const int64_t left = A.n - out0;
+            const bool whole = left >= (REAL ? 2 : 1) * (int64_t)A.V;   // (uniform: every tile but the last)
+            const int lim = (left > (1 << 20) ? (1 << 20) : (int)left) - ts;   // outputs i < lim (relative to this lane's first) exist
+            char *ua0 = reinterpret_cast<char *>(A.y) + (size_t)(out0 * A.up + ph) * ESZ;
+            char *ub0 = ua0 + (size_t)A.V * A.up * ESZ;   // (the pair's second tile, two-real-tiles kernel)
+            const unsigned b0 = (unsigned)ts * (unsigned)A.up * ESZ;
+            const size_t step = (size_t)256 * A.up * ESZ;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                if (a < a0) continue;
+                const int i = 256 * (a - a0);
+                if (REAL) {
+                    if (whole || i < lim) *reinterpret_cast<double *>(ua0 + (size_t)(a - a0) * step + b0) = v[a].x;
+                    if (whole || i < lim - A.V) *reinterpret_cast<double *>(ub0 + (size_t)(a - a0) * step + b0) = v[a].y;
+                } else if (whole || i < lim) {
+                    v2d_t q;
+                    q.x = v[a].x; q.y = v[a].y;
+                    *reinterpret_cast<v2d_t *>(ua0 + (size_t)(a - a0) * step + b0) = q;
+                }
+            }
+        } else if (DEC) {
             // decimating store (multirate_FIR.dn): the tile's (the pair's) kept outputs are ONE run of y.  Every thread drops its kept samples
             // into the idle image at their output positions -- one multiply-high per sample finds them -- and the workgroup writes the run
             // with consecutive stores.  (Before: a 64-bit remainder, a 64-bit quotient and a predicated store per sample.)
@@ -460,12 +495,13 @@ bool fir_ols64_supported(const FirHandle *h)
     return h->dtype == SKDSP_C128 || (h->dtype == SKDSP_F64 && !h->taps_complex);
 }
 
-static int ensure_plan64(FirHandle *h)
+// Tables of one plan: `up` phase filters (phase q: taps up * b[q + up t]) as `up` consecutive H tables; up = 1: the filter itself.
+static int build_plan64(const FirHandle *h, int up, Ols64Plan **out)
 {
-    if (h->ols64) return SKDSP_OK;
     typedef std::complex<long double> cl;
+    const int T = (h->ntaps + up - 1) / up;
     Ols64Plan *p = new Ols64Plan();
-    p->ov = ((h->ntaps - 1 + 255) / 256) * 256;
+    p->ov = ((T - 1 + 255) / 256) * 256;
     if (p->ov == 0) p->ov = 256;
     p->V = kN64 - p->ov;
     // H = DFT_4096(b) / N in long double (plain O(N P) sums: once per handle)
@@ -473,19 +509,22 @@ static int ensure_plan64(FirHandle *h)
     const long double two_pi = 6.283185307179586476925286766559L;
     std::vector<cl> wn(kN64);
     for (int k = 0; k < kN64; ++k) wn[k] = cl(cosl(two_pi * k / kN64), -sinl(two_pi * k / kN64));
-    std::vector<double> Hp((size_t)2 * kN64), W1(2 * 256), W2(2 * 16);
-    for (int k = 0; k < kN64; ++k) {
-        cl acc(0, 0);
-        for (int j = 0; j < h->ntaps; ++j) {
-            const cl bj = comp == 2 ? cl(h->taps_host[2 * j], h->taps_host[2 * j + 1]) : cl(h->taps_host[j], 0);
-            acc += bj * wn[(size_t)(((int64_t)k * j) % kN64)];
+    std::vector<double> Hp((size_t)2 * kN64 * up), W1(2 * 256), W2(2 * 16);
+    for (int q = 0; q < up; ++q)
+        for (int k = 0; k < kN64; ++k) {
+            cl acc(0, 0);
+            for (int t = 0; t < T; ++t) {
+                const int j = q + up * t;
+                if (j >= h->ntaps) break;
+                const cl bj = comp == 2 ? cl(h->taps_host[2 * j], h->taps_host[2 * j + 1]) : cl(h->taps_host[j], 0);
+                acc += bj * wn[(size_t)(((int64_t)k * t) % kN64)];
+            }
+            acc *= (long double)up / (long double)kN64;   // (up = 1: 1 / N; else the gain L of multirate_FIR.up as well)
+            const int k1 = k & 15, k2 = (k >> 4) & 15, k3 = k >> 8;
+            const size_t idx = (size_t)q * kN64 + (size_t)k3 * 256 + 16 * k1 + k2;
+            Hp[2 * idx] = (double)acc.real();
+            Hp[2 * idx + 1] = (double)acc.imag();
         }
-        acc /= (long double)kN64;
-        const int k1 = k & 15, k2 = (k >> 4) & 15, k3 = k >> 8;
-        const size_t idx = (size_t)k3 * 256 + 16 * k1 + k2;
-        Hp[2 * idx] = (double)acc.real();
-        Hp[2 * idx + 1] = (double)acc.imag();
-    }
     for (int t = 0; t < 256; ++t) { W1[2 * t] = (double)wn[t].real(); W1[2 * t + 1] = (double)wn[t].imag(); }
     for (int c = 0; c < 16; ++c) { W2[2 * c] = (double)wn[16 * c].real(); W2[2 * c + 1] = (double)wn[16 * c].imag(); }
     hipError_t e;
@@ -497,8 +536,14 @@ static int ensure_plan64(FirHandle *h)
         fir_ols64_free(p);
         return hip_fail(e, "ols64 tables", __FILE__, __LINE__);
     }
-    h->ols64 = p;
+    *out = p;
     return SKDSP_OK;
+}
+
+static int ensure_plan64(FirHandle *h)
+{
+    if (h->ols64) return SKDSP_OK;
+    return build_plan64(h, 1, &h->ols64);
 }
 
 int fir_ols64_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s, int dec)
@@ -521,6 +566,7 @@ int fir_ols64_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, voi
     A.dec = dec > 1 ? dec : 1;
     A.dec_magic = A.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + A.dec - 1) / A.dec) : 0u;
     A.n_keep = n;
+    A.up = 1;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     if (grid > ntiles) grid = ntiles;
     if (A.dec > 1) {
@@ -530,6 +576,47 @@ int fir_ols64_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, voi
         if (real) hipLaunchKernelGGL((ols64_tile_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
         else hipLaunchKernelGGL((ols64_tile_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
     }
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+// multirate_FIR.up with long phases (see fir_ols.hip, fir_ols_up_launch): complex128, float64 with real taps; 2..2049 taps per phase
+bool fir_ols64_up_supported(const FirHandle *h, int L)
+{
+    if (L < 2 || L > 64) return false;
+    const int T = (h->ntaps + L - 1) / L;
+    if (T < 2 || T - 1 > 2048) return false;
+    return h->dtype == SKDSP_C128 || (h->dtype == SKDSP_F64 && !h->taps_complex);
+}
+
+int fir_ols64_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s)
+{
+    if (n <= 0) return SKDSP_OK;
+    SK_CHECK(fir_ols64_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols64_up: needs complex128 (or float64 with real taps), 2 <= L <= 64, 2..2049 taps per phase");
+    Ols64Plan *p = nullptr;
+    for (auto &u : h->ols64_up)
+        if (u.L == L) p = u.plan;
+    if (!p) {
+        int rc = build_plan64(h, L, &p);
+        if (rc) return rc;
+        h->ols64_up.push_back(FirHandle::Ols64Up{L, p});
+    }
+    Ols64Args A;
+    A.x = (const double *)x; A.y = (double *)y; A.n = n; A.n_hist = n_hist;
+    A.Hp = p->Hp; A.W1 = p->W1; A.W2 = p->W2;
+    A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 256;
+    const bool real = h->dtype == SKDSP_F64;
+    int64_t ntiles = (n + p->V - 1) / p->V;
+    if (real) ntiles = (ntiles + 1) / 2;
+    ntiles *= L;
+    SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols64_up: too many tiles");
+    A.ntiles = ntiles;
+    A.dec = 1; A.dec_magic = 0u; A.n_keep = n;
+    A.up = L;
+    int64_t grid = 2 * (int64_t)ctx().num_cus;
+    if (grid > ntiles) grid = ntiles;
+    if (real) hipLaunchKernelGGL((ols64_tile_kernel<true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL((ols64_tile_kernel<false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
 }

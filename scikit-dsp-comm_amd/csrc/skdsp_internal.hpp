@@ -154,6 +154,8 @@ struct FirHandle : HandleBase {
     struct OlsUp { int L; OlsPlan *plan; };   // overlap-save plans of multirate_FIR.up, keyed by L (fir_ols_up_launch)
     std::vector<OlsUp> ols_up;
     Ols64Plan *ols64 = nullptr;
+    struct Ols64Up { int L; Ols64Plan *plan; };
+    std::vector<Ols64Up> ols64_up;
     // Filters longer than one kernel launch takes (fir_part_len) run as partial FIRs over consecutive tap segments,
     // each applied to the correspondingly delayed input and summed (capi.hip): parts[s] holds taps [s seg, (s+1) seg).
     std::vector<FirHandle *> parts;
@@ -193,6 +195,8 @@ int fir_ols_up_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
 bool fir_ols64_supported(const FirHandle *h);
 int fir_ols64_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, hipStream_t s, int dec = 1);
 void fir_ols64_free(Ols64Plan *p);
+bool fir_ols64_up_supported(const FirHandle *h, int L);
+int fir_ols64_up_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s);
 
 // ---- IIR -----------------------------------------------------------------
 struct IirPlan;  // iir_scan.hip

@@ -12,7 +12,8 @@ _ffi.init(0)
 shapes = [(L, T) for L in (2, 3, 4, 8, 12) for T in (48, 64, 96, 128, 192, 256, 512, 1024)] + [(5, 256), (11, 256), (64, 64)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
-for dt in (np.complex64, np.float32):
+DTYPES = [np.dtype(d).type for d in os.environ.get("DTYPES", "complex64,float32").split(",")]
+for dt in DTYPES:
     for L, T in shapes:
         ntaps = L * T
         n = (1 << int(os.environ.get("NOUT_LOG2", "26"))) // L
