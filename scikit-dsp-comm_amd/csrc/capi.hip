@@ -111,7 +111,7 @@ const OptEntry kOptTable[] = {
     {"sw_no_tile", &Options::sw_no_tile}, {"sw_no_lpt", &Options::sw_no_lpt}, {"mm_ns", &Options::mm_ns},
     {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
-    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
+    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
     {"shard_reserve", &Options::shard_reserve}, {"shard_two_launches", &Options::shard_two_launches},
     {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
     {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline}, {"host_multi_slot", &Options::host_multi_slot},
@@ -379,56 +379,64 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
     if (floor_t < 0) return true;
     if ((opt().fir_algo != SKDSP_FIR_AUTO ? opt().fir_algo : h->algo) == SKDSP_FIR_DIRECT) return false;
     if (fir_needs_parts(h, L)) return true;   // (longer than one polyphase launch takes)
+    // all figures: ms per 2^26 up-rate samples on this board (profiles/r03/fir_up.txt, fir_updn.txt)
     const double Lf = (double)L;
+    const bool cplx = dtype_complex(h->dtype);
+    double ols, base, poly, copy;   // base: the walk without what its stride-L stores cost
+    int V;
     if (dbl) {   // FP64 direct taps against the float64 walk (4096-point tiles)
-        const bool c128 = h->dtype == SKDSP_C128;
-        double ols = c128 ? 0.70 + 0.03 * std::min(Lf, 12.0) : 0.29 + 0.02 * std::min(Lf, 12.0);
-        double poly = c128 ? 0.5 + 0.0055 * T : (T <= 128 ? 0.17 + 0.0018 * T : 0.1 + 0.0028 * T);
-        if (L > 16 && !c128) poly *= 1.0 + Lf / 12.0;
-        const int V = 4096 - ((T - 1 + 255) / 256) * 256;
-        const double slots = 2.0 * ctx().num_cus;
-        const double pairs = (double)((n + V - 1) / V) * (c128 ? 1.0 : 0.5) * Lf;
-        ols *= std::ceil(pairs / slots) * slots * (double)V * (c128 ? 1.0 : 2.0) / 67108864.0;
-        poly *= (double)n * Lf / 67108864.0;
-        if (M > 1) {
-            poly /= (double)M;
-            ols += (c128 ? 0.20 : 0.10) * (double)n * Lf / 67108864.0;
-        }
-        return ols < poly;
+        base = cplx ? 0.42 : 0.26;
+        ols = cplx ? 0.70 + 0.03 * std::min(Lf, 12.0) : 0.29 + 0.02 * std::min(Lf, 12.0);
+        poly = cplx ? 0.5 + 0.0055 * T : (T <= 128 ? 0.17 + 0.0018 * T : 0.1 + 0.0028 * T);
+        if (T > 128) poly *= std::max(1.0, Lf / 4.0);   // (many long phases: the tap tables fall out of the cache)
+        else if (L > 16 && !cplx) poly *= 1.0 + Lf / 12.0;
+        copy = cplx ? 0.20 : 0.10;
+        V = 4096 - ((T - 1 + 255) / 256) * 256;
+    } else {
+        const bool bx = fir_bx_blocks(h, L, M) > 0;   // (the matrix-pipe polyphase kernel covers the shape)
+        base = cplx ? 0.23 : 0.125;
+        ols = cplx ? 0.27 + 0.022 * std::min(Lf, 20.0) : 0.13 + 0.018 * std::min(Lf, 28.0);
+        poly = cplx ? (bx ? 0.06 + 0.0011 * T : 0.02 + 0.0037 * T) : (bx ? 0.055 + 0.0005 * T : 0.03 + 0.0018 * T);
+        if (!bx && T > 256) poly *= std::max(1.0, Lf / 4.0);
+        else if (L > 16 && !bx) poly *= 1.0 + Lf / 12.0;   // (one tap table per phase: the polyphase kernels lose their reuse)
+        copy = cplx ? 0.10 : 0.06;
+        V = 8192 - ((T - 1 + 511) / 512) * 512;
     }
-    const bool cplx = h->dtype == SKDSP_C64, bx = fir_bx_blocks(h, L, M) > 0;
-    double ols = cplx ? 0.27 + 0.022 * std::min(Lf, 20.0) : 0.13 + 0.018 * std::min(Lf, 28.0);
-    double poly = cplx ? (bx ? 0.06 + 0.0011 * T : 0.02 + 0.0037 * T) : (bx ? 0.055 + 0.0005 * T : 0.03 + 0.0018 * T);
-    if (L > 16 && !bx) poly *= 1.0 + Lf / 12.0;   // (one tap table per phase: the polyphase kernels lose their reuse)
-    const int V = 8192 - ((T - 1 + 511) / 512) * 512;
+    if (M > 1) {   // L / M: the polyphase kernels compute the kept outputs only; the walk computes all and stores (or copies) every M-th
+        poly /= (double)M;
+        if (M <= 4096 && opt().fir_updn_fused) ols = base + (ols - base) / (double)M;
+        else ols += copy;
+    }
+    // the walk runs in rounds of one (tile, phase) pair per resident workgroup; the polyphase kernels scale with the length
     const double slots = 2.0 * ctx().num_cus;
     const double pairs = (double)((n + V - 1) / V) * (cplx ? 1.0 : 0.5) * Lf;
     ols *= std::ceil(pairs / slots) * slots * (double)V * (cplx ? 1.0 : 2.0) / 67108864.0;
     poly *= (double)n * Lf / 67108864.0;
-    if (M > 1) {   // L / M: the polyphase kernels compute the kept outputs only; the walk computes all, then a strided copy
-        poly /= (double)M;
-        ols += (cplx ? 0.10 : 0.06) * (double)n * Lf / 67108864.0;
-    }
     return ols < poly;
 }
 
 static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev)
 {
     if (L == 1) return fir_dn_any(h, x_dev, n, n_hist, M, y_dev);
-    auto walk = [&](void *out) {
-        return dtype_double(h->dtype) ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream)
-                                      : fir_ols_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream);
+    auto walk = [&](void *out, int dec) {
+        return dtype_double(h->dtype) ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream, dec)
+                                      : fir_ols_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream, dec);
     };
-    if (M == 1 && fir_up_prefers_ols(h, L, n)) return walk(y_dev);
+    if (M == 1 && fir_up_prefers_ols(h, L, n)) return walk(y_dev, 1);
     if (M > 1 && fir_up_prefers_ols(h, L, n, M)) {   // long phases: all n L outputs by the walk, every M-th of them kept
-        void *full = nullptr;
+        if (M <= 4096 && opt().fir_updn_fused) return walk(y_dev, M);   // ... by its store
+        void *full = nullptr;                                           // ... or out of scratch
         int rc = ws_reserve(2, (size_t)n * L * dtype_size(h->dtype) + 256, &full);
         if (rc) return rc;
-        if ((rc = walk(full))) return rc;
+        if ((rc = walk(full, 1))) return rc;
         return downsample_launch(full, n * L, M, 0, h->dtype, y_dev, ctx().stream);
     }
     if (fir_needs_parts(h, L)) return fir_parts_run(h, x_dev, n, n_hist, L, M, y_dev);
-    return fir_direct_launch(h, x_dev, n, n_hist, L, M, (n * L) / M, y_dev, ctx().stream);
+    int rc = fir_direct_launch(h, x_dev, n, n_hist, L, M, (n * L) / M, y_dev, ctx().stream);
+    if (rc == SKDSP_ERR_UNSUPPORTED && M > 1 && M <= 4096 && opt().fir_up_ols_min != 0 &&
+        (dtype_double(h->dtype) ? fir_ols64_up_supported(h, L) : fir_ols_up_supported(h, L)))
+        return walk(y_dev, M);   // (a stride the polyphase kernels' LDS window does not hold)
+    return rc;
 }
 
 static int fir_filter_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev)

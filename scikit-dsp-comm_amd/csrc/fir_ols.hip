@@ -138,11 +138,13 @@ __device__ __forceinline__ void load_tile(const OlsArgs &A, int64_t tile, int t,
             v[2 * a + 1] = hi(f);
         }
     } else {
+        int tt = t;   // (opaque copy: the 64-bit lane offset of this edge-tile path is not kept -- spilled -- across the tile loop)
+        asm volatile("" : "+v"(tt));
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int64_t g = in0 + 512 * a + 2 * t + e;
+                const int64_t g = in0 + 512 * a + 2 * tt + e;
                 cf val = make_float2(0.f, 0.f);
                 if (g >= -A.n_hist && g < A.n) val = A.x[g];
                 v[2 * a + e] = val;
@@ -232,12 +234,14 @@ template <bool DEC> __device__ __forceinline__ void store_tile(const OlsArgs &A,
     } else {
         int a0 = A.a0;   // opaque copy: keeps the sixteen (mask, offset) pairs of this once-per-launch path out of the tile loop's prologue
         asm volatile("" : "+s"(a0));
+        int tt = t;
+        asm volatile("" : "+v"(tt));
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             if (a < a0) continue;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int64_t g = out0 + 512 * (a - a0) + 2 * t + e;
+                const int64_t g = out0 + 512 * (a - a0) + 2 * tt + e;
                 if (g < A.n) A.y[g] = v[2 * a + e];
             }
         }
@@ -267,12 +271,14 @@ __device__ __forceinline__ void load_tile_real(const OlsArgs &A, int64_t pair, i
             v[2 * a + 1] = make_float2(rb.x, rb.y);
         }
     } else {
+        int tt = t;   // (opaque copy: see load_tile)
+        asm volatile("" : "+v"(tt));
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             float ra[2], rb[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int64_t ga = inA + 512 * a + 2 * t + e, gb = ga + A.V;
+                const int64_t ga = inA + 512 * a + 2 * tt + e, gb = ga + A.V;
                 ra[e] = (ga >= -A.n_hist && ga < A.n) ? xr[ga] : 0.f;
                 rb[e] = (gb >= -A.n_hist && gb < A.n) ? xr[gb] : 0.f;
             }
@@ -347,12 +353,14 @@ template <bool DEC> __device__ __forceinline__ void store_tile_real(const OlsArg
     } else {
         int a0 = A.a0;   // (opaque copy: see store_tile)
         asm volatile("" : "+s"(a0));
+        int tt = t;
+        asm volatile("" : "+v"(tt));
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             if (a < a0) continue;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int64_t ga = outA + 512 * (a - a0) + 2 * t + e, gb = ga + A.V;
+                const int64_t ga = outA + 512 * (a - a0) + 2 * tt + e, gb = ga + A.V;
                 if (ga < A.n) yr[ga] = v[2 * a + e].x;
                 if (gb < A.n) yr[gb] = v[2 * a + e].y;
             }
@@ -390,7 +398,7 @@ __device__ __forceinline__ int up_lane_pos(int t)
 
 // (addresses: a uniform 64-bit base per 512-block plus a 32-bit per-lane byte offset -- the scalar-base form of the store instruction;
 // per-lane 64-bit addresses for the 32 stores were all formed ahead of the first store and cost 14-62 spilled registers)
-__device__ __forceinline__ void store_tile_up(const OlsArgs &A, int64_t tile, int ph, int t, const cf *v)
+template <bool DEC> __device__ __forceinline__ void store_tile_up(const OlsArgs &A, int64_t tile, int ph, int t, const cf *v)
 {
     int a0 = A.a0;
     asm volatile("" : "+s"(a0));
@@ -404,6 +412,14 @@ __device__ __forceinline__ void store_tile_up(const OlsArgs &A, int64_t tile, in
     const bool whole = left >= A.V;   // (uniform: every tile but the last)
     const unsigned b0 = (unsigned)pos * (unsigned)A.up * 8u, b1 = b0 + 64u * (unsigned)A.up * 8u;
     const size_t step = (size_t)512 * A.up * 8;
+    // DEC (L / M): the tile's first up-rate index out0 up + ph = q0 M + r0; tile-local up-rate indices stay below 2^20 + M, where the
+    // multiply-high by ceil(2^32 / M) is the exact quotient for M <= 4096 (checked at launch); n_keep = floor(n up / M) outputs exist
+    const unsigned M = (unsigned)A.dec;
+    const int64_t jt = out0 * A.up + ph, q0 = DEC ? jt / A.dec : 0;
+    const unsigned r0 = DEC ? (unsigned)(jt - q0 * A.dec) : 0u;
+    const int64_t qleft = A.n_keep - q0;
+    const int qlim = qleft > (1 << 24) ? (1 << 24) : (int)qleft;
+    cf *yq = A.y + q0;
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
         if (a < a0) continue;
@@ -411,13 +427,20 @@ __device__ __forceinline__ void store_tile_up(const OlsArgs &A, int64_t tile, in
         lanes_swap_halves(e0.x, e1.x);
         lanes_swap_halves(e0.y, e1.y);
         const int i = 512 * (a - a0);
+        if (DEC) {   // L / M: up-rate index j = (out0 + i) up + ph is kept iff M divides it, at y[j / M]
+            const unsigned j0 = r0 + (unsigned)(i + pos) * (unsigned)A.up, j1 = j0 + 64u * (unsigned)A.up;
+            const unsigned k0 = (unsigned)(((unsigned long long)j0 * A.dec_magic) >> 32), k1 = (unsigned)(((unsigned long long)j1 * A.dec_magic) >> 32);
+            if (k0 * M == j0 && (int)k0 < qlim && (whole || i < lim)) yq[k0] = e0;
+            if (k1 * M == j1 && (int)k1 < qlim && (whole || i + 64 < lim)) yq[k1] = e1;
+            continue;
+        }
         char *ua = ub + (size_t)(a - a0) * step;
         if (whole || i < lim) *reinterpret_cast<cf *>(ua + b0) = e0;
         if (whole || i + 64 < lim) *reinterpret_cast<cf *>(ua + b1) = e1;
     }
 }
 
-__device__ __forceinline__ void store_tile_real_up(const OlsArgs &A, int64_t pair, int ph, int t, const cf *v)
+template <bool DEC> __device__ __forceinline__ void store_tile_real_up(const OlsArgs &A, int64_t pair, int ph, int t, const cf *v)
 {
     int a0 = A.a0;
     asm volatile("" : "+s"(a0));
@@ -433,6 +456,13 @@ __device__ __forceinline__ void store_tile_real_up(const OlsArgs &A, int64_t pai
     const bool whole = left >= 2 * (int64_t)A.V;
     const unsigned b0 = (unsigned)pos * (unsigned)A.up * 4u, b1 = b0 + 64u * (unsigned)A.up * 4u;
     const size_t step = (size_t)512 * A.up * 4;
+    const unsigned M = (unsigned)A.dec;   // (DEC: see store_tile_up)
+    const int64_t jt = outA * A.up + ph, q0 = DEC ? jt / A.dec : 0;
+    const unsigned r0 = DEC ? (unsigned)(jt - q0 * A.dec) : 0u;
+    const int64_t qleft = A.n_keep - q0;
+    const int qlim = qleft > (1 << 24) ? (1 << 24) : (int)qleft;
+    float *yq = reinterpret_cast<float *>(A.y) + q0;
+    const unsigned jv = (unsigned)A.V * (unsigned)A.up;   // the second tile's offset at the up rate
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
         if (a < a0) continue;
@@ -440,6 +470,18 @@ __device__ __forceinline__ void store_tile_real_up(const OlsArgs &A, int64_t pai
         lanes_swap_halves(e0.x, e1.x);
         lanes_swap_halves(e0.y, e1.y);
         const int i = 512 * (a - a0);
+        if (DEC) {
+            const unsigned j0 = r0 + (unsigned)(i + pos) * (unsigned)A.up, j1 = j0 + 64u * (unsigned)A.up;
+            auto keep = [&](unsigned j, float val, bool inside) __attribute__((always_inline)) {
+                const unsigned k = (unsigned)(((unsigned long long)j * A.dec_magic) >> 32);
+                if (k * M == j && (int)k < qlim && inside) yq[k] = val;
+            };
+            keep(j0, e0.x, whole || i < lim);
+            keep(j1, e1.x, whole || i + 64 < lim);
+            keep(j0 + jv, e0.y, whole || i < limb);
+            keep(j1 + jv, e1.y, whole || i + 64 < limb);
+            continue;
+        }
         char *ua = ua0 + (size_t)(a - a0) * step, *ub = ub0 + (size_t)(a - a0) * step;
         if (whole || i < lim) *reinterpret_cast<float *>(ua + b0) = e0.x;
         if (whole || i + 64 < lim) *reinterpret_cast<float *>(ua + b1) = e1.x;
@@ -545,9 +587,9 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         load_any<REAL>(A, phys(tile), t, v);
 #endif
 #if SKDSP_OLS_HREG
-        if (UP) {   // this pair's phase (streamed per pair: 64 KiB from L2.  One phase per workgroup with H held in registers like
-                    // .filter -- a grid that is a multiple of up -- compiled to 14 spilled registers whose reloads wait for the previous
-                    // pair's strided stores: 0.66 vs 0.52 ms at L = 12, never faster)
+        if (UP) {   // this pair's phase (streamed per pair: 64 KiB from L2, requested here, used behind the forward transform.  One phase per
+                    // workgroup with H held in registers like .filter -- a grid that is a multiple of up -- was built and measured:
+                    // 0.66 vs 0.52 ms at L = 12, 0.39 vs 0.35 at L = 4, equal at L = 2; never faster, removed)
             int tt = t;
             asm volatile("" : "+v"(tt));
             const volatile float4 *hp = reinterpret_cast<const volatile float4 *>(A.Hp) + (size_t)phase_of(tile) * 4096;
@@ -627,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         __builtin_amdgcn_s_setprio(0);
 #endif
         if (UP) {
-            if (REAL) store_tile_real_up(A, phys(tile), phase_of(tile), t, v); else store_tile_up(A, phys(tile), phase_of(tile), t, v);
+            if (REAL) store_tile_real_up<DEC>(A, phys(tile), phase_of(tile), t, v); else store_tile_up<DEC>(A, phys(tile), phase_of(tile), t, v);
         } else {
             store_any<REAL, DEC>(A, phys(tile), t, v, lds);
         }
@@ -818,9 +860,10 @@ bool fir_ols_up_supported(const FirHandle *h, int L)
     return h->dtype == SKDSP_C64 || (h->dtype == SKDSP_F32 && !h->taps_complex);
 }
 
-int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s)
+int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec)
 {
     if (n <= 0) return SKDSP_OK;
+    SK_CHECK(dec >= 1 && dec <= 4096, SKDSP_ERR_UNSUPPORTED, "fir_ols_up: M = %d (the fused L / M store takes M <= 4096)", dec);
     SK_CHECK(fir_ols_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols_up: needs complex64 (or float32 with real taps), 2 <= L <= 64, 2..4097 taps per phase");
     OlsPlan *p = nullptr;
     for (auto &u : h->ols_up)
@@ -844,7 +887,9 @@ int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     ntiles *= L;
     SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols_up: too many tiles");
     A.ntiles = ntiles;
-    A.dec = 1; A.dec_magic = 0u; A.n_keep = n;
+    A.dec = dec;
+    A.dec_magic = dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + dec - 1) / dec) : 0u;
+    A.n_keep = dec > 1 ? (n * L) / dec : n;   // (DEC: the number of outputs)
     A.up = L;
     A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr;
     A.trace = nullptr;
@@ -852,8 +897,13 @@ int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     const int reserve_wgs = opt().ols_reserve;
     if (reserve_wgs > 0 && grid > 8 * (int64_t)reserve_wgs) grid -= reserve_wgs;
     if (grid > ntiles) grid = ntiles;
-    if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
-    else hipLaunchKernelGGL((ols_tile_kernel<false, false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    if (dec > 1) {
+        if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((ols_tile_kernel<false, false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    } else {
+        if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((ols_tile_kernel<false, false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    }
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
 }

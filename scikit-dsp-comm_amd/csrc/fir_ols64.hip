@@ -355,10 +355,33 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
             char *ub0 = ua0 + (size_t)A.V * A.up * ESZ;   // (the pair's second tile, two-real-tiles kernel)
             const unsigned b0 = (unsigned)ts * (unsigned)A.up * ESZ;
             const size_t step = (size_t)256 * A.up * ESZ;
+            // DEC here means L / M: up-rate index j = (out0 + i) up + ph is kept iff M divides it, at y[j / M] (as in fir_ols.hip: tile-local
+            // j below 2^20 + M, multiply-high exact for M <= 4096; n_keep = floor(n up / M) outputs exist)
+            const unsigned M = (unsigned)A.dec;
+            const int64_t jt = out0 * A.up + ph, q0 = DEC ? jt / A.dec : 0;
+            const unsigned r0 = DEC ? (unsigned)(jt - q0 * A.dec) : 0u;
+            const int64_t qleft = A.n_keep - q0;
+            const int qlim = qleft > (1 << 24) ? (1 << 24) : (int)qleft;
+            const unsigned jv = (unsigned)A.V * (unsigned)A.up;
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
                 if (a < a0) continue;
                 const int i = 256 * (a - a0);
+                if (DEC) {
+                    const unsigned j0 = r0 + (unsigned)(i + ts) * (unsigned)A.up;
+                    const unsigned k0 = (unsigned)(((unsigned long long)j0 * A.dec_magic) >> 32);
+                    if (REAL) {
+                        const unsigned j1 = j0 + jv;
+                        const unsigned k1 = (unsigned)(((unsigned long long)j1 * A.dec_magic) >> 32);
+                        if (k0 * M == j0 && (int)k0 < qlim && (whole || i < lim)) A.y[q0 + k0] = v[a].x;
+                        if (k1 * M == j1 && (int)k1 < qlim && (whole || i < lim - A.V)) A.y[q0 + k1] = v[a].y;
+                    } else if (k0 * M == j0 && (int)k0 < qlim && (whole || i < lim)) {
+                        v2d_t q;
+                        q.x = v[a].x; q.y = v[a].y;
+                        reinterpret_cast<v2d_t *>(A.y)[q0 + k0] = q;
+                    }
+                    continue;
+                }
                 if (REAL) {
                     if (whole || i < lim) *reinterpret_cast<double *>(ua0 + (size_t)(a - a0) * step + b0) = v[a].x;
                     if (whole || i < lim - A.V) *reinterpret_cast<double *>(ub0 + (size_t)(a - a0) * step + b0) = v[a].y;
@@ -589,9 +612,10 @@ bool fir_ols64_up_supported(const FirHandle *h, int L)
     return h->dtype == SKDSP_C128 || (h->dtype == SKDSP_F64 && !h->taps_complex);
 }
 
-int fir_ols64_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s)
+int fir_ols64_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec)
 {
     if (n <= 0) return SKDSP_OK;
+    SK_CHECK(dec >= 1 && dec <= 4096, SKDSP_ERR_UNSUPPORTED, "fir_ols64_up: M = %d (the fused L / M store takes M <= 4096)", dec);
     SK_CHECK(fir_ols64_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols64_up: needs complex128 (or float64 with real taps), 2 <= L <= 64, 2..2049 taps per phase");
     Ols64Plan *p = nullptr;
     for (auto &u : h->ols64_up)
@@ -611,12 +635,19 @@ int fir_ols64_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, 
     ntiles *= L;
     SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols64_up: too many tiles");
     A.ntiles = ntiles;
-    A.dec = 1; A.dec_magic = 0u; A.n_keep = n;
+    A.dec = dec;
+    A.dec_magic = dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + dec - 1) / dec) : 0u;
+    A.n_keep = dec > 1 ? (n * L) / dec : n;   // (L / M: the number of outputs)
     A.up = L;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     if (grid > ntiles) grid = ntiles;
-    if (real) hipLaunchKernelGGL((ols64_tile_kernel<true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
-    else hipLaunchKernelGGL((ols64_tile_kernel<false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    if (dec > 1) {
+        if (real) hipLaunchKernelGGL((ols64_tile_kernel<true, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((ols64_tile_kernel<false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    } else {
+        if (real) hipLaunchKernelGGL((ols64_tile_kernel<true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((ols64_tile_kernel<false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    }
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
 }
