@@ -280,7 +280,7 @@ def test_fuzz_fir_wide(seed):
         _check(np.asarray(y), ref, dt, "filter %s n=%d taps=%d complex taps %s" % (np.dtype(dt).name, n, ntaps, np.iscomplexobj(b)), bound)
         # fused L / M through the C entry (downsample(up(x, L), M))
         L, M = int(rng.choice([2, 3, 4, 5, 7])), int(rng.choice([2, 3, 5, 9]))
-        bt = signal.firwin(int(rng.choice([32, 129, 512])), 0.9 / max(L, M))
+        bt = signal.firwin(int(rng.choice([32, 129, 512, 2048, 5000])), 0.9 / max(L, M))   # (long ones: the overlap-save walk with the every-M-th store)
         if n * L <= 3_000_000 and (n * L) // M > 0:
             up = np.zeros(n * L, dtype=wide)
             up[::L] = L * xw
