@@ -111,7 +111,7 @@ const OptEntry kOptTable[] = {
     {"sw_no_tile", &Options::sw_no_tile}, {"sw_no_lpt", &Options::sw_no_lpt}, {"mm_ns", &Options::mm_ns},
     {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
-    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
+    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
     {"shard_reserve", &Options::shard_reserve}, {"shard_two_launches", &Options::shard_two_launches},
     {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
     {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline}, {"host_multi_slot", &Options::host_multi_slot},
@@ -370,6 +370,21 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
 // board at 2^26 outputs (tools/time_fir_up.py; ms), scaled to the call: the polyphase kernels cost per tap of a phase -- little where the
 // matrix-pipe kernel covers the shape, 3-4x that where it does not -- the walk costs per (tile, phase) pair whatever the phase length,
 // plus what its stride-L stores cost, and runs in rounds of one pair per resident workgroup.
+// multirate_FIR.up through the overlap-save walk: from which L on the phases leave as rows of scratch and a second kernel weaves them
+// (measured crossovers of profiles/r03/fir_up.txt; 16-byte samples never: their strided stores are full-width requests already)
+static bool fir_up_rows(const FirHandle *h, int L)
+{
+    const int o = opt().fir_up_rows_min;
+    if (o == 0) return false;
+    if (o > 0) return L >= o;
+    switch (h->dtype) {
+    case SKDSP_F32: return L >= 9;
+    case SKDSP_C64: return L >= 7;
+    case SKDSP_F64: return L >= 6;
+    default: return false;
+    }
+}
+
 static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
 {
     const int T = (h->ntaps + L - 1) / L;
@@ -402,6 +417,7 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
         copy = cplx ? 0.10 : 0.06;
         V = 8192 - ((T - 1 + 511) / 512) * 512;
     }
+    if (M == 1 && fir_up_rows(h, L)) ols = std::min(ols, dbl ? 0.45 : (cplx ? 0.45 : 0.245));   // (rows + weave: whatever L is)
     if (M > 1) {   // L / M: the polyphase kernels compute the kept outputs only; the walk computes all and stores (or copies) every M-th
         poly /= (double)M;
         if (M <= 4096 && opt().fir_updn_fused) ols = base + (ols - base) / (double)M;
@@ -422,7 +438,21 @@ static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hi
         return dtype_double(h->dtype) ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream, dec)
                                       : fir_ols_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream, dec);
     };
-    if (M == 1 && fir_up_prefers_ols(h, L, n)) return walk(y_dev, 1);
+    if (M == 1 && fir_up_prefers_ols(h, L, n)) {
+        if (fir_up_rows(h, L)) {
+            // many phases: an output stored between outputs of other phases is a write request of its own, so the phases leave as L rows
+            // with the plain filter's stores and interleave_launch weaves them (one more pass over the output, still cheaper from L = 6 ... 9 on)
+            const int64_t pitch = (int64_t)round_up((size_t)n, 64);
+            void *rows = nullptr;
+            int rc = ws_reserve(2, (size_t)pitch * L * dtype_size(h->dtype) + 256, &rows);
+            if (rc) return rc;
+            rc = dtype_double(h->dtype) ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, rows, ctx().stream, 1, pitch)
+                                        : fir_ols_up_launch(h, x_dev, n, n_hist, L, rows, ctx().stream, 1, pitch);
+            if (rc) return rc;
+            return interleave_launch(rows, n, L, pitch, h->dtype, y_dev, ctx().stream);
+        }
+        return walk(y_dev, 1);
+    }
     if (M > 1 && fir_up_prefers_ols(h, L, n, M)) {   // long phases: all n L outputs by the walk, every M-th of them kept
         if (M <= 4096 && opt().fir_updn_fused) return walk(y_dev, M);   // ... by its store
         void *full = nullptr;                                           // ... or out of scratch

@@ -66,8 +66,10 @@ struct OlsArgs {
     int dec;        // > 1: keep every dec-th output only (multirate_FIR.dn): y[g / dec] = out[g] for g % dec == 0
     unsigned dec_magic;   // ceil(2^32 / dec): (g * dec_magic) >> 32 = g / dec for the tile-local g < 2^15 met in the store
     // up > 1 (multirate_FIR.up with long phases): the walk runs over (tile, phase) pairs -- index w stands for input tile w / up filtered
-    // with the taps of phase w % up (Hp holds up tables of 4096 float4), and output i of that pair lands at y[i * up + phase]
+    // with the taps of phase w % up (Hp holds up tables of 4096 float4), and output i of that pair lands at y[i * up + phase] --
+    // or, up_pitch > 0, at y[phase * up_pitch + i]: the phases as rows (scratch), woven together by interleave_launch afterwards
     int up;
+    int64_t up_pitch;
     int64_t n_keep; // dec * floor(n / dec)
     // Sharded filter (dist.hip): the Ntaps-1 samples in front of x arrive over xGMI on another stream while this launch
     // already runs.  Only tile 0 reads them, so tile 0 is walked LAST and whoever owns it waits for halo_flag >= halo_seq
@@ -669,7 +671,15 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         __builtin_amdgcn_s_setprio(0);
 #endif
         if (UP) {
-            if (REAL) store_tile_real_up<DEC>(A, phys(tile), phase_of(tile), t, v); else store_tile_up<DEC>(A, phys(tile), phase_of(tile), t, v);
+            if (!DEC && A.up_pitch) {   // phases as rows: the plain filter's full-width stores into row phase_of(tile)
+                OlsArgs B = A;
+                B.y = REAL ? reinterpret_cast<cf *>(reinterpret_cast<float *>(A.y) + (int64_t)phase_of(tile) * A.up_pitch) : A.y + (int64_t)phase_of(tile) * A.up_pitch;
+                store_any<REAL, false>(B, phys(tile), t, v, lds);
+            } else if (REAL) {
+                store_tile_real_up<DEC>(A, phys(tile), phase_of(tile), t, v);
+            } else {
+                store_tile_up<DEC>(A, phys(tile), phase_of(tile), t, v);
+            }
         } else {
             store_any<REAL, DEC>(A, phys(tile), t, v, lds);
         }
@@ -806,7 +816,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.dec = dec > 1 ? dec : 1;
     A.dec_magic = A.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + A.dec - 1) / A.dec) : 0u;
     A.n_keep = n;
-    A.up = 1;
+    A.up = 1; A.up_pitch = 0;
     A.halo_flag = halo_flag; A.halo_seq = halo_seq; A.halo_err = halo_err;
     SK_CHECK(!(halo_flag && real), SKDSP_ERR_UNSUPPORTED, "fir_ols: halo flag wait is for complex64 shards");
     int64_t grid = 2 * (int64_t)ctx().num_cus;  // 2 resident workgroups per CU (76 KiB LDS each)
@@ -860,7 +870,7 @@ bool fir_ols_up_supported(const FirHandle *h, int L)
     return h->dtype == SKDSP_C64 || (h->dtype == SKDSP_F32 && !h->taps_complex);
 }
 
-int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec)
+int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch)
 {
     if (n <= 0) return SKDSP_OK;
     SK_CHECK(dec >= 1 && dec <= 4096, SKDSP_ERR_UNSUPPORTED, "fir_ols_up: M = %d (the fused L / M store takes M <= 4096)", dec);
@@ -891,6 +901,7 @@ int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     A.dec_magic = dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + dec - 1) / dec) : 0u;
     A.n_keep = dec > 1 ? (n * L) / dec : n;   // (DEC: the number of outputs)
     A.up = L;
+    A.up_pitch = dec > 1 ? 0 : rows_pitch;
     A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr;
     A.trace = nullptr;
     int64_t grid = 2 * (int64_t)ctx().num_cus;

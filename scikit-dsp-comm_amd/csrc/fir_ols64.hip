@@ -151,6 +151,7 @@ struct Ols64Args {
     // up > 1 (multirate_FIR.up with long phases, as in fir_ols.hip): the walk runs over (tile, phase) pairs -- index w is input tile
     // w / up filtered with phase w % up (Hp: up tables of 4096 bins), output i of the pair lands at y[i * up + phase]
     int up;
+    int64_t up_pitch;   // > 0: the phases as rows, y[phase * up_pitch + i] (scratch; interleave_launch weaves them)
 };
 
 // DEC: the decimating store (multirate_FIR.dn) is its own instantiation: the plain filter carries none of its code
@@ -341,9 +342,11 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
         // (compile-time offsets, no predicates -- as in fir_ols.hip: a run-time a0 made hipcc keep sixteen (exec mask, 64-bit
         // offset) pairs alive across the tile loop, and with them it spilled 72 VGPRs in the complex kernel: 0.691 -> 0.578 ms)
         const int64_t out0 = (REAL ? 2 * tin : tin) * A.V;
-        const bool full = !DEC && !UP && out0 + (REAL ? 2 : 1) * (int64_t)A.V <= A.n;
+        const bool rows = UP && !DEC && A.up_pitch != 0;
+        double *const ybase = rows ? A.y + (int64_t)ph * A.up_pitch * (REAL ? 1 : 2) : A.y;
+        const bool full = !DEC && (!UP || rows) && out0 + (REAL ? 2 : 1) * (int64_t)A.V <= A.n;
         typedef double v2d_t __attribute__((ext_vector_type(2)));
-        if (UP) {
+        if (UP && !rows) {
             // y[(out0 + i) up + ph]: a uniform 64-bit base per 256-block plus a 32-bit per-lane byte offset (scalar-base stores)
             int a0 = A.a0;
             asm volatile("" : "+s"(a0));
@@ -440,12 +443,12 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
 #pragma unroll
                 for (int a = A0; a < 16; ++a) {
                     if (REAL) {
-                        __builtin_nontemporal_store(v[a].x, (A.y + out0) + (unsigned)(256 * (a - A0) + ts));
-                        __builtin_nontemporal_store(v[a].y, (A.y + out0 + A.V) + (unsigned)(256 * (a - A0) + ts));
+                        __builtin_nontemporal_store(v[a].x, (ybase + out0) + (unsigned)(256 * (a - A0) + ts));
+                        __builtin_nontemporal_store(v[a].y, (ybase + out0 + A.V) + (unsigned)(256 * (a - A0) + ts));
                     } else {
                         v2d_t q;
                         q.x = v[a].x; q.y = v[a].y;
-                        __builtin_nontemporal_store(q, (reinterpret_cast<v2d_t *>(A.y) + out0) + (unsigned)(256 * (a - A0) + ts));
+                        __builtin_nontemporal_store(q, (reinterpret_cast<v2d_t *>(ybase) + out0) + (unsigned)(256 * (a - A0) + ts));
                     }
                 }
             };
@@ -473,8 +476,8 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
                         if (ga < A.n_keep && ga % A.dec == 0) A.y[ga / A.dec] = v[a].x;
                         if (gb < A.n_keep && gb % A.dec == 0) A.y[gb / A.dec] = v[a].y;
                     } else {
-                        if (ga < A.n) __builtin_nontemporal_store(v[a].x, A.y + ga);
-                        if (gb < A.n) __builtin_nontemporal_store(v[a].y, A.y + gb);
+                        if (ga < A.n) __builtin_nontemporal_store(v[a].x, ybase + ga);
+                        if (gb < A.n) __builtin_nontemporal_store(v[a].y, ybase + gb);
                     }
                 }
             } else {
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
                     if (DEC) {
                         if (g < A.n_keep && g % A.dec == 0) reinterpret_cast<v2d_t *>(A.y)[g / A.dec] = q;
                     } else if (g < A.n) {
-                        __builtin_nontemporal_store(q, reinterpret_cast<v2d_t *>(A.y) + g);
+                        __builtin_nontemporal_store(q, reinterpret_cast<v2d_t *>(ybase) + g);
                     }
                 }
             }
@@ -589,7 +592,7 @@ int fir_ols64_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, voi
     A.dec = dec > 1 ? dec : 1;
     A.dec_magic = A.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + A.dec - 1) / A.dec) : 0u;
     A.n_keep = n;
-    A.up = 1;
+    A.up = 1; A.up_pitch = 0;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     if (grid > ntiles) grid = ntiles;
     if (A.dec > 1) {
@@ -612,7 +615,7 @@ bool fir_ols64_up_supported(const FirHandle *h, int L)
     return h->dtype == SKDSP_C128 || (h->dtype == SKDSP_F64 && !h->taps_complex);
 }
 
-int fir_ols64_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec)
+int fir_ols64_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch)
 {
     if (n <= 0) return SKDSP_OK;
     SK_CHECK(dec >= 1 && dec <= 4096, SKDSP_ERR_UNSUPPORTED, "fir_ols64_up: M = %d (the fused L / M store takes M <= 4096)", dec);
@@ -639,6 +642,7 @@ int fir_ols64_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, 
     A.dec_magic = dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + dec - 1) / dec) : 0u;
     A.n_keep = dec > 1 ? (n * L) / dec : n;   // (L / M: the number of outputs)
     A.up = L;
+    A.up_pitch = dec > 1 ? 0 : rows_pitch;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     if (grid > ntiles) grid = ntiles;
     if (dec > 1) {

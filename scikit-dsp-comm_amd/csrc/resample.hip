@@ -123,6 +123,90 @@ int upsample_launch(const void *x, int64_t n, int L, int dtype, double scale, vo
     return SKDSP_OK;
 }
 
+// y[i L + p] = src[p pitch + i]: L equally long rows woven into one signal (the second half of multirate_FIR.up through the overlap-save
+// walk for large L, fir_ols.hip: its phases leave as rows first, because an element stored between elements of other rows is a write
+// request of its own).  A workgroup takes I consecutive i (I a power of two): the L row pieces come in with coalesced 16-byte loads and
+// are laid into LDS as rows of pitch I + 1 (conflict-free both ways), then leave as ONE contiguous run of I L elements, 16 bytes per
+// lane; the (i, p) of an output position through a multiply-high by ceil(2^32 / L) (positions below I L < 2^16).
+// VEC = elements per 16 bytes (1: scalar accesses -- complex128, or a destination that is not 16-byte aligned).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void interleave_kernel(const T *__restrict__ src, int64_t n, int L, int64_t pitch, int I, int log2I, unsigned magic,
+                                                         T *__restrict__ y)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *buf = reinterpret_cast<T *>(smem);
+    const int t = threadIdx.x;
+    const int64_t nblk = (n + I - 1) / I;
+    struct alignas(sizeof(T) * VEC) Pack { T e[VEC]; };
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t i0 = blk * I;
+        const int cnt = (int)(n - i0 < I ? n - i0 : I);
+        // loads: (row p, VEC consecutive i) per lane and step
+        const int per_row = I / VEC, steps = per_row * L;
+        for (int q = t; q < steps; q += 256) {
+            const int p = q >> (log2I - (VEC == 4 ? 2 : VEC == 2 ? 1 : 0)), i = (q & (per_row - 1)) * VEC;
+            const T *row = src + (int64_t)p * pitch + i0;
+            T *dst = buf + p * (I + 1) + i;
+            if (i + VEC <= cnt) {
+                const Pack v = *reinterpret_cast<const Pack *>(row + i);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) dst[e] = v.e[e];
+            } else {
+                for (int e = 0; e < VEC && i + e < cnt; ++e) dst[e] = row[i + e];
+            }
+        }
+        __syncthreads();
+        T *out = y + i0 * L;
+        const int total = cnt * L;
+        for (int j = t * VEC; j < total; j += 256 * VEC) {
+            Pack v;
+            unsigned i = (unsigned)(((unsigned long long)(unsigned)j * magic) >> 32);
+            unsigned p = (unsigned)j - i * (unsigned)L;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                v.e[e] = buf[p * (I + 1) + i];   // (reads past `total` in the last pack stay inside the image and are not stored)
+                if (++p == (unsigned)L) { p = 0; ++i; }
+            }
+            if (j + VEC <= total) {
+                *reinterpret_cast<Pack *>(out + j) = v;
+            } else {
+                for (int e = 0; e < VEC && j + e < total; ++e) out[j + e] = v.e[e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int interleave_launch(const void *src, int64_t n, int L, int64_t pitch, int dtype, void *y, hipStream_t s)
+{
+    SK_CHECK(L >= 1 && L <= 4096 && pitch >= n, SKDSP_ERR_BADARG, "interleave: bad arguments (L=%d)", L);
+    if (n <= 0) return SKDSP_OK;
+    const size_t esz = dtype_size(dtype);
+    int I = 1024, log2I = 10;
+    while (I > 16 && (size_t)(I + 1) * L * esz > 48 * 1024 - 64) { I >>= 1; --log2I; }
+    SK_CHECK((size_t)(I + 1) * L * esz <= 64 * 1024, SKDSP_ERR_UNSUPPORTED, "interleave: L = %d rows do not fit the LDS", L);
+    const size_t lds = (size_t)(I + 1) * L * esz + 64;
+    const unsigned magic = (unsigned)((((unsigned long long)1 << 32) + L - 1) / L);
+    const int64_t nblk = (n + I - 1) / I;
+    const int64_t cap = (int64_t)ctx().num_cus * 8;
+    const unsigned g = (unsigned)(nblk < cap ? nblk : cap);
+    // 16-byte accesses need the rows (pitch a multiple of the pack, base) and the destination 16-byte aligned
+    const bool wide = ((uintptr_t)y % 16 == 0) && ((uintptr_t)src % 16 == 0) && (pitch * esz) % 16 == 0 && esz < 16;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef double v2d __attribute__((ext_vector_type(2)));
+#define SK_WEAVE(T, VEC) hipLaunchKernelGGL((interleave_kernel<T, VEC>), dim3(g), dim3(256), lds, s, (const T *)src, n, L, pitch, I, log2I, magic, (T *)y)
+    switch (dtype) {
+    case SKDSP_F32: if (wide) SK_WEAVE(float, 4); else SK_WEAVE(float, 1); break;
+    case SKDSP_C64: if (wide) SK_WEAVE(v2f, 2); else SK_WEAVE(v2f, 1); break;
+    case SKDSP_F64: if (wide) SK_WEAVE(double, 2); else SK_WEAVE(double, 1); break;
+    case SKDSP_C128: SK_WEAVE(v2d, 1); break;
+    default: SK_CHECK(false, SKDSP_ERR_BADARG, "interleave: bad dtype %d", dtype);
+    }
+#undef SK_WEAVE
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
 int downsample_launch(const void *x, int64_t n, int M, int p, int dtype, void *y, hipStream_t s)
 {
     SK_CHECK(M >= 1, SKDSP_ERR_BADARG, "downsample: M must be >= 1 (got %d)", M);

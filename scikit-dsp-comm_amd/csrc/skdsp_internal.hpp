@@ -54,6 +54,8 @@ struct Options {
     int iir_dn_compact = 1;   // 0: the parallel-form .dn keeps the image-and-pick store for every M (A/B switch)
     int fir_up_ols_min = 64;  // multirate_FIR.up: phases of at least this many taps MAY go through the overlap-save walk (the cost model
                               // of fir_up_prefers_ols decides); 0: never; -k: always from k taps per phase on (A/B switch)
+    int fir_up_rows_min = -1; // multirate_FIR.up through the overlap-save walk: from this L on the phases leave as rows and a second kernel weaves them
+                              // (-1: the measured crossover per dtype, fir_up_rows in capi.hip; 0: never)
     int fir_updn_fused = 1;   // 0: L / M through the overlap-save walk writes all n L outputs to scratch and copies every M-th (A/B switch)
     int iir_up_fused = 1;     // 0: multirate_IIR.up / rate_change.up write the zero-stuffed signal first (A/B switch)
     int iir_par_dbg = 0;      // developer timing switches of iir_par_kernel (ParArgs::dbg; wrong results)
@@ -191,13 +193,14 @@ int fir_ols_publish_halo(unsigned *flag, unsigned seq, hipStream_t s);  // one-t
 void fir_ols_free(OlsPlan *p);
 // multirate_FIR.up as an overlap-save walk over (tile, phase) pairs: complex64, float32 with real taps; 2..4097 taps per phase
 bool fir_ols_up_supported(const FirHandle *h, int L);
-int fir_ols_up_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s, int dec = 1);  // dec = M: L / M, floor(n L / M) outputs
+int fir_ols_up_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s, int dec = 1,
+                      int64_t rows_pitch = 0);  // dec = M: L / M, floor(n L / M) outputs; rows_pitch > 0: y[phase * rows_pitch + i] instead of y[i L + phase]
 // FFT overlap-save in float64 (fir_ols64.hip): complex128, and float64 with real taps; 2..2049 taps
 bool fir_ols64_supported(const FirHandle *h);
 int fir_ols64_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, hipStream_t s, int dec = 1);
 void fir_ols64_free(Ols64Plan *p);
 bool fir_ols64_up_supported(const FirHandle *h, int L);
-int fir_ols64_up_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s, int dec = 1);
+int fir_ols64_up_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s, int dec = 1, int64_t rows_pitch = 0);
 
 // ---- IIR -----------------------------------------------------------------
 struct IirPlan;  // iir_scan.hip
@@ -250,6 +253,7 @@ int upsample_launch(const void *x_dev, int64_t n, int L, int dtype, double scale
 int upsample_planes_launch(const void *x_dev, int64_t n, int L, int dtype_complex_in, double scale, void *re_dev, void *im_dev,
                            hipStream_t s);  // complex zero-stuffing straight into two real planes
 int downsample_launch(const void *x_dev, int64_t n, int M, int p, int dtype, void *y_dev, hipStream_t s);
+int interleave_launch(const void *src_dev, int64_t n, int L, int64_t pitch, int dtype, void *y_dev, hipStream_t s);   // y[i L + p] = src[p pitch + i]
 int deinterleave_launch(const void *x_dev, int64_t n, int dtype_complex_in, void *re_dev, void *im_dev, hipStream_t s);
 int interleave_launch(const void *re_dev, const void *im_dev, int64_t n, int dtype_complex_out, void *y_dev, hipStream_t s);
 int widen_launch(const void *src_dev, int64_t nscalars, void *dst_dev, hipStream_t s);  // float32 -> float64

@@ -300,13 +300,27 @@ def test_fir_overlap_save_up(dt, ntaps, L):
         yd = _ffi.DeviceArray(n * L + 8, dt)
         y2 = _ffi.DeviceArray(n * L + 8, dt)
         try:
-            yd.write(np.full(n * L + 8, 7.0, dtype=dt))
-            with _ffi.option("fir_up_ols_min", -12):
-                k.up_dev(xd, yd, L)
+            # the walk's two ways out: every phase stored with stride L / the phases as rows of scratch, woven together by a second kernel
+            both = []
+            for rows_min in (0, 2):
+                yd.write(np.full(n * L + 8, 7.0, dtype=dt))
+                with _ffi.option("fir_up_ols_min", -12), _ffi.option("fir_up_rows_min", rows_min):
+                    k.up_dev(xd, yd, L)
+                both.append(yd.to_host(0, n * L))
+                assert np.all(yd.to_host(n * L, 8) == 7.0), "wrote beyond n * L outputs (L=%d n=%d rows_min=%d)" % (L, n, rows_min)
+            assert np.array_equal(both[0], both[1]), (L, n)
+            if n == 20_000:   # a destination one sample off its allocation (element-aligned only): the weave falls back to scalar accesses
+                y3 = _ffi.DeviceArray(n * L + 9, dt)
+                try:
+                    y3.write(np.full(n * L + 9, 7.0, dtype=dt))
+                    with _ffi.option("fir_up_ols_min", -12), _ffi.option("fir_up_rows_min", 2):
+                        k.up_dev(xd, y3.window(1, n * L), L)
+                    assert np.array_equal(y3.to_host(1, n * L), both[0]) and y3.to_host(0, 1)[0] == 7.0 and np.all(y3.to_host(n * L + 1, 8) == 7.0), (L, n)
+                finally:
+                    y3.free()
             with _ffi.option("fir_up_ols_min", 0):
                 k.up_dev(xd, y2, L)
-            got = yd.to_host(0, n * L)
-            assert np.all(yd.to_host(n * L, 8) == 7.0), "wrote beyond n * L outputs (L=%d n=%d)" % (L, n)
+            got = both[1]
             other = y2.to_host(0, n * L)
             peak = np.max(np.abs(other))
             assert np.max(np.abs(got - other)) <= 2 * tol * peak, ("polyphase kernels", L, n, np.max(np.abs(got - other)) / peak)

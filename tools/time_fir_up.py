@@ -20,15 +20,15 @@ for dt in DTYPES:
         k = _ffi.FirKernel(bench.firwin_lowpass(ntaps, 0.8 / L), _ffi.code_of(dt))
         xd = _ffi.DeviceArray(n, dt).fill_noise(1); yd = _ffi.DeviceArray(n * L, dt)
         ms = []
-        for thr in (0, -2, 64):
-            with _ffi.option("fir_up_ols_min", thr):
+        for thr, rows in ((0, 0), (-2, 0), (-2, 2), (64, -1)):
+            with _ffi.option("fir_up_ols_min", thr), _ffi.option("fir_up_rows_min", rows):
                 for _ in range(3): k.up_dev(xd, yd, L)
                 _ffi.sync(); _ffi.timer_start()
                 for _ in range(10): k.up_dev(xd, yd, L)
                 ms.append(_ffi.timer_stop() / 10)
         isz = np.dtype(dt).itemsize
-        best = min(ms[0], ms[1])
-        print("%-10s up L=%2d %5d taps (%4d per phase) n_in %9d: polyphase %.4f ms  overlap-save %.4f ms  default %.4f ms (%.2f TB/s algorithmic)%s"
-              % (np.dtype(dt).name, L, ntaps, T, n, ms[0], ms[1], ms[2], isz * n * (1 + L) / ms[2] / 1e9,
-                 "" if ms[2] <= 1.08 * best else "   <-- default is not the faster path"), flush=True)
+        best = min(ms[0], ms[1], ms[2])
+        print("%-10s up L=%2d %5d taps (%4d per phase) n_in %9d: polyphase %.4f ms  walk, strided stores %.4f  walk, rows + weave %.4f  default %.4f ms (%.2f TB/s algorithmic)%s"
+              % (np.dtype(dt).name, L, ntaps, T, n, ms[0], ms[1], ms[2], ms[3], isz * n * (1 + L) / ms[3] / 1e9,
+                 "" if ms[3] <= 1.08 * best else "   <-- default is not the fastest path"), flush=True)
         xd.free(); yd.free()
