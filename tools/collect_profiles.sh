@@ -41,5 +41,12 @@ python tools/time_fir_shapes.py > $OUT/fir_shapes.txt 2>&1
 python tools/time_iir_up.py > $OUT/iir_up.txt 2>&1
 python tools/time_iir_dn.py > $OUT/iir_dn.txt 2>&1
 python tools/time_fir_c128.py > $OUT/fir_f64.txt 2>&1
+# multirate_FIR.up / L / M through the overlap-save walk: the timing tables, and a kernel trace of three shapes
+python tools/time_fir_up.py > $OUT/fir_up.txt 2>&1
+DTYPES=float64,complex128 python tools/time_fir_up.py 2x128 2x512 2x1024 4x128 4x512 8x128 8x256 12x256 64x64 >> $OUT/fir_up.txt 2>&1
+python tools/time_fir_updn.py > $OUT/fir_updn.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fir_up -- python $ROOT/tools/time_fir_up.py 2x512 4x256 12x256 > /dev/null 2>&1)
+cp $OUT/trace_fir_up/*/*kernel_stats.csv $OUT/kernel_stats_fir_up.csv 2>/dev/null
+rm -rf $OUT/trace_fir_up
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_dp_pipes.hip -o /tmp/ubench_dp_pipes 2>/dev/null && /tmp/ubench_dp_pipes > $OUT/ubench_dp_pipes.txt 2>&1
 ls -la $OUT
