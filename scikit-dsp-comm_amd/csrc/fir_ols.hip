@@ -28,6 +28,9 @@
 #endif
 #ifndef SKDSP_OLS_HREG
 #define SKDSP_OLS_HREG 1  // this thread's 32 bins of H stay in registers across tiles
+#ifndef SKDSP_OLS_HSTREAM_DEC
+#define SKDSP_OLS_HSTREAM_DEC 1  // ... but for the last few float4 of them in the decimating-store kernels (see HS; 0: all 16 held, for A/B)
+#endif
 #endif
 #ifndef SKDSP_OLS_NT
 #define SKDSP_OLS_NT 1  // nontemporal x loads / y stores (streamed once): 0.300 -> 0.295 ms
@@ -507,6 +510,10 @@ template <bool TRACE, bool REAL, bool DEC, bool UP = false>
 __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 {
     __shared__ float4 lds[kLdsUnits + 2 * kT2Units];
+    // Decimating store (.dn): the last HS of the thread's 16 H registers are fetched per tile (HS x 4 KiB from L2, requested at the top of the
+    // tile, used behind the forward transform).  With all 16 held across tiles hipcc spilled four of them and reloaded them from scratch INSIDE
+    // the H multiply: four round trips per tile on the critical path.
+    constexpr int HS = (DEC && !UP && SKDSP_OLS_HREG && SKDSP_OLS_HSTREAM_DEC) ? (REAL ? 4 : 5) : 0;   // (the counts that leave no spill)
     float4 *T2f = lds + kLdsUnits;            // [k2][q]
     float4 *T2t = lds + kLdsUnits + kT2Units; // [qq][k2] (transposed copy for the inverse)
     const int t = threadIdx.x;
@@ -589,6 +596,12 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         load_any<REAL>(A, phys(tile), t, v);
 #endif
 #if SKDSP_OLS_HREG
+        if (HS > 0) {
+            int tt = t;   // (opaque: the requests stay inside the tile loop)
+            asm volatile("" : "+v"(tt));
+#pragma unroll
+            for (int j = 16 - HS; j < 16; ++j) hh[j] = vld(reinterpret_cast<const volatile float4 *>(A.Hp) + (unsigned)(j * 256 + tt));
+        }
         if (UP) {   // this pair's phase (streamed per pair: 64 KiB from L2, requested here, used behind the forward transform.  One phase per
                     // workgroup with H held in registers like .filter -- a grid that is a multiple of up -- was built and measured:
                     // 0.66 vs 0.52 ms at L = 12, 0.39 vs 0.35 at L = 4, equal at L = 2; never faster, removed)
