@@ -111,7 +111,7 @@ const OptEntry kOptTable[] = {
     {"sw_no_tile", &Options::sw_no_tile}, {"sw_no_lpt", &Options::sw_no_lpt}, {"mm_ns", &Options::mm_ns},
     {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
-    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
+    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up_pair", &Options::fir_up_pair}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
     {"shard_reserve", &Options::shard_reserve}, {"shard_two_launches", &Options::shard_two_launches},
     {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
     {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline}, {"host_multi_slot", &Options::host_multi_slot},
@@ -372,11 +372,12 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
 // plus what its stride-L stores cost, and runs in rounds of one pair per resident workgroup.
 // multirate_FIR.up through the overlap-save walk: from which L on the phases leave as rows of scratch and a second kernel weaves them
 // (measured crossovers of profiles/r03/fir_up.txt; 16-byte samples never: their strided stores are full-width requests already)
-static bool fir_up_rows(const FirHandle *h, int L)
+static bool fir_up_rows(const FirHandle *h, int L, bool paired = false)
 {
     const int o = opt().fir_up_rows_min;
     if (o == 0) return false;
     if (o > 0) return L >= o;
+    if (paired) return L / 2 >= 7;   // (8-byte pairs: the complex64 crossover, in phases)
     switch (h->dtype) {
     case SKDSP_F32: return L >= 9;
     case SKDSP_C64: return L >= 7;
@@ -418,6 +419,10 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
         V = 8192 - ((T - 1 + 511) / 512) * 512;
     }
     if (M == 1 && fir_up_rows(h, L)) ols = std::min(ols, dbl ? 0.45 : (cplx ? 0.45 : 0.245));   // (rows + weave: whatever L is)
+    if (M == 1 && fir_ols_up_pairs(h, L, 1, nullptr)) {   // float32, even L: L / 2 complex passes per tile of real input, 8-byte outputs
+        const double hp = Lf / 2.0;
+        ols = 0.5 * (hp == 1.0 ? 0.235 : std::min(0.27 + 0.022 * hp, fir_up_rows(h, L, true) ? 0.45 : 1e9));
+    }
     if (M > 1) {   // L / M: the polyphase kernels compute the kept outputs only; the walk computes all and stores (or copies) every M-th
         poly /= (double)M;
         if (M <= 4096 && opt().fir_updn_fused) ols = base + (ols - base) / (double)M;
@@ -439,18 +444,23 @@ static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hi
                                       : fir_ols_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream, dec);
     };
     if (M == 1 && fir_up_prefers_ols(h, L, n)) {
-        if (fir_up_rows(h, L)) {
-            // many phases: an output stored between outputs of other phases is a write request of its own, so the phases leave as L rows
+        const bool dbl = dtype_double(h->dtype);
+        const bool paired = !dbl && fir_ols_up_pairs(h, L, 1, y_dev);
+        if (fir_up_rows(h, L, paired) && (!paired || L > 2)) {   // (one pair is one row: nothing to weave)
+            // many phases: an output stored between outputs of other phases is a write request of its own, so the phases leave as rows
             // with the plain filter's stores and interleave_launch weaves them (one more pass over the output, still cheaper from L = 6 ... 9 on)
+            const int rows_n = paired ? L / 2 : L;
+            const int row_dtype = paired ? SKDSP_C64 : h->dtype;
             const int64_t pitch = (int64_t)round_up((size_t)n, 64);
             void *rows = nullptr;
-            int rc = ws_reserve(2, (size_t)pitch * L * dtype_size(h->dtype) + 256, &rows);
+            int rc = ws_reserve(2, (size_t)pitch * rows_n * dtype_size(row_dtype) + 256, &rows);
             if (rc) return rc;
-            rc = dtype_double(h->dtype) ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, rows, ctx().stream, 1, pitch)
-                                        : fir_ols_up_launch(h, x_dev, n, n_hist, L, rows, ctx().stream, 1, pitch);
+            rc = dbl ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, rows, ctx().stream, 1, pitch)
+                     : fir_ols_up_launch(h, x_dev, n, n_hist, L, rows, ctx().stream, 1, pitch, paired);
             if (rc) return rc;
-            return interleave_launch(rows, n, L, pitch, h->dtype, y_dev, ctx().stream);
+            return interleave_launch(rows, n, rows_n, pitch, row_dtype, y_dev, ctx().stream);
         }
+        if (paired) return fir_ols_up_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream, 1, 0, 1);
         return walk(y_dev, 1);
     }
     if (M > 1 && fir_up_prefers_ols(h, L, n, M)) {   // long phases: all n L outputs by the walk, every M-th of them kept

@@ -373,9 +373,39 @@ template <bool DEC> __device__ __forceinline__ void store_tile_real(const OlsArg
     }
 }
 
-template <bool REAL> __device__ __forceinline__ void load_any(const OlsArgs &A, int64_t tile, int t, cf *v)
+// A REAL signal into the COMPLEX tile (imaginary part zero): multirate_FIR.up of float32 signals with an even L runs its phases in
+// pairs -- x * (h_2k + i h_2k+1) = y_2k + i y_2k+1 is one complex pass, and its output IS the interleaved pair (y[iL + 2k], y[iL + 2k + 1])
+// as one 8-byte element.  Same number of transforms as two real tiles per complex tile and one phase per pass, but the stores are 8 bytes
+// wide -- contiguous at L = 2 -- and the input is read once per pair.
+__device__ __forceinline__ void load_tile_xr(const OlsArgs &A, int64_t tile, int t, cf *v)
 {
-    if (REAL) load_tile_real(A, tile, t, v); else load_tile(A, tile, t, v);
+    const float *xr = reinterpret_cast<const float *>(A.x);
+    const int64_t in0 = tile * A.V - A.ov;
+    const bool interior = A.aligned && in0 >= -A.n_hist && in0 + kN <= A.n;
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    if (interior) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const v2f_t r = __builtin_nontemporal_load(reinterpret_cast<const v2f_t *>(xr + in0) + (unsigned)(a * 256 + tt));
+            v[2 * a] = make_float2(r.x, 0.f);
+            v[2 * a + 1] = make_float2(r.y, 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int64_t g = in0 + 512 * a + 2 * tt + e;
+                v[2 * a + e] = make_float2((g >= -A.n_hist && g < A.n) ? xr[g] : 0.f, 0.f);
+            }
+        }
+    }
+}
+
+template <bool REAL, bool XR = false> __device__ __forceinline__ void load_any(const OlsArgs &A, int64_t tile, int t, cf *v)
+{
+    if (XR) load_tile_xr(A, tile, t, v); else if (REAL) load_tile_real(A, tile, t, v); else load_tile(A, tile, t, v);
 }
 template <bool REAL, bool DEC> __device__ __forceinline__ void store_any(const OlsArgs &A, int64_t tile, int t, const cf *v, float4 *lds)
 {
@@ -506,7 +536,7 @@ template <bool DEC> __device__ __forceinline__ void store_tile_real_up(const Ols
 // UP: multirate_FIR.up for phases too long for the polyphase kernels (see OlsArgs::up): the same walk over (tile, phase) pairs, H of the
 // pair's phase fetched per pair, outputs stored with stride up.  Neighbouring walk indices are the phases of one input tile: they run on
 // one XCD at one time, so the tile is fetched from HBM once and the strided stores of its phases meet in that XCD's L2.
-template <bool TRACE, bool REAL, bool DEC, bool UP = false>
+template <bool TRACE, bool REAL, bool DEC, bool UP = false, bool XR = false>   // XR: real signal into the complex tile (see load_tile_xr)
 __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 {
     __shared__ float4 lds[kLdsUnits + 2 * kT2Units];
@@ -578,22 +608,28 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 #if SKDSP_OLS_PREFETCH
     if (tile < A.ntiles) {
         if (t0_last && phys(tile) == 0) wait_halo(A);
-        load_any<REAL>(A, phys(tile), t, v);
+        load_any<REAL, XR>(A, phys(tile), t, v);
     }
     // the loop is entered with no load pending on either edge (see the note in front of the stores):
     // waits placed at the loop top for THIS load would otherwise also be paid by every later tile,
     // where the only pending vector-memory operations are the previous tile's stores
+    if constexpr (XR) {   // (real signal: only the real parts were loaded -- the zeros must not be pinned into registers here)
+#pragma unroll
+        for (int i = 0; i < 32; i += 8)
+            asm volatile("" ::"v"(v[i].x), "v"(v[i + 1].x), "v"(v[i + 2].x), "v"(v[i + 3].x), "v"(v[i + 4].x), "v"(v[i + 5].x), "v"(v[i + 6].x), "v"(v[i + 7].x));
+    } else {
 #pragma unroll
     for (int i = 0; i < 32; i += 8)
         asm volatile("" ::"v"(v[i].x), "v"(v[i].y), "v"(v[i + 1].x), "v"(v[i + 1].y), "v"(v[i + 2].x), "v"(v[i + 2].y),
                      "v"(v[i + 3].x), "v"(v[i + 3].y), "v"(v[i + 4].x), "v"(v[i + 4].y), "v"(v[i + 5].x), "v"(v[i + 5].y),
                      "v"(v[i + 6].x), "v"(v[i + 6].y), "v"(v[i + 7].x), "v"(v[i + 7].y));
+    }
 #endif
     for (; tile < A.ntiles; tile += gridDim.x, ++it) {
         SK_STAMP(0);
 #if !SKDSP_OLS_PREFETCH
         if (t0_last && phys(tile) == 0) wait_halo(A);
-        load_any<REAL>(A, phys(tile), t, v);
+        load_any<REAL, XR>(A, phys(tile), t, v);
 #endif
 #if SKDSP_OLS_HREG
         if (HS > 0) {
@@ -627,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         {   // measurement aid: the tile walk's memory traffic alone (loads, prefetch, stores)
             const int64_t next = tile + gridDim.x;
             cf nx[32];
-            if (next < A.ntiles) load_any<REAL>(A, phys(next), t, nx);
+            if (next < A.ntiles) load_any<REAL, XR>(A, phys(next), t, nx);
             store_any<REAL, DEC>(A, phys(tile), t, v, lds);
 #pragma unroll
             for (int i = 0; i < 32; ++i) v[i] = nx[i];
@@ -654,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 #endif
         if (next < A.ntiles) {
             if (t0_last && phys(next) == 0) wait_halo(A);  // (uniform: the whole workgroup owns that tile)
-            load_any<REAL>(A, phys(next), t, nx);
+            load_any<REAL, XR>(A, phys(next), t, nx);
         }
 #if SKDSP_OLS_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
@@ -671,12 +707,19 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         // whole inverse FFT to land).  Otherwise the wait sits at the top of the next tile, behind the
         // stores below, and vmcnt -- which retires in order -- makes every tile start with a full
         // round trip of its predecessor's stores.
+        if constexpr (XR) {
+#pragma unroll
+            for (int i = 0; i < 32; i += 8)
+                asm volatile("" ::"v"(nx[i].x), "v"(nx[i + 1].x), "v"(nx[i + 2].x), "v"(nx[i + 3].x), "v"(nx[i + 4].x), "v"(nx[i + 5].x), "v"(nx[i + 6].x), "v"(nx[i + 7].x)
+                             : "memory");
+        } else {
 #pragma unroll
         for (int i = 0; i < 32; i += 8)
             asm volatile("" ::"v"(nx[i].x), "v"(nx[i].y), "v"(nx[i + 1].x), "v"(nx[i + 1].y), "v"(nx[i + 2].x), "v"(nx[i + 2].y),
                          "v"(nx[i + 3].x), "v"(nx[i + 3].y), "v"(nx[i + 4].x), "v"(nx[i + 4].y), "v"(nx[i + 5].x), "v"(nx[i + 5].y),
                          "v"(nx[i + 6].x), "v"(nx[i + 6].y), "v"(nx[i + 7].x), "v"(nx[i + 7].y)
                          : "memory");
+        }
 #endif
 #if SKDSP_OLS_PRIO == 1
         __builtin_amdgcn_s_setprio(3);
@@ -721,8 +764,42 @@ bool fir_ols_supported(const FirHandle *h)
 }
 
 // Tables of one plan: `up` phase filters (phase p: taps gain * b[p + up t], t < T) as `up` consecutive Hp tables; up = 1 is the filter itself.
-static int build_plan(const FirHandle *h, int up, OlsPlan **out)
+static int build_plan(const FirHandle *h, int up, OlsPlan **out, bool paired = false)
 {
+    if (paired) {   // real taps, even up: table k holds phase 2k + i phase 2k+1 (see load_tile_xr)
+        const int T = (h->ntaps + up - 1) / up;
+        OlsPlan *p = new OlsPlan();
+        p->ntaps = T;
+        p->ov = ((T - 1 + 511) / 512) * 512;
+        if (p->ov == 0) p->ov = 512;
+        p->V = kN - p->ov;
+        std::vector<float4> T1, T2, Hp, Hall;
+        make_T1(T1);
+        make_T2(T2);
+        std::vector<double> ph((size_t)T * 2);
+        for (int k = 0; k < up / 2; ++k) {
+            std::fill(ph.begin(), ph.end(), 0.0);
+            for (int t = 0; t < T; ++t)
+                for (int c = 0; c < 2; ++c) {
+                    const int j = 2 * k + c + up * t;
+                    if (j < h->ntaps) ph[(size_t)2 * t + c] = (double)up * h->taps_host[j];
+                }
+            make_Hp(ph.data(), T, 2, Hp);
+            Hall.insert(Hall.end(), Hp.begin(), Hp.end());
+        }
+        hipError_t e;
+        if ((e = hipMalloc((void **)&p->T1, T1.size() * sizeof(float4))) != hipSuccess ||
+            (e = hipMalloc((void **)&p->T2, T2.size() * sizeof(float4))) != hipSuccess ||
+            (e = hipMalloc((void **)&p->Hp, Hall.size() * sizeof(float4))) != hipSuccess ||
+            (e = hipMemcpy(p->T1, T1.data(), T1.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(p->T2, T2.data(), T2.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(p->Hp, Hall.data(), Hall.size() * sizeof(float4), hipMemcpyHostToDevice)) != hipSuccess) {
+            fir_ols_free(p);
+            return hip_fail(e, "ols tables (paired phases)", __FILE__, __LINE__);
+        }
+        *out = p;
+        return SKDSP_OK;
+    }
     const int comp = h->taps_complex ? 2 : 1;
     const int T = (h->ntaps + up - 1) / up;
     OlsPlan *p = new OlsPlan();
@@ -883,18 +960,28 @@ bool fir_ols_up_supported(const FirHandle *h, int L)
     return h->dtype == SKDSP_C64 || (h->dtype == SKDSP_F32 && !h->taps_complex);
 }
 
-int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch)
+// float32 signals, even L, no decimation, an 8-byte aligned destination: the phases run in pairs through the complex tile (load_tile_xr)
+bool fir_ols_up_pairs(const FirHandle *h, int L, int dec, const void *y)
+{
+    return opt().fir_up_pair && h->dtype == SKDSP_F32 && !h->taps_complex && L % 2 == 0 && dec <= 1 && ((uintptr_t)y & 7) == 0;
+}
+
+int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch, int paired_in)
 {
     if (n <= 0) return SKDSP_OK;
     SK_CHECK(dec >= 1 && dec <= 4096, SKDSP_ERR_UNSUPPORTED, "fir_ols_up: M = %d (the fused L / M store takes M <= 4096)", dec);
     SK_CHECK(fir_ols_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols_up: needs complex64 (or float32 with real taps), 2 <= L <= 64, 2..4097 taps per phase");
+    // (rows_pitch of a paired launch counts 8-byte elements: the caller weaves L / 2 rows of pairs)
+    const bool paired = paired_in != 0;
+    SK_CHECK(!paired || fir_ols_up_pairs(h, L, dec, y), SKDSP_ERR_BADARG, "fir_ols_up: phases in pairs need float32, real taps, an even L, no decimation and an 8-byte aligned destination");
+    const int key = paired ? -L : L;
     OlsPlan *p = nullptr;
     for (auto &u : h->ols_up)
-        if (u.L == L) p = u.plan;
+        if (u.L == key) p = u.plan;
     if (!p) {
-        int rc = build_plan(h, L, &p);
+        int rc = build_plan(h, L, &p, paired);
         if (rc) return rc;
-        h->ols_up.push_back(FirHandle::OlsUp{L, p});
+        h->ols_up.push_back(FirHandle::OlsUp{key, p});
     }
     OlsArgs A;
     A.x = (const cf *)x;
@@ -903,17 +990,18 @@ int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     A.n_hist = n_hist;
     A.T1 = p->T1; A.T2 = p->T2; A.Hp = p->Hp;
     A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512;
-    const bool real = h->dtype == SKDSP_F32;
-    A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & (real ? 3 : 7)) == 0;
+    const bool real = h->dtype == SKDSP_F32 && !paired;
+    A.aligned = paired ? (((uintptr_t)x & 3) == 0 && ((uintptr_t)y & 7) == 0) : ((((uintptr_t)x) | ((uintptr_t)y)) & (real ? 3 : 7)) == 0;
     int64_t ntiles = (n + p->V - 1) / p->V;
     if (real) ntiles = (ntiles + 1) / 2;
-    ntiles *= L;
+    const int phases = paired ? L / 2 : L;
+    ntiles *= phases;
     SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols_up: too many tiles");
     A.ntiles = ntiles;
     A.dec = dec;
     A.dec_magic = dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + dec - 1) / dec) : 0u;
     A.n_keep = dec > 1 ? (n * L) / dec : n;   // (DEC: the number of outputs)
-    A.up = L;
+    A.up = phases;
     A.up_pitch = dec > 1 ? 0 : rows_pitch;
     A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr;
     A.trace = nullptr;
@@ -921,7 +1009,12 @@ int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     const int reserve_wgs = opt().ols_reserve;
     if (reserve_wgs > 0 && grid > 8 * (int64_t)reserve_wgs) grid -= reserve_wgs;
     if (grid > ntiles) grid = ntiles;
-    if (dec > 1) {
+    if (paired) {
+        // (L = 2 is one pair: "row 0" of the rows form IS the output, written with the plain complex filter's full-width stores.  The
+        // instantiation that also keeps H in registers -- UP = false -- compiles to 18 spilled registers with the real-input loads.)
+        if (phases == 1 && A.up_pitch == 0) A.up_pitch = 1;
+        hipLaunchKernelGGL((ols_tile_kernel<false, false, false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    } else if (dec > 1) {
         if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
         else hipLaunchKernelGGL((ols_tile_kernel<false, false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
     } else {

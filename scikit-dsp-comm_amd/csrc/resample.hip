@@ -182,6 +182,10 @@ int interleave_launch(const void *src, int64_t n, int L, int64_t pitch, int dtyp
     SK_CHECK(L >= 1 && L <= 4096 && pitch >= n, SKDSP_ERR_BADARG, "interleave: bad arguments (L=%d)", L);
     if (n <= 0) return SKDSP_OK;
     const size_t esz = dtype_size(dtype);
+    if (L == 1) {   // one row: a copy
+        SK_HIP(hipMemcpyAsync(y, src, (size_t)n * esz, hipMemcpyDeviceToDevice, s));
+        return SKDSP_OK;
+    }
     int I = 1024, log2I = 10;
     while (I > 16 && (size_t)(I + 1) * L * esz > 48 * 1024 - 64) { I >>= 1; --log2I; }
     SK_CHECK((size_t)(I + 1) * L * esz <= 64 * 1024, SKDSP_ERR_UNSUPPORTED, "interleave: L = %d rows do not fit the LDS", L);

@@ -56,6 +56,7 @@ struct Options {
                               // of fir_up_prefers_ols decides); 0: never; -k: always from k taps per phase on (A/B switch)
     int fir_up_rows_min = -1; // multirate_FIR.up through the overlap-save walk: from this L on the phases leave as rows and a second kernel weaves them
                               // (-1: the measured crossover per dtype, fir_up_rows in capi.hip; 0: never)
+    int fir_up_pair = 1;      // 0: float32 .up through the overlap-save walk never pairs its phases (A/B switch)
     int fir_updn_fused = 1;   // 0: L / M through the overlap-save walk writes all n L outputs to scratch and copies every M-th (A/B switch)
     int iir_up_fused = 1;     // 0: multirate_IIR.up / rate_change.up write the zero-stuffed signal first (A/B switch)
     int iir_par_dbg = 0;      // developer timing switches of iir_par_kernel (ParArgs::dbg; wrong results)
@@ -193,8 +194,10 @@ int fir_ols_publish_halo(unsigned *flag, unsigned seq, hipStream_t s);  // one-t
 void fir_ols_free(OlsPlan *p);
 // multirate_FIR.up as an overlap-save walk over (tile, phase) pairs: complex64, float32 with real taps; 2..4097 taps per phase
 bool fir_ols_up_supported(const FirHandle *h, int L);
+bool fir_ols_up_pairs(const FirHandle *h, int L, int dec, const void *y_dev);   // float32, even L: phases in pairs through the complex tile (8-byte outputs)
 int fir_ols_up_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s, int dec = 1,
-                      int64_t rows_pitch = 0);  // dec = M: L / M, floor(n L / M) outputs; rows_pitch > 0: y[phase * rows_pitch + i] instead of y[i L + phase]
+                      int64_t rows_pitch = 0, int paired = 0);  // dec = M: L / M, floor(n L / M) outputs; rows_pitch > 0: y[phase * rows_pitch + i] instead of
+                                                                 // y[i L + phase]; paired: see fir_ols_up_pairs (rows then hold 8-byte pairs, L / 2 of them)
 // FFT overlap-save in float64 (fir_ols64.hip): complex128, and float64 with real taps; 2..2049 taps
 bool fir_ols64_supported(const FirHandle *h);
 int fir_ols64_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, hipStream_t s, int dec = 1);
