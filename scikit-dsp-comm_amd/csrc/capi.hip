@@ -377,7 +377,7 @@ static bool fir_up_rows(const FirHandle *h, int L, bool paired = false)
     const int o = opt().fir_up_rows_min;
     if (o == 0) return false;
     if (o > 0) return L >= o;
-    if (paired) return L / 2 >= 7;   // (8-byte pairs: the complex64 crossover, in phases)
+    if (paired) return !dtype_double(h->dtype) && L / 2 >= 7;   // (8-byte pairs: the complex64 crossover, in phases; 16-byte pairs never)
     switch (h->dtype) {
     case SKDSP_F32: return L >= 9;
     case SKDSP_C64: return L >= 7;
@@ -419,10 +419,10 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
         V = 8192 - ((T - 1 + 511) / 512) * 512;
     }
     if (M == 1 && fir_up_rows(h, L)) ols = std::min(ols, dbl ? 0.45 : (cplx ? 0.45 : 0.245));   // (rows + weave: whatever L is)
-    if (M == 1 && fir_ols_up_pairs(h, L, 1, nullptr)) {   // float32, even L: L / 2 complex passes per tile of real input, 8-byte outputs
-        const double hp = Lf / 2.0;
-        ols = 0.5 * (hp == 1.0 ? 0.235 : std::min(0.27 + 0.022 * hp, fir_up_rows(h, L, true) ? 0.45 : 1e9));
-    }
+    if (M == 1 && !dbl && fir_ols_up_pairs(h, L, 1, nullptr))   // float32, even L: L / 2 complex passes per tile of real input, 8-byte outputs
+        ols = std::min(0.11 + 0.007 * Lf, 0.235);
+    if (M == 1 && dbl && fir_ols64_up_pairs(h, L, 1, nullptr))   // float64 likewise, 16-byte outputs
+        ols = 0.25 + 0.005 * std::min(Lf, 16.0);
     if (M > 1) {   // L / M: the polyphase kernels compute the kept outputs only; the walk computes all and stores (or copies) every M-th
         poly /= (double)M;
         if (M <= 4096 && opt().fir_updn_fused) ols = base + (ols - base) / (double)M;
@@ -445,22 +445,22 @@ static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hi
     };
     if (M == 1 && fir_up_prefers_ols(h, L, n)) {
         const bool dbl = dtype_double(h->dtype);
-        const bool paired = !dbl && fir_ols_up_pairs(h, L, 1, y_dev);
+        const bool paired = dbl ? fir_ols64_up_pairs(h, L, 1, y_dev) : fir_ols_up_pairs(h, L, 1, y_dev);
         if (fir_up_rows(h, L, paired) && (!paired || L > 2)) {   // (one pair is one row: nothing to weave)
             // many phases: an output stored between outputs of other phases is a write request of its own, so the phases leave as rows
             // with the plain filter's stores and interleave_launch weaves them (one more pass over the output, still cheaper from L = 6 ... 9 on)
             const int rows_n = paired ? L / 2 : L;
-            const int row_dtype = paired ? SKDSP_C64 : h->dtype;
+            const int row_dtype = paired ? (dbl ? SKDSP_C128 : SKDSP_C64) : h->dtype;
             const int64_t pitch = (int64_t)round_up((size_t)n, 64);
             void *rows = nullptr;
             int rc = ws_reserve(2, (size_t)pitch * rows_n * dtype_size(row_dtype) + 256, &rows);
             if (rc) return rc;
-            rc = dbl ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, rows, ctx().stream, 1, pitch)
+            rc = dbl ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, rows, ctx().stream, 1, pitch, paired)
                      : fir_ols_up_launch(h, x_dev, n, n_hist, L, rows, ctx().stream, 1, pitch, paired);
             if (rc) return rc;
             return interleave_launch(rows, n, rows_n, pitch, row_dtype, y_dev, ctx().stream);
         }
-        if (paired) return fir_ols_up_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream, 1, 0, 1);
+        if (paired) return dbl ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream, 1, 0, 1) : fir_ols_up_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream, 1, 0, 1);
         return walk(y_dev, 1);
     }
     if (M > 1 && fir_up_prefers_ols(h, L, n, M)) {   // long phases: all n L outputs by the walk, every M-th of them kept

@@ -157,7 +157,9 @@ struct Ols64Args {
 // DEC: the decimating store (multirate_FIR.dn) is its own instantiation: the plain filter carries none of its code
 // UP: multirate_FIR.up over (tile, phase) pairs; H of the pair's phase streamed from L2, stores with stride up (a thread's outputs are
 //     lane-consecutive here, so every store instruction writes 64 consecutive outputs of the phase as it is)
-template <bool REAL, bool DEC, bool UP = false>
+// XR: a REAL signal into the complex tile (imaginary part zero) -- multirate_FIR.up of float64 signals with an even L runs its phases in pairs,
+//     x * (h_2k + i h_2k+1) = y_2k + i y_2k+1: one complex pass whose output IS the interleaved pair as one 16-byte element (see fir_ols.hip)
+template <bool REAL, bool DEC, bool UP = false, bool XR = false>
 __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args A)
 {
     __shared__ cdd img[16 * kPitch64];
@@ -195,6 +197,20 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
                     if (ga >= -A.n_hist && ga < A.n) re = A.x[ga];
                     if (gb >= -A.n_hist && gb < A.n) im = A.x[gb];
                     dst[a] = make_double2(re, im);
+                }
+            }
+        } else if (XR) {
+            const int64_t in0 = tile * A.V - A.ov;
+            const bool interior = in0 >= -A.n_hist && in0 + kN64 <= A.n;
+            if (interior) {
+                const double *px = A.x + in0;
+#pragma unroll
+                for (int a = 0; a < 16; ++a) dst[a] = make_double2(__builtin_nontemporal_load(px + (unsigned)(256 * a + tl)), 0.0);
+            } else {
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    const int64_t g = in0 + 256 * a + tl;
+                    dst[a] = make_double2((g >= -A.n_hist && g < A.n) ? A.x[g] : 0.0, 0.0);
                 }
             }
         } else {
@@ -522,10 +538,11 @@ bool fir_ols64_supported(const FirHandle *h)
 }
 
 // Tables of one plan: `up` phase filters (phase q: taps up * b[q + up t]) as `up` consecutive H tables; up = 1: the filter itself.
-static int build_plan64(const FirHandle *h, int up, Ols64Plan **out)
+static int build_plan64(const FirHandle *h, int up, Ols64Plan **out, bool paired = false)
 {
     typedef std::complex<long double> cl;
     const int T = (h->ntaps + up - 1) / up;
+    const int ntab = paired ? up / 2 : up;   // paired (real taps, even up): table k holds phase 2k + i phase 2k+1
     Ols64Plan *p = new Ols64Plan();
     p->ov = ((T - 1 + 255) / 256) * 256;
     if (p->ov == 0) p->ov = 256;
@@ -535,14 +552,15 @@ static int build_plan64(const FirHandle *h, int up, Ols64Plan **out)
     const long double two_pi = 6.283185307179586476925286766559L;
     std::vector<cl> wn(kN64);
     for (int k = 0; k < kN64; ++k) wn[k] = cl(cosl(two_pi * k / kN64), -sinl(two_pi * k / kN64));
-    std::vector<double> Hp((size_t)2 * kN64 * up), W1(2 * 256), W2(2 * 16);
-    for (int q = 0; q < up; ++q)
+    std::vector<double> Hp((size_t)2 * kN64 * ntab), W1(2 * 256), W2(2 * 16);
+    for (int q = 0; q < ntab; ++q)
         for (int k = 0; k < kN64; ++k) {
             cl acc(0, 0);
             for (int t = 0; t < T; ++t) {
-                const int j = q + up * t;
+                const int j = (paired ? 2 * q : q) + up * t;
                 if (j >= h->ntaps) break;
-                const cl bj = comp == 2 ? cl(h->taps_host[2 * j], h->taps_host[2 * j + 1]) : cl(h->taps_host[j], 0);
+                const cl bj = paired ? cl(h->taps_host[j], j + 1 < h->ntaps ? h->taps_host[j + 1] : 0.0)
+                                     : (comp == 2 ? cl(h->taps_host[2 * j], h->taps_host[2 * j + 1]) : cl(h->taps_host[j], 0));
                 acc += bj * wn[(size_t)(((int64_t)k * t) % kN64)];
             }
             acc *= (long double)up / (long double)kN64;   // (up = 1: 1 / N; else the gain L of multirate_FIR.up as well)
@@ -615,37 +633,50 @@ bool fir_ols64_up_supported(const FirHandle *h, int L)
     return h->dtype == SKDSP_C128 || (h->dtype == SKDSP_F64 && !h->taps_complex);
 }
 
-int fir_ols64_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch)
+// float64 signals, real taps, even L, no decimation, a 16-byte aligned destination: the phases run in pairs through the complex tile
+bool fir_ols64_up_pairs(const FirHandle *h, int L, int dec, const void *y)
+{
+    return opt().fir_up_pair && h->dtype == SKDSP_F64 && !h->taps_complex && L % 2 == 0 && dec <= 1 && ((uintptr_t)y & 15) == 0;
+}
+
+int fir_ols64_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch, int paired_in)
 {
     if (n <= 0) return SKDSP_OK;
     SK_CHECK(dec >= 1 && dec <= 4096, SKDSP_ERR_UNSUPPORTED, "fir_ols64_up: M = %d (the fused L / M store takes M <= 4096)", dec);
     SK_CHECK(fir_ols64_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols64_up: needs complex128 (or float64 with real taps), 2 <= L <= 64, 2..2049 taps per phase");
+    const bool paired = paired_in != 0;
+    SK_CHECK(!paired || fir_ols64_up_pairs(h, L, dec, y), SKDSP_ERR_BADARG, "fir_ols64_up: phases in pairs need float64, real taps, an even L, no decimation and a 16-byte aligned destination");
+    const int key = paired ? -L : L;
     Ols64Plan *p = nullptr;
     for (auto &u : h->ols64_up)
-        if (u.L == L) p = u.plan;
+        if (u.L == key) p = u.plan;
     if (!p) {
-        int rc = build_plan64(h, L, &p);
+        int rc = build_plan64(h, L, &p, paired);
         if (rc) return rc;
-        h->ols64_up.push_back(FirHandle::Ols64Up{L, p});
+        h->ols64_up.push_back(FirHandle::Ols64Up{key, p});
     }
     Ols64Args A;
     A.x = (const double *)x; A.y = (double *)y; A.n = n; A.n_hist = n_hist;
     A.Hp = p->Hp; A.W1 = p->W1; A.W2 = p->W2;
     A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 256;
-    const bool real = h->dtype == SKDSP_F64;
+    const bool real = h->dtype == SKDSP_F64 && !paired;
+    const int phases = paired ? L / 2 : L;
     int64_t ntiles = (n + p->V - 1) / p->V;
     if (real) ntiles = (ntiles + 1) / 2;
-    ntiles *= L;
+    ntiles *= phases;
     SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols64_up: too many tiles");
     A.ntiles = ntiles;
     A.dec = dec;
     A.dec_magic = dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + dec - 1) / dec) : 0u;
     A.n_keep = dec > 1 ? (n * L) / dec : n;   // (L / M: the number of outputs)
-    A.up = L;
+    A.up = phases;
     A.up_pitch = dec > 1 ? 0 : rows_pitch;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     if (grid > ntiles) grid = ntiles;
-    if (dec > 1) {
+    if (paired) {
+        if (phases == 1 && A.up_pitch == 0) A.up_pitch = 1;   // (L = 2 is one pair: "row 0" is the output, written with the plain filter's stores)
+        hipLaunchKernelGGL((ols64_tile_kernel<false, false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+    } else if (dec > 1) {
         if (real) hipLaunchKernelGGL((ols64_tile_kernel<true, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
         else hipLaunchKernelGGL((ols64_tile_kernel<false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
     } else {

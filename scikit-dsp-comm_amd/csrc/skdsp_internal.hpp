@@ -203,7 +203,8 @@ bool fir_ols64_supported(const FirHandle *h);
 int fir_ols64_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, hipStream_t s, int dec = 1);
 void fir_ols64_free(Ols64Plan *p);
 bool fir_ols64_up_supported(const FirHandle *h, int L);
-int fir_ols64_up_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s, int dec = 1, int64_t rows_pitch = 0);
+bool fir_ols64_up_pairs(const FirHandle *h, int L, int dec, const void *y_dev);
+int fir_ols64_up_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s, int dec = 1, int64_t rows_pitch = 0, int paired = 0);
 
 // ---- IIR -----------------------------------------------------------------
 struct IirPlan;  // iir_scan.hip
