@@ -256,6 +256,7 @@ static bool fir_needs_parts(const FirHandle *h, int L = 1)
     return per_phase > (dtype_double(h->dtype) ? 2049 : 4097);
 }
 static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev);
+static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev, bool scratch_free = true);
 static int fir_filter_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev);
 static int ols_launch_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, int dec = 1);
 // y[j] = L sum_t b[(j M mod L) + L t] x[(j M div L) - t] with b cut into segments of `seg` taps, seg a multiple of lcm(L, M):
@@ -314,7 +315,7 @@ static int fir_parts_run(FirHandle *h, const void *x_dev, int64_t n, int64_t n_h
         else if (L == 1)
             rc = fir_dn_any(p, xs, n_s, n_hist - d, M, dst);
         else
-            rc = fir_direct_launch(p, xs, n_s, n_hist - d, L, M, cnt, dst, s);
+            rc = fir_updn_any(p, xs, n_s, n_hist - d, L, M, dst, false);   // (workspace slot 2 is `tmp` here: no scratch-using forms; writes (n_s L) / M <= n_out outputs)
         if (rc) return rc;
         if (si > 0 && (rc = accumulate_launch((char *)y_dev + (size_t)off * esz, tmp, cnt * scal, dtype_double(h->dtype), s))) return rc;
     }
@@ -436,7 +437,8 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
     return ols < poly;
 }
 
-static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev)
+// scratch_free: workspace slot 2 may be used (rows of the .up walk, the unfused L / M copy); false inside fir_parts_run, which holds it
+static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev, bool scratch_free)
 {
     if (L == 1) return fir_dn_any(h, x_dev, n, n_hist, M, y_dev);
     auto walk = [&](void *out, int dec) {
@@ -446,7 +448,7 @@ static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hi
     if (M == 1 && fir_up_prefers_ols(h, L, n)) {
         const bool dbl = dtype_double(h->dtype);
         const bool paired = dbl ? fir_ols64_up_pairs(h, L, 1, y_dev) : fir_ols_up_pairs(h, L, 1, y_dev);
-        if (fir_up_rows(h, L, paired) && (!paired || L > 2)) {   // (one pair is one row: nothing to weave)
+        if (scratch_free && fir_up_rows(h, L, paired) && (!paired || L > 2)) {   // (one pair is one row: nothing to weave)
             // many phases: an output stored between outputs of other phases is a write request of its own, so the phases leave as rows
             // with the plain filter's stores and interleave_launch weaves them (one more pass over the output, still cheaper from L = 6 ... 9 on)
             const int rows_n = paired ? L / 2 : L;
@@ -463,7 +465,7 @@ static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hi
         if (paired) return dbl ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream, 1, 0, 1) : fir_ols_up_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream, 1, 0, 1);
         return walk(y_dev, 1);
     }
-    if (M > 1 && fir_up_prefers_ols(h, L, n, M)) {   // long phases: all n L outputs by the walk, every M-th of them kept
+    if (M > 1 && (scratch_free || (M <= 4096 && opt().fir_updn_fused)) && fir_up_prefers_ols(h, L, n, M)) {   // long phases: all n L outputs by the walk, every M-th of them kept
         if (M <= 4096 && opt().fir_updn_fused) return walk(y_dev, M);   // ... by its store
         void *full = nullptr;                                           // ... or out of scratch
         int rc = ws_reserve(2, (size_t)n * L * dtype_size(h->dtype) + 256, &full);
