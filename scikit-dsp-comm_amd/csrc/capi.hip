@@ -378,7 +378,8 @@ static bool fir_up_rows(const FirHandle *h, int L, bool paired = false)
     const int o = opt().fir_up_rows_min;
     if (o == 0) return false;
     if (o > 0) return L >= o;
-    if (paired) return !dtype_double(h->dtype) && L / 2 >= 7;   // (8-byte pairs: the complex64 crossover, in phases; 16-byte pairs never)
+    if (paired) return !dtype_double(h->dtype) && L % 2 == 0 && L / 2 >= 7;   // (8-byte pairs: the complex64 crossover, in phases; 16-byte pairs never;
+                                                                              //  odd L in pairs: the strided form only)
     switch (h->dtype) {
     case SKDSP_F32: return L >= 9;
     case SKDSP_C64: return L >= 7;
@@ -447,8 +448,12 @@ static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hi
     };
     if (M == 1 && fir_up_prefers_ols(h, L, n)) {
         const bool dbl = dtype_double(h->dtype);
-        const bool paired = dbl ? fir_ols64_up_pairs(h, L, 1, y_dev) : fir_ols_up_pairs(h, L, 1, y_dev);
-        if (scratch_free && fir_up_rows(h, L, paired) && (!paired || L > 2)) {   // (one pair is one row: nothing to weave)
+        bool paired = dbl ? fir_ols64_up_pairs(h, L, 1, y_dev) : fir_ols_up_pairs(h, L, 1, y_dev);
+        bool rows = scratch_free && fir_up_rows(h, L, paired) && !(paired && L == 2);   // (one pair is one row: nothing to weave)
+        if (rows && paired && L % 2) {   // an odd L in pairs has the strided form only: rows asked for by option win, else the pairs
+            if (opt().fir_up_rows_min > 0) paired = false; else rows = false;
+        }
+        if (rows) {
             // many phases: an output stored between outputs of other phases is a write request of its own, so the phases leave as rows
             // with the plain filter's stores and interleave_launch weaves them (one more pass over the output, still cheaper from L = 6 ... 9 on)
             const int rows_n = paired ? L / 2 : L;

@@ -73,6 +73,10 @@ struct OlsArgs {
     // or, up_pitch > 0, at y[phase * up_pitch + i]: the phases as rows (scratch), woven together by interleave_launch afterwards
     int up;
     int64_t up_pitch;
+    // the strided store of a pair: output i of local phase q lands up_sb * i + up_pb0 + up_pbs * q BYTES behind y (the plain cases: up_sb =
+    // up * element size, up_pbs = element size, up_pb0 = 0; a launch may also cover SOME phases of an L-fold interpolation -- pairs of
+    // phases as 8-byte elements in a float32 output, or the last phase of an odd L on its own)
+    int up_sb, up_pbs, up_pb0;
     int64_t n_keep; // dec * floor(n / dec)
     // Sharded filter (dist.hip): the Ntaps-1 samples in front of x arrive over xGMI on another stream while this launch
     // already runs.  Only tile 0 reads them, so tile 0 is walked LAST and whoever owns it waits for halo_flag >= halo_seq
@@ -441,12 +445,12 @@ template <bool DEC> __device__ __forceinline__ void store_tile_up(const OlsArgs 
     asm volatile("" : "+v"(tt));
     const int pos = up_lane_pos(tt);   // this lane's first output inside a 512-block (the second: + 64)
     const int64_t out0 = tile * A.V;
-    char *ub = reinterpret_cast<char *>(A.y + out0 * A.up + ph);   // uniform
+    char *ub = reinterpret_cast<char *>(A.y) + out0 * A.up_sb + A.up_pb0 + (int64_t)ph * A.up_pbs;   // uniform
     const int64_t left = A.n - out0;
     const int lim = (left > (1 << 20) ? (1 << 20) : (int)left) - pos;   // outputs i < lim (relative to this lane's first) exist
     const bool whole = left >= A.V;   // (uniform: every tile but the last)
-    const unsigned b0 = (unsigned)pos * (unsigned)A.up * 8u, b1 = b0 + 64u * (unsigned)A.up * 8u;
-    const size_t step = (size_t)512 * A.up * 8;
+    const unsigned b0 = (unsigned)pos * (unsigned)A.up_sb, b1 = b0 + 64u * (unsigned)A.up_sb;
+    const size_t step = (size_t)512 * A.up_sb;
     // DEC (L / M): the tile's first up-rate index out0 up + ph = q0 M + r0; tile-local up-rate indices stay below 2^20 + M, where the
     // multiply-high by ceil(2^32 / M) is the exact quotient for M <= 4096 (checked at launch); n_keep = floor(n up / M) outputs exist
     const unsigned M = (unsigned)A.dec;
@@ -483,14 +487,14 @@ template <bool DEC> __device__ __forceinline__ void store_tile_real_up(const Ols
     asm volatile("" : "+v"(tt));
     const int pos = up_lane_pos(tt);
     const int64_t outA = (2 * pair) * A.V;
-    char *ua0 = reinterpret_cast<char *>(reinterpret_cast<float *>(A.y) + outA * A.up + ph);   // uniform
-    char *ub0 = ua0 + (size_t)A.V * A.up * 4;   // the pair's second tile
+    char *ua0 = reinterpret_cast<char *>(A.y) + outA * A.up_sb + A.up_pb0 + (int64_t)ph * A.up_pbs;   // uniform
+    char *ub0 = ua0 + (size_t)A.V * A.up_sb;   // the pair's second tile
     const int64_t left = A.n - outA;
     const int lim = (left > (1 << 20) ? (1 << 20) : (int)left) - pos;
     const int limb = lim - A.V;
     const bool whole = left >= 2 * (int64_t)A.V;
-    const unsigned b0 = (unsigned)pos * (unsigned)A.up * 4u, b1 = b0 + 64u * (unsigned)A.up * 4u;
-    const size_t step = (size_t)512 * A.up * 4;
+    const unsigned b0 = (unsigned)pos * (unsigned)A.up_sb, b1 = b0 + 64u * (unsigned)A.up_sb;
+    const size_t step = (size_t)512 * A.up_sb;
     const unsigned M = (unsigned)A.dec;   // (DEC: see store_tile_up)
     const int64_t jt = outA * A.up + ph, q0 = DEC ? jt / A.dec : 0;
     const unsigned r0 = DEC ? (unsigned)(jt - q0 * A.dec) : 0u;
@@ -764,9 +768,11 @@ bool fir_ols_supported(const FirHandle *h)
 }
 
 // Tables of one plan: `up` phase filters (phase p: taps gain * b[p + up t], t < T) as `up` consecutive Hp tables; up = 1 is the filter itself.
-static int build_plan(const FirHandle *h, int up, OlsPlan **out, bool paired = false)
+// kind 0: all `up` phases; 1: pairs of phases (real taps: table k holds phase 2k + i phase 2k+1, see load_tile_xr; an odd up leaves its last
+// phase out); 2: the last phase alone (what kind 1 leaves out)
+static int build_plan(const FirHandle *h, int up, OlsPlan **out, int kind = 0)
 {
-    if (paired) {   // real taps, even up: table k holds phase 2k + i phase 2k+1 (see load_tile_xr)
+    if (kind == 1) {
         const int T = (h->ntaps + up - 1) / up;
         OlsPlan *p = new OlsPlan();
         p->ntaps = T;
@@ -802,6 +808,7 @@ static int build_plan(const FirHandle *h, int up, OlsPlan **out, bool paired = f
     }
     const int comp = h->taps_complex ? 2 : 1;
     const int T = (h->ntaps + up - 1) / up;
+    const int q_first = kind == 2 ? up - 1 : 0;
     OlsPlan *p = new OlsPlan();
     p->ntaps = T;
     p->ov = ((T - 1 + 511) / 512) * 512;
@@ -814,7 +821,7 @@ static int build_plan(const FirHandle *h, int up, OlsPlan **out, bool paired = f
         make_Hp(h->taps_host.data(), h->ntaps, comp, Hall);
     } else {
         std::vector<double> ph((size_t)T * comp);
-        for (int q = 0; q < up; ++q) {
+        for (int q = q_first; q < up; ++q) {
             std::fill(ph.begin(), ph.end(), 0.0);
             for (int t = 0; t < T; ++t) {
                 const int k = q + up * t;
@@ -906,7 +913,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.dec = dec > 1 ? dec : 1;
     A.dec_magic = A.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + A.dec - 1) / A.dec) : 0u;
     A.n_keep = n;
-    A.up = 1; A.up_pitch = 0;
+    A.up = 1; A.up_pitch = 0; A.up_sb = A.up_pbs = A.up_pb0 = 0;
     A.halo_flag = halo_flag; A.halo_seq = halo_seq; A.halo_err = halo_err;
     SK_CHECK(!(halo_flag && real), SKDSP_ERR_UNSUPPORTED, "fir_ols: halo flag wait is for complex64 shards");
     int64_t grid = 2 * (int64_t)ctx().num_cus;  // 2 resident workgroups per CU (76 KiB LDS each)
@@ -960,29 +967,38 @@ bool fir_ols_up_supported(const FirHandle *h, int L)
     return h->dtype == SKDSP_C64 || (h->dtype == SKDSP_F32 && !h->taps_complex);
 }
 
-// float32 signals, even L, no decimation, an 8-byte aligned destination: the phases run in pairs through the complex tile (load_tile_xr)
+// float32 signals, no decimation: the phases run in pairs through the complex tile (load_tile_xr).  Even L: an 8-byte aligned destination
+// (L / 2 rows of pairs in the rows form).  Odd L (7 .. 13, strided form only): (L - 1) / 2 pairs as 8-byte elements at 4-byte aligned
+// addresses, then the last phase on its own (two real tiles per pass) -- L passes per two tiles either way.  Measured against one phase
+// per pass (2^26 outputs, 256 taps per phase): L = 7 0.237 -> 0.216 ms, 9 0.248 (rows) -> 0.209, 11 0.255 -> 0.229, 13 0.254 -> 0.245;
+// L = 3, 5 lose (0.168 -> 0.186, 0.200 -> 0.208: the misaligned 8-byte stores and the second launch), 15 loses to the rows form.
 bool fir_ols_up_pairs(const FirHandle *h, int L, int dec, const void *y)
 {
-    return opt().fir_up_pair && h->dtype == SKDSP_F32 && !h->taps_complex && L % 2 == 0 && dec <= 1 && ((uintptr_t)y & 7) == 0;
+    if (!opt().fir_up_pair || h->dtype != SKDSP_F32 || h->taps_complex || dec > 1) return false;
+    if (L % 2 == 0) return ((uintptr_t)y & 7) == 0;
+    return L >= 7 && L <= 13 && ((uintptr_t)y & 3) == 0;
 }
 
-int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch, int paired_in)
+static int up_plan(FirHandle *h, int L, int kind, OlsPlan **out)
 {
-    if (n <= 0) return SKDSP_OK;
-    SK_CHECK(dec >= 1 && dec <= 4096, SKDSP_ERR_UNSUPPORTED, "fir_ols_up: M = %d (the fused L / M store takes M <= 4096)", dec);
-    SK_CHECK(fir_ols_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols_up: needs complex64 (or float32 with real taps), 2 <= L <= 64, 2..4097 taps per phase");
-    // (rows_pitch of a paired launch counts 8-byte elements: the caller weaves L / 2 rows of pairs)
-    const bool paired = paired_in != 0;
-    SK_CHECK(!paired || fir_ols_up_pairs(h, L, dec, y), SKDSP_ERR_BADARG, "fir_ols_up: phases in pairs need float32, real taps, an even L, no decimation and an 8-byte aligned destination");
-    const int key = paired ? -L : L;
-    OlsPlan *p = nullptr;
+    const int key = kind == 1 ? -L : (kind == 2 ? 1000 + L : L);
     for (auto &u : h->ols_up)
-        if (u.L == key) p = u.plan;
-    if (!p) {
-        int rc = build_plan(h, L, &p, paired);
-        if (rc) return rc;
-        h->ols_up.push_back(FirHandle::OlsUp{key, p});
-    }
+        if (u.L == key) { *out = u.plan; return SKDSP_OK; }
+    int rc = build_plan(h, L, out, kind);
+    if (rc) return rc;
+    h->ols_up.push_back(FirHandle::OlsUp{key, *out});
+    return SKDSP_OK;
+}
+
+// one launch of the walk over `cnt` phases (kind as in build_plan)
+static int up_walk(FirHandle *h, int kind, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch)
+{
+    OlsPlan *p = nullptr;
+    int rc = up_plan(h, L, kind, &p);
+    if (rc) return rc;
+    const bool xr = kind == 1;                              // real signal into the complex tile
+    const bool real = h->dtype == SKDSP_F32 && !xr;         // two real tiles per complex tile
+    const int cnt = kind == 1 ? L / 2 : (kind == 2 ? 1 : L);
     OlsArgs A;
     A.x = (const cf *)x;
     A.y = (cf *)y;
@@ -990,29 +1006,31 @@ int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     A.n_hist = n_hist;
     A.T1 = p->T1; A.T2 = p->T2; A.Hp = p->Hp;
     A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512;
-    const bool real = h->dtype == SKDSP_F32 && !paired;
-    A.aligned = paired ? (((uintptr_t)x & 3) == 0 && ((uintptr_t)y & 7) == 0) : ((((uintptr_t)x) | ((uintptr_t)y)) & (real ? 3 : 7)) == 0;
+    const int esz = h->dtype == SKDSP_F32 ? 4 : 8;
+    A.aligned = xr ? (((uintptr_t)x & 3) == 0 && ((uintptr_t)y & (L % 2 ? 3 : 7)) == 0) : ((((uintptr_t)x) | ((uintptr_t)y)) & (real ? 3 : 7)) == 0;
     int64_t ntiles = (n + p->V - 1) / p->V;
     if (real) ntiles = (ntiles + 1) / 2;
-    const int phases = paired ? L / 2 : L;
-    ntiles *= phases;
+    ntiles *= cnt;
     SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols_up: too many tiles");
     A.ntiles = ntiles;
     A.dec = dec;
     A.dec_magic = dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + dec - 1) / dec) : 0u;
     A.n_keep = dec > 1 ? (n * L) / dec : n;   // (DEC: the number of outputs)
-    A.up = phases;
+    A.up = cnt;   // (DEC launches cover all L phases: there it is also the interpolation factor of the up-rate index)
     A.up_pitch = dec > 1 ? 0 : rows_pitch;
+    A.up_sb = L * esz;
+    A.up_pbs = xr ? 8 : esz;
+    A.up_pb0 = kind == 2 ? (L - 1) * esz : 0;
     A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr;
     A.trace = nullptr;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     const int reserve_wgs = opt().ols_reserve;
     if (reserve_wgs > 0 && grid > 8 * (int64_t)reserve_wgs) grid -= reserve_wgs;
     if (grid > ntiles) grid = ntiles;
-    if (paired) {
+    if (xr) {
         // (L = 2 is one pair: "row 0" of the rows form IS the output, written with the plain complex filter's full-width stores.  The
         // instantiation that also keeps H in registers -- UP = false -- compiles to 18 spilled registers with the real-input loads.)
-        if (phases == 1 && A.up_pitch == 0) A.up_pitch = 1;
+        if (L == 2 && A.up_pitch == 0) A.up_pitch = 1;
         hipLaunchKernelGGL((ols_tile_kernel<false, false, false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
     } else if (dec > 1) {
         if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
@@ -1023,6 +1041,20 @@ int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     }
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
+}
+
+int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch, int paired)
+{
+    if (n <= 0) return SKDSP_OK;
+    SK_CHECK(dec >= 1 && dec <= 4096, SKDSP_ERR_UNSUPPORTED, "fir_ols_up: M = %d (the fused L / M store takes M <= 4096)", dec);
+    SK_CHECK(fir_ols_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols_up: needs complex64 (or float32 with real taps), 2 <= L <= 64, 2..4097 taps per phase");
+    if (!paired) return up_walk(h, 0, x, n, n_hist, L, y, s, dec, rows_pitch);
+    // (rows_pitch of a paired launch counts 8-byte elements: the caller weaves L / 2 rows of pairs)
+    SK_CHECK(fir_ols_up_pairs(h, L, dec, y) && (L % 2 == 0 || rows_pitch == 0), SKDSP_ERR_BADARG,
+             "fir_ols_up: phases in pairs need float32, real taps, no decimation, and an 8-byte aligned destination (even L) or the strided form (odd L, 7 .. 13)");
+    int rc = up_walk(h, 1, x, n, n_hist, L, y, s, 1, rows_pitch);
+    if (rc || L % 2 == 0) return rc;
+    return up_walk(h, 2, x, n, n_hist, L, y, s, 1, 0);   // the odd L's last phase
 }
 
 }  // namespace skdsp

@@ -308,8 +308,13 @@ def test_fir_overlap_save_up(dt, ntaps, L):
                     k.up_dev(xd, yd, L)
                 both.append(yd.to_host(0, n * L))
                 assert np.all(yd.to_host(n * L, 8) == 7.0), "wrote beyond n * L outputs (L=%d n=%d rows_min=%d)" % (L, n, rows_min)
-            assert np.array_equal(both[0], both[1]), (L, n)
-            if dt in (np.float32, np.float64) and L % 2 == 0:   # real signal, even L: the phases ran in pairs through the complex tile; one phase per pass agrees to rounding
+            # (float32, odd L = 7 .. 13: pairs of phases in the strided form only, so the rows form ran one phase per pass: equal to rounding)
+            odd_pairs = dt == np.float32 and L % 2 == 1 and 7 <= L <= 13
+            if odd_pairs:
+                assert np.max(np.abs(both[0] - both[1])) <= 2 * tol * np.max(np.abs(both[0])), (L, n)
+            else:
+                assert np.array_equal(both[0], both[1]), (L, n)
+            if (dt in (np.float32, np.float64) and L % 2 == 0) or odd_pairs:   # real signal: the phases ran in pairs through the complex tile; one phase per pass agrees to rounding
                 for rows_min in (0, 2):
                     with _ffi.option("fir_up_ols_min", -12), _ffi.option("fir_up_rows_min", rows_min), _ffi.option("fir_up_pair", 0):
                         k.up_dev(xd, yd, L)
@@ -323,7 +328,7 @@ def test_fir_overlap_save_up(dt, ntaps, L):
                         k.up_dev(xd, y3.window(1, n * L), L)
                     off1 = y3.to_host(1, n * L)
                     assert y3.to_host(0, 1)[0] == 7.0 and np.all(y3.to_host(n * L + 1, 8) == 7.0), (L, n)
-                    if dt in (np.float32, np.float64) and L % 2 == 0:   # (no pairs into a destination aligned to one sample only: one phase per pass, other rounding)
+                    if dt in (np.float32, np.float64) and (L % 2 == 0 or odd_pairs):   # (rows asked for / no pairs into a destination aligned to one sample only: other rounding)
                         assert np.max(np.abs(off1 - both[0])) <= 2 * tol * np.max(np.abs(both[0])), (L, n)
                     else:
                         assert np.array_equal(off1, both[0]), (L, n)
