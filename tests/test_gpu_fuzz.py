@@ -257,6 +257,52 @@ def test_fuzz_device_views_at_odd_offsets(seed):
             ybuf.free()
 
 
+@pytest.mark.parametrize("seed", range(NSEED))
+def test_fuzz_fir_up_walk_forms(seed):
+    """multirate_FIR.up and L / M through the overlap-save walk over (tile, phase) pairs, forced (option fir_up_ols_min < 0) so that short phases and
+    short signals take it too: every form it has -- strided stores, rows + weave, phases in pairs for real signals (even and odd L), the every-M-th
+    store -- on device windows at random element offsets (aligned and not), guard words around the output, history in front of the input."""
+    import contextlib
+    rng = np.random.default_rng(7000 + seed)
+    for _ in range(10):
+        dt = DTYPES[rng.integers(len(DTYPES))]
+        cplx = np.dtype(dt).kind == "c"
+        wide = np.complex128 if cplx else np.float64
+        L = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 12, 13, 16, 33]))
+        M = int(rng.choice([1, 1, 1, 2, 3, 5, 7]))
+        ntaps = int(rng.integers(2 * L, 40 * L + 1)) if rng.random() < 0.7 else int(rng.choice([1024, 2500, 4097]))
+        n = int(rng.choice([8192, 8193, 12_000, 16384 + 5, 3 * 8192 - 1, 40_001]))
+        b = signal.firwin(ntaps, 0.9 / max(L, M))
+        if cplx and rng.random() < 0.3:
+            b = b * np.exp(0.05j * np.arange(ntaps))
+        hist = int(rng.choice([0, 0, (ntaps - 1 + L - 1) // L]))
+        ox, oy = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+        n_out = (n * L) // M
+        x = _signal(rng, n + hist, dt)
+        xbuf = _ffi.DeviceArray(n + hist + 8, dt)
+        ybuf = _ffi.DeviceArray(n_out + 16, dt)
+        try:
+            xbuf.write(np.concatenate([np.zeros(ox, dt), x, np.zeros(8 - ox, dt)]))
+            ybuf.write(np.full(n_out + 16, 7.0, dtype=dt))
+            k = _ffi.FirKernel(b, _ffi.code_of(dt))
+            with contextlib.ExitStack() as st:
+                st.enter_context(_ffi.option("fir_up_ols_min", -2))
+                st.enter_context(_ffi.option("fir_up_rows_min", int(rng.choice([-1, 0, 2]))))
+                st.enter_context(_ffi.option("fir_up_pair", int(rng.integers(0, 2))))
+                st.enter_context(_ffi.option("fir_updn_fused", int(rng.integers(0, 2))))
+                k.updn_dev(xbuf.window(ox + hist, n), ybuf.window(oy, n_out), L, M, n_hist=hist)
+            up = np.zeros((n + hist) * L, dtype=np.complex128 if np.iscomplexobj(b) else wide)
+            up[::L] = L * x.astype(up.dtype)
+            ref = signal.lfilter(b, [1], up)[hist * L:][::M][:n_out]
+            got = ybuf.to_host()
+            what = "walk %s L/M=%d/%d taps=%d n=%d hist=%d offsets %d/%d" % (np.dtype(dt).name, L, M, ntaps, n, hist, ox, oy)
+            assert np.all(got[:oy] == 7.0) and np.all(got[oy + n_out:] == 7.0), "guard words overwritten: " + what
+            _check(got[oy:oy + n_out], ref, dt, what, float(np.sum(np.abs(b)) * L * np.max(np.abs(x))))
+        finally:
+            xbuf.free()
+            ybuf.free()
+
+
 @pytest.mark.parametrize("seed", range(max(NSEED // 2, 1)))
 def test_fuzz_fir_wide(seed):
     """The FIR corners the first FIR fuzz leaves out: complex taps, tap counts beyond one launch (tap segments), the fused L / M resampler,
