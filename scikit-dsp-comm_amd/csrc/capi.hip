@@ -393,7 +393,11 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
     const int T = (h->ntaps + L - 1) / L;
     const int floor_t = opt().fir_up_ols_min;   // < 0: wherever supported from -floor_t taps per phase on, no cost model (tests, A/B timing)
     const bool dbl = dtype_double(h->dtype);
-    if (floor_t == 0 || T < std::abs(floor_t) || n < 8192 || !(dbl ? fir_ols64_up_supported(h, L) : fir_ols_up_supported(h, L))) return false;
+    int floor_eff = std::abs(floor_t);   // (many phases: the polyphase kernels lose their reuse early -- let the cost model see shorter phases too)
+    if (floor_t > 0 && L > 64) floor_eff = std::max(8, floor_t / 8);
+    else if (floor_t > 0 && L > 16) floor_eff = std::max(8, floor_t / 4);
+    if (floor_t == 0 || T < floor_eff || n < 8192 || !(dbl ? fir_ols64_up_supported(h, L) : fir_ols_up_supported(h, L))) return false;
+    if (M > 1 && L > 64) return false;   // (the every-M-th store's exact-division range; the scratch + copy form is not worth it there)
     if (floor_t < 0) return true;
     if ((opt().fir_algo != SKDSP_FIR_AUTO ? opt().fir_algo : h->algo) == SKDSP_FIR_DIRECT) return false;
     if (fir_needs_parts(h, L)) return true;   // (longer than one polyphase launch takes)
@@ -404,8 +408,9 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
     int V;
     if (dbl) {   // FP64 direct taps against the float64 walk (4096-point tiles)
         base = cplx ? 0.42 : 0.26;
-        ols = cplx ? 0.70 + 0.03 * std::min(Lf, 12.0) : 0.29 + 0.02 * std::min(Lf, 12.0);
+        ols = cplx ? 0.60 + 0.008 * std::min(Lf, 24.0) : 0.29 + 0.02 * std::min(Lf, 12.0);
         poly = cplx ? 0.5 + 0.0055 * T : (T <= 128 ? 0.17 + 0.0018 * T : 0.1 + 0.0028 * T);
+        if (cplx && L > 16) poly = std::max(poly, 1.0);   // (measured 1.02 ... 1.12 from L = 24 on, whatever the phase length)
         if (T > 128) poly *= std::max(1.0, Lf / 4.0);   // (many long phases: the tap tables fall out of the cache)
         else if (L > 16 && !cplx) poly *= 1.0 + Lf / 12.0;
         copy = cplx ? 0.20 : 0.10;
@@ -480,7 +485,7 @@ static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hi
     }
     if (fir_needs_parts(h, L)) return fir_parts_run(h, x_dev, n, n_hist, L, M, y_dev);
     int rc = fir_direct_launch(h, x_dev, n, n_hist, L, M, (n * L) / M, y_dev, ctx().stream);
-    if (rc == SKDSP_ERR_UNSUPPORTED && M > 1 && M <= 4096 && opt().fir_up_ols_min != 0 &&
+    if (rc == SKDSP_ERR_UNSUPPORTED && M > 1 && M <= 4096 && L <= 64 && opt().fir_up_ols_min != 0 &&
         (dtype_double(h->dtype) ? fir_ols64_up_supported(h, L) : fir_ols_up_supported(h, L)))
         return walk(y_dev, M);   // (a stride the polyphase kernels' LDS window does not hold)
     return rc;

@@ -961,7 +961,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
 // phase) pairs is cheaper: every pair costs what one tile of .filter costs, whatever the phase length.
 bool fir_ols_up_supported(const FirHandle *h, int L)
 {
-    if (L < 2 || L > 64) return false;
+    if (L < 2 || L > 256) return false;   // (the every-M-th store: L <= 64, checked at launch)
     const int T = (h->ntaps + L - 1) / L;
     if (T < 2 || T - 1 > 4096) return false;
     return h->dtype == SKDSP_C64 || (h->dtype == SKDSP_F32 && !h->taps_complex);
@@ -1046,8 +1046,8 @@ static int up_walk(FirHandle *h, int kind, const void *x, int64_t n, int64_t n_h
 int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch, int paired)
 {
     if (n <= 0) return SKDSP_OK;
-    SK_CHECK(dec >= 1 && dec <= 4096, SKDSP_ERR_UNSUPPORTED, "fir_ols_up: M = %d (the fused L / M store takes M <= 4096)", dec);
-    SK_CHECK(fir_ols_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols_up: needs complex64 (or float32 with real taps), 2 <= L <= 64, 2..4097 taps per phase");
+    SK_CHECK(dec >= 1 && dec <= 4096 && (dec == 1 || L <= 64), SKDSP_ERR_UNSUPPORTED, "fir_ols_up: L / M = %d / %d (the fused L / M store takes L <= 64, M <= 4096)", L, dec);
+    SK_CHECK(fir_ols_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols_up: needs complex64 (or float32 with real taps), 2 <= L <= 256, 2..4097 taps per phase");
     if (!paired) return up_walk(h, 0, x, n, n_hist, L, y, s, dec, rows_pitch);
     // (rows_pitch of a paired launch counts 8-byte elements: the caller weaves L / 2 rows of pairs)
     SK_CHECK(fir_ols_up_pairs(h, L, dec, y) && (L % 2 == 0 || rows_pitch == 0), SKDSP_ERR_BADARG,

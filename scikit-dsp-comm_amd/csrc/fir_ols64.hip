@@ -553,22 +553,39 @@ static int build_plan64(const FirHandle *h, int up, Ols64Plan **out, bool paired
     std::vector<cl> wn(kN64);
     for (int k = 0; k < kN64; ++k) wn[k] = cl(cosl(two_pi * k / kN64), -sinl(two_pi * k / kN64));
     std::vector<double> Hp((size_t)2 * kN64 * ntab), W1(2 * 256), W2(2 * 16);
-    for (int q = 0; q < ntab; ++q)
+    // each table: the 4096-point DFT of the phase's taps, radix-2 in long double (the O(N T) sums this replaces took seconds for the L tables
+    // of a long interpolator)
+    std::vector<cl> f(kN64);
+    for (int q = 0; q < ntab; ++q) {
+        std::fill(f.begin(), f.end(), cl(0, 0));
+        for (int t = 0; t < T; ++t) {
+            const int j = (paired ? 2 * q : q) + up * t;
+            if (j >= h->ntaps) break;
+            f[t] = paired ? cl(h->taps_host[j], j + 1 < h->ntaps ? h->taps_host[j + 1] : 0.0)
+                          : (comp == 2 ? cl(h->taps_host[2 * j], h->taps_host[2 * j + 1]) : cl(h->taps_host[j], 0));
+        }
+        for (int i = 1, j = 0; i < kN64; ++i) {   // bit reversal
+            int bit = kN64 >> 1;
+            for (; j & bit; bit >>= 1) j ^= bit;
+            j ^= bit;
+            if (i < j) std::swap(f[i], f[j]);
+        }
+        for (int len = 2; len <= kN64; len <<= 1)
+            for (int i = 0; i < kN64; i += len)
+                for (int k = 0; k < len / 2; ++k) {
+                    const cl u = f[i + k], w = f[i + k + len / 2] * wn[(size_t)k * (kN64 / len)];
+                    f[i + k] = u + w;
+                    f[i + k + len / 2] = u - w;
+                }
         for (int k = 0; k < kN64; ++k) {
-            cl acc(0, 0);
-            for (int t = 0; t < T; ++t) {
-                const int j = (paired ? 2 * q : q) + up * t;
-                if (j >= h->ntaps) break;
-                const cl bj = paired ? cl(h->taps_host[j], j + 1 < h->ntaps ? h->taps_host[j + 1] : 0.0)
-                                     : (comp == 2 ? cl(h->taps_host[2 * j], h->taps_host[2 * j + 1]) : cl(h->taps_host[j], 0));
-                acc += bj * wn[(size_t)(((int64_t)k * t) % kN64)];
-            }
+            cl acc = f[k];
             acc *= (long double)up / (long double)kN64;   // (up = 1: 1 / N; else the gain L of multirate_FIR.up as well)
             const int k1 = k & 15, k2 = (k >> 4) & 15, k3 = k >> 8;
             const size_t idx = (size_t)q * kN64 + (size_t)k3 * 256 + 16 * k1 + k2;
             Hp[2 * idx] = (double)acc.real();
             Hp[2 * idx + 1] = (double)acc.imag();
         }
+    }
     for (int t = 0; t < 256; ++t) { W1[2 * t] = (double)wn[t].real(); W1[2 * t + 1] = (double)wn[t].imag(); }
     for (int c = 0; c < 16; ++c) { W2[2 * c] = (double)wn[16 * c].real(); W2[2 * c + 1] = (double)wn[16 * c].imag(); }
     hipError_t e;
@@ -627,7 +644,7 @@ int fir_ols64_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, voi
 // multirate_FIR.up with long phases (see fir_ols.hip, fir_ols_up_launch): complex128, float64 with real taps; 2..2049 taps per phase
 bool fir_ols64_up_supported(const FirHandle *h, int L)
 {
-    if (L < 2 || L > 64) return false;
+    if (L < 2 || L > 256) return false;   // (the every-M-th store: L <= 64, checked at launch)
     const int T = (h->ntaps + L - 1) / L;
     if (T < 2 || T - 1 > 2048) return false;
     return h->dtype == SKDSP_C128 || (h->dtype == SKDSP_F64 && !h->taps_complex);
@@ -642,8 +659,8 @@ bool fir_ols64_up_pairs(const FirHandle *h, int L, int dec, const void *y)
 int fir_ols64_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch, int paired_in)
 {
     if (n <= 0) return SKDSP_OK;
-    SK_CHECK(dec >= 1 && dec <= 4096, SKDSP_ERR_UNSUPPORTED, "fir_ols64_up: M = %d (the fused L / M store takes M <= 4096)", dec);
-    SK_CHECK(fir_ols64_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols64_up: needs complex128 (or float64 with real taps), 2 <= L <= 64, 2..2049 taps per phase");
+    SK_CHECK(dec >= 1 && dec <= 4096 && (dec == 1 || L <= 64), SKDSP_ERR_UNSUPPORTED, "fir_ols64_up: L / M = %d / %d (the fused L / M store takes L <= 64, M <= 4096)", L, dec);
+    SK_CHECK(fir_ols64_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols64_up: needs complex128 (or float64 with real taps), 2 <= L <= 256, 2..2049 taps per phase");
     const bool paired = paired_in != 0;
     SK_CHECK(!paired || fir_ols64_up_pairs(h, L, dec, y), SKDSP_ERR_BADARG, "fir_ols64_up: phases in pairs need float64, real taps, an even L, no decimation and a 16-byte aligned destination");
     const int key = paired ? -L : L;

@@ -187,7 +187,7 @@ int interleave_launch(const void *src, int64_t n, int L, int64_t pitch, int dtyp
         return SKDSP_OK;
     }
     int I = 1024, log2I = 10;
-    while (I > 16 && (size_t)(I + 1) * L * esz > 48 * 1024 - 64) { I >>= 1; --log2I; }
+    while (I > 4 && (size_t)(I + 1) * L * esz > 48 * 1024 - 64) { I >>= 1; --log2I; }
     SK_CHECK((size_t)(I + 1) * L * esz <= 64 * 1024, SKDSP_ERR_UNSUPPORTED, "interleave: L = %d rows do not fit the LDS", L);
     const size_t lds = (size_t)(I + 1) * L * esz + 64;
     const unsigned magic = (unsigned)((((unsigned long long)1 << 32) + L - 1) / L);

@@ -278,7 +278,7 @@ def test_fir_overlap_save_decimating_store(dt, ntaps, M):
             yd.free()
 
 
-@pytest.mark.parametrize("L", [2, 3, 4, 7, 12, 64])
+@pytest.mark.parametrize("L", [2, 3, 4, 7, 12, 64, 100, 256])
 @pytest.mark.parametrize("dt,ntaps", [(np.complex64, 1024), (np.float32, 1024), (np.float32, 777), (np.complex64, 4099), (np.complex64, 9001),
                                       (np.float64, 1024), (np.complex128, 1500), (np.float64, 4099), (np.complex128, 777)])
 def test_fir_overlap_save_up(dt, ntaps, L):
@@ -294,7 +294,7 @@ def test_fir_overlap_save_up(dt, ntaps, L):
     if cplx and ntaps in (4099, 777):
         b = b * np.exp(0.07j * np.arange(ntaps))   # complex taps
     hist = (ntaps - 1 + L - 1) // L
-    for n in (700_001, 7169 * 2 + 5, 16384, 20_000):
+    for n in ((700_001 if L <= 64 else 90_001), 7169 * 2 + 5, 16384, 20_000):
         k = _ffi.FirKernel(b, _ffi.code_of(dt))
         xd = _ffi.DeviceArray(n, dt).fill_noise(L + ntaps)
         yd = _ffi.DeviceArray(n * L + 8, dt)
