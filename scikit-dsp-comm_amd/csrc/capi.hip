@@ -804,6 +804,18 @@ static int iir_any_dev(IirHandle *h, const void *x_dev, int64_t n, void *y_dev, 
     }
     if (!dtype_complex(h->dtype)) return iir_launch_planar(h, x_dev, n, 1, 0, y_dev, s, zi, zf);
     const bool planar_only = opt().iir_planar != 0;  // developer A/B switch (and the tests)
+    if (!planar_only && !h->groups.empty() && !h->twin64 && !zi && !zf && opt().iir_par > 0) {
+        // more than 8 biquads on a complex signal: group after group in place behind the first, each through the parallel form on the
+        // interleaved samples where it applies (else whatever that group's own dispatch takes) -- not the whole cascade through two planes
+        for (size_t gi = 0; gi < h->groups.size(); ++gi) {
+            IirHandle *g = h->groups[gi];
+            const void *src = gi == 0 ? x_dev : y_dev;
+            int rc = iir_par_launch(g, src, n, 1, 0, 0, y_dev, s, 1, 1, 1);
+            if (rc == 1) rc = iir_any_dev(g, src, n, y_dev);
+            if (rc) return rc;
+        }
+        return SKDSP_OK;
+    }
     if (!planar_only) {
         // decaying filters: both components stay interleaved end to end (iir_k1c / iir_k3c kernels)
         const int r1 = iir_launch_planar(h, x_dev, n, 2, 0, y_dev, s, zi, zf, 1);
