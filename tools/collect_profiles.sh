@@ -48,5 +48,10 @@ python tools/time_fir_updn.py > $OUT/fir_updn.txt 2>&1
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fir_up -- python $ROOT/tools/time_fir_up.py 2x512 4x256 12x256 > /dev/null 2>&1)
 cp $OUT/trace_fir_up/*/*kernel_stats.csv $OUT/kernel_stats_fir_up.csv 2>/dev/null
 rm -rf $OUT/trace_fir_up
+for c in FETCH_SIZE WRITE_SIZE; do   # HBM counters of the walk, strided stores vs rows + weave (tools/reduce_pmc_up.py)
+  (cd /tmp && DTYPES=complex64 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_up_$c -- python $ROOT/tools/time_fir_up.py 4x256 12x256 > /dev/null 2>&1)
+  cp $OUT/pmc_up_$c/*/*counter_collection.csv $OUT/pmc_fir_up_$c.csv 2>/dev/null
+  rm -rf $OUT/pmc_up_$c
+done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_dp_pipes.hip -o /tmp/ubench_dp_pipes 2>/dev/null && /tmp/ubench_dp_pipes > $OUT/ubench_dp_pipes.txt 2>&1
 ls -la $OUT
