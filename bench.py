@@ -106,6 +106,82 @@ def reduce_parity(tr, halo_err, interior_err, fallback_used):
     return hmax, imax, [int(v) for v in tab[:, 2]], ok
 
 
+# ------------------------------------------------------------------------------ BASELINE config 5 inside an N > 1 run
+CONFIG5_TOTAL_LOG2N = 30
+
+
+def config5_n1_reference():
+    """The N = 1 figure of BASELINE config 5 (all 2^30 samples on ONE GPU): the newest committed
+    profiles/rNN/bench_fir1024_2p30_one_gpu.json (`python bench.py --scaling strong --total-log2n 30`).  That line records the
+    hashes of the kernel sources it ran; when they differ from the sources on disk the figure is withheld, like roofline.traffic."""
+    prof = os.path.join(ROOT, "profiles")
+    best = None
+    for d in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        f = os.path.join(prof, d, "bench_fir1024_2p30_one_gpu.json")
+        if os.path.exists(f):
+            best = f
+    if best is None:
+        return {"ms": None, "why": "no committed profiles/rNN/bench_fir1024_2p30_one_gpu.json"}
+    try:
+        j = json.loads(open(best).read().strip().splitlines()[-1])
+        ref = {"profile": os.path.relpath(best, ROOT), "ms": float(j["ms_per_step"]), "value": float(j["value"]),
+               "kernel_source_sha256": j.get("kernel_source_sha256")}
+        if int(j["config"]["total_samples"]) != 1 << CONFIG5_TOTAL_LOG2N or int(j["n_gpus"]) != 1:
+            return {"ms": None, "why": "%s is not a 1-GPU run over 2^%d samples" % (ref["profile"], CONFIG5_TOTAL_LOG2N)}
+        if j.get("kernel_source_sha256") != source_hashes("fir1024"):
+            ref["stale"] = "the kernel sources changed after this N = 1 line was recorded: speedup withheld"
+            ref["ms"] = None
+        return ref
+    except Exception as e:
+        return {"ms": None, "why": "%s: %s" % (type(e).__name__, e)}
+
+
+def config5_summary(total, world, step_ms, kernel_ms, parity, n1):
+    """BASELINE config 5 as one record: `total` samples split over `world` GPUs (strong scaling), whole-job MSamples/s, the
+    per-GPU fraction of the HBM roofline (16 B per sample over the slowest rank's step), and the speed-up over the committed
+    N = 1 run of the same 2^30 samples (north_star: >= 6x at 8 GPUs)."""
+    out = {"what": "BASELINE config 5: 1024-tap complex64 FIR, 2^%d samples sharded by contiguous sample block over %d GPU(s), "
+                   "%d-sample RCCL halo r -> r+1 beside the interior tiles (strong scaling)" % (total.bit_length() - 1, world, 1023),
+           "total_samples": total, "samples_per_gpu": total // world, "n_gpus": world, "ms": step_ms, "kernel_ms_max": kernel_ms,
+           "value": total / (step_ms * 1e-3) / 1e6, "unit": "MSamples/s",
+           "frac_per_gpu": 16.0 * (total // world) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "n1_reference": n1, "speedup_vs_n1": (n1["ms"] / step_ms) if n1.get("ms") else None}
+    if parity is not None:
+        out["parity_halo_max_err"], out["parity_interior_max_err"], out["halo_fallback_used"], out["parity_ok"] = parity
+    return out
+
+
+def config5_leg(args, rank, world, tr, _ffi, sharding):
+    """After the weak-scaling steps of an N > 1 run: the same filter over 2^30 samples in total (2^30 / N per rank), timed and
+    verified exactly like the main line (barrier + sync on both sides, max over ranks; every rank checks the outputs that consumed
+    its neighbour's halo).  -> (record on rank 0 / None elsewhere, parity ok)."""
+    total = 1 << CONFIG5_TOTAL_LOG2N
+    if total % world:
+        return ({"skipped": "%d GPUs do not divide 2^%d samples" % (world, CONFIG5_TOTAL_LOG2N)} if rank == 0 else None), True
+    n5 = total // world
+    w5 = make_workload("fir1024", n5, rank, world, tr, _ffi, sharding)
+    try:
+        K5 = max(10, min(args.steps, 50))
+        elapsed, ev_ms, _ = timed_steps(w5, K5, 10, 0.2, tr, _ffi)
+        kind, coeffs, seed = w5.shard
+
+        def get_x(g0, count):
+            t = _ffi.DeviceArray(count, w5.dtype).fill_noise(seed, first_index=g0)
+            try:
+                return t.to_host()
+            finally:
+                t.free()
+        herr, ierr = shard_parity(kind, coeffs, n5, rank, get_x, lambda i0, c: w5.yd.to_host(i0, c))
+        parity = reduce_parity(tr, herr, ierr, _ffi.get_option("shard_two_launches"))
+    finally:
+        free_workload(w5)
+    rec = None
+    if rank == 0:
+        rec = config5_summary(total, world, elapsed * 1e3 / K5, ev_ms / K5, parity, config5_n1_reference())
+        rec["steps"] = K5
+    return rec, parity[3]
+
+
 # ------------------------------------------------------------------------------ launcher
 def self_launch(args):
     """No launcher set WORLD_SIZE: spawn one rank per GPU ourselves (torchrun's environment contract)."""
@@ -264,9 +340,85 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
         w.metric = "%s MSamples/s (%s, %s samples)" % ("complex64" if name == "iir8c64" else "float32", "SOS IIR, " + what, lg)
         if name == "iirlp8":
             w.compute = ("FP64 vector (v_fma_f64)", 78.6, 36.0 * n)
+    elif name in RATE_WORKLOADS:
+        make_rate_workload(w, name, n, lg, _ffi)
     else:
         raise ValueError(name)
     return w
+
+
+# The .up / .dn / resampling rows of SURVEY.md 8(a), each at the reference's defaults, sized by the HIGH rate (n samples on the fast side):
+# name -> (reference call, file:line under /root/reference/src/sk_dsp_comm)
+RATE_WORKLOADS = {
+    "upsample4": ("sigsys.upsample(x, 4), complex64", "sigsys.py:3031-3053"),
+    "downsample3": ("sigsys.downsample(x, 3), complex64", "sigsys.py:3056-3083"),
+    "firup12": ("multirate_FIR(512-tap lowpass).up(x) at the default L_change = 12, complex64", "multirate_helper.py:112-118"),
+    "firdn12": ("multirate_FIR(512-tap lowpass).dn(x) at the default M_change = 12, complex64", "multirate_helper.py:121-127"),
+    "firup4": ("multirate_FIR(1024-tap lowpass).up(x, 4), complex64 (256 taps per phase: frequency-domain interpolator)", "multirate_helper.py:112-118"),
+    "firdn4": ("multirate_FIR(1024-tap lowpass).dn(x, 4), complex64 (frequency-domain decimator)", "multirate_helper.py:121-127"),
+    "rcup12": ("rate_change(12).up(x): order-8 Butterworth, float32", "multirate_helper.py:69-75"),
+    "rcdn12": ("rate_change(12).dn(x): order-8 Butterworth, float32", "multirate_helper.py:77-83"),
+    "iirup2": ("multirate_IIR(8-biquad elliptic bandpass).up(x, 2), float32", "multirate_helper.py:177-184"),
+    "iirdn3": ("multirate_IIR(8-biquad elliptic bandpass).dn(x, 3), float32", "multirate_helper.py:186-192"),
+}
+
+
+def make_rate_workload(w, name, n, lg, _ffi):
+    """n = samples at the HIGH rate (outputs of an interpolator, inputs of a decimator).  Algorithmic bytes as SURVEY.md 8(d) counts
+    them: every input sample read once, every output sample written once."""
+    what, ref = RATE_WORKLOADS[name]
+    up = name in ("upsample4", "firup12", "firup4", "rcup12", "iirup2")
+    R = {"upsample4": 4, "downsample3": 3, "firup12": 12, "firdn12": 12, "firup4": 4, "firdn4": 4, "rcup12": 12, "rcdn12": 12, "iirup2": 2, "iirdn3": 3}[name]
+    cplx = name in ("upsample4", "downsample3", "firup12", "firdn12", "firup4", "firdn4")
+    w.dtype, w.arith = (np.complex64, "c64") if cplx else (np.float32, "f32 I/O, f64 state")
+    esz = 8 if cplx else 4
+    n_in = n // R if up else n
+    n_out = n_in * R if up else n_in // R
+    w.units = n_in
+    w.xd = _ffi.DeviceArray(n_in, w.dtype).fill_noise(2026)
+    w.yd = _ffi.DeviceArray(n_out, w.dtype)
+    w.alg_bytes = float(esz) * (n_in + n_out)
+    code = _ffi.code_of(w.dtype)
+    L = _ffi.load()
+    import ctypes
+    xp, yp = ctypes.c_void_p(w.xd.ptr), ctypes.c_void_p(w.yd.ptr)
+    if name == "upsample4":
+        w.step = lambda: _ffi.check(L.skdsp_upsample_dev(xp, n_in, R, code, ctypes.c_double(1.0), yp))
+        w.kern = "upsample_kernel (resample.hip)"
+    elif name == "downsample3":
+        w.step = lambda: _ffi.check(L.skdsp_downsample_dev(xp, n_in, R, 0, code, yp))
+        w.kern = "downsample_kernel (resample.hip)"
+    elif name.startswith("fir"):
+        b = firwin_lowpass(1024, 0.2 / 4) if name in ("firup4", "firdn4") else firwin_lowpass(512, 0.9 / 12)
+        w.taps = b
+        k = _ffi.FirKernel(b, _ffi.C64)
+        w.step = (lambda: k.up_dev(w.xd, w.yd, R)) if up else (lambda: k.dn_dev(w.xd, w.yd, R))
+        w.kern = "AUTO dispatch of skdsp_fir_%s_dev (%d taps, %d per phase)" % ("up" if up else "dn", len(b), -(-len(b) // R))
+    else:
+        sos = _ffi.tf2sos(*_butter8_rate_change12()) if name.startswith("rc") else elliptic_bpf_sos()
+        w.sos = sos
+        k = _ffi.IirKernel(code, sos=sos)
+        w.step = (lambda: k.up_dev(w.xd, w.yd, R)) if up else (lambda: k.dn_dev(w.xd, w.yd, R))
+        w.kern = "iir_par_kernel (parallel-form single-pass scan; %s)" % ("zero-stuffing fused into the staging" if up else "kept outputs gathered on chip")
+    w.rate = {"factor": R, "direction": "up" if up else "dn", "n_in": n_in, "n_out": n_out}
+    w.wl = "%s [%s]: %s samples at the high rate (%d in, %d out)" % (what, ref, lg, n_in, n_out)
+    w.metric = "%s input MSamples/s (%s, %s high-rate samples)" % ("complex64" if cplx else "float32", name, lg)
+
+    def check():   # the head of the result against the oracle (checker only; the IIR paths start from rest like the reference)
+        from oracle import oracle as orc
+        m = 6000
+        x = w.xd.to_host(0, m)
+        if name == "upsample4":
+            return float(np.max(np.abs(w.yd.to_host(0, m * R) - orc.upsample(x, R).astype(w.dtype))))
+        if name == "downsample3":
+            return float(np.max(np.abs(w.yd.to_host(0, m // R) - x[: (m // R) * R: R])))
+        if name.startswith("fir"):
+            ref = orc.fir_up(w.taps, x, R) if up else orc.downsample(orc.fir_filter(w.taps, x), R)
+        else:
+            ref = orc.sos_filter(w.sos, R * orc.upsample(x, R)) if up else orc.downsample(orc.sos_filter(w.sos, x), R)
+        got = w.yd.to_host(0, ref.size)
+        return float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+    w.check = check
 
 
 def _butter8_rate_change12():
@@ -462,13 +614,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--settle-seconds", type=float, default=0.5,
                     help="untimed passes before the warm-up steps until the GPU clock has left its idle state")
-    ap.add_argument("--workload", default="fir1024", choices=["fir1024", "updn43", "iir8", "fir127", "iir8tp", "iir8cas", "iirlp8", "iir8c64", "fir1024c128"])
+    ap.add_argument("--workload", default="fir1024", choices=["fir1024", "updn43", "iir8", "fir127", "iir8tp", "iir8cas", "iirlp8", "iir8c64", "fir1024c128"] + sorted(RATE_WORKLOADS))
     ap.add_argument("--log2n", type=int, default=26, help="weak scaling: samples per GPU = 2^log2n")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--total-log2n", type=int, default=30, help="strong scaling: 2^total samples shared by all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--other-steps", type=int, default=100)
+    ap.add_argument("--no-config5", action="store_true", help="N > 1: skip the 2^30-sample strong-scaling leg behind the weak-scaling line")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="target CPU time of each baseline sample")
     ap.add_argument("--launch-timeout", type=float, default=1500.0)
     ap.add_argument("--board-seconds", type=float, default=1.5, help="0: skip the power / clock reading and the device-copy reference")
@@ -554,6 +707,7 @@ def main():
                        "n_ranks_rccl": n_comm,
                        "device": info["name"], "compute_units": info["compute_units"]},
             "roofline": roofline_of(w, ev_ms, K, log2n),
+            "kernel_source_sha256": source_hashes(args.workload),
         }
         c = compute_of(w, ev_ms, K)
         if c is not None:
@@ -594,7 +748,7 @@ def main():
     if world == 1 and args.workload == "fir1024" and not args.no_other_configs and args.scaling == "weak":
         free_workload(w)
         others = {}
-        for name in ("updn43", "iir8", "fir127", "iir8tp", "iir8cas", "iirlp8", "iir8c64", "fir1024c128"):
+        for name in ("updn43", "iir8", "fir127", "iir8tp", "iir8cas", "iirlp8", "iir8c64", "fir1024c128") + OTHER_RATE_WORKLOADS:
             try:
                 o = make_workload(name, 1 << 26, 0, 1, tr, _ffi, sharding)
                 Ko = args.other_steps if name != "fir1024c128" else max(args.other_steps // 5, 5)
@@ -603,7 +757,10 @@ def main():
                 others[name] = {"workload": o.wl, "value": float(o.units) * Ko / el / 1e6, "unit": "MSamples/s (input)",
                                 "steps": Ko, "ms": el * 1e3 / Ko, "kernel_ms": r["kernel_ms"], "achieved_GBps": r["achieved"],
                                 "frac": r["frac"], "traffic": r["traffic"],
-                                "algorithmic_bytes_per_launch": o.alg_bytes}
+                                "algorithmic_bytes_per_launch": o.alg_bytes, "traffic_source": r["traffic_source"], "kernel": o.kern}
+                if getattr(o, "rate", None):   # a SURVEY 8(a) .up / .dn row: sizes at both rates, and the head of the result against the oracle
+                    others[name]["rate"] = o.rate
+                    others[name]["parity_spot_check_max_err"] = o.check()
                 c = compute_of(o, ev, Ko)
                 if c is not None:
                     others[name]["compute"] = c
@@ -618,18 +775,36 @@ def main():
                 others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["other_configs"] = others
 
+    # ------------------------------------------- N > 1: BASELINE config 5 (2^30 samples in total, strong scaling) behind the weak-scaling line
+    c5_ok = True
+    if world > 1 and args.workload == "fir1024" and args.scaling == "weak" and not args.no_config5:
+        free_workload(w)
+        try:
+            rec, c5_ok = config5_leg(args, rank, world, tr, _ffi, sharding)
+        except Exception as e:   # (a failure here must not take the weak-scaling line with it -- but it must be visible)
+            rec, c5_ok = {"error": "%s: %s" % (type(e).__name__, e)}, True
+        if rank == 0:
+            out["config5"] = rec
+
     if rank == 0:
         print(json.dumps(out), flush=True)
     tr.close()
-    if parity is not None and not parity[3]:
+    if (parity is not None and not parity[3]) or not c5_ok:
         sys.exit(3)   # a wrong halo / state hand-off must not look like a result
 
+
+# the SURVEY 8(a) .up / .dn rows timed behind the headline, in the order of that table
+OTHER_RATE_WORKLOADS = ("upsample4", "downsample3", "firup12", "firdn12", "firup4", "firdn4", "rcup12", "rcdn12", "iirup2", "iirdn3")
 
 # kernel sources whose change makes a committed PMC measurement stale (workload -> files under scikit-dsp-comm_amd/csrc)
 TRAFFIC_SOURCES = {
     "fir1024": ["fir_ols.hip", "ols_core.hpp"], "fir127": ["fir_bx.hip"], "updn43": ["fir_bx.hip"],
     "fir1024c128": ["fir_ols64.hip"], "iir8": ["iir_par.hip"], "iirlp8": ["iir_par.hip"], "iir8c64": ["iir_par.hip"],
     "iir8cas": ["iir_fused.hip", "iir_common.hpp"], "iir8tp": ["iir_scan.hip", "iir_common.hpp"],
+    "upsample4": ["resample.hip"], "downsample3": ["resample.hip"],
+    "firup12": ["fir_up4k.hip", "ols4k_core.hpp", "fir_bx.hip"], "firup4": ["fir_up4k.hip", "ols4k_core.hpp"],
+    "firdn12": ["fir_dn4k.hip", "ols4k_core.hpp", "fir_bx.hip"], "firdn4": ["fir_dn4k.hip", "ols4k_core.hpp"],
+    "rcup12": ["iir_par.hip"], "rcdn12": ["iir_par.hip"], "iirup2": ["iir_par.hip"], "iirdn3": ["iir_par.hip"],
 }
 
 

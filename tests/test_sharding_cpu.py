@@ -87,6 +87,13 @@ def test_gloo_world2_sharded_fir(tmp_path):
         assert not ok and hmax > 1e-3 and imax < 1e-12 and flags == [0, 1]
         hmax, imax, flags, ok = par["good_iir"]
         assert ok and hmax < 1e-12 and imax < 1e-12
+        # the config-5 record of an N > 1 run: whole-job rate over the slowest rank's step, per-GPU roofline fraction, speed-up
+        # over the committed N = 1 line (withheld when that line is stale), the reduced parity verdict
+        c5 = par["c5"]
+        assert c5["n_gpus"] == 2 and c5["total_samples"] == 20000 and c5["samples_per_gpu"] == 10000 and c5["ms"] == 2.0
+        assert abs(c5["value"] - 20000 / 2e-3 / 1e6) < 1e-9 and abs(c5["speedup_vs_n1"] - 1.5) < 1e-12 and c5["parity_ok"]
+        assert abs(c5["frac_per_gpu"] - 16.0 * 10000 / 2e-3 / 1e9 / 8000.0) < 1e-12
+        assert par["c5_stale"]["speedup_vs_n1"] is None and not par["c5_stale"]["parity_ok"]
 
 
 class _Mailbox:
@@ -154,3 +161,37 @@ def test_bench_reads_board_power_and_clock_from_rocm_smi(monkeypatch):
         raise FileNotFoundError("rocm-smi")
     monkeypatch.setattr(subprocess, "run", missing)
     assert bench._smi_sample() == (None, None, None)
+
+
+def test_bench_config5_n1_reference_is_hash_checked(tmp_path, monkeypatch):
+    """bench.py's N > 1 line quotes its speed-up over the committed 1-GPU run of the same 2^30 samples
+    (profiles/rNN/bench_fir1024_2p30_one_gpu.json); a line recorded with other kernel sources is withheld."""
+    import json
+    import bench
+    real_root = bench.ROOT
+    d = tmp_path / "profiles" / "r99"
+    d.mkdir(parents=True)
+    line = {"ms_per_step": 3.7, "value": 290000.0, "n_gpus": 1, "config": {"total_samples": 1 << 30},
+            "kernel_source_sha256": bench.source_hashes("fir1024")}
+    (d / "bench_fir1024_2p30_one_gpu.json").write_text(json.dumps(line) + "\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    # (source_hashes reads the kernel sources under ROOT: keep it on the real tree)
+    monkeypatch.setattr(bench, "source_hashes", lambda w, _r=real_root, _f=bench.source_hashes: _with_root(bench, _r, _f, w))
+    ref = bench.config5_n1_reference()
+    assert ref["ms"] == 3.7 and "stale" not in ref
+    line["kernel_source_sha256"] = {"fir_ols.hip": "0" * 16, "ols_core.hpp": "0" * 16}
+    (d / "bench_fir1024_2p30_one_gpu.json").write_text(json.dumps(line) + "\n")
+    ref = bench.config5_n1_reference()
+    assert ref["ms"] is None and "stale" in ref
+    line["config"]["total_samples"] = 1 << 26
+    (d / "bench_fir1024_2p30_one_gpu.json").write_text(json.dumps(line) + "\n")
+    assert bench.config5_n1_reference()["ms"] is None
+
+
+def _with_root(bench, root, fn, w):
+    saved = bench.ROOT
+    bench.ROOT = root
+    try:
+        return fn(w)
+    finally:
+        bench.ROOT = saved
