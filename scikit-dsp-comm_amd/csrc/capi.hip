@@ -111,7 +111,7 @@ const OptEntry kOptTable[] = {
     {"sw_no_tile", &Options::sw_no_tile}, {"sw_no_lpt", &Options::sw_no_lpt}, {"mm_ns", &Options::mm_ns},
     {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
-    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up_pair", &Options::fir_up_pair}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
+    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up4k", &Options::fir_up4k}, {"fir_up4k_group", &Options::fir_up4k_group}, {"fir_up4k_dbg", &Options::fir_up4k_dbg}, {"fir_up4k_staged", &Options::fir_up4k_staged}, {"fir_up2k", &Options::fir_up2k}, {"fir_up_pair", &Options::fir_up_pair}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
     {"shard_reserve", &Options::shard_reserve}, {"shard_two_launches", &Options::shard_two_launches},
     {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
     {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline}, {"host_multi_slot", &Options::host_multi_slot},
@@ -451,6 +451,17 @@ static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hi
         return dtype_double(h->dtype) ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream, dec)
                                       : fir_ols_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream, dec);
     };
+    // one workgroup per input tile, all L phases from ONE forward transform, 32 contiguous output bytes per lane (fir_up4k.hip); option
+    // fir_up4k: 0 never, 2 wherever it applies (tests, A/B timing), 1 where the cost model below preferred the frequency domain
+    if (M == 1 && !dtype_double(h->dtype) && opt().fir_up4k && fir_up4k_supported(h, L) && n >= 2048 &&
+        (opt().fir_up4k >= 2 || fir_up_prefers_ols(h, L, n))) {
+        // up to four passes (complex64: L <= 4, float32: L <= 8) fit one thread of the 4096-point tile; more need the 2048-point tile
+        // with 8 points per thread, whose threads hold all phases of their samples (a row must leave in one burst: fir_up2k.hip)
+        const int passes = h->dtype == SKDSP_F32 ? (L + 1) / 2 : L;
+        if (opt().fir_up2k && fir_up2k_supported(h, L) && (opt().fir_up2k >= 2 || passes > 4))
+            return fir_up2k_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream);
+        return fir_up4k_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream);
+    }
     if (M == 1 && fir_up_prefers_ols(h, L, n)) {
         const bool dbl = dtype_double(h->dtype);
         bool paired = dbl ? fir_ols64_up_pairs(h, L, 1, y_dev) : fir_ols_up_pairs(h, L, 1, y_dev);

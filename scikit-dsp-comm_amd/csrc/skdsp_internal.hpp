@@ -57,6 +57,11 @@ struct Options {
     int fir_up_rows_min = -1; // multirate_FIR.up through the overlap-save walk: from this L on the phases leave as rows and a second kernel weaves them
                               // (-1: the measured crossover per dtype, fir_up_rows in capi.hip; 0: never)
     int fir_up_pair = 1;      // 0: float32 .up through the overlap-save walk never pairs its phases (A/B switch)
+    int fir_up4k = 1;         // 0: multirate_FIR.up never through the one-workgroup-per-input-tile interpolator (fir_up4k.hip); the older engines instead (A/B switch)
+    int fir_up2k = 1;         // the 2048-point tile with all phases per thread (fir_up2k.hip): 1 from five passes on (complex64: L >= 5, float32: L >= 9), 2 always, 0 never (A/B switch)
+    int fir_up4k_group = 4;   // phases (float32: pairs of phases) whose results a thread of that kernel holds before it stores: 4 (32 bytes per lane) or 2 (A/B switch)
+    int fir_up4k_staged = 1;  // 0: four-pass groups of that kernel store each lane's own 32 bytes (A/B switch)
+    int fir_up4k_dbg = 0;     // developer timing switches of up4k_kernel (wrong results)
     int fir_updn_fused = 1;   // 0: L / M through the overlap-save walk writes all n L outputs to scratch and copies every M-th (A/B switch)
     int iir_up_fused = 1;     // 0: multirate_IIR.up / rate_change.up write the zero-stuffed signal first (A/B switch)
     int iir_par_dbg = 0;      // developer timing switches of iir_par_kernel (ParArgs::dbg; wrong results)
@@ -157,6 +162,8 @@ struct FirHandle : HandleBase {
     OlsPlan *ols = nullptr;
     struct OlsUp { int L; OlsPlan *plan; };   // overlap-save plans of multirate_FIR.up, keyed by L (fir_ols_up_launch)
     std::vector<OlsUp> ols_up;
+    void *up4k = nullptr;   // plans of the frequency-domain interpolator, keyed by L (fir_up4k.hip)
+    void *up2k = nullptr;   // ... of its many-phase form (fir_up2k.hip)
     Ols64Plan *ols64 = nullptr;
     struct Ols64Up { int L; Ols64Plan *plan; };
     std::vector<Ols64Up> ols64_up;
@@ -198,6 +205,15 @@ bool fir_ols_up_pairs(const FirHandle *h, int L, int dec, const void *y_dev);   
 int fir_ols_up_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s, int dec = 1,
                       int64_t rows_pitch = 0, int paired = 0);  // dec = M: L / M, floor(n L / M) outputs; rows_pitch > 0: y[phase * rows_pitch + i] instead of
                                                                  // y[i L + phase]; paired: see fir_ols_up_pairs (rows then hold 8-byte pairs, L / 2 of them)
+// multirate_FIR.up, one workgroup per input tile, all L phases from one forward transform (fir_up4k.hip): complex64, float32 with real
+// taps; at most 2049 taps per phase
+bool fir_up4k_supported(const FirHandle *h, int L);
+int fir_up4k_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s);
+void fir_up4k_free(void *plans);
+// the same with a 2048-point tile and ALL phases of a sample in one thread (fir_up2k.hip): at most 1025 taps per phase
+bool fir_up2k_supported(const FirHandle *h, int L);
+int fir_up2k_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s);
+void fir_up2k_free(void *plans);
 // FFT overlap-save in float64 (fir_ols64.hip): complex128, and float64 with real taps; 2..2049 taps
 bool fir_ols64_supported(const FirHandle *h);
 int fir_ols64_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, hipStream_t s, int dec = 1);

@@ -143,6 +143,19 @@ def test_ols_tile_index_algebra_host_emulation(tmp_path):
     assert out.strip().endswith("OK"), out
 
 
+@pytest.mark.parametrize("name", ["ols4k_emul", "ols2k_emul"])
+def test_interpolator_decimator_tiles_host_emulation(tmp_path, name):
+    """Compiles csrc/ols4k_core.hpp (4096 points, 16 per thread) / csrc/ols2k_core.hpp (2048 points, 8 per thread) for the HOST and
+    runs whole tiles of the frequency-domain interpolator (multirate_FIR.up: one forward transform, L products + inverse transforms)
+    and decimator (multirate_FIR.dn: M forward transforms accumulated, one inverse) with the tables the library builds, against the
+    float64 polyphase sums."""
+    exe = str(tmp_path / name)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "scikit-dsp-comm_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host", name + ".cpp"), "-o", exe])
+    out = subprocess.run([exe], stdout=subprocess.PIPE).stdout.decode()
+    assert out.strip().endswith("OK"), out
+
+
 def test_tf2sos_factorisation_matches_reference_tf_outputs():
     """skdsp_tf_create runs (b,a) as biquads (host-only factorisation, no GPU needed): the
     factored cascade, evaluated by the oracle's sosfilt, must reproduce the REFERENCE's
