@@ -802,8 +802,8 @@ TRAFFIC_SOURCES = {
     "fir1024c128": ["fir_ols64.hip"], "iir8": ["iir_par.hip"], "iirlp8": ["iir_par.hip"], "iir8c64": ["iir_par.hip"],
     "iir8cas": ["iir_fused.hip", "iir_common.hpp"], "iir8tp": ["iir_scan.hip", "iir_common.hpp"],
     "upsample4": ["resample.hip"], "downsample3": ["resample.hip"],
-    "firup12": ["fir_up4k.hip", "ols4k_core.hpp", "fir_bx.hip"], "firup4": ["fir_up4k.hip", "ols4k_core.hpp"],
-    "firdn12": ["fir_dn4k.hip", "ols4k_core.hpp", "fir_bx.hip"], "firdn4": ["fir_dn4k.hip", "ols4k_core.hpp"],
+    "firup12": ["fir_up2k.hip", "ols2k_core.hpp", "fir_bx.hip"], "firup4": ["fir_up4k.hip", "ols4k_core.hpp"],
+    "firdn12": ["fir_dn2k.hip", "ols2k_core.hpp", "fir_bx.hip"], "firdn4": ["fir_dn4k.hip", "ols4k_core.hpp"],
     "rcup12": ["iir_par.hip"], "rcdn12": ["iir_par.hip"], "iirup2": ["iir_par.hip"], "iirdn3": ["iir_par.hip"],
 }
 

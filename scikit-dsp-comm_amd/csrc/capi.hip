@@ -388,6 +388,38 @@ static bool fir_up_rows(const FirHandle *h, int L, bool paired = false)
     }
 }
 
+// The one-workgroup-per-input-tile interpolators (fir_up4k.hip: up to four passes per thread; fir_up2k.hip: all passes of a row per
+// thread): which one a call takes (0: none applies), and what it costs in ms per 2^26 outputs on this board (round-4 timings,
+// tools/time_up4k.py; the measured shapes had 3 - 6 % of their tile in the overlap, so the figure is scaled to the call's overlap).
+static int fir_up_tile_kind(const FirHandle *h, int L)
+{
+    if (dtype_double(h->dtype) || !opt().fir_up4k) return 0;
+    const int passes = h->dtype == SKDSP_F32 ? (L + 1) / 2 : L;   // (float32: two phases per complex pass)
+    if (opt().fir_up2k && fir_up2k_supported(h, L) && (opt().fir_up2k >= 2 || passes > 4)) return 2;
+    return fir_up4k_supported(h, L) ? 4 : 0;
+}
+static double fir_up_tile_ms(const FirHandle *h, int L, int kind, int *V_out)
+{
+    const int T = (h->ntaps + L - 1) / L;
+    const int passes = h->dtype == SKDSP_F32 ? (L + 1) / 2 : L;
+    const bool cplx = h->dtype == SKDSP_C64;
+    double ms;
+    int N, ov;
+    if (kind == 4) {   // 4096-point tile, groups of four passes: one group is one burst per row, more are pieces written far apart
+        N = 4096; ov = std::max(256, (T - 1 + 255) / 256 * 256);
+        ms = cplx ? (passes <= 4 ? 0.175 : 0.30 + 0.012 * std::min(passes, 12)) : (passes <= 4 ? 0.089 : 0.10 + 0.005 * std::min(passes, 12));
+        ms *= (4096.0 - 256.0) / 4096.0;
+    } else {           // 2048-point tile, up to twelve passes per thread
+        N = 2048; ov = std::max(64, (T - 1 + 63) / 64 * 64);
+        if (passes <= 12) ms = cplx ? 0.185 + 0.0035 * passes : 0.085 + 0.0035 * passes;
+        else ms = cplx ? 0.36 : 0.16;
+        if (passes % 2) ms *= 1.07;   // (an odd row: every lane stores its own pieces)
+        ms *= (2048.0 - 64.0) / 2048.0;
+    }
+    *V_out = N - ov;
+    return ms * (double)N / (double)(N - ov);
+}
+
 static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
 {
     const int T = (h->ntaps + L - 1) / L;
@@ -440,6 +472,15 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
     const double pairs = (double)((n + V - 1) / V) * (cplx ? 1.0 : 0.5) * Lf;
     ols *= std::ceil(pairs / slots) * slots * (double)V * (cplx ? 1.0 : 2.0) / 67108864.0;
     poly *= (double)n * Lf / 67108864.0;
+    if (M == 1) {   // the tile interpolators replace the walk wherever they apply: rounds of one INPUT tile (all phases) per resident workgroup
+        const int kind = fir_up_tile_kind(h, L);
+        if (kind) {
+            int Vt = 0;
+            const double ms = fir_up_tile_ms(h, L, kind, &Vt);
+            const double tiles = (double)((n + Vt - 1) / Vt);
+            ols = std::min(ols, ms * std::ceil(tiles / slots) * slots * (double)Vt * Lf / 67108864.0);
+        }
+    }
     return ols < poly;
 }
 
@@ -451,16 +492,12 @@ static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hi
         return dtype_double(h->dtype) ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream, dec)
                                       : fir_ols_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream, dec);
     };
-    // one workgroup per input tile, all L phases from ONE forward transform, 32 contiguous output bytes per lane (fir_up4k.hip); option
-    // fir_up4k: 0 never, 2 wherever it applies (tests, A/B timing), 1 where the cost model below preferred the frequency domain
-    if (M == 1 && !dtype_double(h->dtype) && opt().fir_up4k && fir_up4k_supported(h, L) && n >= 2048 &&
-        (opt().fir_up4k >= 2 || fir_up_prefers_ols(h, L, n))) {
-        // up to four passes (complex64: L <= 4, float32: L <= 8) fit one thread of the 4096-point tile; more need the 2048-point tile
-        // with 8 points per thread, whose threads hold all phases of their samples (a row must leave in one burst: fir_up2k.hip)
-        const int passes = h->dtype == SKDSP_F32 ? (L + 1) / 2 : L;
-        if (opt().fir_up2k && fir_up2k_supported(h, L) && (opt().fir_up2k >= 2 || passes > 4))
-            return fir_up2k_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream);
-        return fir_up4k_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream);
+    // one workgroup per input tile, all L phases from ONE forward transform (fir_up4k.hip / fir_up2k.hip); option fir_up4k: 0 never, 2
+    // wherever one applies (tests, A/B timing), 1 where the cost model above prefers the frequency domain
+    if (M == 1 && n >= 2048) {
+        const int kind = fir_up_tile_kind(h, L);
+        if (kind && (opt().fir_up4k >= 2 || fir_up_prefers_ols(h, L, n)))
+            return kind == 2 ? fir_up2k_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream) : fir_up4k_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream);
     }
     if (M == 1 && fir_up_prefers_ols(h, L, n)) {
         const bool dbl = dtype_double(h->dtype);

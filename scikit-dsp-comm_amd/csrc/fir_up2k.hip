@@ -96,6 +96,13 @@ template <bool XR> __device__ __forceinline__ void up2k_settle_x(const cf *v)
                      "v"(v[5].x), "v"(v[5].y), "v"(v[6].x), "v"(v[6].y), "v"(v[7].x), "v"(v[7].y)
                      : "memory");
 }
+// "these are the results, in these registers, now": without it hipcc carries a finished pass in a form of its own (24 live registers per
+// pass instead of 16 -- 142 / 236 / 256 + 68 spilled for 4 / 8 / 12 passes per thread; with it 122 / 184 / 250 and no spill)
+__device__ __forceinline__ void up2k_pin(cf *v)
+{
+    asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y), "+v"(v[4].x), "+v"(v[4].y),
+                 "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y));
+}
 __device__ __forceinline__ float4 up2k_vld(const volatile float4 *p)
 {
     float4 r;
@@ -110,23 +117,24 @@ template <int PH> struct Up2kStage {
     static constexpr int kWaveUnits = 64 * kRowUnits;
 };
 
-// Rows of the passes g0 .. g0 + cnt - 1 (cnt even, no tail) of (block m, this wave): 64 consecutive rows of y, one contiguous run
-// when the group is the whole row; a lane writes its row into the staging image, then the wave copies the image out as consecutive
-// 16-byte units (unit u = lane + 64 k of the run: row u / upr, piece u % upr).
-template <int PH> __device__ __forceinline__ void up2k_store_staged(const Up2kArgs &A, int64_t tile, int g0, int cnt, int t, const cf *out, float4 *stage)
+// The rows of (block m, this wave) when the launch holds ALL passes of a row per thread (cnt = passes, even, no tail): 64 consecutive
+// rows of y = one contiguous run.  A lane writes its row into the staging image, then the wave copies the image out as consecutive
+// 16-byte units (unit u = lane + 64 k of the run sits in the image at row u / upr, piece u % upr): uniform 64-bit base + one 32-bit
+// lane offset per store.
+template <int PH> __device__ __forceinline__ void up2k_store_staged(const Up2kArgs &A, int64_t tile, int cnt, int t, const cf *out, float4 *stage)
 {
     if (A.dbg & 1) return;
     constexpr int RU = Up2kStage<PH>::kRowUnits;
     int tt = t;   // (opaque copy: nothing of the store addressing is hoisted out of the tile loop)
     asm volatile("" : "+v"(tt));
     const int lane = tt & 63, wv = tt >> 6;
-    const int upr = cnt >> 1;                                          // 16-byte units per row piece of this group
-    const int r0 = (int)(((unsigned)lane * A.upr_magic) >> 16);      // lane / upr   (upr_magic is made for the launch's upr)
+    const int upr = cnt >> 1;                                          // 16-byte units per row
+    const int r0 = (int)(((unsigned)lane * A.upr_magic) >> 16);      // lane / upr
     const int j0 = lane - r0 * upr;
     const int q64 = 64 / upr, m64 = 64 - q64 * upr;                   // 64 = q64 upr + m64
     const int64_t out0 = tile * A.V;
     const int64_t left = A.n - out0;                                   // rows of this tile that exist
-    const bool whole_row = A.row_bytes == 8 * cnt;                    // (the group is the whole row: the wave's rows are one contiguous run)
+    const unsigned voff = 16u * (unsigned)lane;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int s0 = 256 * m + 64 * wv - A.ov;                      // first tile-local output row of (block, wave); uniform
@@ -135,14 +143,13 @@ template <int PH> __device__ __forceinline__ void up2k_store_staged(const Up2kAr
 #pragma unroll
         for (int j = 0; j < PH / 2; ++j)
             if (j < upr) stage[lane * RU + j] = make_float4(out[8 * (2 * j) + m].x, out[8 * (2 * j) + m].y, out[8 * (2 * j + 1) + m].x, out[8 * (2 * j + 1) + m].y);
-        char *run = reinterpret_cast<char *>(A.y) + (out0 + s0) * A.row_bytes + 8 * g0;   // uniform
+        char *run = reinterpret_cast<char *>(A.y) + (out0 + s0) * A.row_bytes;   // uniform
         int r = r0, j = j0;
 #pragma unroll
         for (int k = 0; k < PH / 2; ++k) {
             if (k < upr) {
                 const float4 w = stage[r * RU + j];
-                char *p = whole_row ? run + 16 * (lane + 64 * k) : run + (size_t)r * A.row_bytes + 16 * j;
-                if (r < rows) *reinterpret_cast<v4f_t *>(p) = v4f_t{w.x, w.y, w.z, w.w};
+                if (r < rows) *reinterpret_cast<v4f_t *>(run + 1024 * k + voff) = v4f_t{w.x, w.y, w.z, w.w};
                 r += q64; j += m64;
                 if (j >= upr) { j -= upr; r += 1; }
             }
@@ -191,12 +198,12 @@ template <int PH, bool TAIL> __device__ __forceinline__ void up2k_store_direct(c
 // ZL (twelve passes per thread): the spectrum waits in thread-private LDS slots instead of 16 registers and the next tile is not
 // requested ahead -- with 192 result registers, the landing registers of a pass's LDS reads and its twiddles, there is no room
 // for either (199 - 221 spilled registers otherwise, whatever the instruction scheduler).
-template <bool XR, int PH> __global__ __launch_bounds__(256, 2) void up2k_kernel(Up2kArgs A)
+template <bool XR, int PH, bool STAGED> __global__ __launch_bounds__(256, 2) void up2k_kernel(Up2kArgs A)
 {
     constexpr bool ZL = PH > 8;
     __shared__ cf img[kImgUnits];
     __shared__ cf tw1l[kTw1Units], tw2l[kTw2Units], tw3l[kTw3Units];
-    __shared__ float4 stage[4 * Up2kStage<PH>::kWaveUnits];
+    __shared__ float4 stage[STAGED ? 4 * Up2kStage<PH>::kWaveUnits : 1];
     __shared__ cf zl[ZL ? 8 * 256 : 1];   // [slot][thread]
     const int t = threadIdx.x;
     {
@@ -251,26 +258,26 @@ template <bool XR, int PH> __global__ __launch_bounds__(256, 2) void up2k_kernel
                         for (int k = 0; k < 4; ++k) hh[k] = up2k_vld(hp + (unsigned)(k * 256 + tt));
                     }
                     if constexpr (ZL) {
-                        cf z[8];
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) z[k] = zl[k * 256 + t];
-                        mul_H(hh, z, out + 8 * q);
+                        for (int k = 0; k < 8; ++k) out[8 * q + k] = zl[k * 256 + t];
+                        mul_H(hh, out + 8 * q, out + 8 * q);
                     } else {
                         mul_H(hh, Z, out + 8 * q);
                         if (q == cnt - 1 && last_group && pre_next)   // the tile's last pass: the spectrum is dead, the next tile's samples land in its registers
                             up2k_load_interior<XR>(A, tile + gridDim.x, t, Z);
                     }
                     inv_pass4(t, img, out + 8 * q);
-                    inv_pass3(t, tw3l, img);
-                    inv_pass2(t, tw2l, img);
+                    inv_pass3<ZL>(t, tw3l, img);
+                    inv_pass2<ZL>(t, tw2l, img);
                     __syncthreads();
                     inv_pass1(t, tw1l, img, out + 8 * q);
                     __syncthreads();   // every wave has read the image before the next pass (or tile) overwrites it
+                    up2k_pin(out + 8 * q);
                 }
             });
             if (!ZL && last_group && pre_next) up2k_settle_x<XR>(Z);
-            if (A.staged) {
-                up2k_store_staged<PH>(A, tile, g0, cnt, t, out, stage + Up2kStage<PH>::kWaveUnits * (t >> 6));
+            if constexpr (STAGED) {
+                up2k_store_staged<PH>(A, tile, cnt, t, out, stage + Up2kStage<PH>::kWaveUnits * (t >> 6));
             } else if constexpr (XR) {
                 if (A.odd_tail && last_group) up2k_store_direct<PH, true>(A, tile, g0, cnt, t, out);
                 else up2k_store_direct<PH, false>(A, tile, g0, cnt, t, out);
@@ -369,9 +376,8 @@ int fir_up2k_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int 
     // passes held per thread: the smallest instantiation that takes the row in ONE group; longer rows go in groups of 12 (float32
     // and complex64 alike: 96-byte pieces)
     const int PH = p->passes <= 4 ? 4 : (p->passes <= 8 ? 8 : 12);
-    // the staging image takes groups with an even number of passes and no 4-byte tail: every group of the launch must qualify
-    const bool even_groups = !A.odd_tail && p->passes % 2 == 0 && (p->passes <= PH || PH % 2 == 0);
-    A.staged = opt().fir_up4k_staged && even_groups && (p->passes <= PH || p->passes % PH == 0);
+    // the staging image takes whole rows with an even number of passes and no 4-byte tail
+    A.staged = opt().fir_up4k_staged && !A.odd_tail && p->passes % 2 == 0 && p->passes <= PH;
     {
         const int cnt0 = p->passes < PH ? p->passes : PH;
         const int upr = cnt0 / 2 > 0 ? cnt0 / 2 : 1;
@@ -382,15 +388,18 @@ int fir_up2k_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int 
     if (reserve_wgs > 0 && grid > 8 * (int64_t)reserve_wgs) grid -= reserve_wgs;
     if (grid > A.ntiles) grid = A.ntiles;
     const dim3 g((unsigned)grid), b(256);
-    if (p->pairs) {
-        if (PH == 4) hipLaunchKernelGGL((up2k_kernel<true, 4>), g, b, 0, s, A);
-        else if (PH == 8) hipLaunchKernelGGL((up2k_kernel<true, 8>), g, b, 0, s, A);
-        else hipLaunchKernelGGL((up2k_kernel<true, 12>), g, b, 0, s, A);
-    } else {
-        if (PH == 4) hipLaunchKernelGGL((up2k_kernel<false, 4>), g, b, 0, s, A);
-        else if (PH == 8) hipLaunchKernelGGL((up2k_kernel<false, 8>), g, b, 0, s, A);
-        else hipLaunchKernelGGL((up2k_kernel<false, 12>), g, b, 0, s, A);
-    }
+    auto launch = [&](auto xr, auto ph) {
+        constexpr bool X = decltype(xr)::value;
+        constexpr int P = decltype(ph)::value;
+        if (A.staged) hipLaunchKernelGGL((up2k_kernel<X, P, true>), g, b, 0, s, A);
+        else hipLaunchKernelGGL((up2k_kernel<X, P, false>), g, b, 0, s, A);
+    };
+    auto by_ph = [&](auto xr) {
+        if (PH == 4) launch(xr, std::integral_constant<int, 4>{});
+        else if (PH == 8) launch(xr, std::integral_constant<int, 8>{});
+        else launch(xr, std::integral_constant<int, 12>{});
+    };
+    if (p->pairs) by_ph(std::true_type{}); else by_ph(std::false_type{});
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
 }

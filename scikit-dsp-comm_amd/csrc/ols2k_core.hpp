@@ -181,12 +181,24 @@ SK_HD void inv_pass4(int t, cf *img, cf *P)
     SK_UNROLL
     for (int d = 0; d < 8; ++d) img[unit(k1, k2, k3, d)] = P[d];
 }
-SK_HD void inv_pass3(int t, const cf *tw3, cf *img)
+// LEAN: the eight image reads and seven twiddle reads of a pass are issued in two batches with a fence between them (14 instead
+// of 30 landing registers in flight) -- for the kernel that holds twelve results per thread and has no register to spare
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SK_2K_FENCE() asm volatile("" ::: "memory")
+#else
+#define SK_2K_FENCE() do {} while (0)
+#endif
+template <bool LEAN = false> SK_HD void inv_pass3(int t, const cf *tw3, cf *img)
 {
     const int k1 = t >> 6, k2 = (t >> 3) & 7, d = t & 7;
     cf v[8];
     v[P8(0)] = img[unit(k1, k2, 0, d)];
-    static_for<1, 8>([&](auto kc) {
+    static_for<1, 4>([&](auto kc) {
+        constexpr int k3 = decltype(kc)::value;
+        v[P8(k3)] = cmulc(img[unit(k1, k2, k3, d)], tw3[k3 * 8 + d]);
+    });
+    if (LEAN) SK_2K_FENCE();
+    static_for<4, 8>([&](auto kc) {
         constexpr int k3 = decltype(kc)::value;
         v[P8(k3)] = cmulc(img[unit(k1, k2, k3, d)], tw3[k3 * 8 + d]);
     });
@@ -194,12 +206,17 @@ SK_HD void inv_pass3(int t, const cf *tw3, cf *img)
     SK_UNROLL
     for (int c = 0; c < 8; ++c) img[unit(k1, k2, c, d)] = v[c];
 }
-SK_HD void inv_pass2(int t, const cf *tw2, cf *img)
+template <bool LEAN = false> SK_HD void inv_pass2(int t, const cf *tw2, cf *img)
 {
     const int k1 = t >> 6, c = (t >> 3) & 7, d = t & 7;
     cf v[8];
     v[P8(0)] = img[unit(k1, 0, c, d)];
-    static_for<1, 8>([&](auto kc) {
+    static_for<1, 4>([&](auto kc) {
+        constexpr int k2 = decltype(kc)::value;
+        v[P8(k2)] = cmulc(img[unit(k1, k2, c, d)], tw2[k2 * 64 + (t & 63)]);
+    });
+    if (LEAN) SK_2K_FENCE();
+    static_for<4, 8>([&](auto kc) {
         constexpr int k2 = decltype(kc)::value;
         v[P8(k2)] = cmulc(img[unit(k1, k2, c, d)], tw2[k2 * 64 + (t & 63)]);
     });

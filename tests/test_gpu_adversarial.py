@@ -163,12 +163,13 @@ def test_up_dn_updn_coherent_inputs(cplx, taps, kind):
     # the same through the overlap-save walk over (tile, phase) pairs (long enough inputs; real signals: two phases per complex pass)
     for L in (2, 12):
         xl = signal_of("tone" if stop else kind, 3 * 8192 + 100, cplx, f0 * L)
-        with _ffi.option("fir_up_ols_min", -2):
-            yl = k.up(xl, L)
-        if stop:
-            check_forward(yl, orc.fir_up(b, xl, L), b, xl, "up%d/walk %s" % (L, tag), phase_gain(L))
-        else:   # (an 8192-point float32 transform per phase, the phase taps scaled by L: measured worst 6.4e-7 -- firwin1024, L = 12, tones)
-            check(yl, orc.fir_up(b, xl, L), "up%d/walk %s" % (L, tag), 7e-7)
+        for engine, tile in (("walk", 0), ("tile", 2)):   # the walk over (tile, phase) pairs / the one-workgroup-per-input-tile interpolators
+            with _ffi.option("fir_up_ols_min", -2), _ffi.option("fir_up4k", tile):
+                yl = k.up(xl, L)
+            if stop:
+                check_forward(yl, orc.fir_up(b, xl, L), b, xl, "up%d/%s %s" % (L, engine, tag), phase_gain(L))
+            else:   # (an 8192-point float32 transform per phase, the phase taps scaled by L: measured worst 6.4e-7 -- firwin1024, L = 12, tones)
+                check(yl, orc.fir_up(b, xl, L), "up%d/%s %s" % (L, engine, tag), 7e-7)
     x = signal_of("tone" if stop else kind, n, cplx, f0)
     ref_dn = orc.fir_dn(b, x, 12)
     for engine, algo in ENGINES:

@@ -259,9 +259,10 @@ def test_fuzz_device_views_at_odd_offsets(seed):
 
 @pytest.mark.parametrize("seed", range(NSEED))
 def test_fuzz_fir_up_walk_forms(seed):
-    """multirate_FIR.up and L / M through the overlap-save walk over (tile, phase) pairs, forced (option fir_up_ols_min < 0) so that short phases and
-    short signals take it too: every form it has -- strided stores, rows + weave, phases in pairs for real signals (even and odd L), the every-M-th
-    store -- on device windows at random element offsets (aligned and not), guard words around the output, history in front of the input."""
+    """multirate_FIR.up and L / M in the frequency domain, forced (option fir_up_ols_min < 0) so that short phases and short signals take it too:
+    the walk over (tile, phase) pairs in every form it has -- strided stores, rows + weave, phases in pairs for real signals (even and odd L),
+    the every-M-th store -- and (M = 1) the one-workgroup-per-input-tile interpolators fir_up4k / fir_up2k in theirs, on device windows at
+    random element offsets (aligned and not), guard words around the output, history in front of the input."""
     import contextlib
     rng = np.random.default_rng(7000 + seed)
     for _ in range(10):
@@ -287,6 +288,14 @@ def test_fuzz_fir_up_walk_forms(seed):
             k = _ffi.FirKernel(b, _ffi.code_of(dt))
             with contextlib.ExitStack() as st:
                 st.enter_context(_ffi.option("fir_up_ols_min", -2))
+                # M = 1: the walk (fir_up4k = 0) or the one-workgroup-per-input-tile interpolators in every form they have (four / two phases
+                # per store of the 4096-point tile; the 2048-point tile with all phases per thread from five passes on, or always; rows
+                # through the staging image or each lane its own)
+                tile = int(rng.choice([0, 2, 2]))
+                st.enter_context(_ffi.option("fir_up4k", tile))
+                st.enter_context(_ffi.option("fir_up2k", int(rng.choice([1, 2]))))
+                st.enter_context(_ffi.option("fir_up4k_group", int(rng.choice([2, 4]))))
+                st.enter_context(_ffi.option("fir_up4k_staged", int(rng.integers(0, 2))))
                 st.enter_context(_ffi.option("fir_up_rows_min", int(rng.choice([-1, 0, 2]))))
                 st.enter_context(_ffi.option("fir_up_pair", int(rng.integers(0, 2))))
                 st.enter_context(_ffi.option("fir_updn_fused", int(rng.integers(0, 2))))
@@ -295,7 +304,7 @@ def test_fuzz_fir_up_walk_forms(seed):
             up[::L] = L * x.astype(up.dtype)
             ref = signal.lfilter(b, [1], up)[hist * L:][::M][:n_out]
             got = ybuf.to_host()
-            what = "walk %s L/M=%d/%d taps=%d n=%d hist=%d offsets %d/%d" % (np.dtype(dt).name, L, M, ntaps, n, hist, ox, oy)
+            what = "%s %s L/M=%d/%d taps=%d n=%d hist=%d offsets %d/%d" % ("tile" if tile and M == 1 else "walk", np.dtype(dt).name, L, M, ntaps, n, hist, ox, oy)
             assert np.all(got[:oy] == 7.0) and np.all(got[oy + n_out:] == 7.0), "guard words overwritten: " + what
             _check(got[oy:oy + n_out], ref, dt, what, float(np.sum(np.abs(b)) * L * np.max(np.abs(x))))
         finally:

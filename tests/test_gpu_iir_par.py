@@ -304,7 +304,7 @@ def test_fir_overlap_save_up(dt, ntaps, L):
             both = []
             for rows_min in (0, 2):
                 yd.write(np.full(n * L + 8, 7.0, dtype=dt))
-                with _ffi.option("fir_up_ols_min", -12), _ffi.option("fir_up_rows_min", rows_min):
+                with _ffi.option("fir_up4k", 0), _ffi.option("fir_up_ols_min", -12), _ffi.option("fir_up_rows_min", rows_min):
                     k.up_dev(xd, yd, L)
                 both.append(yd.to_host(0, n * L))
                 assert np.all(yd.to_host(n * L, 8) == 7.0), "wrote beyond n * L outputs (L=%d n=%d rows_min=%d)" % (L, n, rows_min)
@@ -316,7 +316,7 @@ def test_fir_overlap_save_up(dt, ntaps, L):
                 assert np.array_equal(both[0], both[1]), (L, n)
             if (dt in (np.float32, np.float64) and L % 2 == 0) or odd_pairs:   # real signal: the phases ran in pairs through the complex tile; one phase per pass agrees to rounding
                 for rows_min in (0, 2):
-                    with _ffi.option("fir_up_ols_min", -12), _ffi.option("fir_up_rows_min", rows_min), _ffi.option("fir_up_pair", 0):
+                    with _ffi.option("fir_up4k", 0), _ffi.option("fir_up_ols_min", -12), _ffi.option("fir_up_rows_min", rows_min), _ffi.option("fir_up_pair", 0):
                         k.up_dev(xd, yd, L)
                     single_phase = yd.to_host(0, n * L)
                     assert np.max(np.abs(single_phase - both[0])) <= 2 * tol * np.max(np.abs(both[0])), (L, n, rows_min)
@@ -324,7 +324,7 @@ def test_fir_overlap_save_up(dt, ntaps, L):
                 y3 = _ffi.DeviceArray(n * L + 9, dt)
                 try:
                     y3.write(np.full(n * L + 9, 7.0, dtype=dt))
-                    with _ffi.option("fir_up_ols_min", -12), _ffi.option("fir_up_rows_min", 2):
+                    with _ffi.option("fir_up4k", 0), _ffi.option("fir_up_ols_min", -12), _ffi.option("fir_up_rows_min", 2):
                         k.up_dev(xd, y3.window(1, n * L), L)
                     off1 = y3.to_host(1, n * L)
                     assert y3.to_host(0, 1)[0] == 7.0 and np.all(y3.to_host(n * L + 1, 8) == 7.0), (L, n)
@@ -353,10 +353,83 @@ def test_fir_overlap_save_up(dt, ntaps, L):
             h0 = n // 2
             if h0 > hist:
                 yd.write(np.full(n * L + 8, 7.0, dtype=dt))
-                with _ffi.option("fir_up_ols_min", -12):
+                with _ffi.option("fir_up4k", 0), _ffi.option("fir_up_ols_min", -12):
                     k.up_dev(xd.window(h0, n - h0), yd, L, n_hist=hist)
                 cont = yd.to_host(0, (n - h0) * L)
                 assert np.max(np.abs(cont - got[h0 * L:])) <= 2 * tol * peak, ("continuation", L, n)
+        finally:
+            xd.free()
+            yd.free()
+            y2.free()
+
+
+@pytest.mark.parametrize("L", [2, 3, 4, 5, 6, 8, 9, 12, 13, 16, 24, 26, 33])
+@pytest.mark.parametrize("dt,ntaps", [(np.complex64, 1024), (np.float32, 1024), (np.float32, 777), (np.complex64, 4099), (np.complex64, 516), (np.float32, 516)])
+def test_fir_up_one_workgroup_per_input_tile(dt, ntaps, L):
+    """multirate_FIR.up (multirate_helper.py:112-118) through the one-workgroup-per-input-tile interpolators (fir_up4k.hip: 4096-point tile,
+    up to four passes per thread; fir_up2k.hip: 2048-point tile, all passes of a row per thread): one forward transform per tile, L products +
+    inverse transforms.  Every form -- four / two phases per store, rows through the staging image or lane by lane, the 2048-point tile
+    forced for short rows too -- against the oracle on windows and against the polyphase kernels on everything; lengths that end inside a
+    tile; complex taps; a streamed continuation (n_hist); a destination one element off its allocation; nothing written beyond n L outputs."""
+    import bench
+    T = (ntaps + L - 1) // L
+    if T - 1 > 1024:
+        pytest.skip("more than 1025 taps per phase: the walk over (tile, phase) pairs")
+    b = bench.firwin_lowpass(ntaps, 0.8 / L)
+    cplx = np.dtype(dt).kind == "c"
+    if cplx and ntaps == 4099:
+        b = b * np.exp(0.07j * np.arange(ntaps))   # complex taps
+    tol = 1e-6
+    hist = T - 1
+    forms = [{"fir_up4k": 2}, {"fir_up4k": 2, "fir_up4k_staged": 0}, {"fir_up4k": 2, "fir_up4k_group": 2}, {"fir_up4k": 2, "fir_up2k": 2},
+             {"fir_up4k": 2, "fir_up2k": 2, "fir_up4k_staged": 0}, {"fir_up4k": 2, "fir_up2k": 0}]
+    import contextlib
+    for n in (400_001, 3840 * 2 + 5, 2048, 20_000):
+        k = _ffi.FirKernel(b, _ffi.code_of(dt))
+        xd = _ffi.DeviceArray(n, dt).fill_noise(L + ntaps)
+        yd = _ffi.DeviceArray(n * L + 9, dt)
+        y2 = _ffi.DeviceArray(n * L + 8, dt)
+        try:
+            with _ffi.option("fir_up_ols_min", 0):   # the polyphase kernels
+                k.up_dev(xd, y2, L)
+            other = y2.to_host(0, n * L)
+            peak = np.max(np.abs(other))
+            outs = []
+            for f in forms:
+                for off in ((0, 1) if n == 20_000 else (0,)):   # (off 1: a destination aligned to one element only)
+                    yd.write(np.full(n * L + 9, 7.0, dtype=dt))
+                    with contextlib.ExitStack() as st:
+                        for name, val in f.items():
+                            st.enter_context(_ffi.option(name, val))
+                        k.up_dev(xd, yd.window(off, n * L), L)
+                    got = yd.to_host(off, n * L)
+                    assert np.all(yd.to_host(0, off) == 7.0) and np.all(yd.to_host(off + n * L, 8) == 7.0), ("wrote outside its n L outputs", f, L, n, off)
+                    assert np.max(np.abs(got - other)) <= 2 * tol * peak, (f, L, n, off, np.max(np.abs(got - other)) / peak)
+                    outs.append(got)
+            # the staging image changes which lane stores a value, not the value (forms 0 / 1 and 3 / 4, each with `per` outputs)
+            per = 2 if n == 20_000 else 1
+            assert np.array_equal(outs[0], outs[per]) and np.array_equal(outs[3 * per], outs[4 * per]), (L, n)
+            got = outs[0]
+            x = xd.to_host().astype(np.complex128 if cplx else np.float64)
+            for o0 in (0, (n * L) // 2 + 1, n * L - 400):
+                cnt = min(400, n * L - o0)
+                i0 = max(o0 // L - hist - 1, 0)
+                i1 = (o0 + cnt + L - 1) // L
+                up = np.zeros((i1 - i0) * L, dtype=x.dtype)
+                up[::L] = L * x[i0:i1]
+                ref = orc.fir_filter(b, up)[o0 - i0 * L:][:cnt]
+                assert np.max(np.abs(got[o0:o0 + cnt] - ref)) <= tol * peak, (L, n, o0)
+            # streamed continuation: the second half with the first half's tail as history == the one-shot result
+            h0 = n // 2
+            if h0 > hist:
+                for f in (forms[0], forms[3]):
+                    yd.write(np.full(n * L + 9, 7.0, dtype=dt))
+                    with contextlib.ExitStack() as st:
+                        for name, val in f.items():
+                            st.enter_context(_ffi.option(name, val))
+                        k.up_dev(xd.window(h0, n - h0), yd, L, n_hist=hist)
+                    cont = yd.to_host(0, (n - h0) * L)
+                    assert np.max(np.abs(cont - got[h0 * L:])) <= 2 * tol * peak, ("continuation", f, L, n)
         finally:
             xd.free()
             yd.free()
