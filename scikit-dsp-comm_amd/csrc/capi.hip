@@ -111,7 +111,7 @@ const OptEntry kOptTable[] = {
     {"sw_no_tile", &Options::sw_no_tile}, {"sw_no_lpt", &Options::sw_no_lpt}, {"mm_ns", &Options::mm_ns},
     {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
-    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up4k", &Options::fir_up4k}, {"fir_up4k_group", &Options::fir_up4k_group}, {"fir_up4k_dbg", &Options::fir_up4k_dbg}, {"fir_up4k_staged", &Options::fir_up4k_staged}, {"fir_up2k", &Options::fir_up2k}, {"fir_up_pair", &Options::fir_up_pair}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
+    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up4k", &Options::fir_up4k}, {"fir_up4k_group", &Options::fir_up4k_group}, {"fir_up4k_dbg", &Options::fir_up4k_dbg}, {"fir_up4k_staged", &Options::fir_up4k_staged}, {"fir_up2k", &Options::fir_up2k}, {"fir_dn4k", &Options::fir_dn4k}, {"fir_up_pair", &Options::fir_up_pair}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
     {"shard_reserve", &Options::shard_reserve}, {"shard_two_launches", &Options::shard_two_launches},
     {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
     {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline}, {"host_multi_slot", &Options::host_multi_slot},
@@ -351,6 +351,14 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
         if (kb > 0) ols = h->dtype == SKDSP_C64 && kb > 4 * M;
         else ols = h->ntaps / M >= (h->dtype == SKDSP_C64 ? 24 : 64);  // the two-real-tiles store pays two divides per sample
     }
+    // M <= 4: the frequency-domain decimator (fir_dn4k.hip: M forward transforms accumulated, ONE inverse per tile of kept outputs) wherever
+    // the decimating overlap-save store would run (which spends 2 M transforms on the same outputs); option fir_dn4k = 2: wherever it applies
+    // (measured, 2^26 inputs, round 4 -- tools/check_dn4k.py: float32 512 taps M = 3 0.125 -> 0.101 ms, 1024 taps M = 4 0.130 -> 0.119, 4096 taps
+    // 0.199 -> 0.129; complex64 1024 taps M = 2 0.231 -> 0.208, 4096 taps M = 4 0.356 -> 0.271, but 512 taps M = 3 and 1024 taps M = 4 a tie:
+    // its loads are the bulk of its traffic and wait where the interpolator's stores do not)
+    if (M > 1 && opt().fir_dn4k && fir_dn4k_supported(h, M) && n / M >= 2048 &&
+        (opt().fir_dn4k >= 2 || (ols && (h->dtype == SKDSP_F32 || M == 2 || h->ntaps > 1536))))
+        return fir_dn4k_launch(h, x_dev, n, n_hist, M, y_dev, ctx().stream);
     if (ols) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
     int rc = fir_direct_launch(h, x_dev, n, n_hist, 1, M, n / M, y_dev, ctx().stream);
     if (rc == SKDSP_ERR_UNSUPPORTED && M > 1) {

@@ -566,6 +566,7 @@ FirHandle::~FirHandle()
     for (auto &u : ols_up) fir_ols_free(u.plan);
     if (up4k) fir_up4k_free(up4k);
     if (up2k) fir_up2k_free(up2k);
+    if (dn4k) fir_dn4k_free(dn4k);
     if (ols64) fir_ols64_free(ols64);
     for (auto &u : ols64_up) fir_ols64_free(u.plan);
     for (FirHandle *p : parts) delete p;

@@ -171,6 +171,15 @@ __device__ __forceinline__ void up4k_store4_staged(const Up4kArgs &A, int64_t ti
     }
 }
 
+// "these are the results, in these registers, now": without it hipcc carries a finished pass in a form of its own (more live registers per
+// pass than its 32 results: fir_up2k.hip measured 24 instead of 16 for its eight)
+__device__ __forceinline__ void up4k_pin(cf *v)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i += 8)
+        asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i + 1].x), "+v"(v[i + 1].y), "+v"(v[i + 2].x), "+v"(v[i + 2].y), "+v"(v[i + 3].x), "+v"(v[i + 3].y),
+                     "+v"(v[i + 4].x), "+v"(v[i + 4].y), "+v"(v[i + 5].x), "+v"(v[i + 5].y), "+v"(v[i + 6].x), "+v"(v[i + 6].y), "+v"(v[i + 7].x), "+v"(v[i + 7].y));
+}
 // volatile 16-byte load: keeps the request at its program position (the scheduler would otherwise sink a prefetch to its first use)
 __device__ __forceinline__ float4 up4k_vld(const volatile float4 *p)
 {
@@ -293,6 +302,7 @@ template <bool XR, int G> __global__ __launch_bounds__(256, 2) void up4k_kernel(
                     __syncthreads();
                     inv_pass1(t, twl, img, out + 16 * j);
                     __syncthreads();   // every wave has read the image before the next pass (or tile) overwrites it
+                    up4k_pin(out + 16 * j);
                 }
             });
             // the table of the next group's first pass: requested and waited for in front of the stores (an L2 round trip, exposed; held

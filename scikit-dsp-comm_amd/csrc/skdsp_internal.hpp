@@ -59,6 +59,7 @@ struct Options {
     int fir_up_pair = 1;      // 0: float32 .up through the overlap-save walk never pairs its phases (A/B switch)
     int fir_up4k = 1;         // 0: multirate_FIR.up never through the one-workgroup-per-input-tile interpolator (fir_up4k.hip); the older engines instead (A/B switch)
     int fir_up2k = 1;         // the 2048-point tile with all phases per thread (fir_up2k.hip): 1 from five passes on (complex64: L >= 5, float32: L >= 9), 2 always, 0 never (A/B switch)
+    int fir_dn4k = 1;         // multirate_FIR.dn through the frequency-domain decimator (fir_dn4k.hip): 1 where the cost model prefers it, 2 wherever it applies, 0 never (A/B switch)
     int fir_up4k_group = 4;   // phases (float32: pairs of phases) whose results a thread of that kernel holds before it stores: 4 (32 bytes per lane) or 2 (A/B switch)
     int fir_up4k_staged = 1;  // 0: four-pass groups of that kernel store each lane's own 32 bytes (A/B switch)
     int fir_up4k_dbg = 0;     // developer timing switches of up4k_kernel (wrong results)
@@ -164,6 +165,7 @@ struct FirHandle : HandleBase {
     std::vector<OlsUp> ols_up;
     void *up4k = nullptr;   // plans of the frequency-domain interpolator, keyed by L (fir_up4k.hip)
     void *up2k = nullptr;   // ... of its many-phase form (fir_up2k.hip)
+    void *dn4k = nullptr;   // plans of the frequency-domain decimator, keyed by M (fir_dn4k.hip)
     Ols64Plan *ols64 = nullptr;
     struct Ols64Up { int L; Ols64Plan *plan; };
     std::vector<Ols64Up> ols64_up;
@@ -214,6 +216,10 @@ void fir_up4k_free(void *plans);
 bool fir_up2k_supported(const FirHandle *h, int L);
 int fir_up2k_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s);
 void fir_up2k_free(void *plans);
+// multirate_FIR.dn, one workgroup per OUTPUT tile: M forward transforms accumulated in the frequency domain, one inverse (fir_dn4k.hip)
+bool fir_dn4k_supported(const FirHandle *h, int M);
+int fir_dn4k_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev, hipStream_t s);
+void fir_dn4k_free(void *plans);
 // FFT overlap-save in float64 (fir_ols64.hip): complex128, and float64 with real taps; 2..2049 taps
 bool fir_ols64_supported(const FirHandle *h);
 int fir_ols64_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, hipStream_t s, int dec = 1);

@@ -236,6 +236,14 @@ def test_fuzz_device_views_at_odd_offsets(seed):
                 bound = np.sum(np.abs(signal.sosfilt(sos, np.r_[1.0, np.zeros(4095)])))
                 name = "iir %d sections" % len(sos)
                 lf = lambda v: signal.sosfilt(sos, v)
+            # (half of the FIR cases force the frequency-domain interpolator / decimator where they apply: fir_up4k / fir_up2k / fir_dn4k)
+            forced = int(rng.choice([1, 2]))
+            import contextlib
+            st = contextlib.ExitStack()
+            st.enter_context(_ffi.option("fir_up4k", forced))
+            st.enter_context(_ffi.option("fir_dn4k", forced))
+            if forced == 2:
+                st.enter_context(_ffi.option("fir_up_ols_min", -2))
             if op == "filter":
                 k.filter_dev(xv, yv)
                 ref = lf(x.astype(wide))
@@ -248,6 +256,7 @@ def test_fuzz_device_views_at_odd_offsets(seed):
             else:
                 k.dn_dev(xv, yv, f)
                 ref = lf(x.astype(wide))[::f][:n_out]
+            st.close()
             got = ybuf.to_host()
             what = "%s %s %s n=%d f=%d offsets %d/%d" % (name, op, np.dtype(dt).name, n, f, ox, oy)
             assert np.all(got[:oy] == 7.0) and np.all(got[oy + n_out:] == 7.0), "guard words overwritten: " + what

@@ -255,12 +255,22 @@ def test_fir_overlap_save_decimating_store(dt, ntaps, M):
         yd = _ffi.DeviceArray(n // M + 8, dt)
         try:
             yd.write(np.full(n // M + 8, 7.0, dtype=dt))
-            k.dn_dev(xd, yd, M)
+            with _ffi.option("fir_dn4k", 0):
+                k.dn_dev(xd, yd, M)
             got = yd.to_host(0, n // M)
             assert np.all(yd.to_host(n // M, 8) == 7.0), "wrote beyond floor(n / M) outputs (M=%d n=%d)" % (M, n)
             x = xd.to_host().astype(np.complex128 if cplx else np.float64)
             if n // M == 0:
                 continue
+            if M <= 4 and np.dtype(dt).itemsize // (2 if cplx else 1) == 4 and n // M >= 2048:
+                # the frequency-domain decimator (fir_dn4k.hip: M forward transforms accumulated, one inverse) on the same call: the same
+                # outputs to rounding, and nothing beyond them either
+                yd.write(np.full(n // M + 8, 7.0, dtype=dt))
+                with _ffi.option("fir_dn4k", 2):
+                    k.dn_dev(xd, yd, M)
+                got4 = yd.to_host(0, n // M)
+                assert np.all(yd.to_host(n // M, 8) == 7.0), "fir_dn4k wrote beyond floor(n / M) outputs (M=%d n=%d)" % (M, n)
+                assert np.max(np.abs(got4 - got)) <= 2e-6 * np.max(np.abs(got)), ("fir_dn4k vs decimating store", M, n)
             tol = 1e-6 if np.dtype(dt).itemsize // (2 if cplx else 1) == 4 else 1e-12
             if n <= 40_000:
                 ref = orc.fir_filter(b, x)[::M][:n // M]
@@ -273,6 +283,61 @@ def test_fir_overlap_save_decimating_store(dt, ntaps, M):
                     ref = seg[::M][:cnt]
                     # (float32 contract: 1e-6 of the output's peak; a window inside the start-up transient is far below it)
                     assert np.max(np.abs(got[o0:o0 + cnt] - ref)) <= tol * np.max(np.abs(got)), (M, n, o0)
+        finally:
+            xd.free()
+            yd.free()
+
+
+@pytest.mark.parametrize("M", [2, 3, 4])
+@pytest.mark.parametrize("dt,ntaps", [(np.complex64, 512), (np.float32, 1024), (np.float32, 300), (np.complex64, 4099), (np.complex64, 64), (np.float32, 4097)])
+def test_fir_dn_frequency_domain_decimator(dt, ntaps, M):
+    """multirate_FIR.dn (multirate_helper.py:121-127) through fir_dn4k.hip: the M phase signals u_r[i] = x[i M + r] of an output tile loaded as
+    8 M contiguous bytes per sample, M forward transforms, products with G_r (g_r[j] = b[j M - r]) accumulated in the frequency domain, ONE
+    inverse.  Against the oracle on everything short and on windows of long results; lengths that end inside a tile / inside an output
+    period; complex taps; a streamed continuation (n_hist); a source and a destination one element off their allocations; nothing
+    written beyond floor(n / M) outputs."""
+    import bench
+    b = bench.firwin_lowpass(ntaps, 0.8 / M)
+    cplx = np.dtype(dt).kind == "c"
+    if cplx and ntaps == 4099:
+        b = b * np.exp(0.07j * np.arange(ntaps))   # complex taps
+    tol = 1e-6
+    for n in (2_000_003, 3840 * M * 2 + M + 1, 2048 * M, 70_001):
+        k = _ffi.FirKernel(b, _ffi.code_of(dt))
+        xd = _ffi.DeviceArray(n + 1, dt).fill_noise(M + ntaps)
+        yd = _ffi.DeviceArray(n // M + 9, dt)
+        try:
+            x = xd.to_host(0, n).astype(np.complex128 if cplx else np.float64)
+            peak = None
+            for off in (0, 1):
+                xs = xd.window(off, n - off)
+                m = n - off
+                yd.write(np.full(n // M + 9, 7.0, dtype=dt))
+                with _ffi.option("fir_dn4k", 2):
+                    k.dn_dev(xs, yd.window(off, m // M), M)
+                got = yd.to_host(off, m // M)
+                assert np.all(yd.to_host(0, off) == 7.0) and np.all(yd.to_host(off + m // M, 8) == 7.0), ("wrote outside its floor(n / M) outputs", M, n, off)
+                xo = x[off:]
+                peak = np.max(np.abs(got))
+                if m <= 80_000:
+                    ref = orc.fir_filter(b, xo)[::M][:m // M]
+                    assert np.max(np.abs(got - ref)) <= tol * max(peak, np.max(np.abs(ref))), (M, n, off)
+                else:
+                    for o0 in (0, (m // M) // 2, m // M - 300):
+                        cnt = min(300, m // M - o0)
+                        lo = max(o0 * M - (ntaps - 1), 0)
+                        seg = orc.fir_filter(b, xo[lo:(o0 + cnt) * M])[o0 * M - lo:]
+                        assert np.max(np.abs(got[o0:o0 + cnt] - seg[::M][:cnt])) <= tol * peak, (M, n, off, o0)
+                if off == 0:
+                    whole = got
+            # streamed continuation: the second part with the first part's tail as history == the one-shot result
+            h0 = (n // 2 // M) * M
+            if h0 > ntaps:
+                yd.write(np.full(n // M + 9, 7.0, dtype=dt))
+                with _ffi.option("fir_dn4k", 2):
+                    k.dn_dev(xd.window(h0, n - h0), yd, M, n_hist=ntaps - 1)
+                cont = yd.to_host(0, (n - h0) // M)
+                assert np.max(np.abs(cont - whole[h0 // M:])) <= 2 * tol * np.max(np.abs(whole)), ("continuation", M, n)
         finally:
             xd.free()
             yd.free()
