@@ -107,12 +107,12 @@ namespace {
 struct OptEntry { const char *name; int Options::*field; };
 const OptEntry kOptTable[] = {
     {"device", &Options::device}, {"fir_algo", &Options::fir_algo}, {"dn_no_ols", &Options::dn_no_ols},
-    {"fir_mm", &Options::fir_mm}, {"fir_bx", &Options::fir_bx}, {"fir_no_sw", &Options::fir_no_sw}, {"bx_even_odd", &Options::bx_even_odd},
-    {"sw_no_tile", &Options::sw_no_tile}, {"sw_no_lpt", &Options::sw_no_lpt}, {"mm_ns", &Options::mm_ns},
-    {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, {"iir_no_unit", &Options::iir_no_unit},
-    {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, {"iir_no_k1r", &Options::iir_no_k1r},
-    {"k1r_wgs", &Options::k1r_wgs}, {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_split", &Options::iir_split}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up4k", &Options::fir_up4k}, {"fir_up4k_group", &Options::fir_up4k_group}, {"fir_up4k_dbg", &Options::fir_up4k_dbg}, {"fir_up4k_staged", &Options::fir_up4k_staged}, {"fir_up2k", &Options::fir_up2k}, {"fir_dn4k", &Options::fir_dn4k}, {"fir_up_pair", &Options::fir_up_pair}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, {"iir_par_dbg", &Options::iir_par_dbg}, {"shard_no_overlap", &Options::shard_no_overlap},
-    {"shard_reserve", &Options::shard_reserve}, {"shard_two_launches", &Options::shard_two_launches},
+    {"fir_mm", &Options::fir_mm}, {"fir_bx", &Options::fir_bx}, 
+    
+    {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, 
+    {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, 
+    {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up4k", &Options::fir_up4k}, {"fir_up4k_group", &Options::fir_up4k_group}, {"fir_up4k_staged", &Options::fir_up4k_staged}, {"fir_up2k", &Options::fir_up2k}, {"fir_dn4k", &Options::fir_dn4k}, {"fir_up_pair", &Options::fir_up_pair}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, 
+    {"shard_two_launches", &Options::shard_two_launches},
     {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
     {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline}, {"host_multi_slot", &Options::host_multi_slot},
 };
@@ -1574,7 +1574,7 @@ static int iir_create_common(int nsec, int order, const std::vector<double> &coe
     h->nsec = nsec;
     h->order = order;
     h->coef = coef;
-    if (nsec > 12 || (nsec > 8 && opt().iir_split)) {
+    if (nsec > 12 || nsec > 8) {
         // groups of at most 8 sections, as even as possible (10 -> 5 + 5): each a handle of its own, made from the CALLER's factorisation.
         // Between two groups the signal is stored in the handle's precision.  For float32 handles that rounding (6e-8 of the
         // INTERMEDIATE's peak, then amplified by the rest of the cascade) must stay below the float32 contract on the output: with
@@ -1642,7 +1642,7 @@ static int iir_create_common(int nsec, int order, const std::vector<double> &coe
         return SKDSP_OK;
     }
 single_group:
-    if (order == 2 && nsec >= 2 && !opt().iir_no_unit) {
+    if (order == 2 && nsec >= 2) {
         // unit-tail re-factorisation (see IirHandle): H_0' = H_0 * prod_{j>=1} b0_j,  H_k' = H_k / b0_k
         bool ok = true;
         for (int s = 0; s < nsec && ok; ++s) {

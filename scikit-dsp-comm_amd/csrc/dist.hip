@@ -279,7 +279,7 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
         // 8 KB halo crosses xGMI on a second stream; tile 0 follows once it has landed.
         int V = 0;
         if (h->dtype == SKDSP_C64 && rc().comm && fir_algo_for(h, n_local) == SKDSP_FIR_OLS &&
-            !opt().shard_no_overlap) {
+            true) {
             int r0 = fir_ols_tile_outputs(h, &V);
             if (r0) return r0;
         }
@@ -315,7 +315,7 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
             // the launch walks it last, behind a device flag that a one-thread kernel on the halo stream sets once the
             // RCCL receive is complete -- no second launch, no 1-workgroup tail (option shard_two_launches restores
             // that form: interior tiles, stream wait on the halo event, tile 0 as its own launch).
-            const int reserve = opt().shard_reserve;
+            const int reserve = 8;   // workgroup slots the persistent launch leaves to the RCCL send / recv kernel
             if (opt().shard_two_launches) {
                 SK_HIP(hipEventRecord(c.ev_halo, c.comm_stream));
                 r1 = fir_ols_launch(h, (char *)x_dev + (size_t)V * esz, n_local - V, V, (char *)y_dev + (size_t)V * esz, c.stream, 1, reserve);

@@ -27,15 +27,6 @@
 #include <numeric>
 #include <vector>
 
-#ifndef SK_BX_NT_ST
-#define SK_BX_NT_ST 1  // nontemporal output stores: 0.317 -> 0.312 ms (config 3), 0.1365 -> 0.1243 ms (127-tap float32); nontemporal window LOADS cost 25 %: neighbours share halos through the cache
-#endif
-#ifndef SK_BX_PRIO
-#define SK_BX_PRIO 1  // raised wave priority while stores and the window prefetch are issued: config 3 0.3214 -> 0.3154 ms (priority over the whole split / store / load phase, none at all, or the two workgroups of a CU taking turns: the same within 0.5 %)
-#endif
-#ifndef SK_BX_NT_LD
-#define SK_BX_NT_LD 0
-#endif
 
 namespace skdsp {
 
@@ -62,9 +53,6 @@ struct BxArgs {
     // s col mod 16 shifted by one): 2-way conflicts on a third of the reads, 42 % of the LDS cycles of L/M = 4/3
     // (s = 3).  With every second column both row sets hit the eight EVEN (odd) residues exactly once: none.
     int eo;
-#ifdef SK_BX_TRACE_BUILD  // developer build (tools/bx_trace.py): [workgroup][iteration < 64][wave][10]: 9 s_memtime stamps (the ninth: prefetched window arrived) + (XCC_ID << 32 | HW_ID) of one launch
-    unsigned long long *trace;
-#endif
 };
 
 // (a, b) -> three packed bf16 pairs, a in the low half: a = a1 + a2 + a3 exactly (24 = 3 x 8 mantissa bits).
@@ -72,19 +60,8 @@ struct BxArgs {
 // v_pk_add_f32 runs on the datapath the matrix pipe uses, so while the other workgroup of the CU is in its MFMA phase a packed
 // split does not advance at all (tools/bx_trace.py: the split of one workgroup ended ~240 clocks after the partner's last MFMA,
 // every window, which is what locked the two workgroups of a CU in phase).
-#ifndef SK_BX_PK_SPLIT
-#define SK_BX_PK_SPLIT 0
-#endif
 __device__ __forceinline__ void bx_split2(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3)
 {
-#if SK_BX_PK_SPLIT
-    v2f_bx v = {a, b};
-    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, v2bf_bx));
-    v2f_bx r = {a - __uint_as_float(p1 << 16), b - __uint_as_float(p1 & 0xffff0000u)};
-    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, v2bf_bx));
-    v2f_bx r2 = {r.x - __uint_as_float(p2 << 16), r.y - __uint_as_float(p2 & 0xffff0000u)};
-    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, v2bf_bx));
-#else
     auto cvt = [](float lo, float hi) -> unsigned {
         unsigned p;
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(lo), "v"(hi));
@@ -100,7 +77,6 @@ __device__ __forceinline__ void bx_split2(float a, float b, unsigned &p1, unsign
     p2 = cvt(ra, rb);
     const float sa = sub(ra, p2 << 16), sb = sub(rb, p2 & 0xffff0000u);
     p3 = cvt(sa, sb);
-#endif
 }
 
 __device__ __forceinline__ v4f_bx bx_mfma(uint4 a, uint4 b, v4f_bx c)
@@ -140,14 +116,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int u = min(tid + 256 * h, nunits - 1);
             const float4 *s4 = reinterpret_cast<const float4 *>(src + (size_t)u * 8 * C);
 #pragma unroll
-#if SK_BX_NT_LD
-            for (int w = 0; w < F4; ++w) {
-                const v4f_bx q = __builtin_nontemporal_load(reinterpret_cast<const v4f_bx *>(s4) + w);
-                pre[h][w] = make_float4(q.x, q.y, q.z, q.w);
-            }
-#else
             for (int w = 0; w < F4; ++w) pre[h][w] = s4[w];
-#endif
         }
     };
     // 8 samples v[0 .. 8 C) -> one 16-byte row per bf16 piece and component at unit u
@@ -220,16 +189,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int64_t wnext = wdx + gridDim.x;
     fast = wnext < nwin && interior(wnext);
     if (fast) load_window(wnext);
-#ifdef SK_BX_TRACE_BUILD
-    unsigned long long stamp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int it = 0;
-#define BX_STAMP(k) stamp[k] = __builtin_readcyclecounter();
-#else
-#define BX_STAMP(k)
-#endif
 #pragma unroll 1
     for (; wdx < nwin;) {
-        BX_STAMP(0)
         const int64_t S0 = wdx * a.NS;  // first column of this window
         v4f_bx big[RT][C], small[RT][C];
         // column (within the window) of tile ct, tile row r
@@ -258,15 +219,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             read_b(0, 0);
             read_b(0, 1);
             read_b(0, 2);
-#ifdef SK_BX_NOMFMA
-#define SK_BX(PA, PB, ACC)                                                                              \
-    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int c = 0; c < C; ++c)    \
-        ACC[rt][c][0] += __uint_as_float(areg[kb][rt][PA].x ^ b[c][PB].x);
-#else
 #define SK_BX(PA, PB, ACC)                                                                              \
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int c = 0; c < C; ++c)    \
         ACC[rt][c] = bx_mfma(b[c][PB], areg[kb][rt][PA], ACC[rt][c]);
-#endif
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 SK_BX(2, 0, small)
@@ -301,24 +256,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 return r;
             };
             auto put = [&](int rt, int i, int off) __attribute__((always_inline)) {
-#if SK_BX_NT_ST
                 if (CPLX) {
                     v2f_bx o = {sum(big[rt][0][i], small[rt][0][i]), sum(big[rt][C - 1][i], small[rt][C - 1][i])};
                     __builtin_nontemporal_store(o, reinterpret_cast<v2f_bx *>(yb + 2 * off));
                 } else {
                     __builtin_nontemporal_store(sum(big[rt][0][i], small[rt][0][i]), yb + off);
                 }
-#else
-                if (CPLX)
-                    *reinterpret_cast<float2 *>(yb + 2 * off) =
-                        make_float2(sum(big[rt][0][i], small[rt][0][i]), sum(big[rt][C - 1][i], small[rt][C - 1][i]));
-                else
-                    yb[off] = sum(big[rt][0][i], small[rt][0][i]);
-#endif
             };
-#ifdef SK_BX_NOSTORE
-            if (big[0][0][0] != 12345.678f) return;
-#endif
             // whole tile inside the output and all 16 RT rows in use (uniform): no per-store guards
             if ((a.RS & 15) == 0 && (int64_t)a.RS * (S0 + (a.eo ? 32 * (ct >> 1) + 32 : ct * 16 + 16)) <= a.n_out) {
 #pragma unroll
@@ -339,68 +283,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll 1
         for (; ct + 4 < ntiles; ct += 4) {
             mma_tile(ct);
-#if SK_BX_PRIO
             __builtin_amdgcn_s_setprio(3);
-#endif
             store_tile(ct);
-#if SK_BX_PRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
         }
-        BX_STAMP(1)
         const bool has_last = ct < ntiles;
         if (has_last) mma_tile(ct);
-        BX_STAMP(2)
         __syncthreads();  // everyone is done reading the planes
-        BX_STAMP(3)
         if (wnext < nwin) {
             if (fast) {
-#ifdef SK_BX_TRACE_BUILD
-#pragma unroll
-                for (int h = 0; h < UPT; ++h)
-#pragma unroll
-                    for (int w = 0; w < F4; ++w) asm volatile("" : "+v"(pre[h][w].x), "+v"(pre[h][w].y), "+v"(pre[h][w].z), "+v"(pre[h][w].w));
-                BX_STAMP(8)
-#endif
                 store_window();
             } else {
                 stage_window_slow(wnext);
             }
         }
-        BX_STAMP(4)
-#if SK_BX_PRIO
         __builtin_amdgcn_s_setprio(3);
-#endif
         if (has_last) store_tile(ct);
-#if SK_BX_PRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
-        BX_STAMP(5)
         __syncthreads();  // the planes hold window w+1
-        BX_STAMP(6)
         const int64_t wnext2 = wnext + gridDim.x;
         fast = wnext2 < nwin && interior(wnext2);
-#if SK_BX_PRIO
         __builtin_amdgcn_s_setprio(3);
-#endif
         if (fast) load_window(wnext2);
-#if SK_BX_PRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef SK_BX_TRACE_BUILD
-        BX_STAMP(7)
-        if (a.trace && lane == 0 && it < 64) {
-            unsigned long long *t = a.trace + (((size_t)blockIdx.x * 64 + it) * 4 + wave) * 10;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) t[k] = stamp[k];
-            t[9] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        }
-        ++it;
-#endif
         wdx = wnext;
         wnext = wnext2;
     }
-#undef BX_STAMP
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -560,35 +468,15 @@ int fir_bx_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L,
     a.NS = bx_columns(t, cplx ? 2 : 1, n_out);
     SK_CHECK(a.NS > 0, SKDSP_ERR_UNSUPPORTED, "fir_bx: window does not fit LDS (L=%d M=%d)", L, M);
     a.win = ((a.q_ds * (a.NS - 1) + 32 * t->KB) + 7) / 8 * 8;
-    a.eo = ((a.q_ds / 8) & 1) && a.NS % 32 == 0 && opt().bx_even_odd ? 1 : 0;
+    a.eo = ((a.q_ds / 8) & 1) && a.NS % 32 == 0 ? 1 : 0;
     const size_t lds = (size_t)(cplx ? 6 : 3) * (a.win * 2 + 16);  // (+ a dump row per plane)
     const int64_t ncols = (n_out + a.RS - 1) / a.RS;
     const int64_t nwin = (ncols + a.NS - 1) / a.NS;
     const unsigned grid = (unsigned)std::min<int64_t>(nwin, (int64_t)2 * ctx().num_cus);  // persistent: two per CU
-#ifdef SK_BX_TRACE_BUILD
-    a.trace = nullptr;
-    const char *trace_path = getenv("SKDSP_BX_TRACE");
-    if (trace_path) {
-        SK_HIP(hipMalloc((void **)&a.trace, (size_t)grid * 64 * 4 * 10 * 8));
-        SK_HIP(hipMemsetAsync(a.trace, 0, (size_t)grid * 64 * 4 * 10 * 8, s));
-    }
-#endif
     const bool ok = cplx ? bx_dispatch<true>(t->KB, t->RT, grid, lds, s, x, t->At, a, y)
                          : bx_dispatch<false>(t->KB, t->RT, grid, lds, s, x, t->At, a, y);
     SK_CHECK(ok, SKDSP_ERR_UNSUPPORTED, "fir_bx: no kernel for %d blocks x %d row tiles", t->KB, t->RT);
     SK_HIP(hipGetLastError());
-#ifdef SK_BX_TRACE_BUILD
-    if (trace_path) {
-        std::vector<unsigned long long> hbuf((size_t)grid * 64 * 4 * 10);
-        SK_HIP(hipMemcpyAsync(hbuf.data(), a.trace, hbuf.size() * 8, hipMemcpyDeviceToHost, s));
-        SK_HIP(hipStreamSynchronize(s));
-        SK_HIP(hipFree(a.trace));
-        if (FILE *f = fopen(trace_path, "wb")) {
-            fwrite(hbuf.data(), 8, hbuf.size(), f);
-            fclose(f);
-        }
-    }
-#endif
     return SKDSP_OK;
 }
 

@@ -686,7 +686,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     const size_t lds_cap = 80 * 1024;  // <= 2 workgroups per CU of the 160 KiB LDS
 
     // ---- preferred: register sliding window (R consecutive outputs per thread) ----
-    const bool no_sw = opt().fir_no_sw != 0;  // developer A/B switch
+    const bool no_sw = false;
     if (!no_sw) {
         const int Rmax = dtype_double(h->dtype) && dtype_complex(h->dtype) ? 4 : 8;
         for (int R = Rmax; R >= 2; R >>= 1) {
@@ -702,7 +702,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
             // interpolation by more than 4 classes: the whole output run of the workgroup is staged
             // in LDS (needs 256*R*Lp elements next to the window) -- prefer a smaller R that fits
             const size_t tile_bytes = (size_t)256 * R * a.Lp * esz;
-            const bool want_tile = a.Lp > 4 && !opt().sw_no_tile;  // up to 4 classes the per-class row transposition measured faster
+            const bool want_tile = a.Lp > 4;  // up to 4 classes the per-class row transposition measured faster
             const bool tile_fits = (size_t)phys * esz + 4096 + tile_bytes <= lds_cap;
             if (want_tile && !tile_fits && R > 2) continue;
             const FirHandle::SwTab *tab = nullptr;
@@ -721,8 +721,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
             }
             w.out_off = -1;
             w.out_tile = 0;
-            const bool lpt_ok = h->dtype == SKDSP_C64 && !h->taps_complex && R == 8 && w.tap_off >= 0 && a.Lp >= 2 && a.Lp <= 4 &&
-                                !opt().sw_no_lpt;
+            const bool lpt_ok = h->dtype == SKDSP_C64 && !h->taps_complex && R == 8 && w.tap_off >= 0 && a.Lp >= 2 && a.Lp <= 4;
             if (lpt_ok) {
                 w.out_off = 0;  // unrolled-class kernel: its output tiles alias the (finished) window image
             } else if (want_tile && tile_fits) {

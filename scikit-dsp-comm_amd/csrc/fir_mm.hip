@@ -247,7 +247,7 @@ int fir_mm_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L,
     a.n = n; a.n_hist = n_hist; a.n_out = n_out;
     a.q_ds = t->q * t->DS; a.RS = t->RS; a.K4 = t->K4; a.U0 = t->U0;
     // column blocks per workgroup: as many as a 64 KiB window holds (2 workgroups per CU), at most 512
-    int NS = opt().mm_ns > 0 ? opt().mm_ns : 256;
+    int NS = 256;
     while (NS > 64 && ((size_t)a.q_ds * (NS - 1) + 4 * a.K4) * 9 / 8 * esz > (size_t)63 * 1024) NS -= 64;
     const int64_t ncols = (n_out + a.RS - 1) / a.RS;
     while (NS > 64 && (ncols + NS - 1) / NS < 2 * ctx().num_cus) NS -= 64;  // small problems: more workgroups

@@ -23,27 +23,6 @@
 #include <cstdlib>
 #include <cstdio>
 
-#ifndef SKDSP_OLS_NOMEM
-#define SKDSP_OLS_NOMEM 0  // diagnostic: FFT/LDS work only, no x/y traffic (wrong results)
-#endif
-#ifndef SKDSP_OLS_HREG
-#define SKDSP_OLS_HREG 1  // this thread's 32 bins of H stay in registers across tiles
-#ifndef SKDSP_OLS_HSTREAM_DEC
-#define SKDSP_OLS_HSTREAM_DEC 1  // ... but for the last few float4 of them in the decimating-store kernels (see HS; 0: all 16 held, for A/B)
-#endif
-#endif
-#ifndef SKDSP_OLS_NT
-#define SKDSP_OLS_NT 1  // nontemporal x loads / y stores (streamed once): 0.300 -> 0.295 ms
-#endif
-#ifndef SKDSP_OLS_PRIO
-#define SKDSP_OLS_PRIO 1  // 1: raised wave priority while memory instructions are issued; 2: raised during the FFT phases (A/B builds)
-#endif
-#ifndef SKDSP_OLS_NT_LD
-#define SKDSP_OLS_NT_LD SKDSP_OLS_NT
-#endif
-#ifndef SKDSP_OLS_NT_ST
-#define SKDSP_OLS_NT_ST SKDSP_OLS_NT
-#endif
 
 namespace skdsp {
 
@@ -62,7 +41,6 @@ struct OlsArgs {
     cf *y;
     int64_t n, n_hist;
     const float4 *T1, *T2, *Hp;
-    unsigned long long *trace;  // developer phase timing (SKDSP_OLS_TRACE), else null
     int ov, V, a0;  // a0 = ov / 512: first stored 512-block
     int aligned;    // x and y element-aligned (8 bytes complex64, 4 bytes float32)
     int64_t ntiles;
@@ -120,29 +98,15 @@ __device__ __forceinline__ void load_tile(const OlsArgs &A, int64_t tile, int t,
 {
     const int64_t in0 = tile * A.V - A.ov;
     const bool interior = A.aligned && in0 >= -A.n_hist && in0 + kN <= A.n;
-#if SKDSP_OLS_NOMEM
-    if (A.n != -12345) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) v[i] = make_float2(t * 0.001f + i, (float)tile * 0.5f);
-        return;
-    }
-#endif
     if (interior) {
         // opaque copy of t: stops LICM from hoisting 16 loop-invariant 64-bit addresses (which
         // were then spilled and reloaded in front of every load)
         int tt = t;
         asm volatile("" : "+v"(tt));
-#if !SKDSP_OLS_NT_LD
-        const volatile float4 *xp = reinterpret_cast<const volatile float4 *>(A.x + in0);
-#endif
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-#if SKDSP_OLS_NT_LD
             const v4f_t nv = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(A.x + in0) + (unsigned)(a * 256 + tt));
             const float4 f = make_float4(nv.x, nv.y, nv.z, nv.w);
-#else
-            const float4 f = vld(xp + (unsigned)(a * 256 + tt));  // 512 complex = 256 float4
-#endif
             v[2 * a] = lo(f);
             v[2 * a + 1] = hi(f);
         }
@@ -168,9 +132,6 @@ template <bool DEC> __device__ __forceinline__ void store_tile(const OlsArgs &A,
 {
     const int64_t out0 = tile * A.V;
     const bool full = A.aligned && out0 + A.V <= A.n;
-#if SKDSP_OLS_NOMEM
-    if (A.n != -12345) return;
-#endif
     if (DEC) {
         // decimating store: the full-rate convolution is computed (it is memory-bound, and cheaper than
         // Ntaps/dec direct taps per kept sample once Ntaps/dec exceeds a few dozen), 1/dec of it leaves.  The tile's kept outputs are
@@ -221,13 +182,9 @@ template <bool DEC> __device__ __forceinline__ void store_tile(const OlsArgs &A,
             constexpr int A0 = decltype(a0c)::value;
 #pragma unroll
             for (int a = A0; a < 16; ++a) {
-#if SKDSP_OLS_NT_ST
                 v4f_t nv;
                 nv.x = v[2 * a].x; nv.y = v[2 * a].y; nv.z = v[2 * a + 1].x; nv.w = v[2 * a + 1].y;
                 __builtin_nontemporal_store(nv, reinterpret_cast<v4f_t *>(yp) + (a - A0) * 256);
-#else
-                yp[(a - A0) * 256] = pack(v[2 * a], v[2 * a + 1]);
-#endif
             }
         };
         switch (A.a0) {
@@ -540,14 +497,14 @@ template <bool DEC> __device__ __forceinline__ void store_tile_real_up(const Ols
 // UP: multirate_FIR.up for phases too long for the polyphase kernels (see OlsArgs::up): the same walk over (tile, phase) pairs, H of the
 // pair's phase fetched per pair, outputs stored with stride up.  Neighbouring walk indices are the phases of one input tile: they run on
 // one XCD at one time, so the tile is fetched from HBM once and the strided stores of its phases meet in that XCD's L2.
-template <bool TRACE, bool REAL, bool DEC, bool UP = false, bool XR = false>   // XR: real signal into the complex tile (see load_tile_xr)
+template <bool REAL, bool DEC, bool UP = false, bool XR = false>   // XR: real signal into the complex tile (see load_tile_xr)
 __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 {
     __shared__ float4 lds[kLdsUnits + 2 * kT2Units];
     // Decimating store (.dn): the last HS of the thread's 16 H registers are fetched per tile (HS x 4 KiB from L2, requested at the top of the
     // tile, used behind the forward transform).  With all 16 held across tiles hipcc spilled four of them and reloaded them from scratch INSIDE
     // the H multiply: four round trips per tile on the critical path.
-    constexpr int HS = (DEC && !UP && SKDSP_OLS_HREG && SKDSP_OLS_HSTREAM_DEC) ? (REAL ? 4 : 5) : 0;   // (the counts that leave no spill)
+    constexpr int HS = (DEC && !UP) ? (REAL ? 4 : 5) : 0;   // (the counts that leave no spill)
     float4 *T2f = lds + kLdsUnits;            // [k2][q]
     float4 *T2t = lds + kLdsUnits + kT2Units; // [qq][k2] (transposed copy for the inverse)
     const int t = threadIdx.x;
@@ -565,37 +522,14 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 
     __syncthreads();
     int it = 0;
-#ifndef SKDSP_OLS_NO_XCD_MAP
-#define SKDSP_OLS_NO_XCD_MAP 0
-#endif
-#ifndef SKDSP_OLS_PREFETCH
-#define SKDSP_OLS_PREFETCH 1  // request x(tile+1) after the H multiply: 0.311 -> 0.300 ms
-#endif
-    // TRACE build: s_memtime stamps at phase boundaries (each preceded by a full wait so
-    // the phases do not overlap) for wave 0 of the first 16 workgroups, first 8 tiles.
-#define SK_STAMP(k)                                                                          \
-    do {                                                                                     \
-        if (TRACE) {                                                                         \
-            asm volatile(SK_WAIT ::: "memory");                                             \
-            if (t == 0 && blockIdx.x < 16 && it < 8)                                         \
-                A.trace[((size_t)blockIdx.x * 8 + it) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
-        }                                                                                    \
-    } while (0)
-#if SKDSP_OLS_PREFETCH
-#define SK_WAIT "s_waitcnt lgkmcnt(0)"
-#else
-#define SK_WAIT "s_waitcnt vmcnt(0) lgkmcnt(0)"
-#endif
     // This thread's 32 bins of H stay in registers for every tile it processes: streaming
     // them per tile cost 64 KiB of L2->CU traffic per tile, a third of everything the CU's
     // vector-memory pipe (~10 B/clk) had to move, and that pipe is what bounds the kernel.
-#if SKDSP_OLS_HREG
     float4 hh[16];
-#endif
     // XCD-aware walk: workgroup w runs on XCD w % 8, so give each XCD a contiguous run of tiles per
     // round -- neighbouring tiles share Ntaps-1 input samples, which then hit that XCD's L2 instead of
     // being fetched twice from HBM (the 7.6 % of traffic above the algorithmic bytes)
-    int64_t tile = (gridDim.x % 8 == 0 && !SKDSP_OLS_NO_XCD_MAP) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8
+    int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8
                                                                  : (int64_t)blockIdx.x;
     // (sharded launches walk tile 0 last: walk index w stands for tile w + 1, the last index for tile 0)
     const bool t0_last = A.halo_flag != nullptr;
@@ -605,11 +539,8 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         return t0_last ? (w + 1 < A.ntiles ? w + 1 : 0) : w;
     };
     auto phase_of = [&](int64_t w) -> int { return (int)((unsigned)w % (unsigned)A.up); };
-#if SKDSP_OLS_HREG
     if (!UP) load_H(t, A.Hp, hh);
-#endif
     cf v[32];
-#if SKDSP_OLS_PREFETCH
     if (tile < A.ntiles) {
         if (t0_last && phys(tile) == 0) wait_halo(A);
         load_any<REAL, XR>(A, phys(tile), t, v);
@@ -628,14 +559,7 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
                      "v"(v[i + 3].x), "v"(v[i + 3].y), "v"(v[i + 4].x), "v"(v[i + 4].y), "v"(v[i + 5].x), "v"(v[i + 5].y),
                      "v"(v[i + 6].x), "v"(v[i + 6].y), "v"(v[i + 7].x), "v"(v[i + 7].y));
     }
-#endif
     for (; tile < A.ntiles; tile += gridDim.x, ++it) {
-        SK_STAMP(0);
-#if !SKDSP_OLS_PREFETCH
-        if (t0_last && phys(tile) == 0) wait_halo(A);
-        load_any<REAL, XR>(A, phys(tile), t, v);
-#endif
-#if SKDSP_OLS_HREG
         if (HS > 0) {
             int tt = t;   // (opaque: the requests stay inside the tile loop)
             asm volatile("" : "+v"(tt));
@@ -651,62 +575,26 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 #pragma unroll
             for (int j = 0; j < 16; ++j) hh[j] = vld(hp + (unsigned)(j * 256 + tt));
         }
-#endif
-#if !SKDSP_OLS_HREG
-        float4 hh[16];
-        {
-            int tt = t;
-            asm volatile("" : "+v"(tt));
-            const volatile float4 *hp = reinterpret_cast<const volatile float4 *>(A.Hp);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) hh[j] = vld(hp + (unsigned)(j * 256 + tt));
-        }
-#endif
-        SK_STAMP(1);
-#if defined(SKDSP_OLS_COPYONLY)
-        {   // measurement aid: the tile walk's memory traffic alone (loads, prefetch, stores)
-            const int64_t next = tile + gridDim.x;
-            cf nx[32];
-            if (next < A.ntiles) load_any<REAL, XR>(A, phys(next), t, nx);
-            store_any<REAL, DEC>(A, phys(tile), t, v, lds);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) v[i] = nx[i];
-            continue;
-        }
-#endif
         if (REAL) fwd_pass1_real(t, v, tw, lds); else fwd_pass1(t, v, tw, lds);
-        SK_STAMP(2);
         __syncthreads();
-        SK_STAMP(3);
         cf Z[32];
         fwd_pass23(t, T2f, lds, Z);
-        SK_STAMP(4);
         mul_H(hh, Z);
-#if SKDSP_OLS_PREFETCH
         // x of the next tile: requested now, consumed at the top of the next iteration -- in flight during the
         // whole inverse FFT (requested one phase earlier, right behind pass 1: 61 spilled VGPRs in the float32 variant and
         // 0.240 vs 0.236 ms for complex64: not kept).  The wave runs at raised priority while it issues memory
         // instructions (here and at the stores): -1.1 % (0.2314 vs 0.2339 ms, alternating runs)
         const int64_t next = tile + gridDim.x;
         cf nx[32];
-#if SKDSP_OLS_PRIO == 1
         __builtin_amdgcn_s_setprio(3);
-#endif
         if (next < A.ntiles) {
             if (t0_last && phys(next) == 0) wait_halo(A);  // (uniform: the whole workgroup owns that tile)
             load_any<REAL, XR>(A, phys(next), t, nx);
         }
-#if SKDSP_OLS_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
-#endif
-#endif
         inv_pass32(t, T2t, lds, Z);
-        SK_STAMP(5);
         __syncthreads();
-        SK_STAMP(6);
         inv_pass1(t, tw, lds, v);
-        SK_STAMP(7);
-#if SKDSP_OLS_PREFETCH
         // Have hipcc wait for the prefetch HERE, while only loads are outstanding (they have had the
         // whole inverse FFT to land).  Otherwise the wait sits at the top of the next tile, behind the
         // stores below, and vmcnt -- which retires in order -- makes every tile start with a full
@@ -724,12 +612,7 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
                          "v"(nx[i + 6].x), "v"(nx[i + 6].y), "v"(nx[i + 7].x), "v"(nx[i + 7].y)
                          : "memory");
         }
-#endif
-#if SKDSP_OLS_PRIO == 1
         __builtin_amdgcn_s_setprio(3);
-#elif SKDSP_OLS_PRIO == 2
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if (UP) {
             if (!DEC && A.up_pitch) {   // phases as rows: the plain filter's full-width stores into row phase_of(tile)
                 OlsArgs B = A;
@@ -743,20 +626,11 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         } else {
             store_any<REAL, DEC>(A, phys(tile), t, v, lds);
         }
-#if SKDSP_OLS_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
-#elif SKDSP_OLS_PRIO == 2
-        __builtin_amdgcn_s_setprio(2);
-#endif
-        SK_STAMP(8);
-#if SKDSP_OLS_PREFETCH
 #pragma unroll
         for (int i = 0; i < 32; ++i) v[i] = nx[i];
-#endif
         __syncthreads();  // every wave is done reading the image before the next tile overwrites it
-        SK_STAMP(9);
     }
-#undef SK_STAMP
 }
 
 bool fir_ols_supported(const FirHandle *h)
@@ -922,34 +796,12 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     if (reserve_wgs < 0) reserve_wgs = opt().ols_reserve;
     if (reserve_wgs > 0 && grid > 8 * (int64_t)reserve_wgs) grid -= reserve_wgs;
     if (grid > ntiles) grid = ntiles;
-    A.trace = nullptr;
-#ifdef SKDSP_OLS_TRACE_BUILD  // developer build only (-DSKDSP_OLS_TRACE_BUILD): not part of the product launch path
-    if (const char *tp = getenv("SKDSP_OLS_TRACE")) {  // developer diagnostics: dump phase stamps of one launch
-        const size_t nw = 16 * 8 * 16;
-        unsigned long long *d = nullptr;
-        SK_HIP(hipMalloc((void **)&d, nw * 8));
-        SK_HIP(hipMemsetAsync(d, 0, nw * 8, s));
-        A.trace = d;
-        hipLaunchKernelGGL((ols_tile_kernel<true, false, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
-        std::vector<unsigned long long> hbuf(nw);
-        SK_HIP(hipMemcpyAsync(hbuf.data(), d, nw * 8, hipMemcpyDeviceToHost, s));
-        SK_HIP(hipStreamSynchronize(s));
-        SK_HIP(hipFree(d));
-        if (FILE *f = fopen(tp, "w")) {
-            for (size_t r = 0; r < 16 * 8; ++r) {
-                for (int k = 0; k < 10; ++k) fprintf(f, "%llu%s", hbuf[r * 16 + k], k == 9 ? "\n" : ",");
-            }
-            fclose(f);
-        }
-        return SKDSP_OK;
-    }
-#endif
     if (A.dec > 1) {
-        if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
-        else hipLaunchKernelGGL((ols_tile_kernel<false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        if (real) hipLaunchKernelGGL((ols_tile_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((ols_tile_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
     } else {
-        if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
-        else hipLaunchKernelGGL((ols_tile_kernel<false, false, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        if (real) hipLaunchKernelGGL((ols_tile_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((ols_tile_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, s, A);
     }
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
@@ -1022,7 +874,6 @@ static int up_walk(FirHandle *h, int kind, const void *x, int64_t n, int64_t n_h
     A.up_pbs = xr ? 8 : esz;
     A.up_pb0 = kind == 2 ? (L - 1) * esz : 0;
     A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr;
-    A.trace = nullptr;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     const int reserve_wgs = opt().ols_reserve;
     if (reserve_wgs > 0 && grid > 8 * (int64_t)reserve_wgs) grid -= reserve_wgs;
@@ -1031,13 +882,13 @@ static int up_walk(FirHandle *h, int kind, const void *x, int64_t n, int64_t n_h
         // (L = 2 is one pair: "row 0" of the rows form IS the output, written with the plain complex filter's full-width stores.  The
         // instantiation that also keeps H in registers -- UP = false -- compiles to 18 spilled registers with the real-input loads.)
         if (L == 2 && A.up_pitch == 0) A.up_pitch = 1;
-        hipLaunchKernelGGL((ols_tile_kernel<false, false, false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        hipLaunchKernelGGL((ols_tile_kernel<false, false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
     } else if (dec > 1) {
-        if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
-        else hipLaunchKernelGGL((ols_tile_kernel<false, false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        if (real) hipLaunchKernelGGL((ols_tile_kernel<true, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((ols_tile_kernel<false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
     } else {
-        if (real) hipLaunchKernelGGL((ols_tile_kernel<false, true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
-        else hipLaunchKernelGGL((ols_tile_kernel<false, false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        if (real) hipLaunchKernelGGL((ols_tile_kernel<true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((ols_tile_kernel<false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
     }
     SK_HIP(hipGetLastError());
     return SKDSP_OK;

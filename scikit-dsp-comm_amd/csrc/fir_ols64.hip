@@ -23,21 +23,12 @@
 #include <vector>
 #include <cmath>
 
-#ifndef SK_OLS64_L2_TOUCH
-#define SK_OLS64_L2_TOUCH 1
-#endif
 
 namespace skdsp {
 
 namespace {
 
 typedef double2 cdd;
-#ifndef SK_OLS64_HREG
-#define SK_OLS64_HREG -1  // -1: per kernel (see below); 0 / 1: force
-#endif
-#ifndef SK_OLS64_WPE
-#define SK_OLS64_WPE 2
-#endif
 
 constexpr int kN64 = 4096;
 constexpr int kPitch64 = 16 * 17;  // complex elements per k1 row of the LDS image
@@ -160,19 +151,17 @@ struct Ols64Args {
 // XR: a REAL signal into the complex tile (imaginary part zero) -- multirate_FIR.up of float64 signals with an even L runs its phases in pairs,
 //     x * (h_2k + i h_2k+1) = y_2k + i y_2k+1: one complex pass whose output IS the interleaved pair as one 16-byte element (see fir_ols.hip)
 template <bool REAL, bool DEC, bool UP = false, bool XR = false>
-__global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args A)
+__global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
 {
     __shared__ cdd img[16 * kPitch64];
-#if SK_OLS64_L2_TOUCH
     __shared__ unsigned touch_lds[4 * 128];   // landing area of the next tile's cache-line touches (never read)
-#endif
     const int t = threadIdx.x;
     const int hi4 = t >> 4, lo4 = t & 15;
     const cdd w1 = A.W1[t];        // W_4096^t            (pass 1: t = 16 b + c)
     const cdd w2 = A.W2[lo4];      // W_256^c             (pass 2: thread (k1, c))
     // This thread's 16 bins of H: in registers for the whole launch in the complex kernel (0.691 vs 0.738 ms at 2^26), streamed
     // from L2 per tile in the two-real-tiles kernel (registers there: 0.487 vs 0.401 ms -- its loads and stores need more of them)
-    constexpr bool HREG = !UP && (SK_OLS64_HREG < 0 ? !REAL : SK_OLS64_HREG != 0);
+    constexpr bool HREG = !UP && !REAL;
     cdd hh[HREG ? 16 : 1];
     if (HREG) {
 #pragma unroll
@@ -249,7 +238,6 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
         int tl = t, th = t, ts = t;
         asm volatile("" : "+v"(tl));
         load_tile(tin, tl, v);
-#if SK_OLS64_L2_TOUCH
         // Two-real-tiles kernel: the next pair's 512 cache lines are pulled towards the L2 while this one is transformed: one
         // 4-byte load per line, two per thread, straight into a scratch corner of the LDS (global_load_lds_dword: no
         // destination VGPR -- a register prefetch of the 16 values spilled in every form tried, and so did two live "touch"
@@ -275,7 +263,6 @@ __global__ __launch_bounds__(256, SK_OLS64_WPE) void ols64_tile_kernel(Ols64Args
                 }
             }
         }
-#endif
         // ---- pass 1: DFT16 over a, twiddle W_4096^(t k1) (running power), write [k1][b][c] ----
         dft16_f(v);   // X[k1] at v[P16(k1)]
         {

@@ -45,7 +45,6 @@ struct Up2kArgs {
     int staged;              // rows leave through the staging image (needs an even number of passes and no tail)
     unsigned upr_magic;      // staged: ceil(65536 / (row_bytes / 16)): lane / units-per-row by multiply-high
     int64_t ntiles;
-    int dbg;                 // developer timing switch (option fir_up4k_dbg; wrong results): 1 = no stores
 };
 
 __device__ __forceinline__ bool up2k_interior(const Up2kArgs &A, int64_t tile)
@@ -123,7 +122,6 @@ template <int PH> struct Up2kStage {
 // lane offset per store.
 template <int PH> __device__ __forceinline__ void up2k_store_staged(const Up2kArgs &A, int64_t tile, int cnt, int t, const cf *out, float4 *stage)
 {
-    if (A.dbg & 1) return;
     constexpr int RU = Up2kStage<PH>::kRowUnits;
     int tt = t;   // (opaque copy: nothing of the store addressing is hoisted out of the tile loop)
     asm volatile("" : "+v"(tt));
@@ -161,7 +159,6 @@ template <int PH> __device__ __forceinline__ void up2k_store_staged(const Up2kAr
 // passes.  The pieces of a row still leave back to back.
 template <int PH, bool TAIL> __device__ __forceinline__ void up2k_store_direct(const Up2kArgs &A, int64_t tile, int g0, int cnt, int t, const cf *out)
 {
-    if (A.dbg & 1) return;
     int tt = t;
     asm volatile("" : "+v"(tt));
     const int64_t out0 = tile * A.V;
@@ -372,7 +369,6 @@ int fir_up2k_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int 
     A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & (esz - 1)) == 0;
     A.ntiles = (n + p->V - 1) / p->V;
     SK_CHECK(A.ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_up2k: too many tiles");
-    A.dbg = opt().fir_up4k_dbg;
     // passes held per thread: the smallest instantiation that takes the row in ONE group; longer rows go in groups of 12 (float32
     // and complex64 alike: 96-byte pieces)
     const int PH = p->passes <= 4 ? 4 : (p->passes <= 8 ? 8 : 12);

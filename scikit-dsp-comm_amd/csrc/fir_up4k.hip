@@ -41,7 +41,6 @@ struct Up4kArgs {
     int aligned;             // x and y element-aligned
     int64_t ntiles;
     int staged;              // four-pass groups leave through the wave-private staging image (option fir_up4k_staged; 0 = as they lie, for A/B)
-    int dbg;                 // developer timing switches (option fir_up4k_dbg; wrong results): 1 = no stores, 2 = only the first group computed, stored into every group's place
 };
 
 // x[in0 + 256 a + t] -> v[a]; zero outside [-n_hist, n).  XR: a float32 signal into the real parts (the imaginary parts are
@@ -88,7 +87,6 @@ template <bool XR> __device__ __noinline__ void up4k_load_edge(const void *x, in
 // y + i row_bytes + 8 g0 (the last 4 of them missing when TAIL: the odd L's single last phase of a float32 signal).
 template <int CNT, bool TAIL> __device__ __forceinline__ void up4k_store(const Up4kArgs &A, int64_t tile, int g0, int t, const cf *out)
 {
-    if (A.dbg & 1) return;
     int a0 = A.a0;   // (opaque copies: nothing of the store addressing is hoisted out of the tile loop)
     asm volatile("" : "+s"(a0));
     int tt = t;
@@ -138,12 +136,11 @@ template <int CNT, bool TAIL> __device__ __forceinline__ void up4k_store(const U
 // carries 16 bytes into each of 64 different 64-byte blocks once the rows are 64 bytes or longer, and the vector L1 forwards
 // one write request per block: measured 278 clocks per store instruction at L = 8 and 379 at L = 12 against 68 at L = 4 (two lanes
 // per block) -- 0.27 and 0.37 ms per 2^26 outputs for the stores alone, whether or not a row's pieces leave at the same time
-// (option fir_up4k_dbg = 2).  Through the staging image lane l of the i-th instruction writes half l & 1 of sample 32 i + (l >> 1):
+//.  Through the staging image lane l of the i-th instruction writes half l & 1 of sample 32 i + (l >> 1):
 // half the requests at any L, and at L = 4 whole 64-byte blocks (1 KiB of consecutive output per instruction).  Wave-private:
 // the 64 lanes of a wave own the 64 samples they stage, LDS operations of a wave execute in order -- no barrier.
 __device__ __forceinline__ void up4k_store4_staged(const Up4kArgs &A, int64_t tile, int g0, int t, const cf *out, float4 *stage /* this wave's 128 float4 */)
 {
-    if (A.dbg & 1) return;
     int a0 = A.a0;   // (opaque copies: nothing of the store addressing is hoisted out of the tile loop)
     asm volatile("" : "+s"(a0));
     int tt = t;
@@ -329,12 +326,6 @@ template <bool XR, int G> __global__ __launch_bounds__(256, 2) void up4k_kernel(
             if constexpr (XR) {
                 if (tail) store(std::true_type{}); else store(std::false_type{});
             } else {
-                if (A.dbg & 2) {   // timing aid (wrong results): the first group's results into EVERY group's place, back to back, no other group computed:
-                                   // what the stores cost when a sample's whole row leaves in one burst
-                    for (int gg = G; gg < A.passes; gg += G) up4k_store<G, false>(A, tile, gg, t, out);   // (unstaged on purpose: the measurement this switch exists for)
-                    store(std::false_type{});
-                    break;
-                }
                 store(std::false_type{});
             }
         }
@@ -420,7 +411,6 @@ int fir_up4k_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int 
     A.odd_tail = p->pairs && (L & 1);
     A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & (esz - 1)) == 0;
     A.ntiles = (n + p->V - 1) / p->V;
-    A.dbg = opt().fir_up4k_dbg;
     A.staged = opt().fir_up4k_staged;
     SK_CHECK(A.ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_up4k: too many tiles");
     int64_t grid = 2 * (int64_t)ctx().num_cus;

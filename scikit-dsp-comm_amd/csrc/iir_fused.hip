@@ -6,9 +6,6 @@
 #include <cstdlib>
 #include <vector>
 
-#ifndef SK_FUSED_DIAG
-#define SK_FUSED_DIAG 0  // developer builds: 1 no recurrence, 2 no scan / correction, 4 no MFMAs, 8 no look-back poll (wrong results)
-#endif
 
 namespace skdsp {
 
@@ -118,7 +115,6 @@ struct FusedArgs {
     int dec;                     // > 1: only y[k * dec] is stored (at y[k]), k < n_keep / dec  (.dn: no full-rate result in HBM)
     int dec_dq, dec_dr;          // (rows between a thread's staged segments x T) div / mod dec
     int64_t n_keep;              // (n / dec) * dec
-    unsigned long long *trace;   // developer builds (-DSK_FUSED_TRACE_BUILD): [nseg][16] phase stamps, else null
 };
 
 template <int NSEC, typename IO, bool UNIT>
@@ -150,20 +146,6 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
     for (int i = tid; i < (T / 4) * 64; i += kIirThreads) gl[i] = gtab[i];
     __syncthreads();
     const int seg = seg_sh;
-#ifdef SK_FUSED_TRACE_BUILD  // developer build: s_memrealtime (100 MHz) stamps of thread 0 at the phase boundaries (tools/fused_trace.py)
-#define SK_STAMP(slot) do { if (a.trace && tid == 0) a.trace[(size_t)seg * 16 + (slot)] = wall_clock64(); } while (0)
-    const long long c0_trace = clock64();
-#else
-#define SK_STAMP(slot) do { } while (0)
-#endif
-    SK_STAMP(0);
-#ifdef SK_FUSED_STAGGER
-    // the two workgroups of a CU start together and would walk their phases in lock step (memory | matrix | LDS | VALU);
-    // delaying every second one of the first round by about half a segment's duration lets one's memory phases run
-    // under the other's arithmetic for the rest of the launch (workgroups b and b + 256 share a CU: 8 XCDs x 32 CUs)
-    if (seg < 2 * 256 && ((seg >> SK_FUSED_STAGGER_BIT) & 1))
-        for (int i = 0; i < SK_FUSED_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     const IO *x = reinterpret_cast<const IO *>(a.x) + (size_t)bat * a.batch_stride;
     IO *y = reinterpret_cast<IO *>(a.y) + (size_t)bat * a.batch_stride;
     const int64_t row0 = (int64_t)seg * kIirThreads;   // first chunk of the segment
@@ -229,7 +211,7 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
             const double ga = gl[(p * (kPiece / 4) + s) * 64 + lane];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                if (!(SK_FUSED_DIAG & 4)) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, (double)xs[g * 16 * St::pitch + 4 * s], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, (double)xs[g * 16 * St::pitch + 4 * s], acc[g], 0, 0, 0);
         }
         wave_lds_sync();
     }
@@ -240,7 +222,6 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
     // FMAs per thread and level on the VALU), per thread on the VALU for smaller ones (the MFMA tiles are 16 x 16 whatever D
     // is: one biquad 0.121 -> 0.147 ms, order 8 0.138 -> 0.148 ms with them; 8 biquads 0.197 -> 0.182 ms, float64 0.321 -> 0.277)
     if constexpr (MSCAN) {
-        SK_STAMP(1);
         // ---- S: from-rest inclusive scan of each wave's 64 chunk maps, on the matrix pipe (scan_level_rows) ----------------
         {
             AOps A0 = load_aops(pwa, 0, lane), A1 = load_aops(pwa, 1, lane);
@@ -284,7 +265,6 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
         }
         __syncthreads();
 
-        SK_STAMP(2);
         // ---- L: publish the segment's end state from rest, fetch the predecessor's ------------------------------------
         if (tid < 2 * D) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(aggsh[tid >> 1]);
@@ -292,7 +272,7 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
             unsigned long long *slot = a.lb + ((size_t)bat * a.nseg + seg) * 32 + tid;
             __hip_atomic_store(slot, ((unsigned long long)a.epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned got = 0;
-            if (seg > 0 && !(SK_FUSED_DIAG & 8)) {
+            if (seg > 0) {
                 const unsigned long long *src = a.lb + ((size_t)bat * a.nseg + seg - 1) * 32 + tid;
                 unsigned long long g = 0;
                 int spins = 0;
@@ -317,7 +297,6 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
         }
         __syncthreads();
 
-        SK_STAMP(3);
         // ---- C: the exact state e_w at the start of wave w = M^(64 w) c + P_(w-1); correction columns M^(jl+1) e_w by doubling;
         //         z_j = (scan + correction) of the column to the left -----------------------------------------------------------
         v4d_t cm;
@@ -378,7 +357,6 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
         for (int d = 0; d < D; ++d) z[d] = lane ? sc[d * kIirThreads + tid - 1] : esh[wave * 16 + d];
 
     } else {
-    SK_STAMP(1);
         // chunk end states from the accumulator layout (col = lane & 15, row = (lane >> 4) + 4 reg) to one thread per chunk
     #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -394,7 +372,6 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
         __syncthreads();
 
         // ---- S: from-rest inclusive scan of the 256 chunk maps ---------------------------------------------------------
-        if (SK_FUSED_DIAG & 2) a.n_lv = 0;
     #pragma unroll 1
         for (int l = 0; l < a.n_lv; ++l) {
             const int s = 1 << l;
@@ -415,7 +392,6 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
     #pragma unroll
         for (int d = 0; d < D; ++d) z[d] = tid ? sc[d * kIirThreads + tid - 1] : 0.0;
 
-        SK_STAMP(2);
         // ---- L: publish the segment's end state from rest, fetch the predecessor's ------------------------------------
         if (tid < 2 * D) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(sc[(tid >> 1) * kIirThreads + kIirThreads - 1]);
@@ -423,7 +399,7 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
             unsigned long long *slot = a.lb + ((size_t)bat * a.nseg + seg) * 32 + tid;
             __hip_atomic_store(slot, ((unsigned long long)a.epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned got = 0;
-            if (seg > 0 && !(SK_FUSED_DIAG & 8)) {
+            if (seg > 0) {
                 const unsigned long long *src = a.lb + ((size_t)bat * a.nseg + seg - 1) * 32 + tid;
                 unsigned long long g = 0;
                 int spins = 0;
@@ -446,7 +422,6 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
         }
         __syncthreads();
 
-        SK_STAMP(3);
         // ---- C: z_j = p_(j-1) + M^j c ------------------------------------------------------------------------------------
         if ((wave << 6) < (1 << a.n_lv)) {  // (M^j c is below 1e-30 of c for j >= 2^n_lv)
             double u[D];
@@ -470,7 +445,6 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
         }
 
     }
-    SK_STAMP(4);
     // ---- B: the recurrence over the register-resident chunk; outputs leave through the LDS image --------------------
     const int64_t cj = row0 + tid;
     const bool zf_owner = a.zf != nullptr && cj == (a.n - 1) / T;
@@ -496,10 +470,9 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
         }
 #pragma unroll
         for (int k = 0; k < kPiece; ++k) {
-            const double yv = (SK_FUSED_DIAG & 1) ? (double)xr[k] + z[0] : cascade_step<NSEC, ORD, UNIT>(cf, z, (double)xr[k]);
+            const double yv = cascade_step<NSEC, ORD, UNIT>(cf, z, (double)xr[k]);
             xr[k] = (IO)yv;
         }
-        SK_STAMP(5 + 2 * p);
         wave_lds_sync();  // the wave's rows are free (its previous piece's stores have read them)
 #pragma unroll
         for (int sgi = 0; sgi < St::segs; ++sgi) {
@@ -556,16 +529,7 @@ __global__ __launch_bounds__(kIirThreads, 2) void iir_fused_kernel(FusedArgs a, 
                     if (g + e < a.n) y[g + e] = tmp[e];
             }
         }
-        SK_STAMP(6 + 2 * p);
     }
-#ifdef SK_FUSED_TRACE_BUILD
-    SK_STAMP(13);
-    if (a.trace && tid == 0) {
-        a.trace[(size_t)seg * 16 + 14] = clock64() - c0_trace;
-        a.trace[(size_t)seg * 16 + 15] = (unsigned long long)blockIdx.x << 32;
-    }
-#endif
-#undef SK_STAMP
 }
 
 // ---- interleaved complex signals ---------------------------------------------------------------------------------
@@ -921,17 +885,8 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
     // the look-back array stay consistent and later calls on this handle are unaffected
     a.err = async_err_dev(kAsyncErrIirLookback);
     SK_CHECK(a.err, SKDSP_ERR_HIP, "iir: no host-mapped error word");
-    a.trace = nullptr;
     for (int b = 0; b < (interleaved ? 1 : nbatch); ++b) p->ticket_count[b] += (unsigned long long)nseg;
     const dim3 grid((unsigned)nseg, (unsigned)(interleaved ? 1 : nbatch));
-#ifdef SK_FUSED_TRACE_BUILD  // developer build only: dump the phase stamps of every segment of this launch (real signals)
-    const char *trace_path = interleaved ? nullptr : getenv("SKDSP_FUSED_TRACE");
-    if (trace_path) {
-        SK_HIP(hipMalloc((void **)&a.trace, (size_t)nseg * 16 * 8));
-        SK_HIP(hipMemsetAsync(a.trace, 0, (size_t)nseg * 16 * 8, s));
-    }
-    if (const char *e = getenv("SKDSP_FUSED_NLV")) a.n_lv = atoi(e);  // timing experiment (wrong results)
-#endif
     if (interleaved) {
 #define SK_FUSEDC(N)                                                                                                  \
     case N: {                                                                                                        \
@@ -942,9 +897,7 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
         break;                                                                                                       \
     }
         switch (h->nsec) {
-#ifndef SK_FUSED_ONLY8
             SK_FUSEDC(1) SK_FUSEDC(2) SK_FUSEDC(3) SK_FUSEDC(4) SK_FUSEDC(5) SK_FUSEDC(6) SK_FUSEDC(7)
-#endif
             SK_FUSEDC(8)
             default: SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "iir: single-pass scan takes 1..8 biquads");
         }
@@ -961,27 +914,12 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
         break;                                                                                                       \
     }
     switch (h->nsec) {
-#ifndef SK_FUSED_ONLY8  // (developer builds instantiate the 8-biquad kernels only)
         SK_FUSED(1) SK_FUSED(2) SK_FUSED(3) SK_FUSED(4) SK_FUSED(5) SK_FUSED(6) SK_FUSED(7)
-#endif
         SK_FUSED(8)
         default: SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "iir: single-pass scan takes 1..8 biquads");
     }
 #undef SK_FUSED
     SK_HIP(hipGetLastError());
-#ifdef SK_FUSED_TRACE_BUILD
-    if (trace_path) {
-        std::vector<unsigned long long> hbuf((size_t)nseg * 16);
-        SK_HIP(hipMemcpyAsync(hbuf.data(), a.trace, hbuf.size() * 8, hipMemcpyDeviceToHost, s));
-        SK_HIP(hipStreamSynchronize(s));
-        SK_HIP(hipFree(a.trace));
-        if (FILE *f = fopen(trace_path, "w")) {
-            for (int64_t r = 0; r < nseg; ++r)
-                for (int q = 0; q < 16; ++q) fprintf(f, "%llu%s", hbuf[(size_t)r * 16 + q], q == 15 ? "\n" : ",");
-            fclose(f);
-        }
-    }
-#endif
     return SKDSP_OK;
 }
 

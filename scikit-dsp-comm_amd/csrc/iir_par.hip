@@ -48,18 +48,10 @@ constexpr int kParMaxK = 8;   // look-back depth served (segments the filter may
 // words of K segments live behind the scan exchange inside the wave's stage image, which is twice as large for float64)
 constexpr int par_max_k(bool dbl) { return dbl ? 8 : 4; }
 constexpr int kParTickets = 16;   // segment dispensers per launch
-#ifndef SK_PAR_T32
-#define SK_PAR_T32 128   // samples per lane (float32 signals); float64 signals: half
-#endif
-#ifndef SK_PAR_PRIO
-#define SK_PAR_PRIO 3
-#endif
-#ifndef SK_PAR_PRIO_ST
-#define SK_PAR_PRIO_ST 1
-#endif
-#ifndef SK_PAR_OCC
-#define SK_PAR_OCC 2     // waves per SIMD the register budget is set for
-#endif
+constexpr int SK_PAR_T32 = 128;   // samples per lane (float32 signals); float64 signals: half
+constexpr int SK_PAR_PRIO = 3;      // wave priority in front of the recurrence (float32 signals, 6 - 8 biquads: DESIGN.md)
+constexpr int SK_PAR_PRIO_ST = 1;   // ... and on a piece's way out through the image
+constexpr int SK_PAR_OCC = 2;     // waves per SIMD the register budget is set for
 
 template <int NSEC> struct ParCoef {
     double na1[NSEC], na2[NSEC];   // -a1, -a2
@@ -97,10 +89,6 @@ struct ParArgs {
     int up;
     unsigned up_magic;           // ceil(2^32 / up): (v * up_magic) >> 32 = v / up for the v < 2^15 met here
     int64_t n_in;
-#ifdef SK_PAR_TRACE_BUILD        // developer build (tools/par_trace.py): [segment ticket][16]: 12 s_memtime stamps, HW_ID, XCC_ID
-    unsigned long long *trace;
-#endif
-    int dbg;                     // developer timing switches (option iir_par_dbg; wrong results): 1 no MFMAs, 2 no recurrence, 4 no scan / look-back, 8 no stores, 16 no loads
 };
 
 // v += P * left, P = the level's 2 x 2 block of every section (row-major), through the scalar cache
@@ -146,13 +134,6 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 
     // (the wave index through readfirstlane: segment, row and every base address are then wave-uniform SGPR values)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef SK_PAR_TRACE_BUILD
-    unsigned long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define PAR_STAMP(k) stamp[k] = __builtin_readcyclecounter();
-#else
-#define PAR_STAMP(k)
-#endif
-    PAR_STAMP(0)
     // Everything in front of the recurrence runs at raised priority -- where the recurrence is what the launch waits for.  The
     // recurrence of the wave that shares this SIMD is a dense v_fma_f64 stream and, being the older wave, wins every issue
     // arbitration: a younger wave's G x products (the same FP64 datapath), its scan and its correction then crawl
@@ -182,7 +163,6 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     __syncthreads();   // the only workgroup barrier
     const int tk = __builtin_amdgcn_readfirstlane(base_sh) + wave;
     if (tk >= a.total) return;
-    PAR_STAMP(1)
     const int row = a.nseg == a.total ? 0 : __builtin_amdgcn_readfirstlane(tk / a.nseg), seg = tk - row * a.nseg;
     const IO *x = reinterpret_cast<const IO *>(a.x) + (size_t)row * a.x_stride;
     IO *y = reinterpret_cast<IO *>(a.y) + (size_t)row * a.y_stride;
@@ -314,11 +294,10 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     const int c = lane & 15, j = lane >> 4;
     IO *myrow = stage + lane * St::pitch;
     // (every piece of the segment is requested up front: the landing registers are the ones the chunk will occupy anyway)
-    if (ld_fast && !(a.dbg & 16)) {
+    if (ld_fast) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) load_piece(p);
     }
-    PAR_STAMP(2)
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         if (ld_fast) {
@@ -333,7 +312,6 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 #pragma unroll
         for (int sgi = 0; sgi < St::segs; ++sgi) xq[p * St::segs + sgi] = *reinterpret_cast<const xv_t *>(myrow + sgi * St::elems);
         const IO *xs = stage + c * St::pitch + j;
-        if (!(a.dbg & 1))
 #pragma unroll
         for (int s = 0; s < kPiece / 4; ++s) {
             const double ga = gl[(p * (kPiece / 4) + s) * 64 + lane];
@@ -343,7 +321,6 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         wave_lds_sync();
     }
 
-    PAR_STAMP(3)
     // chunk end states from the accumulator layout (column = lane & 15, state row = (lane >> 4) + 4 reg) to one lane per chunk
     double v[D];
 #pragma unroll
@@ -364,7 +341,6 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     }
 
     // ---- S: from-rest inclusive scan of the wave's 64 chunk states ------------------------------------------------------
-    if (a.dbg & 4) a.n_lv = 0;
 #pragma unroll 1
     for (int l = 0; l < a.n_lv; ++l) {
         const int s = LS << l;
@@ -382,7 +358,6 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         for (int k = 0; k < NSEC; ++k) *reinterpret_cast<v2d_t *>(E + (k * 64 + lane) * 2) = v2d_t{v[2 * k], v[2 * k + 1]};
         wave_lds_sync();
     }
-    PAR_STAMP(4)
     double z[D];
 #pragma unroll
     for (int k = 0; k < NSEC; ++k) {
@@ -400,7 +375,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         __hip_atomic_store(a.lb + (size_t)tk * GR + lane, ((unsigned long long)a.epoch << 32) | half, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (seg > 0 && !(a.dbg & 4)) {
+    if (seg > 0) {
 #pragma unroll 1
         for (int k0 = 0; k0 < a.K; k0 += 64 / GR) {
             const int back = k0 + (CPLX ? 0 : (lane >> 5)) + 1;   // this lane's predecessor distance
@@ -425,7 +400,6 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
             if (back <= KMAX) cw[(back - 1) * GR + gi] = got;
         }
         wave_lds_sync();
-        PAR_STAMP(5)
 
         // ---- C: z_j += Phi^j c,  c = sum_m Psi^m P_(s-1-m) ---------------------------------------------------------------
         double u[D];
@@ -465,7 +439,6 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         }
     }
     wave_lds_sync();  // the image is free again
-    PAR_STAMP(6)
     if (PRIO) __builtin_amdgcn_s_setprio(0);
 
     // ---- B: the recurrence over the register-resident chunk; outputs leave through the LDS image ------------------------
@@ -498,7 +471,6 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     const unsigned olim = olim64 <= 0 ? 0u : (olim64 > 0x7fffffff ? 0x7fffffffu : (unsigned)olim64);   // outputs of this row from dec_q0 on
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        if (!(a.dbg & 2))
 #pragma unroll
         for (int k = 0; k < kPiece; ++k) {
             const double xd = (double)xq[(p * kPiece + k) / St::elems][(p * kPiece + k) % St::elems];
@@ -516,9 +488,6 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
             }
             xq[(p * kPiece + k) / St::elems][(p * kPiece + k) % St::elems] = (IO)yv;
         }
-#ifdef SK_PAR_TRACE_BUILD
-        if (p < 4) { stamp[7 + (p < 4 ? p : 3)] = __builtin_readcyclecounter(); }
-#endif
         if (compact) {
 #pragma unroll
             for (int sgi = 0; sgi < St::segs; ++sgi) {
@@ -544,7 +513,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         for (int sgi = 0; sgi < St::segs; ++sgi) *reinterpret_cast<xv_t *>(myrow + sgi * St::elems) = xq[p * St::segs + sgi];
         wave_lds_sync();
         if (!DEC && interior) {
-            if (!(a.dbg & 8)) {
+            {
                 // (all reads of the image first, into the registers the piece has just left: issued one behind the other they cost
                 // one LDS round trip; hipcc otherwise cycles two staging vectors through four read -> wait -> store rounds)
                 pre_t outq[St::per_thread];
@@ -657,18 +626,6 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 #pragma unroll 1
         for (int i = lane; i < cnt; i += 64) __builtin_nontemporal_store(stage[i + (i >> 5)], yo + i);
     }
-#ifdef SK_PAR_TRACE_BUILD
-    PAR_STAMP(11)
-    if (a.trace && lane == 0) {
-        unsigned long long *t = a.trace + (size_t)tk * 16;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) t[k] = stamp[k];
-        t[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        t[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        t[14] = blockIdx.x;
-    }
-#endif
-#undef PAR_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------------- host side
@@ -960,15 +917,6 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
     a.up = up > 1 ? up : 1;
     a.up_magic = a.up > 1 ? (unsigned)((((unsigned long long)1 << 32) + a.up - 1) / a.up) : 0u;
     a.n_in = a.up > 1 ? n / a.up : n;
-    a.dbg = opt().iir_par_dbg;
-#ifdef SK_PAR_TRACE_BUILD
-    a.trace = nullptr;
-    const char *trace_path = getenv("SKDSP_PAR_TRACE");
-    if (trace_path) {
-        SK_HIP(hipMalloc((void **)&a.trace, (size_t)total * 16 * 8));
-        SK_HIP(hipMemsetAsync(a.trace, 0, (size_t)total * 16 * 8, s));
-    }
-#endif
     a.n_keep = (n / a.dec) * a.dec;
     {
         const int64_t step = (int64_t)(64 / Stage<IO>::segs) * T;   // samples between a lane's staged segments
@@ -997,26 +945,12 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
         break;                                                                                                          \
     }
     switch (h->nsec) {
-#ifndef SK_FUSED_ONLY8
         SK_PAR(1) SK_PAR(2) SK_PAR(3) SK_PAR(4) SK_PAR(5) SK_PAR(6) SK_PAR(7)
-#endif
         SK_PAR(8)
         default: SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "iir: parallel-form scan takes 1..8 biquads");
     }
 #undef SK_PAR
     SK_HIP(hipGetLastError());
-#ifdef SK_PAR_TRACE_BUILD
-    if (trace_path) {
-        std::vector<unsigned long long> hbuf((size_t)total * 16);
-        SK_HIP(hipMemcpyAsync(hbuf.data(), a.trace, hbuf.size() * 8, hipMemcpyDeviceToHost, s));
-        SK_HIP(hipStreamSynchronize(s));
-        SK_HIP(hipFree(a.trace));
-        if (FILE *f = fopen(trace_path, "wb")) {
-            fwrite(hbuf.data(), 8, hbuf.size(), f);
-            fclose(f);
-        }
-    }
-#endif
     return SKDSP_OK;
 }
 

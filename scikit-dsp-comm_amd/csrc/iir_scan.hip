@@ -36,12 +36,6 @@
 // algorithmic bytes = 8 B per f32 sample (4 in + 4 out).
 #include "iir_common.hpp"
 
-#ifndef SK_IIR_NT_ST
-#define SK_IIR_NT_ST 1   // nontemporal y stores in K3: config 4 0.2011 -> 0.1875 ms (same box, alternating)
-#endif
-#ifndef SK_IIR_NT_STC
-#define SK_IIR_NT_STC 0  // ... in the interleaved complex K3: no gain (0.470 vs 0.458-0.47 ms)
-#endif
 
 // SK_SCAN_PART: this file is compiled twice so that its ~150 kernel instantiations (the long pole of the build: 136 s in one
 // piece) compile side by side: 1 = host side + the float32 kernels (build/iir_scan.o), 2 = the float64 kernels and their dispatch
@@ -278,15 +272,11 @@ __global__ __launch_bounds__(kIirThreads) void iir_chunk_kernel(IirArgs a, Coef<
                     dr_run += a.dec_dr;
                     if (dr_run >= a.dec) { dr_run -= a.dec; ++dq_run; }
                 } else if (interior || g + St::elems <= a.n) {
-#if SK_IIR_NT_ST
                     {
                         typedef float nt4_t __attribute__((ext_vector_type(4)));
                         nt4_t q = {val.x, val.y, val.z, val.w};
                         __builtin_nontemporal_store(q, reinterpret_cast<nt4_t *>(y + g));
                     }
-#else
-                    *reinterpret_cast<float4 *>(y + g) = val;
-#endif
                 } else if (g < a.n) {
                     const IO *tmp = reinterpret_cast<const IO *>(&val);
 #pragma unroll
@@ -852,14 +842,7 @@ __global__ __launch_bounds__(kIirThreads) __attribute__((amdgpu_waves_per_eu(NSE
                 dr_run += a.dec_dr;
                 if (dr_run >= a.dec) { dr_run -= a.dec; ++dq_run; }
             } else if (interior || g + E / 2 <= a.n) {
-#if SK_IIR_NT_STC
-                {
-                    typedef float nt4_t __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store(*reinterpret_cast<const nt4_t *>(out), reinterpret_cast<nt4_t *>(y + 2 * g));
-                }
-#else
                 *reinterpret_cast<float4 *>(y + 2 * g) = *reinterpret_cast<const float4 *>(out);
-#endif
             } else if (g < a.n) {
 #pragma unroll
                 for (int e = 0; e < E; ++e)
@@ -1154,12 +1137,12 @@ static int launch_shape(IirHandle *h, IirArgs &a, int nbatch, int W, hipStream_t
     }
     if (fast) {
         const int64_t waves = (a.J + 15) / 16;
-        const bool no_k1r = opt().iir_no_k1r != 0;  // developer A/B switch
+        const bool no_k1r = false;
         const int np = (int)(a.T / kMmPiece);
         if (D <= 16 && !no_k1r && (np == 1 || np == 2 || np == 4) && a.T == (int64_t)np * kMmPiece) {
             // G in registers: persistent workgroups (3 per CU), each iteration 4 / np groups of 16 chunks
             const int64_t ngroups = waves, per_wg = 4 / np;
-            const int wgs_per_cu = opt().k1r_wgs > 0 ? opt().k1r_wgs : 2;
+            const int wgs_per_cu = 2;
             const unsigned grid = (unsigned)std::min<int64_t>((ngroups + per_wg - 1) / per_wg, (int64_t)wgs_per_cu * ctx().num_cus);
 #define SK_K1R(NP) hipLaunchKernelGGL((iir_k1r_kernel<IO, NP>), dim3(grid, nbatch), dim3(256), 0, s, (const IO *)a.x, a.n, a.J, a.batch_stride, (const double *)p->gt_dev, a.v, D)
             if (np == 1) SK_K1R(1);

@@ -37,19 +37,11 @@ struct Options {
     int dn_no_ols = 0;        // .dn never through the overlap-save decimating store
     int fir_mm = 1;           // 0: no matrix-pipe FIR kernels at all (register sliding-window kernels instead)
     int fir_bx = 1;           // 0: no bf16x3 matrix-pipe kernel (FP32 matrix pipe instead)
-    int bx_even_odd = 1;      // 0: fir_bx tiles of 16 consecutive columns also for odd column strides (bank conflicts; A/B switch)
-    int fir_no_sw = 0;        // skip the register sliding-window kernel (generic polyphase fallback)
-    int sw_no_tile = 0, sw_no_lpt = 0;
-    int mm_ns = 256;          // column blocks per workgroup of fir_mm_kernel
     int ols_reserve = 8;      // workgroup slots a persistent overlap-save launch leaves free
     int iir_planar = 0;       // complex IIR through two real planes (tests compare it with the interleaved kernels)
-    int iir_no_unit = 0;      // keep general biquads (no unit-tail re-factorisation)
     int iir_dn_full = 0;      // .dn as full-rate scan + downsample kernel
     int iir_no_mfma = 0;      // recurrence K1 instead of the matrix-pipe K1
-    int iir_no_k1r = 0;
-    int k1r_wgs = 2;
     int iir_two_pass = 0;     // 1: K1 + carries + K3 even where the single-pass scan applies; -1: single pass wherever it applies
-    int iir_split = 1;        // 0: cascades of 9 .. 12 biquads stay one launch sequence of the cascade kernels (no groups; more than 12 always split)
     int iir_par = 1;          // 0: never the parallel-form scan (iir_par.hip); the cascade kernels everywhere
     int iir_dn_compact = 1;   // 0: the parallel-form .dn keeps the image-and-pick store for every M (A/B switch)
     int fir_up_ols_min = 64;  // multirate_FIR.up: phases of at least this many taps MAY go through the overlap-save walk (the cost model
@@ -62,12 +54,8 @@ struct Options {
     int fir_dn4k = 1;         // multirate_FIR.dn through the frequency-domain decimator (fir_dn4k.hip): 1 where the cost model prefers it, 2 wherever it applies, 0 never (A/B switch)
     int fir_up4k_group = 4;   // phases (float32: pairs of phases) whose results a thread of that kernel holds before it stores: 4 (32 bytes per lane) or 2 (A/B switch)
     int fir_up4k_staged = 1;  // 0: four-pass groups of that kernel store each lane's own 32 bytes (A/B switch)
-    int fir_up4k_dbg = 0;     // developer timing switches of up4k_kernel (wrong results)
     int fir_updn_fused = 1;   // 0: L / M through the overlap-save walk writes all n L outputs to scratch and copies every M-th (A/B switch)
     int iir_up_fused = 1;     // 0: multirate_IIR.up / rate_change.up write the zero-stuffed signal first (A/B switch)
-    int iir_par_dbg = 0;      // developer timing switches of iir_par_kernel (ParArgs::dbg; wrong results)
-    int shard_no_overlap = 0; // sharded FIR: halo exchange in front of the whole filter instead of beside the interior tiles
-    int shard_reserve = 8;
     int shard_two_launches = 0; // sharded FIR: tile 0 as its own launch behind the halo event (instead of the in-kernel flag wait)
     int shard_self_halo = 0;    // test hook: a 1-rank communicator sends its tail to ITSELF (exercises the whole halo path on one GPU)
     int dist_force_comm = 0;  // build an RCCL communicator for a 1-rank job too (exercises the plumbing on one GPU)
