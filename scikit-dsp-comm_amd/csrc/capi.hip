@@ -255,7 +255,7 @@ static bool fir_needs_parts(const FirHandle *h, int L = 1)
     const int per_phase = (h->ntaps + L - 1) / L;
     return per_phase > (dtype_double(h->dtype) ? 2049 : 4097);
 }
-static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev);
+static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev, bool scratch_free = true);
 static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev, bool scratch_free = true);
 static int fir_filter_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev);
 static int ols_launch_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev, int dec = 1);
@@ -313,7 +313,7 @@ static int fir_parts_run(FirHandle *h, const void *x_dev, int64_t n, int64_t n_h
             rc = fir_algo_for(p, n_s) == SKDSP_FIR_OLS ? ols_launch_any(p, xs, n_s, n_hist - d, dst)
                                                         : fir_direct_launch(p, xs, n_s, n_hist - d, 1, 1, n_s, dst, s);
         else if (L == 1)
-            rc = fir_dn_any(p, xs, n_s, n_hist - d, M, dst);
+            rc = fir_dn_any(p, xs, n_s, n_hist - d, M, dst, false);   // (workspace slot 2 is `tmp` -- possibly `dst` -- here)
         else
             rc = fir_updn_any(p, xs, n_s, n_hist - d, L, M, dst, false);   // (workspace slot 2 is `tmp` here: no scratch-using forms; writes (n_s L) / M <= n_out outputs)
         if (rc) return rc;
@@ -328,8 +328,11 @@ static int ols_launch_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_
     return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, dec);
 }
 
-static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev)
+// scratch_free: workspace slot 2 may hold the full-rate result of the last-resort path (false inside fir_parts_run, which holds it: slot 3 then --
+// the planes of a complex IIR call, never alive during a FIR call)
+static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int M, void *y_dev, bool scratch_free)
 {
+    const int full_slot = scratch_free ? 2 : 3;
     if (fir_needs_parts(h)) return fir_parts_run(h, x_dev, (n / M) * M, n_hist, 1, M, y_dev);
     if (dtype_double(h->dtype)) {  // float64: the decimating overlap-save store beats Ntaps / M direct FP64 taps per kept sample early
         if (M > 1 && pick_fir_algo(h, n) == SKDSP_FIR_OLS && !opt().dn_no_ols && h->ntaps / M >= 24)
@@ -339,7 +342,7 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
             if (fir_ols64_supported(h) && !opt().dn_no_ols) return fir_ols64_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
             void *full = nullptr;
             const int64_t nk = (n / M) * M;
-            if ((rc = ws_reserve(2, (size_t)nk * dtype_size(h->dtype) + 256, &full))) return rc;
+            if ((rc = ws_reserve(full_slot, (size_t)nk * dtype_size(h->dtype) + 256, &full))) return rc;
             if ((rc = fir_filter_any(h, x_dev, nk, n_hist, full))) return rc;
             return downsample_launch(full, nk, M, 0, h->dtype, y_dev, ctx().stream);
         }
@@ -367,7 +370,7 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
         if (fir_ols_supported(h) && !opt().dn_no_ols) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
         void *full = nullptr;
         const int64_t nk = (n / M) * M;
-        if ((rc = ws_reserve(2, (size_t)nk * dtype_size(h->dtype) + 256, &full))) return rc;
+        if ((rc = ws_reserve(full_slot, (size_t)nk * dtype_size(h->dtype) + 256, &full))) return rc;
         if ((rc = fir_filter_any(h, x_dev, nk, n_hist, full))) return rc;
         return downsample_launch(full, nk, M, 0, h->dtype, y_dev, ctx().stream);
     }
@@ -415,11 +418,14 @@ static double fir_up_tile_ms(const FirHandle *h, int L, int kind, int *V_out)
     int N, ov;
     if (kind == 4) {   // 4096-point tile, groups of four passes: one group is one burst per row, more are pieces written far apart
         N = 4096; ov = std::max(256, (T - 1 + 255) / 256 * 256);
-        ms = cplx ? (passes <= 4 ? 0.175 : 0.30 + 0.012 * std::min(passes, 12)) : (passes <= 4 ? 0.089 : 0.10 + 0.005 * std::min(passes, 12));
+        // (one group: the forward transform is shared by `passes` inverse ones -- 0.2025 / 0.199 / 0.187 ms at 2 / 3 / 4 complex64 passes,
+        // 0.1225 / 0.0946 / 0.105 / 0.096 at 1 .. 4 float32 passes, profiles/r04/fir_up.txt)
+        static const double c4[5] = {0.0, 0.26, 0.2025, 0.199, 0.187}, f4[5] = {0.0, 0.1225, 0.0946, 0.105, 0.096};
+        ms = cplx ? (passes <= 4 ? c4[passes] : 0.30 + 0.012 * std::min(passes, 12)) : (passes <= 4 ? f4[passes] : 0.10 + 0.005 * std::min(passes, 12));
         ms *= (4096.0 - 256.0) / 4096.0;
     } else {           // 2048-point tile, up to twelve passes per thread
         N = 2048; ov = std::max(64, (T - 1 + 63) / 64 * 64);
-        if (passes <= 12) ms = cplx ? 0.185 + 0.0035 * passes : 0.085 + 0.0035 * passes;
+        if (passes <= 12) ms = cplx ? 0.19 + 0.0025 * passes : 0.085 + 0.0035 * passes;
         else ms = cplx ? 0.36 : 0.16;
         if (passes % 2) ms *= 1.07;   // (an odd row: every lane stores its own pieces)
         ms *= (2048.0 - 64.0) / 2048.0;
@@ -436,6 +442,7 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
     int floor_eff = std::abs(floor_t);   // (many phases: the polyphase kernels lose their reuse early -- let the cost model see shorter phases too)
     if (floor_t > 0 && L > 64) floor_eff = std::max(8, floor_t / 8);
     else if (floor_t > 0 && L > 16) floor_eff = std::max(8, floor_t / 4);
+    if (M == 1 && floor_t > 0 && fir_up_tile_kind(h, L)) floor_eff = std::min(floor_eff, 24);   // (the tile interpolators cross over with the polyphase kernels at short phases already)
     if (floor_t == 0 || T < floor_eff || n < 8192 || !(dbl ? fir_ols64_up_supported(h, L) : fir_ols_up_supported(h, L))) return false;
     if (M > 1 && L > 64) return false;   // (the every-M-th store's exact-division range; the scratch + copy form is not worth it there)
     if (floor_t < 0) return true;
@@ -460,6 +467,9 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
         base = cplx ? 0.23 : 0.125;
         ols = cplx ? 0.27 + 0.022 * std::min(Lf, 20.0) : 0.13 + 0.018 * std::min(Lf, 28.0);
         poly = cplx ? (bx ? 0.06 + 0.0011 * T : 0.02 + 0.0037 * T) : (bx ? 0.055 + 0.0005 * T : 0.03 + 0.0018 * T);
+        // (the matrix-pipe kernel's row tiles grow with L: measured against the L <= 4 line, 48 taps per phase: x 1.14 at L = 8, x 1.8 - 2.2 at L = 12)
+        if (bx && L > 4) poly *= L <= 8 ? 1.0 + 0.035 * (Lf - 4.0) : 1.14 + 0.2 * (Lf - 8.0);
+        if (!bx && L > 8 && L <= 16) poly *= 1.0 + 0.05 * (Lf - 8.0);   // (48 taps per phase: 0.116 modelled, 0.1395 measured at L = 12)
         if (!bx && T > 256) poly *= std::max(1.0, Lf / 4.0);
         else if (L > 16 && !bx) poly *= 1.0 + Lf / 12.0;   // (one tap table per phase: the polyphase kernels lose their reuse)
         copy = cplx ? 0.10 : 0.06;
@@ -547,8 +557,31 @@ static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hi
     return rc;
 }
 
+// A call from rest over n < Ntaps samples computes y[m] = sum_(k <= m) b[k] x[m - k], m < n: taps b[n ...] are never reached.  It runs on a
+// copy of the filter cut to the next power of two >= n (at most log2(Ntaps) copies per handle) -- the same outputs exactly, less work, and
+// the rounding of a float32 engine (a few 1e-8 of sum |b| max |x|: the FFT engines round against the WHOLE filter) shrinks with the taps
+// that matter.  (Found by the differential test at north_star's bound without its former factor 2: 17 rows of 100 samples through a
+// 1024-tap low-pass, whose first 100 taps are its tail -- 1.7e-6 of the tiny start-up transient before, far inside 1e-6 after.)
+static FirHandle *fir_head(FirHandle *h, int64_t n)
+{
+    if (n >= h->ntaps || n < 1) return h;
+    int keep = 1;
+    while (keep < n) keep <<= 1;
+    if (keep >= h->ntaps) return h;
+    for (FirHandle *t : h->heads)
+        if (t->ntaps == keep) { t->algo = h->algo; return t; }
+    const int comp = h->taps_complex ? 2 : 1;
+    FirHandle *t = new FirHandle();
+    t->kind = H_FIR; t->dtype = h->dtype; t->slot = h->slot; t->taps_complex = h->taps_complex; t->algo = h->algo;
+    t->ntaps = keep;
+    t->taps_host.assign(h->taps_host.begin(), h->taps_host.begin() + (size_t)keep * comp);
+    h->heads.push_back(t);
+    return t;
+}
+
 static int fir_filter_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, void *y_dev)
 {
+    if (n_hist == 0 && n < h->ntaps) h = fir_head(h, n);
     if (fir_needs_parts(h)) return fir_parts_run(h, x_dev, n, n_hist, 1, 1, y_dev);
     if (pick_fir_algo(h, n) == SKDSP_FIR_OLS) return ols_launch_any(h, x_dev, n, n_hist, y_dev);
     return fir_direct_launch(h, x_dev, n, n_hist, 1, 1, n, y_dev, ctx().stream);
@@ -1479,10 +1512,12 @@ static int fir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M
 // rest: every output sees exactly the window a launch over its row alone would see (zeros in front of every row), so the
 // results agree to the kernels' rounding (the overlap-save tile boundaries fall elsewhere).  Host form: one pitched copy in, one launch, one pitched copy out;
 // device form: the two pitched copies are device-to-device.  Costs (Ntaps-1)/n extra samples.
-static int64_t fir_rows_pitch(const FirHandle *h, int64_t n) { return (int64_t)round_up((size_t)(n + h->ntaps - 1), 4); }
+constexpr size_t kRowsBlockBudget = (size_t)16 << 30;   // bytes of the staged block of an N-D call (its output block is as large again)
+static int64_t fir_rows_pitch(FirHandle *h, int64_t n) { return (int64_t)round_up((size_t)(n + fir_head(h, n)->ntaps - 1), 4); }
 
 static int fir_rows_run(FirHandle *h, int64_t n, int64_t nrow, int64_t pitch, void *xp, void *yp)
 {
+    h = fir_head(h, n);   // (rows shorter than the filter: only the first n taps are ever reached)
     const size_t esz = dtype_size(h->dtype);
     // zeros between the rows (the last row needs none behind it)
     if (nrow > 1)
@@ -1502,6 +1537,10 @@ int skdsp_fir_filter_rows(skdsp_handle hh, const void *x, int64_t n, int64_t nro
     const size_t esz = dtype_size(h->dtype);
     const int64_t pitch = fir_rows_pitch(h, n);
     const size_t total = (size_t)nrow * (size_t)pitch * esz;
+    // one block holds every row behind its zeros: refused beyond what a pitched copy takes / a sane staging budget (the caller then filters
+    // row by row, each through the chunk pipeline)
+    SK_CHECK((size_t)pitch * esz * 2 < ((size_t)1 << 31) && total <= kRowsBlockBudget, SKDSP_ERR_UNSUPPORTED,
+             "fir_filter_rows: %lld rows of %lld samples do not fit one staged block (%zu bytes)", (long long)nrow, (long long)n, total);
     void *base = nullptr, *yp = nullptr;
     const bool wide = h->wide_out && !dtype_double(h->dtype);
     int rc = ws_reserve(0, kHeadroomBytes + (wide ? 2 : 1) * total + 256, &base);
@@ -1532,6 +1571,9 @@ int skdsp_fir_filter_rows_dev(skdsp_handle hh, const void *x_dev, int64_t n, int
     const size_t esz = dtype_size(h->dtype);
     const int64_t pitch = fir_rows_pitch(h, n);
     const size_t total = (size_t)nrow * (size_t)pitch * esz;
+    SK_CHECK((size_t)pitch * esz < ((size_t)1 << 31) && (size_t)x_stride * esz < ((size_t)1 << 31) && (size_t)y_stride * esz < ((size_t)1 << 31) &&
+                 total <= kRowsBlockBudget, SKDSP_ERR_UNSUPPORTED,
+             "fir_filter_rows_dev: %lld rows of %lld samples do not fit one staged block (%zu bytes)", (long long)nrow, (long long)n, total);
     void *base = nullptr, *yp = nullptr;
     int rc = ws_reserve(0, kHeadroomBytes + total + 256, &base);
     if (rc) return rc;
@@ -1574,7 +1616,7 @@ static int iir_create_common(int nsec, int order, const std::vector<double> &coe
     h->nsec = nsec;
     h->order = order;
     h->coef = coef;
-    if (nsec > 12 || nsec > 8) {
+    if (nsec > 8) {
         // groups of at most 8 sections, as even as possible (10 -> 5 + 5): each a handle of its own, made from the CALLER's factorisation.
         // Between two groups the signal is stored in the handle's precision.  For float32 handles that rounding (6e-8 of the
         // INTERMEDIATE's peak, then amplified by the rest of the cascade) must stay below the float32 contract on the output: with
@@ -1599,19 +1641,28 @@ static int iir_create_common(int nsec, int order, const std::vector<double> &coe
             auto l1 = [&](const std::vector<double> &v) { double a = 0.0; for (double q : v) a += std::fabs(q); return a; };
             std::vector<double> imp(NH, 0.0);
             imp[0] = 1.0;
-            std::vector<double> whole = imp;
-            run(0, nsec, whole);
-            const double T = l1(whole);
             const int ng8 = (nsec + 7) / 8;
-            double worst = 0.0;
-            std::vector<double> head = imp;
-            for (int g = 0, s0 = 0; g + 1 < ng8; ++g) {
-                const int cnt = nsec / ng8 + (g < nsec % ng8 ? 1 : 0);
-                run(s0, s0 + cnt, head);
-                s0 += cnt;
-                std::vector<double> tail = imp;
-                run(s0, nsec, tail);
-                worst = std::max(worst, l1(head) * l1(tail) / std::max(T, 1e-300));
+            // the boundaries' costs ADD UP (ng8 - 1 of them), so their sum is what is bounded; the l1 norms behind every boundary come from
+            // ONE backward pass (sections commute: the tail from boundary g is the sections of group g applied to the tail from boundary
+            // g + 1), the ones in front of it from one forward pass: O(nsec NH) in all.  Cascades of more than 256 sections are not
+            // analysed (seconds of host work inside handle creation): they take the float64 twin.
+            double worst = 1e300;
+            if (nsec <= 256) {
+                std::vector<int> first(ng8 + 1, 0);
+                for (int g = 0; g < ng8; ++g) first[g + 1] = first[g] + nsec / ng8 + (g < nsec % ng8 ? 1 : 0);
+                std::vector<double> tail_l1(ng8 + 1, 0.0), v = imp;
+                for (int g = ng8 - 1; g >= 1; --g) {   // v = impulse response of the sections [first[g], nsec)
+                    run(first[g], first[g + 1], v);
+                    tail_l1[g] = l1(v);
+                }
+                run(first[0], first[1], v);
+                const double T = l1(v);
+                std::vector<double> head = imp;
+                worst = 0.0;
+                for (int g = 0; g + 1 < ng8; ++g) {
+                    run(first[g], first[g + 1], head);
+                    worst += l1(head) * tail_l1[g + 1] / std::max(T, 1e-300);
+                }
             }
             if (!(worst <= 16.0)) {
                 if (nsec <= 12) goto single_group;      // one launch sequence of the cascade kernels: float64 between ALL sections

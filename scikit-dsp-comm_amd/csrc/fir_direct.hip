@@ -570,6 +570,7 @@ FirHandle::~FirHandle()
     if (ols64) fir_ols64_free(ols64);
     for (auto &u : ols64_up) fir_ols64_free(u.plan);
     for (FirHandle *p : parts) delete p;
+    for (FirHandle *p : heads) delete p;
 }
 
 // polyphase bank for interpolation factor L in the compute precision

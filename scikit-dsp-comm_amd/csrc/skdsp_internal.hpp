@@ -161,6 +161,9 @@ struct FirHandle : HandleBase {
     // each applied to the correspondingly delayed input and summed (capi.hip): parts[s] holds taps [s seg, (s+1) seg).
     std::vector<FirHandle *> parts;
     int part_seg = 0;
+    // Calls FROM REST over fewer samples than taps only ever reach the first n taps: they run on a copy of the filter cut to the next power of
+    // two >= n (capi.hip, fir_head) -- exact, and the float32 rounding then scales with the taps that matter, not with the whole filter
+    std::vector<FirHandle *> heads;
     ~FirHandle();
 };
 

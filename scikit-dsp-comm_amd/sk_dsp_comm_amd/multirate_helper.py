@@ -112,7 +112,11 @@ class multirate_FIR(object):
             raise ValueError("v cannot be empty")
         k = self._kern.get(xg.dtype)
         if xg.ndim > 1:   # N-D: every row of the last axis in one call (rows laid end to end behind Ntaps-1 zeros)
-            y = k.filter_rows(xg.reshape(-1, xg.shape[-1]), wide=strict).reshape(xg.shape)
+            x2 = xg.reshape(-1, xg.shape[-1])
+            try:
+                y = k.filter_rows(x2, wide=strict).reshape(xg.shape)
+            except NotImplementedError:   # the rows do not fit one staged block: row by row, each through the chunk pipeline
+                y = np.stack([k.filter(np.ascontiguousarray(r), wide=strict) for r in x2]).reshape(xg.shape)
         else:
             y = k.filter(xg, wide=strict)
         return y.astype(ref_dt, copy=False) if strict else y
@@ -248,8 +252,13 @@ class multirate_IIR(object):
             # (where the parallel-form scan applies) run as one launch
             ks = self._kern.get(xg.dtype)
             y = xg.reshape(-1, xg.shape[-1])
+            step = 1 << 23   # (rows of one launch: below the kernels' 2^24 row limit)
             for i, k in enumerate(ks):
-                y = k.filter_rows(y, wide=_wide() and i == len(ks) - 1)
+                w = _wide() and i == len(ks) - 1
+                if y.shape[0] <= step:
+                    y = k.filter_rows(y, wide=w)
+                else:
+                    y = np.concatenate([k.filter_rows(np.ascontiguousarray(y[r:r + step]), wide=w) for r in range(0, y.shape[0], step)])
             return _finish(y.reshape(xg.shape), ref_dt)
         return _finish(self._chain(xg, lambda k, v, w: k.filter(v, wide=w)), ref_dt)
 

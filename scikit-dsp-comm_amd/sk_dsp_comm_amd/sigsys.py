@@ -374,15 +374,18 @@ def fft_filt_bank(x_in, h_filt, n_fft2=512, n_bands2=0, bs=0.2, fs=1.0, n_band_o
     if n_use and n_tot:
         single = x_in.dtype in (np.float32, np.complex64) and not config.strict_dtype
         cdt = np.complex64 if single else np.complex128
-        # one device-resident input, every band filtered into its row of ONE device block, one copy back
+        # one device-resident input; the bands in batches of rows of ONE device block (2 GiB at most), one copy back per batch
         xd = _ffi.DeviceArray.from_host(np.ascontiguousarray(x_in[:n_use], dtype=cdt))
-        yd = _ffi.DeviceArray(n_use * n_tot, cdt)
+        per = max(1, min(n_tot, (2 << 30) // max(n_use * np.dtype(cdt).itemsize, 1)))
+        yd = _ffi.DeviceArray(n_use * per, cdt)
         try:
             n = np.arange(len(h_filt))
-            for j, sft in enumerate(shifts):
-                taps = h_filt * np.exp(2j * np.pi * sft * n / (2 * n_fft2))
-                _ffi.FirKernel(taps, _ffi.code_of(cdt)).filter_dev(xd, yd.window(j * n_use, n_use))
-            y[:, :n_use] = yd.to_host().reshape(n_tot, n_use)
+            for j0 in range(0, n_tot, per):
+                rows = min(per, n_tot - j0)
+                for j in range(rows):
+                    taps = h_filt * np.exp(2j * np.pi * shifts[j0 + j] * n / (2 * n_fft2))
+                    _ffi.FirKernel(taps, _ffi.code_of(cdt)).filter_dev(xd, yd.window(j * n_use, n_use))
+                y[j0:j0 + rows, :n_use] = yd.to_host(0, rows * n_use).reshape(rows, n_use)
         finally:
             xd.free()
             yd.free()

@@ -30,8 +30,19 @@ def _tol(dt, ref, gain=1.0):
     return (1e-6 if single else 1e-10) * gain
 
 
+def _log_close_call(what, err, scale, spread):
+    try:
+        root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(root, exist_ok=True)
+        with open(os.path.join(root, "fuzz_close_calls.txt"), "a") as f:
+            f.write("%s: err / scale %.3g (err %.3g, scale %.3g, reference spread %.3g)\n" % (what, err / scale, err, scale, spread))
+    except OSError:
+        pass
+
+
 def _check(y, ref, dt, what, bound, ref_spread=0.0):
-    """1e-6 (1e-10) of the output's peak -- or, for outputs far below the input (stop bands, start-up), of the forward bound.
+    """1e-6 (1e-10) of the output's peak (north_star's bound, no slack factor) -- or, for outputs far below the input (stop bands, start-up),
+    of 1 % of the forward bound.
     ref_spread: how far two float64 evaluations of the reference itself lie apart (sections in another order): a cascade whose
     float64 result is only good to 1e-6 (a 40th-order Chebyshev) cannot be matched closer than that by anybody -- and the scans here,
     which combine chunk transitions instead of running the recursion sample by sample, lose up to ~100 x that spread on such
@@ -41,7 +52,10 @@ def _check(y, ref, dt, what, bound, ref_spread=0.0):
         return
     scale = max(float(np.max(np.abs(ref))), 1e-2 * bound)
     err = float(np.max(np.abs(y - ref)))
-    assert err <= _tol(dt, ref) * scale * 2 + 300.0 * ref_spread, "%s: err %.3g, scale %.3g, reference spread %.3g" % (what, err, scale, ref_spread)
+    single = np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4
+    if err > (7e-7 if single else 7e-11) * scale:   # every case in the upper third of the contract is put on record (merged back by gpurun)
+        _log_close_call(what, err, scale, ref_spread)
+    assert err <= _tol(dt, ref) * scale + 300.0 * ref_spread, "%s: err %.3g, scale %.3g, reference spread %.3g" % (what, err, scale, ref_spread)
 
 
 @pytest.mark.parametrize("seed", range(NSEED))
@@ -139,7 +153,7 @@ def test_fuzz_rate_change_and_resamplers(seed):
             ref = signal.lfilter(rc.b, rc.a, up)
             spread = float(np.max(np.abs(ref - signal.sosfilt(sos_true, up))))
             y = rc.up(x)
-            assert np.max(np.abs(y - ref)) <= (2e-6 if single else 1e-7) * max(np.max(np.abs(ref)), 1e-2 * bound * M) + 3.0 * spread, \
+            assert np.max(np.abs(y - ref)) <= (1e-6 if single else 1e-7) * max(np.max(np.abs(ref)), 1e-2 * bound * M) + 3.0 * spread, \
                 ("rc.up", np.dtype(dt).name, n, M, order, ftype, spread)
         full = signal.lfilter(rc.b, rc.a, xw)
         spread = float(np.max(np.abs(full - signal.sosfilt(sos_true, xw)))) if n else 0.0
@@ -147,7 +161,7 @@ def test_fuzz_rate_change_and_resamplers(seed):
         y = np.asarray(rc.dn(x))
         assert y.shape == ref.shape
         if ref.size:
-            assert np.max(np.abs(y - ref)) <= (2e-6 if single else 1e-7) * max(np.max(np.abs(ref)), 1e-2 * bound) + 3.0 * spread, \
+            assert np.max(np.abs(y - ref)) <= (1e-6 if single else 1e-7) * max(np.max(np.abs(ref)), 1e-2 * bound) + 3.0 * spread, \
                 ("rc.dn", np.dtype(dt).name, n, M, order, ftype, spread)
         L = int(rng.choice([1, 2, 3, 7]))
         u = ss.upsample(x, L)

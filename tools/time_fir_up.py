@@ -1,6 +1,8 @@
-"""Developer timing: multirate_FIR.up through the overlap-save walk over (tile, phase) pairs against the polyphase kernels
-(option fir_up_ols_min), device-resident signals, 2^NOUT_LOG2 outputs (default 26).
+"""Developer timing: multirate_FIR.up through its engines -- the polyphase kernels, the overlap-save walk over (tile, phase) pairs (strided
+stores / rows + weave), the one-workgroup-per-input-tile interpolators (fir_up4k / fir_up2k) -- and what the default dispatch takes,
+device-resident signals, 2^NOUT_LOG2 outputs (default 26), settled clock.
 Run on the GPU box: python tools/time_fir_up.py [LxT ...]"""
+import time
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scikit-dsp-comm_amd"))
@@ -20,15 +22,18 @@ for dt in DTYPES:
         k = _ffi.FirKernel(bench.firwin_lowpass(ntaps, 0.8 / L), _ffi.code_of(dt))
         xd = _ffi.DeviceArray(n, dt).fill_noise(1); yd = _ffi.DeviceArray(n * L, dt)
         ms = []
-        for thr, rows in ((0, 0), (-2, 0), (-2, 2), (64, -1)):
-            with _ffi.option("fir_up_ols_min", thr), _ffi.option("fir_up_rows_min", rows):
-                for _ in range(3): k.up_dev(xd, yd, L)
-                _ffi.sync(); _ffi.timer_start()
-                for _ in range(10): k.up_dev(xd, yd, L)
-                ms.append(_ffi.timer_stop() / 10)
+        for thr, rows, tile in ((0, 0, 0), (-2, 0, 0), (-2, 2, 0), (-2, -1, 2), (64, -1, 1)):
+            with _ffi.option("fir_up_ols_min", thr), _ffi.option("fir_up_rows_min", rows), _ffi.option("fir_up4k", tile):
+                t0 = time.perf_counter()
+                while time.perf_counter() - t0 < 0.15:
+                    for _ in range(10): k.up_dev(xd, yd, L)
+                    _ffi.sync()
+                _ffi.timer_start()
+                for _ in range(40): k.up_dev(xd, yd, L)
+                ms.append(_ffi.timer_stop() / 40)
         isz = np.dtype(dt).itemsize
-        best = min(ms[0], ms[1], ms[2])
-        print("%-10s up L=%2d %5d taps (%4d per phase) n_in %9d: polyphase %.4f ms  walk, strided stores %.4f  walk, rows + weave %.4f  default %.4f ms (%.2f TB/s algorithmic)%s"
-              % (np.dtype(dt).name, L, ntaps, T, n, ms[0], ms[1], ms[2], ms[3], isz * n * (1 + L) / ms[3] / 1e9,
-                 "" if ms[3] <= 1.08 * best else "   <-- default is not the fastest path"), flush=True)
+        best = min(ms[:4])
+        print("%-10s up L=%2d %5d taps (%4d per phase) n_in %9d: polyphase %.4f ms  walk, strided stores %.4f  walk, rows + weave %.4f  input-tile interpolator %.4f  default %.4f ms (%.2f TB/s algorithmic)%s"
+              % (np.dtype(dt).name, L, ntaps, T, n, ms[0], ms[1], ms[2], ms[3], ms[4], isz * n * (1 + L) / ms[4] / 1e9,
+                 "" if ms[4] <= 1.08 * best else "   <-- default is not the fastest path"), flush=True)
         xd.free(); yd.free()
