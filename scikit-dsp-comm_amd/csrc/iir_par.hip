@@ -469,16 +469,31 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     const int64_t n_out = a.n_keep / a.dec;
     const int64_t olim64 = n_out - dec_q0;
     const unsigned olim = olim64 <= 0 ? 0u : (olim64 > 0x7fffffff ? 0x7fffffffu : (unsigned)olim64);   // outputs of this row from dec_q0 on
+    // .dn, compact form: an output is a 2 NSEC + 1 term sum over the states, and only every dec-th one is kept -- the sum is formed for the
+    // kept samples only (e0r: the kept element of the current 16-byte unit, if any, as the gathering below finds it).  The lanes of a wave
+    // walk different phases unless dec divides the chunk length, so a sample's sum is skipped only where NO lane keeps it: at dec = 12 the
+    // 64 chunks of a segment start at three different phases (128 mod 12 = 8) and three of twelve samples pay for the sum instead of all.
+    unsigned dtr = dt, e0r = 0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
         for (int k = 0; k < kPiece; ++k) {
-            const double xd = (double)xq[(p * kPiece + k) / St::elems][(p * kPiece + k) % St::elems];
-            double yv = gam * xd;
+            constexpr int kE = St::elems;
+            const int e = (p * kPiece + k) % kE;
+            if (DEC && e == 0) {
+                e0r = dtr == 0 ? 0u : (unsigned)a.dec - dtr;
+                dtr += kE;
+                if (dtr >= (unsigned)a.dec) dtr -= (unsigned)a.dec;
+            }
+            const double xd = (double)xq[(p * kPiece + k) / kE][e];
+            if (!DEC || !compact || e0r == (unsigned)e) {
+                double yv = gam * xd;
 #pragma unroll
-            for (int s = 0; s < NSEC; ++s) {
-                yv = fma(al[s], z[2 * s], yv);
-                yv = fma(be[s], z[2 * s + 1], yv);
+                for (int s = 0; s < NSEC; ++s) {
+                    yv = fma(al[s], z[2 * s], yv);
+                    yv = fma(be[s], z[2 * s + 1], yv);
+                }
+                xq[(p * kPiece + k) / kE][e] = (IO)yv;
             }
 #pragma unroll
             for (int s = 0; s < NSEC; ++s) {
@@ -486,7 +501,6 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
                 z[2 * s + 1] = z[2 * s];
                 z[2 * s] = w0;
             }
-            xq[(p * kPiece + k) / St::elems][(p * kPiece + k) % St::elems] = (IO)yv;
         }
         if (compact) {
 #pragma unroll
