@@ -4,19 +4,20 @@
 #   gpurun --timeout 600 -- 'bash tools/collect_profiles.sh r03 pmc iir8 iirlp8'    (only the PMC passes of the workloads named, added to an existing collection)
 # Writes gpurun_out/profiles_<round>/ ; copy what should be judged into profiles/<round>/.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$R
 PMC_ONLY=""
 if [ "${2:-}" = pmc ]; then shift 2; PMC_ONLY="$*"; mkdir -p $OUT; else rm -rf $OUT && mkdir -p $OUT; fi
 cd /tmp && export TMPDIR=/tmp
-[ -z "$PMC_ONLY" ] && for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; do
+RATE="upsample4 downsample3 firup12 firdn12 firup4 firdn4 rcup12 rcdn12 iirup2 iirdn3"
+[ -z "$PMC_ONLY" ] && for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python $ROOT/bench.py --workload $w --no-cpu-baseline --no-other-configs --board-seconds 0 > /dev/null 2>&1
   cp $OUT/trace_$w/*/*kernel_stats.csv $OUT/kernel_stats_$w.csv
   rm -rf $OUT/trace_$w
 done
 # PMC passes, each counter group in its own run (never combined with other trace domains)
-for w in ${PMC_ONLY:-fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128}; do
+for w in ${PMC_ONLY:-fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE}; do
   sets=("FETCH_SIZE" "WRITE_SIZE")
   [ $w = fir1024 ] && sets+=("SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES")
   # the issue / wait picture of config 4, before (cascade form) and after (parallel form)
@@ -31,8 +32,8 @@ done
 cd $ROOT
 [ -n "$PMC_ONLY" ] && { ls -la $OUT | tail -5; exit 0; }
 python bench.py > $OUT/bench_fir1024.json 2>$OUT/bench_fir1024.err
-for w in updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128; do
-  python bench.py --workload $w --no-other-configs > $OUT/bench_$w.json 2>/dev/null
+for w in updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE; do
+  python bench.py --workload $w --no-other-configs --no-cpu-baseline > $OUT/bench_$w.json 2>/dev/null
 done
 python bench.py --scaling strong --total-log2n 30 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_fir1024_2p30_one_gpu.json 2>/dev/null
 python tools/power_probe.py idle copy fir1024 fir1024f32 fir1024f64 fir1024c128 updn43 fir127 iir8 iir8cas iir8c64 iirlp8 > $OUT/power_probe.txt 2>&1
@@ -41,17 +42,10 @@ python tools/time_fir_shapes.py > $OUT/fir_shapes.txt 2>&1
 python tools/time_iir_up.py > $OUT/iir_up.txt 2>&1
 python tools/time_iir_dn.py > $OUT/iir_dn.txt 2>&1
 python tools/time_fir_c128.py > $OUT/fir_f64.txt 2>&1
-# multirate_FIR.up / L / M through the overlap-save walk: the timing tables, and a kernel trace of three shapes
+# multirate_FIR.up: every engine (polyphase, walk over (tile, phase) pairs, the input-tile interpolators) and the default dispatch; .dn likewise
 python tools/time_fir_up.py > $OUT/fir_up.txt 2>&1
-DTYPES=float64,complex128 python tools/time_fir_up.py 2x128 2x512 2x1024 4x128 4x512 8x128 8x256 12x256 64x64 >> $OUT/fir_up.txt 2>&1
 python tools/time_fir_updn.py > $OUT/fir_updn.txt 2>&1
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fir_up -- python $ROOT/tools/time_fir_up.py 2x512 4x256 12x256 > /dev/null 2>&1)
-cp $OUT/trace_fir_up/*/*kernel_stats.csv $OUT/kernel_stats_fir_up.csv 2>/dev/null
-rm -rf $OUT/trace_fir_up
-for c in FETCH_SIZE WRITE_SIZE; do   # HBM counters of the walk, strided stores vs rows + weave (tools/reduce_pmc_up.py)
-  (cd /tmp && DTYPES=complex64 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_up_$c -- python $ROOT/tools/time_fir_up.py 4x256 12x256 > /dev/null 2>&1)
-  cp $OUT/pmc_up_$c/*/*counter_collection.csv $OUT/pmc_fir_up_$c.csv 2>/dev/null
-  rm -rf $OUT/pmc_up_$c
-done
+python tools/check_dn4k.py time > $OUT/fir_dn.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_strided_store.hip -o /tmp/ubss 2>/dev/null && /tmp/ubss > $OUT/ubench_strided_store.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_dp_pipes.hip -o /tmp/ubench_dp_pipes 2>/dev/null && /tmp/ubench_dp_pipes > $OUT/ubench_dp_pipes.txt 2>&1
 ls -la $OUT
