@@ -463,12 +463,16 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
         copy = cplx ? 0.20 : 0.10;
         V = 4096 - ((T - 1 + 255) / 256) * 256;
     } else {
-        const bool bx = fir_bx_blocks(h, L, M) > 0;   // (the matrix-pipe polyphase kernel covers the shape)
+        int bx_rt = 0;
+        const int bx_kb = fir_bx_blocks(h, L, M, &bx_rt);   // (the matrix-pipe polyphase kernel covers the shape: its time goes with its 32-lag blocks)
+        const bool bx = bx_kb > 0;
         base = cplx ? 0.23 : 0.125;
         ols = cplx ? 0.27 + 0.022 * std::min(Lf, 20.0) : 0.13 + 0.018 * std::min(Lf, 28.0);
-        poly = cplx ? (bx ? 0.06 + 0.0011 * T : 0.02 + 0.0037 * T) : (bx ? 0.055 + 0.0005 * T : 0.03 + 0.0018 * T);
-        // (the matrix-pipe kernel's row tiles grow with L: measured against the L <= 4 line, 48 taps per phase: x 1.14 at L = 8, x 1.8 - 2.2 at L = 12)
-        if (bx && L > 4) poly *= L <= 8 ? 1.0 + 0.035 * (Lf - 4.0) : 1.14 + 0.2 * (Lf - 8.0);
+        // profiles/r04/fir_up.txt: complex64 0.119 / 0.130 - 0.138 / 0.164 / 0.191 ms for 2 / 3 / 4 / 5 blocks at L = 4 ... 16 (one row tile, L = 2:
+        // 0.13 / 0.155 / 0.185 / 0.215); float32 0.082 - 0.093 / 0.088 - 0.095 / 0.092 / 0.102 (L = 2: 0.082 / 0.093 / 0.104 / 0.118)
+        if (bx && cplx) poly = bx_rt == 1 ? 0.07 + 0.029 * bx_kb : std::max(0.111, 0.057 + 0.027 * bx_kb);
+        else if (bx) poly = (bx_rt == 1 ? 0.054 + 0.0138 * bx_kb : std::max(0.082, 0.06 + 0.0085 * bx_kb)) * (L > 8 ? 1.1 : 1.0);
+        else poly = cplx ? 0.02 + 0.0037 * T : 0.03 + 0.0018 * T;
         if (!bx && L > 8 && L <= 16) poly *= 1.0 + 0.05 * (Lf - 8.0);   // (48 taps per phase: 0.116 modelled, 0.1395 measured at L = 12)
         if (!bx && T > 256) poly *= std::max(1.0, Lf / 4.0);
         else if (L > 16 && !bx) poly *= 1.0 + Lf / 12.0;   // (one tap table per phase: the polyphase kernels lose their reuse)

@@ -53,6 +53,11 @@ struct BxArgs {
     // s col mod 16 shifted by one): 2-way conflicts on a third of the reads, 42 % of the LDS cycles of L/M = 4/3
     // (s = 3).  With every second column both row sets hit the eight EVEN (odd) residues exactly once: none.
     int eo;
+    // pad_s > 0 (s = q_ds / 8 a multiple of 4: decimators): one pad unit behind every s units of a plane.  Unpadded, the 16 columns of a
+    // fragment read start s units apart -- s = 4 / 8 / 16 / 24 puts them on 4 / 2 / 1 / 2 of the 16 bank residues (4- to 16-way conflicts
+    // on every read: M = 8, 512 taps, complex64 ran at 0.30 ms per 2^26 inputs); padded, the stride is s + 1 (odd).
+    int pad_s;
+    unsigned pad_magic;   // ceil(2^32 / s)
 };
 
 // (a, b) -> three packed bf16 pairs, a in the low half: a = a1 + a2 + a3 exactly (24 = 3 x 8 mantissa bits).
@@ -87,18 +92,35 @@ __device__ __forceinline__ v4f_bx bx_mfma(uint4 a, uint4 b, v4f_bx c)
 // Persistent 256-thread workgroups: window w+1 is requested into registers before window w is multiplied, so
 // its HBM latency hides behind the MFMAs of the same workgroup; the workgroups of a CU run out of phase with
 // each other, which is what overlaps the bf16 split / LDS writes / stores of one with the MFMAs of another.
-template <bool CPLX, int KB, int RT>
+//
+// RSP = 2 (row split): the taps of a geometry with many row tiles do not fit one wave's registers (L = 12: 96 rows = 6 row tiles x 2
+// blocks = 144 VGPRs).  The waves of a workgroup then pair up: wave w takes the row tiles [RT (w & 1), RT (w & 1) + RT) of the column
+// tiles w >> 1, w >> 1 + 2, ... -- RT is the per-wave count, the table holds RT RSP row tiles.  A window fragment is read from the planes
+// by both waves of a pair; a wave's 16 RT rows of a column are still one run of y (L = 12: 48 outputs = 384 bytes = three whole lines).
+//
+// KSP = 4 (lag split; RT = RSP = 1): a decimator with a large M spreads the 16 rows of its one row tile over 16 M input samples, so its lag
+// range is 16 M + Ntaps long (M = 12, 512 taps: 22 blocks = 264 VGPRs of taps) while a window holds one or two column tiles -- nothing for
+// three of the four waves to do.  The waves then split the LAGS: wave w takes the blocks [KB w, KB w + KB) of every column tile (KB is
+// the per-wave count; the table holds 4 KB blocks, the last ones zero-padded), the four partial tiles meet in the LDS, and wave w
+// stores column 4 j + w of every lane's four.
+template <bool CPLX, int KB, int RT, int RSP, int KSP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_bx_kernel(const float *__restrict__ x, const uint4 *__restrict__ At, BxArgs a,
                                                      float *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) char bx_smem[];
     constexpr int C = CPLX ? 2 : 1;
-    constexpr int K = 32 * KB;
+    static_assert(KSP == 1 || (RT == 1 && RSP == 1), "the lag split serves one-row-tile geometries");
+    constexpr int K = 32 * KB * KSP;
     constexpr int UPT = (CPLX ? kBxUnitsC : kBxUnitsR) / 256;   // staged 8-sample units per thread
     constexpr int F4 = 2 * C;             // 16-byte loads per unit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int RTT = RT * RSP;                                   // row tiles of the table
+    const int rt0 = RSP > 1 ? RT * __builtin_amdgcn_readfirstlane(wave % RSP) : 0;   // this wave's first
+    constexpr int CW = 4 / RSP;                                     // waves that share the column tiles of a window
+    const int kb0 = KSP > 1 ? KB * __builtin_amdgcn_readfirstlane(wave) : 0;   // this wave's first 32-lag block
     const int nunits = a.win / 8;
-    const int plane_bytes = a.win * 2 + 16;  // + a dump row for the threads beyond the window
+    auto padded = [&](int u) -> int { return a.pad_s ? u + (int)(((unsigned long long)(unsigned)u * a.pad_magic) >> 32) : u; };   // unit -> its place in a plane
+    const int plane_bytes = (padded(nunits) + 1) * 16;  // + a dump row for the threads beyond the window
 
     // Interior windows (16-byte aligned, fully inside [-n_hist, n)) are prefetched into registers one window
     // ahead; the few others (first / last windows, element-aligned views) are staged synchronously by their own
@@ -126,7 +148,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             unsigned p1[4], p2[4], p3[4];
 #pragma unroll
             for (int w = 0; w < 4; ++w) bx_split2(v[(2 * w) * C + c], v[(2 * w + 1) * C + c], p1[w], p2[w], p3[w]);
-            char *base = bx_smem + (size_t)(3 * c) * plane_bytes + (size_t)u * 16;
+            char *base = bx_smem + (size_t)(3 * c) * plane_bytes + (size_t)padded(u) * 16;
             *reinterpret_cast<uint4 *>(base) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
             *reinterpret_cast<uint4 *>(base + plane_bytes) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
             *reinterpret_cast<uint4 *>(base + 2 * plane_bytes) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
@@ -166,7 +188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) areg[kb][rt][p] = At[((kb * RT + rt) * 3 + p) * 64 + lane];
+            for (int p = 0; p < 3; ++p) areg[kb][rt][p] = At[(((kb0 + kb) * RTT + rt0 + rt) * 3 + p) * 64 + lane];
 
     const int ncol = lane & 15, j = lane >> 4;
     const int ntiles = a.NS / 16;
@@ -201,7 +223,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         auto mma_tile = [&](int ct) __attribute__((always_inline)) {
             // window element of (column n, block kb, group j, i): q_ds n + 32 kb + 8 j + i
-            const char *bbase = bx_smem + ((size_t)a.q_ds * col_of(ct, ncol) + 8 * j) * 2;
+            // (padded planes: unit s col + r lies at s col + r + col + r / s, and r / s = (4 (kb0 + kb)) / s for every lane since 4 divides s)
+            const int colr = col_of(ct, ncol);
+            const char *bbase = bx_smem + ((size_t)a.q_ds * colr + 8 * j + 32 * kb0) * 2 + (a.pad_s ? 16 * colr : 0);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -211,10 +235,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // Small products (relative size 2^-9 .. 2^-18) go to their own accumulator; consecutive MFMAs
             // go to different accumulators (row tile x component).
             uint4 b[C][3];
+            int kpad[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) kpad[kb] = a.pad_s ? (int)(((unsigned long long)(unsigned)(4 * (kb0 + kb)) * a.pad_magic) >> 32) : 0;
             auto read_b = [&](int kb, int p) {
 #pragma unroll
                 for (int c = 0; c < C; ++c)
-                    b[c][p] = *reinterpret_cast<const uint4 *>(bbase + (size_t)(3 * c + p) * plane_bytes + 64 * kb);
+                    b[c][p] = *reinterpret_cast<const uint4 *>(bbase + (size_t)(3 * c + p) * plane_bytes + 64 * kb + 16 * kpad[kb]);
             };
             read_b(0, 0);
             read_b(0, 1);
@@ -245,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // 16 consecutive outputs (128 bytes of complex64) per store instead of 16-byte pieces 32 bytes apart.
             // (the four columns of a lane are consecutive tile rows 4 j + i: consecutive columns, or every second one)
             const int cstep = a.eo ? 2 * a.RS : a.RS;
-            const int64_t m_base = (int64_t)a.RS * (S0 + col_of(ct, 4 * j)) + ncol;   // output of (row tile 0, i = 0)
+            const int64_t m_base = (int64_t)a.RS * (S0 + col_of(ct, 4 * j)) + ncol + 16 * rt0;   // output of (this wave's row tile 0, i = 0)
             float *yb = y + m_base * C;
             const int64_t left = a.n_out - m_base;
             const int rem = left > (int64_t)0x7fffffff ? 0x7fffffff : (left < 0 ? 0 : (int)left);
@@ -275,13 +302,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int off = i * cstep + 16 * rt;
-                        if (16 * rt + ncol < a.RS && off < rem) put(rt, i, off);
+                        if (16 * (rt0 + rt) + ncol < a.RS && off < rem) put(rt, i, off);
                     }
             }
         };
-        int ct = wave;
+        if constexpr (KSP > 1) {
+            // every wave multiplies its lags of every column tile; partial tiles [parity][wave][component, i][lane] behind the planes
+            float *red = reinterpret_cast<float *>(bx_smem + (size_t)(3 * C) * plane_bytes);
+            const int cstep = a.eo ? 2 * a.RS : a.RS;
 #pragma unroll 1
-        for (; ct + 4 < ntiles; ct += 4) {
+            for (int ct = 0; ct < ntiles; ++ct) {
+                mma_tile(ct);
+                float *mine = red + ((size_t)((ct & 1) * 4 + wave) * (4 * C)) * 64 + lane;
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mine[(c * 4 + i) * 64] = big[0][c][i] + small[0][c][i];
+                __syncthreads();
+                const float *all = red + ((size_t)((ct & 1) * 4) * (4 * C)) * 64 + lane;
+                float o[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    o[c] = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) o[c] += all[((size_t)w * (4 * C) + c * 4 + wave) * 64];
+                }
+                const int64_t m = (int64_t)a.RS * (S0 + col_of(ct, 4 * j)) + ncol + (int64_t)wave * cstep;
+                if (ncol < a.RS && m < a.n_out) {
+                    if (CPLX) __builtin_nontemporal_store(v2f_bx{o[0], o[C - 1]}, reinterpret_cast<v2f_bx *>(y + 2 * m));
+                    else __builtin_nontemporal_store(o[0], y + m);
+                }
+            }
+            __syncthreads();  // everyone is done reading the planes
+            if (wnext < nwin) {
+                if (fast) store_window();
+                else stage_window_slow(wnext);
+            }
+            __syncthreads();  // the planes hold window w+1
+            const int64_t wnext2 = wnext + gridDim.x;
+            fast = wnext2 < nwin && interior(wnext2);
+            if (fast) load_window(wnext2);
+            wdx = wnext;
+            wnext = wnext2;
+            continue;
+        }
+        int ct = wave / RSP;
+#pragma unroll 1
+        for (; ct + CW < ntiles; ct += CW) {
             mma_tile(ct);
             __builtin_amdgcn_s_setprio(3);
             store_tile(ct);
@@ -351,11 +418,32 @@ static bool bx_geometry(const FirHandle *h, int L, int M, FirHandle::BxTab *t)
     const int al = dtype_complex(h->dtype) ? 2 : 4;
     U0 += (al - (U0 + 1) % al) % al;
     const int KB = (T + U0 + 31) / 32;
-    if (KB * RT > 12) return false;  // A operands: 12 VGPRs per (block, row tile)
     const int comp = dtype_complex(h->dtype) ? 2 : 1;
-    // 256 VGPRs (2 waves per SIMD): A operands + accumulators + B fragments + 32 prefetch registers + ~52 others
-    if (12 * KB * RT + 8 * comp * RT + 12 * comp + 32 + 52 > (comp == 2 ? 276 : 256)) return false;
-    t->L = L; t->M = M; t->Lp = Lp; t->q = q; t->DS = DS; t->RS = RS; t->RT = RT; t->U0 = U0; t->KB = KB; t->At = nullptr;
+    // 256 VGPRs (2 waves per SIMD): A operands (12 per block and row tile) + accumulators + B fragments + 32 prefetch registers + ~52
+    // others.  What does not fit one wave is tried with the row tiles dealt to wave pairs (RSP = 2: see the kernel).
+    int RSP = 0;
+    for (int rsp = 1; rsp <= 2 && !RSP; ++rsp) {
+        if (RT % rsp || (rsp > 1 && RT < 4)) continue;
+        const int rtw = RT / rsp;
+        if (KB * rtw > 12) continue;
+        if (12 * KB * rtw + 8 * comp * rtw + 12 * comp + 32 + 52 > (comp == 2 ? 276 : 256)) continue;
+        RSP = rsp;
+    }
+    // One row tile and a window that holds fewer column tiles than the workgroup has waves (a decimator with a large M), or more blocks
+    // than one wave's registers take: the waves split the lags (KSP = 4: see the kernel); the table is padded to 4 equal shares.
+    int KSP = 1, KBT = KB;
+    if (RT == 1) {
+        const int cap = 8 * (comp == 2 ? kBxUnitsC : kBxUnitsR);
+        const int ns_max = cap > 32 * KB ? (cap - 32 * KB) / (q * DS) + 1 : 0;
+        if (!RSP || ns_max < 64) {
+            const int kbw = (KB + 3) / 4;
+            if (kbw <= 8 && cap >= 32 * 4 * kbw + q * DS * 15) { KSP = 4; KBT = 4 * kbw; RSP = 1; }
+        }
+    }
+    if (!RSP) return false;
+    t->RSP = RSP;
+    t->KSP = KSP;
+    t->L = L; t->M = M; t->Lp = Lp; t->q = q; t->DS = DS; t->RS = RS; t->RT = RT; t->U0 = U0; t->KB = KBT; t->At = nullptr;
     return true;
 }
 
@@ -384,12 +472,14 @@ bool fir_bx_supported(const FirHandle *h, int L, int M, int64_t n_out)
 }
 
 // 32-lag blocks the kernel would run for (L, M); 0: not covered (cost model of the callers)
-int fir_bx_blocks(const FirHandle *h, int L, int M)
+int fir_bx_blocks(const FirHandle *h, int L, int M, int *row_tiles)
 {
     if (h->taps_complex || dtype_double(h->dtype)) return 0;
     if (!opt().fir_bx || !opt().fir_mm) return 0;
     FirHandle::BxTab t;
-    return bx_geometry(h, L, M, &t) ? t.KB : 0;
+    if (!bx_geometry(h, L, M, &t)) return 0;
+    if (row_tiles) *row_tiles = t.RT;
+    return t.KB;
 }
 
 // A-operand table of one (L, M): At[((kb RT + rt) 3 + piece) 64 + lane] = 8 bf16 of row 16 rt + (lane & 15),
@@ -430,29 +520,48 @@ static int get_bx_table(FirHandle *h, int L, int M, const FirHandle::BxTab **out
     return SKDSP_OK;
 }
 
-template <bool CPLX, int KB, int RT>
+template <bool CPLX, int KB, int RT, int RSP, int KSP = 1>
 static void bx_launch_one(unsigned grid, size_t lds, hipStream_t s, const void *x, const void *At, const BxArgs &a, void *y)
 {
     if (lds > (size_t)64 * 1024)
-        (void)hipFuncSetAttribute((const void *)fir_bx_kernel<CPLX, KB, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((fir_bx_kernel<CPLX, KB, RT>), dim3(grid), dim3(256), lds, s, (const float *)x, (const uint4 *)At, a, (float *)y);
+        (void)hipFuncSetAttribute((const void *)fir_bx_kernel<CPLX, KB, RT, RSP, KSP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((fir_bx_kernel<CPLX, KB, RT, RSP, KSP>), dim3(grid), dim3(256), lds, s, (const float *)x, (const uint4 *)At, a, (float *)y);
 }
 
+// (KB: 32-lag blocks per wave, RT: row tiles per wave)
 template <bool CPLX>
-static bool bx_dispatch(int KB, int RT, unsigned grid, size_t lds, hipStream_t s, const void *x, const void *At, const BxArgs &a, void *y)
+static bool bx_dispatch(int KB, int RT, int RSP, int KSP, unsigned grid, size_t lds, hipStream_t s, const void *x, const void *At, const BxArgs &a, void *y)
 {
-#define SK_BXC(kb, rt) case (kb) * 16 + (rt): bx_launch_one<CPLX, kb, rt>(grid, lds, s, x, At, a, y); return true;
-    switch (KB * 16 + RT) {
-        SK_BXC(1, 1) SK_BXC(1, 2) SK_BXC(1, 3) SK_BXC(1, 4) SK_BXC(1, 5) SK_BXC(1, 6) SK_BXC(1, 7) SK_BXC(1, 8)
-        SK_BXC(2, 1) SK_BXC(2, 2) SK_BXC(2, 3) SK_BXC(2, 4) SK_BXC(2, 5) SK_BXC(2, 6)
-        SK_BXC(3, 1) SK_BXC(3, 2) SK_BXC(3, 3) SK_BXC(3, 4)
-        SK_BXC(4, 1) SK_BXC(4, 2) SK_BXC(4, 3)
-        SK_BXC(5, 1) SK_BXC(5, 2)
-        SK_BXC(6, 1) SK_BXC(6, 2)
-        SK_BXC(7, 1) SK_BXC(8, 1) SK_BXC(9, 1) SK_BXC(10, 1) SK_BXC(11, 1) SK_BXC(12, 1)
+#define SK_BXC(kb, rt) case (kb) * 16 + (rt): bx_launch_one<CPLX, kb, rt, 1>(grid, lds, s, x, At, a, y); return true;
+#define SK_BXR(kb, rt) case (kb) * 16 + (rt): bx_launch_one<CPLX, kb, rt, 2>(grid, lds, s, x, At, a, y); return true;
+#define SK_BXK(kb) case (kb): bx_launch_one<CPLX, kb, 1, 1, 4>(grid, lds, s, x, At, a, y); return true;
+    if (KSP == 4) {
+        switch (KB) {
+            SK_BXK(1) SK_BXK(2) SK_BXK(3) SK_BXK(4) SK_BXK(5) SK_BXK(6) SK_BXK(7) SK_BXK(8)
+        default: return false;
+        }
+    }
+    if (RSP == 1) {
+        switch (KB * 16 + RT) {
+            SK_BXC(1, 1) SK_BXC(1, 2) SK_BXC(1, 3) SK_BXC(1, 4) SK_BXC(1, 5) SK_BXC(1, 6) SK_BXC(1, 7) SK_BXC(1, 8)
+            SK_BXC(2, 1) SK_BXC(2, 2) SK_BXC(2, 3) SK_BXC(2, 4) SK_BXC(2, 5) SK_BXC(2, 6)
+            SK_BXC(3, 1) SK_BXC(3, 2) SK_BXC(3, 3) SK_BXC(3, 4)
+            SK_BXC(4, 1) SK_BXC(4, 2) SK_BXC(4, 3)
+            SK_BXC(5, 1) SK_BXC(5, 2)
+            SK_BXC(6, 1) SK_BXC(6, 2)
+            SK_BXC(7, 1) SK_BXC(8, 1) SK_BXC(9, 1) SK_BXC(10, 1) SK_BXC(11, 1) SK_BXC(12, 1)
+        default: return false;
+        }
+    }
+    switch (KB * 16 + RT) {   // per-wave row tiles of geometries the switch above does not hold
+        SK_BXR(3, 2) SK_BXR(4, 2) SK_BXR(5, 2) SK_BXR(6, 2)
+        SK_BXR(2, 3) SK_BXR(3, 3)
+        SK_BXR(1, 4) SK_BXR(2, 4)
     default: return false;
     }
 #undef SK_BXC
+#undef SK_BXR
+#undef SK_BXK
 }
 
 int fir_bx_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, int M, int64_t n_out, void *y, hipStream_t s)
@@ -469,12 +578,17 @@ int fir_bx_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L,
     SK_CHECK(a.NS > 0, SKDSP_ERR_UNSUPPORTED, "fir_bx: window does not fit LDS (L=%d M=%d)", L, M);
     a.win = ((a.q_ds * (a.NS - 1) + 32 * t->KB) + 7) / 8 * 8;
     a.eo = ((a.q_ds / 8) & 1) && a.NS % 32 == 0 ? 1 : 0;
-    const size_t lds = (size_t)(cplx ? 6 : 3) * (a.win * 2 + 16);  // (+ a dump row per plane)
+    const int su = a.q_ds / 8;
+    a.pad_s = su % 4 == 0 ? su : 0;
+    a.pad_magic = a.pad_s ? (unsigned)(((1ull << 32) + su - 1) / su) : 0u;
+    const int units = a.win / 8;
+    size_t lds = (size_t)(cplx ? 6 : 3) * (size_t)(units + (a.pad_s ? units / su : 0) + 1) * 16;  // (+ a dump row per plane)
+    if (t->KSP > 1) lds += (size_t)2 * 4 * (cplx ? 8 : 4) * 64 * sizeof(float);   // the partial tiles of the lag split, two generations
     const int64_t ncols = (n_out + a.RS - 1) / a.RS;
     const int64_t nwin = (ncols + a.NS - 1) / a.NS;
     const unsigned grid = (unsigned)std::min<int64_t>(nwin, (int64_t)2 * ctx().num_cus);  // persistent: two per CU
-    const bool ok = cplx ? bx_dispatch<true>(t->KB, t->RT, grid, lds, s, x, t->At, a, y)
-                         : bx_dispatch<false>(t->KB, t->RT, grid, lds, s, x, t->At, a, y);
+    const bool ok = cplx ? bx_dispatch<true>(t->KB / t->KSP, t->RT / t->RSP, t->RSP, t->KSP, grid, lds, s, x, t->At, a, y)
+                         : bx_dispatch<false>(t->KB / t->KSP, t->RT / t->RSP, t->RSP, t->KSP, grid, lds, s, x, t->At, a, y);
     SK_CHECK(ok, SKDSP_ERR_UNSUPPORTED, "fir_bx: no kernel for %d blocks x %d row tiles", t->KB, t->RT);
     SK_HIP(hipGetLastError());
     return SKDSP_OK;

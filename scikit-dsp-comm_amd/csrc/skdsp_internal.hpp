@@ -146,7 +146,7 @@ struct FirHandle : HandleBase {
     struct MmTab { int L, M, Lp, q, DS, RS, U0, K4; void *At; };
     std::vector<MmTab> mm;
     // bf16x3 Toeplitz-product A-operand tables, keyed by (L, M)  -- fir_bx.hip
-    struct BxTab { int L, M, Lp, q, DS, RS, RT, U0, KB; void *At; };
+    struct BxTab { int L, M, Lp, q, DS, RS, RT, U0, KB, RSP, KSP; void *At; };   // RT / KB: row tiles / 32-lag blocks of the table; RSP / KSP: waves they are dealt to
     std::vector<BxTab> bx;
     OlsPlan *ols = nullptr;
     struct OlsUp { int L; OlsPlan *plan; };   // overlap-save plans of multirate_FIR.up, keyed by L (fir_ols_up_launch)
@@ -177,7 +177,7 @@ int fir_mm_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, in
                   hipStream_t s);
 // Toeplitz product on the BF16 matrix pipe in float32 precision (3-way bf16 split, fir_bx.hip): same coverage, tried first
 bool fir_bx_supported(const FirHandle *h, int L, int M, int64_t n_out);
-int fir_bx_blocks(const FirHandle *h, int L, int M);  // 32-lag blocks per output tile, 0 = not covered
+int fir_bx_blocks(const FirHandle *h, int L, int M, int *row_tiles = nullptr);  // 32-lag blocks per output tile, 0 = not covered
 int fir_bx_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, int64_t n_out, void *y_dev,
                   hipStream_t s);
 // FFT overlap-save (fir_ols.hip): c64 (and packed f32) .filter

@@ -1056,7 +1056,11 @@ def test_direct_fir_kernels_behind_the_default_path(switch):
 
 @pytest.mark.parametrize("dt", [np.float32, np.complex64])
 @pytest.mark.parametrize("P,L,M", [(40, 1, 1), (301, 1, 1), (192, 12, 1), (192, 1, 12), (75, 5, 1), (96, 3, 2), (64, 2, 1),
-                                   (33, 1, 3), (140, 7, 1), (90, 9, 4), (1024, 4, 3)])
+                                   (33, 1, 3), (140, 7, 1), (90, 9, 4), (1024, 4, 3),
+                                   # row tiles dealt to wave pairs (taps that do not fit one wave's registers)
+                                   (512, 12, 1), (1000, 12, 1), (700, 8, 1), (1100, 8, 1), (500, 16, 1), (420, 12, 5), (333, 8, 3),
+                                   # one row tile, lags dealt to the four waves (decimators with a large M)
+                                   (512, 1, 12), (1000, 1, 12), (128, 1, 12), (300, 1, 16), (512, 1, 24), (77, 1, 20), (640, 1, 8)])
 def test_bf16x3_matrix_pipe_geometries(dt, P, L, M):
     """Row-tile / lag-block geometries of the bf16x3 Toeplitz kernel (1..7 row tiles, 1..10 lag blocks, shapes it
     hands on to the kernels behind it), ragged lengths, history: against the oracle at the float32 tolerance."""
