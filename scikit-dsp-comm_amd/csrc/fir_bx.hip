@@ -235,13 +235,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // Small products (relative size 2^-9 .. 2^-18) go to their own accumulator; consecutive MFMAs
             // go to different accumulators (row tile x component).
             uint4 b[C][3];
-            int kpad[KB];
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) kpad[kb] = a.pad_s ? (int)(((unsigned long long)(unsigned)(4 * (kb0 + kb)) * a.pad_magic) >> 32) : 0;
+            // (pad units in front of block kb0 + kb: wave-uniform)
+            auto kpad = [&](int kb) -> int { return __builtin_amdgcn_readfirstlane((int)(((unsigned long long)(unsigned)(4 * (kb0 + kb)) * a.pad_magic) >> 32)); };
             auto read_b = [&](int kb, int p) {
 #pragma unroll
                 for (int c = 0; c < C; ++c)
-                    b[c][p] = *reinterpret_cast<const uint4 *>(bbase + (size_t)(3 * c + p) * plane_bytes + 64 * kb + 16 * kpad[kb]);
+                    b[c][p] = *reinterpret_cast<const uint4 *>(bbase + (size_t)(3 * c + p) * plane_bytes + 64 * kb + 16 * kpad(kb));
             };
             read_b(0, 0);
             read_b(0, 1);
@@ -395,6 +394,14 @@ static double bx_bf16_val(unsigned short h)
     return (double)f;
 }
 
+// does a wave's share fit its 256 VGPRs (2 waves per SIMD)?  A operands (12 per 32-lag block and row tile) + accumulators + B fragments +
+// 32 prefetch registers + ~52 others; kb, rt: blocks / row tiles PER WAVE.  Used by the geometry below and by the dispatch, so that only
+// kernels the geometry can pick are instantiated.
+static constexpr bool bx_fits(bool cplx, int kb, int rt)
+{
+    return kb * rt <= 12 && 12 * kb * rt + 8 * (cplx ? 2 : 1) * rt + 12 * (cplx ? 2 : 1) + 32 + 52 <= (cplx ? 276 : 256);
+}
+
 // geometry of one (L, M): false if the kernel family does not cover it
 static bool bx_geometry(const FirHandle *h, int L, int M, FirHandle::BxTab *t)
 {
@@ -419,15 +426,14 @@ static bool bx_geometry(const FirHandle *h, int L, int M, FirHandle::BxTab *t)
     U0 += (al - (U0 + 1) % al) % al;
     const int KB = (T + U0 + 31) / 32;
     const int comp = dtype_complex(h->dtype) ? 2 : 1;
-    // 256 VGPRs (2 waves per SIMD): A operands (12 per block and row tile) + accumulators + B fragments + 32 prefetch registers + ~52
-    // others.  What does not fit one wave is tried with the row tiles dealt to wave pairs (RSP = 2: see the kernel).
+    // What does not fit one wave (bx_fits) is tried with the row tiles dealt to wave pairs (RSP = 2: see the kernel); four or more row tiles
+    // always are (the same speed where both fit -- L = 8, 48 taps per phase: 0.1245 / 0.1259 ms -- and the one-wave forms of 4 x 2, 6 x 1 spilled)
     int RSP = 0;
-    for (int rsp = 1; rsp <= 2 && !RSP; ++rsp) {
+    const bool pairs_first = RT >= 4 && RT % 2 == 0;
+    for (int i = 0; i < 2 && !RSP; ++i) {
+        const int rsp = (i == 0) == pairs_first ? 2 : 1;
         if (RT % rsp || (rsp > 1 && RT < 4)) continue;
-        const int rtw = RT / rsp;
-        if (KB * rtw > 12) continue;
-        if (12 * KB * rtw + 8 * comp * rtw + 12 * comp + 32 + 52 > (comp == 2 ? 276 : 256)) continue;
-        RSP = rsp;
+        if (bx_fits(comp == 2, KB, RT / rsp)) RSP = rsp;
     }
     // One row tile and a window that holds fewer column tiles than the workgroup has waves (a decimator with a large M), or more blocks
     // than one wave's registers take: the waves split the lags (KSP = 4: see the kernel); the table is padded to 4 equal shares.
@@ -529,33 +535,41 @@ static void bx_launch_one(unsigned grid, size_t lds, hipStream_t s, const void *
 }
 
 // (KB: 32-lag blocks per wave, RT: row tiles per wave)
+template <bool CPLX, int KB, int RT, int RSP, int KSP>
+static bool bx_launch_if(unsigned grid, size_t lds, hipStream_t s, const void *x, const void *At, const BxArgs &a, void *y)
+{
+    if constexpr (bx_fits(CPLX, KB, RT)) {
+        bx_launch_one<CPLX, KB, RT, RSP, KSP>(grid, lds, s, x, At, a, y);
+        return true;
+    } else {
+        return false;
+    }
+}
 template <bool CPLX>
 static bool bx_dispatch(int KB, int RT, int RSP, int KSP, unsigned grid, size_t lds, hipStream_t s, const void *x, const void *At, const BxArgs &a, void *y)
 {
-#define SK_BXC(kb, rt) case (kb) * 16 + (rt): bx_launch_one<CPLX, kb, rt, 1>(grid, lds, s, x, At, a, y); return true;
-#define SK_BXR(kb, rt) case (kb) * 16 + (rt): bx_launch_one<CPLX, kb, rt, 2>(grid, lds, s, x, At, a, y); return true;
-#define SK_BXK(kb) case (kb): bx_launch_one<CPLX, kb, 1, 1, 4>(grid, lds, s, x, At, a, y); return true;
+#define SK_BXC(kb, rt) case (kb) * 16 + (rt): return bx_launch_if<CPLX, kb, rt, 1, 1>(grid, lds, s, x, At, a, y);
+#define SK_BXR(kb, rt) case (kb) * 16 + (rt): return bx_launch_if<CPLX, kb, rt, 2, 1>(grid, lds, s, x, At, a, y);
+#define SK_BXK(kb) case (kb): return bx_launch_if<CPLX, kb, 1, 1, 4>(grid, lds, s, x, At, a, y);
     if (KSP == 4) {
         switch (KB) {
             SK_BXK(1) SK_BXK(2) SK_BXK(3) SK_BXK(4) SK_BXK(5) SK_BXK(6) SK_BXK(7) SK_BXK(8)
         default: return false;
         }
     }
-    if (RSP == 1) {
+    if (RSP == 1) {   // one, two, three, five or seven row tiles
         switch (KB * 16 + RT) {
-            SK_BXC(1, 1) SK_BXC(1, 2) SK_BXC(1, 3) SK_BXC(1, 4) SK_BXC(1, 5) SK_BXC(1, 6) SK_BXC(1, 7) SK_BXC(1, 8)
-            SK_BXC(2, 1) SK_BXC(2, 2) SK_BXC(2, 3) SK_BXC(2, 4) SK_BXC(2, 5) SK_BXC(2, 6)
-            SK_BXC(3, 1) SK_BXC(3, 2) SK_BXC(3, 3) SK_BXC(3, 4)
-            SK_BXC(4, 1) SK_BXC(4, 2) SK_BXC(4, 3)
-            SK_BXC(5, 1) SK_BXC(5, 2)
-            SK_BXC(6, 1) SK_BXC(6, 2)
-            SK_BXC(7, 1) SK_BXC(8, 1) SK_BXC(9, 1) SK_BXC(10, 1) SK_BXC(11, 1) SK_BXC(12, 1)
+            SK_BXC(1, 1) SK_BXC(2, 1) SK_BXC(3, 1) SK_BXC(4, 1) SK_BXC(5, 1) SK_BXC(6, 1) SK_BXC(7, 1) SK_BXC(8, 1) SK_BXC(9, 1) SK_BXC(10, 1) SK_BXC(11, 1) SK_BXC(12, 1)
+            SK_BXC(1, 2) SK_BXC(2, 2) SK_BXC(3, 2) SK_BXC(4, 2) SK_BXC(5, 2) SK_BXC(6, 2)
+            SK_BXC(1, 3) SK_BXC(2, 3) SK_BXC(3, 3) SK_BXC(4, 3)
+            SK_BXC(1, 5) SK_BXC(2, 5)
+            SK_BXC(1, 7)
         default: return false;
         }
     }
-    switch (KB * 16 + RT) {   // per-wave row tiles of geometries the switch above does not hold
-        SK_BXR(3, 2) SK_BXR(4, 2) SK_BXR(5, 2) SK_BXR(6, 2)
-        SK_BXR(2, 3) SK_BXR(3, 3)
+    switch (KB * 16 + RT) {   // four, six or eight row tiles: half of them per wave
+        SK_BXR(1, 2) SK_BXR(2, 2) SK_BXR(3, 2) SK_BXR(4, 2) SK_BXR(5, 2) SK_BXR(6, 2)
+        SK_BXR(1, 3) SK_BXR(2, 3) SK_BXR(3, 3)
         SK_BXR(1, 4) SK_BXR(2, 4)
     default: return false;
     }

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 {
     constexpr bool DEC = DECM != 0;
     constexpr int D = 2 * NSEC;
+    constexpr bool G4 = D <= 12;   // V = G x by 4 x 4 x 4 products over the row groups in use (see phase A)
     constexpr int T = SK_PAR_T32 * 4 / (int)sizeof(IO);
     constexpr int NP = T / kPiece;
     using St = Stage<IO>;
@@ -248,36 +249,58 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     const IO *xup = x + up_q0 * LS;   // (uniform base + 32-bit lane offsets: the input samples this segment needs start here)
     const int64_t in_left = a.n_in - up_q0;
     const unsigned in_lim = in_left > 0x7fffffff ? 0x7fffffffu : (in_left > 0 ? (unsigned)in_left : 0u);
-    auto stage_up = [&](int p) {
+    // up_request(p): the one or two input samples of every unit of piece p, all requested before any is used (as load_piece does for the plain
+    // filter; until round 4 a unit's loads were issued and waited for unit by unit -- 8 dependent round trips per piece, 32 per segment,
+    // which is what held rate_change(12).up at 0.13 ms per 2^26 outputs); up_put(p): the units, zero-stuffed, into the image.
+    // (they land in pre[][] -- the registers the plain filter's pieces land in: a unit of more than two samples, float32 only, can hold two
+    // inputs, anything else one, so a unit's inputs are 16 bytes at most)
+    static_assert((St::elems / LS > 2 ? 2 : 1) * LS * sizeof(IO) <= sizeof(pre_t), "a unit's inputs fit its landing register");
+    auto up_unit = [&](int p, int i, unsigned &e0, unsigned &qa) __attribute__((always_inline)) {
+        constexpr int EL = St::elems / LS;
+        const int idx = i * 64 + lane;
+        const int r = idx / USEG, sg = idx % USEG;
+        // v: the unit's first sample (a complex sample for CPLX) counted from the last multiple of up in front of the segment
+        const unsigned v = up_r0 + (unsigned)(r * T + p * kPiece + sg * EL);   // < up + 64 T
+        const unsigned q = (unsigned)(((unsigned long long)v * a.up_magic) >> 32);
+        const unsigned rem = v - q * (unsigned)a.up;
+        e0 = rem ? (unsigned)a.up - rem : 0u;
+        qa = q + (rem ? 1u : 0u);
+    };
+    auto up_request = [&](int p) __attribute__((always_inline)) {
+        const unsigned last = in_lim ? in_lim - 1u : 0u;
+#pragma unroll
+        for (int i = 0; i < St::per_thread; ++i) {
+            unsigned e0, qa;
+            up_unit(p, i, e0, qa);
+            const unsigned q0 = qa < last ? qa : last, q1 = qa + 1u < last ? qa + 1u : last;   // (clamped: the put decides what is used)
+            pre_t val = {0.f, 0.f, 0.f, 0.f};
+            IO *e4 = reinterpret_cast<IO *>(&val);
+#pragma unroll
+            for (int c = 0; c < LS; ++c) {
+                e4[c] = xup[q0 * LS + c];
+                if (St::elems / LS > 2) e4[LS + c] = xup[q1 * LS + c];
+            }
+            pre[p][i] = val;
+        }
+    };
+    auto up_put = [&](int p) __attribute__((always_inline)) {
         constexpr int EL = St::elems / LS;
         const IO gain = (IO)a.up;
-#pragma unroll 1
+#pragma unroll
         for (int i = 0; i < St::per_thread; ++i) {
-            const int idx = i * 64 + lane;
-            const int r = idx / USEG, sg = idx % USEG;
-            // v: the unit's first sample (a complex sample for CPLX) counted from the last multiple of up in front of the segment
-            const unsigned v = up_r0 + (unsigned)(r * T + p * kPiece + sg * EL);   // < up + 64 T
-            const unsigned q = (unsigned)(((unsigned long long)v * a.up_magic) >> 32);
-            const unsigned rem = v - q * (unsigned)a.up;
-            const unsigned e0 = rem ? (unsigned)a.up - rem : 0u, qa = q + (rem ? 1u : 0u);
+            unsigned e0, qa;
+            up_unit(p, i, e0, qa);
             const unsigned e1 = e0 + (unsigned)a.up;
-            IO A[LS], B[LS];
-#pragma unroll
-            for (int c = 0; c < LS; ++c) A[c] = B[c] = IO(0);
-            if (e0 < (unsigned)EL && qa < in_lim) {
-#pragma unroll
-                for (int c = 0; c < LS; ++c) A[c] = gain * xup[qa * LS + c];
-            }
-            if (EL > 2 && e1 < (unsigned)EL && qa + 1 < in_lim) {
-#pragma unroll
-                for (int c = 0; c < LS; ++c) B[c] = gain * xup[(qa + 1) * LS + c];
-            }
+            const bool okA = e0 < (unsigned)EL && qa < in_lim, okB = EL > 2 && e1 < (unsigned)EL && qa + 1u < in_lim;
+            const pre_t got = pre[p][i];
+            const IO *in = reinterpret_cast<const IO *>(&got);
             pre_t val;
             IO *e4 = reinterpret_cast<IO *>(&val);
 #pragma unroll
             for (int e = 0; e < St::elems; ++e) {
                 const unsigned es = (unsigned)(e / LS);
-                e4[e] = es == e0 ? A[e % LS] : ((EL > 2 && es == e1) ? B[e % LS] : IO(0));
+                const IO va = gain * in[e % LS], vb = EL > 2 ? gain * in[LS + e % LS] : IO(0);
+                e4[e] = (okA && es == e0) ? va : ((okB && es == e1) ? vb : IO(0));
             }
             image_put(i, val);
         }
@@ -297,6 +320,16 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     if (ld_fast) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) load_piece(p);
+    } else if (a.up > 1) {
+        if (in_lim) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) up_request(p);
+        } else {   // (nothing of the input reaches this segment: up_put selects zeros)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int i = 0; i < St::per_thread; ++i) pre[p][i] = pre_t{0.f, 0.f, 0.f, 0.f};
+        }
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -304,7 +337,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 #pragma unroll
             for (int i = 0; i < St::per_thread; ++i) image_put(i, pre[p][i]);
         } else if (a.up > 1) {
-            stage_up(p);
+            up_put(p);
         } else {
             stage_slow(p);
         }
@@ -314,9 +347,27 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         const IO *xs = stage + c * St::pitch + j;
 #pragma unroll
         for (int s = 0; s < kPiece / 4; ++s) {
-            const double ga = gl[(p * (kPiece / 4) + s) * 64 + lane];
+            if constexpr (G4) {
+                // v_mfma_f64_4x4x4_4b: four independent 4 x 4 x 4 products -- here the SAME four state rows against four groups of four chunks.
+                // Its B operand (lane = 16 k + chunk) and its result (lane = 16 (row mod 4) + chunk) lie exactly where the 16 x 16 x 4
+                // instruction has them, and register r of the accumulator is row group r; its A operand is G[4 r + (lane & 3)][k = lane >> 4]
+                // in every group of four lanes -- read from the same table.  16 cycles against 64 (tools/ubench_mfma_f64_4x4.hip: 7.3 / 35 ns),
+                // and only the row groups that hold states are multiplied: 4 biquads pay 2 x 16 cycles per step and column tile, not 64.
+                constexpr int NG = (D + 3) / 4;   // row groups that hold states (rows >= D of the table are zero)
+                double ga[NG];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, (double)xs[g * 16 * St::pitch + 4 * s], acc[g], 0, 0, 0);
+                for (int r = 0; r < NG; ++r) ga[r] = gl[(p * (kPiece / 4) + s) * 64 + (lane & 48) + 4 * r + (lane & 3)];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const double b = (double)xs[g * 16 * St::pitch + 4 * s];
+#pragma unroll
+                    for (int r = 0; r < NG; ++r) acc[g][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(ga[r], b, acc[g][r], 0, 0, 0);
+                }
+            } else {
+                const double ga = gl[(p * (kPiece / 4) + s) * 64 + lane];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, (double)xs[g * 16 * St::pitch + 4 * s], acc[g], 0, 0, 0);
+            }
         }
         wave_lds_sync();
     }

@@ -21,7 +21,7 @@ for w in ${PMC_ONLY:-fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fi
   sets=("FETCH_SIZE" "WRITE_SIZE")
   [ $w = fir1024 ] && sets+=("SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES")
   # the issue / wait picture of config 4, before (cascade form) and after (parallel form)
-  case $w in iir8|iir8cas) sets+=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS");; esac
+  case $w in iir8|iir8cas|rcdn12|rcup12) sets+=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS");; esac
   for set in "${sets[@]}"; do
     tag=$(echo $set | cut -d' ' -f1)
     rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$tag -- python $ROOT/bench.py --workload $w --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs --board-seconds 0 > /dev/null 2>&1
@@ -45,7 +45,7 @@ python tools/time_fir_c128.py > $OUT/fir_f64.txt 2>&1
 # multirate_FIR.up: every engine (polyphase, walk over (tile, phase) pairs, the input-tile interpolators) and the default dispatch; .dn likewise
 python tools/time_fir_up.py > $OUT/fir_up.txt 2>&1
 python tools/time_fir_updn.py > $OUT/fir_updn.txt 2>&1
-python tools/check_dn4k.py time > $OUT/fir_dn.txt 2>&1
+python tools/time_fir_dn.py > $OUT/fir_dn.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_strided_store.hip -o /tmp/ubss 2>/dev/null && /tmp/ubss > $OUT/ubench_strided_store.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_dp_pipes.hip -o /tmp/ubench_dp_pipes 2>/dev/null && /tmp/ubench_dp_pipes > $OUT/ubench_dp_pipes.txt 2>&1
 ls -la $OUT
