@@ -350,9 +350,10 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
     }
     bool ols = M > 1 && fir_ols_supported(h) && pick_fir_algo(h, n) == SKDSP_FIR_OLS && !opt().dn_no_ols;
     if (ols) {
+        // the matrix-pipe kernel where it covers the shape (profiles/r04/fir_dn.txt), except the long filters of M <= 4, whose kept outputs still
+        // cost it a good part of the full-rate work: complex64 M = 3, 512 taps 0.256 ms against 0.215 in the frequency domain, float32 0.132 / 0.100
         const int kb = h->algo == SKDSP_FIR_OLS ? 0 : fir_bx_blocks(h, 1, M);
-        if (kb > 0) ols = h->dtype == SKDSP_C64 && kb > 4 * M;
-        else ols = h->ntaps / M >= (h->dtype == SKDSP_C64 ? 24 : 64);  // the two-real-tiles store pays two divides per sample
+        ols = kb == 0 || (M <= 4 && kb > 12) || (h->dtype == SKDSP_C64 && kb > 32);   // (complex64 M = 24, 1024 taps: 0.254 against 0.232)
     }
     // M <= 4: the frequency-domain decimator (fir_dn4k.hip: M forward transforms accumulated, ONE inverse per tile of kept outputs) wherever
     // the decimating overlap-save store would run (which spends 2 M transforms on the same outputs); option fir_dn4k = 2: wherever it applies
@@ -468,10 +469,10 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
         const bool bx = bx_kb > 0;
         base = cplx ? 0.23 : 0.125;
         ols = cplx ? 0.27 + 0.022 * std::min(Lf, 20.0) : 0.13 + 0.018 * std::min(Lf, 28.0);
-        // profiles/r04/fir_up.txt: complex64 0.119 / 0.130 - 0.138 / 0.164 / 0.191 ms for 2 / 3 / 4 / 5 blocks at L = 4 ... 16 (one row tile, L = 2:
-        // 0.13 / 0.155 / 0.185 / 0.215); float32 0.082 - 0.093 / 0.088 - 0.095 / 0.092 / 0.102 (L = 2: 0.082 / 0.093 / 0.104 / 0.118)
-        if (bx && cplx) poly = bx_rt == 1 ? 0.07 + 0.029 * bx_kb : std::max(0.111, 0.057 + 0.027 * bx_kb);
-        else if (bx) poly = (bx_rt == 1 ? 0.054 + 0.0138 * bx_kb : std::max(0.082, 0.06 + 0.0085 * bx_kb)) * (L > 8 ? 1.1 : 1.0);
+        // profiles/r04/fir_up.txt (fp16 pieces): complex64 0.106 - 0.122 up to 3 blocks, then + 0.0145 per block (5: 0.13, 7: 0.165; one row tile, L = 2:
+        // 0.122 / 0.127 / 0.143 / 0.159 / 0.194 / 0.223 for 2 / 3 / 4 / 5 / 7 / 9); float32 0.080 - 0.096 up to 5 blocks, 0.099 at 7 (L = 2: 0.075 ... 0.133)
+        if (bx && cplx) poly = bx_rt == 1 ? 0.093 + 0.0145 * bx_kb : std::max(L >= 8 ? 0.118 : 0.106, 0.062 + 0.0145 * bx_kb);
+        else if (bx) poly = bx_rt == 1 ? 0.058 + 0.0084 * bx_kb : std::max(0.081 * (L > 8 ? 1.15 : (L == 8 ? 1.06 : 1.0)), 0.04 + 0.0084 * bx_kb);
         else poly = cplx ? 0.02 + 0.0037 * T : 0.03 + 0.0018 * T;
         if (!bx && L > 8 && L <= 16) poly *= 1.0 + 0.05 * (Lf - 8.0);   // (48 taps per phase: 0.116 modelled, 0.1395 measured at L = 12)
         if (!bx && T > 256) poly *= std::max(1.0, Lf / 4.0);

@@ -23,6 +23,7 @@
 // tile comes out transposed (col = lane & 15 = row of the tile, the four registers = four columns), so that
 // the 16 lanes of a group store 16 consecutive outputs.
 #include "skdsp_internal.hpp"
+#include <cmath>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -32,8 +33,7 @@ namespace skdsp {
 
 typedef float v4f_bx __attribute__((ext_vector_type(4)));
 typedef float v2f_bx __attribute__((ext_vector_type(2)));
-typedef __bf16 v8bf_bx __attribute__((ext_vector_type(8)));
-typedef __bf16 v2bf_bx __attribute__((ext_vector_type(2)));
+typedef _Float16 v8h_bx __attribute__((ext_vector_type(8)));
 
 constexpr int kBxUnitsC = 512;   // 8-sample units of one complex64 window (2 per thread: 32 prefetch VGPRs)
 constexpr int kBxUnitsR = 1024;  // float32: 4 per thread, the same 32 VGPRs
@@ -58,35 +58,51 @@ struct BxArgs {
     // on every read: M = 8, 512 taps, complex64 ran at 0.30 ms per 2^26 inputs); padded, the stride is s + 1 (odd).
     int pad_s;
     unsigned pad_magic;   // ceil(2^32 / s)
+    float tap_inv;        // 2^-te: the taps of the table are L b 2^te (scaled into the fp16 range on the host)
 };
 
-// (a, b) -> three packed bf16 pairs, a in the low half: a = a1 + a2 + a3 exactly (24 = 3 x 8 mantissa bits).
-// The residuals are formed with SCALAR subtractions on purpose (SK_BX_PK_SPLIT=1: the packed form, half the instructions):
-// v_pk_add_f32 runs on the datapath the matrix pipe uses, so while the other workgroup of the CU is in its MFMA phase a packed
-// split does not advance at all (tools/bx_trace.py: the split of one workgroup ended ~240 clocks after the partner's last MFMA,
-// every window, which is what locked the two workgroups of a CU in phase).
-__device__ __forceinline__ void bx_split2(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3)
+#ifndef SK_BX_PX
+#define SK_BX_PX 2
+#endif
+constexpr int kBxPx = SK_BX_PX;   // fp16 pieces of a signal sample (2: 22 bits; 3: all 24, one more product per tap piece pair)
+constexpr int kBxPh = 2;          // fp16 pieces of a tap
+
+// (a, b), already scaled into the fp16 range -> kBxPx packed fp16 pairs, a in the low half: a = a1 + a2 (+ a3) to 2^-22 (exactly).
+// Round-to-nearest pieces (v_cvt_pk_f16_f32), so each residual is at most half an ulp of the piece before it.
+// The residuals are formed with SCALAR subtractions on purpose: v_pk_add_f32 runs on the datapath the matrix pipe uses, so while the
+// other workgroup of the CU is in its MFMA phase a packed split does not advance at all (round 3: the split of one workgroup ended
+// ~240 clocks after the partner's last MFMA, every window, which is what locked the two workgroups of a CU in phase).
+__device__ __forceinline__ void bx_split2(float a, float b, unsigned (&p)[kBxPx])
 {
     auto cvt = [](float lo, float hi) -> unsigned {
-        unsigned p;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(lo), "v"(hi));
-        return p;
-    };
-    auto sub = [](float x, unsigned piece) -> float {   // (an asm statement: hipcc's SLP vectoriser would pair two of these into v_pk_add_f32)
-        float r;
-        asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(piece));
+        unsigned r;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
         return r;
     };
-    p1 = cvt(a, b);
-    const float ra = sub(a, p1 << 16), rb = sub(b, p1 & 0xffff0000u);
-    p2 = cvt(ra, rb);
-    const float sa = sub(ra, p2 << 16), sb = sub(rb, p2 & 0xffff0000u);
-    p3 = cvt(sa, sb);
+    auto sub_lo = [](float x, unsigned piece) -> float {   // x - (float)piece.lo  (asm statements: hipcc's SLP vectoriser would pair the subtractions into v_pk_add_f32)
+        float f, r;
+        asm("v_cvt_f32_f16 %0, %1" : "=v"(f) : "v"(piece));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(f));
+        return r;
+    };
+    auto sub_hi = [](float x, unsigned piece) -> float {
+        float f, r;
+        asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "v"(piece));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(f));
+        return r;
+    };
+    p[0] = cvt(a, b);
+#pragma unroll
+    for (int i = 1; i < kBxPx; ++i) {
+        a = sub_lo(a, p[i - 1]);
+        b = sub_hi(b, p[i - 1]);
+        p[i] = cvt(a, b);
+    }
 }
 
 __device__ __forceinline__ v4f_bx bx_mfma(uint4 a, uint4 b, v4f_bx c)
 {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf_bx, a), __builtin_bit_cast(v8bf_bx, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h_bx, a), __builtin_bit_cast(v8h_bx, b), c, 0, 0, 0);
 }
 
 // Persistent 256-thread workgroups: window w+1 is requested into registers before window w is multiplied, so
@@ -141,22 +157,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int w = 0; w < F4; ++w) pre[h][w] = s4[w];
         }
     };
-    // 8 samples v[0 .. 8 C) -> one 16-byte row per bf16 piece and component at unit u
+    // The window's scale.  fp16 holds 2^-14 .. 2^16, so a window is multiplied by the power of two that puts its largest magnitude
+    // into [2^14, 2^15) before it is split (exact), and its outputs by the inverse (times the taps' 2^-te).  wmax_sh[wave]: the waves'
+    // maxima of |x| as integer bit patterns (written in front of the barrier that frees the planes, read behind it).
+    unsigned *wmax_sh = reinterpret_cast<unsigned *>(bx_smem + (size_t)(kBxPx * C) * plane_bytes + (KSP > 1 ? (size_t)2 * 4 * (4 * C) * 64 * 4 : 0));
+    float wscale = 1.f, winv_next = 1.f;
+    auto publish_max = [&](unsigned m) {   // m: this thread's maximum of |x| bits
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+        if (lane == 0) wmax_sh[wave] = m;
+    };
+    auto fetch_scale = [&]() {   // behind the barrier: wscale for the split, winv_next for this window's outputs
+        const unsigned m = max(max(wmax_sh[0], wmax_sh[1]), max(wmax_sh[2], wmax_sh[3]));
+        int e = (int)(m >> 23);                       // biased exponent of the largest magnitude
+        if (e == 0 || e == 255) e = 141;              // all zero (or not finite: nothing sensible to do): scale 1
+        e = e < 16 ? 16 : e;                          // (2^(141 - e) must stay a normal float)
+        wscale = __uint_as_float((unsigned)(141 - e + 127) << 23);
+        winv_next = __uint_as_float((unsigned)(e - 141 + 127) << 23) * a.tap_inv;
+    };
+    auto pre_max = [&]() -> unsigned {   // over the prefetched window
+        unsigned m = 0;
+#pragma unroll
+        for (int h = 0; h < UPT; ++h)
+#pragma unroll
+            for (int w = 0; w < F4; ++w) {
+                m = max(m, __float_as_uint(pre[h][w].x) & 0x7fffffffu);
+                m = max(m, __float_as_uint(pre[h][w].y) & 0x7fffffffu);
+                m = max(m, __float_as_uint(pre[h][w].z) & 0x7fffffffu);
+                m = max(m, __float_as_uint(pre[h][w].w) & 0x7fffffffu);
+            }
+        return m;
+    };
+    // 8 samples v[0 .. 8 C) -> one 16-byte row per fp16 piece and component at unit u
     auto split_unit = [&](const float *v, int u) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            unsigned p1[4], p2[4], p3[4];
+            unsigned pc[4][kBxPx];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) bx_split2(v[(2 * w) * C + c], v[(2 * w + 1) * C + c], p1[w], p2[w], p3[w]);
-            char *base = bx_smem + (size_t)(3 * c) * plane_bytes + (size_t)padded(u) * 16;
-            *reinterpret_cast<uint4 *>(base) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
-            *reinterpret_cast<uint4 *>(base + plane_bytes) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
-            *reinterpret_cast<uint4 *>(base + 2 * plane_bytes) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+            for (int w = 0; w < 4; ++w) bx_split2(v[(2 * w) * C + c] * wscale, v[(2 * w + 1) * C + c] * wscale, pc[w]);
+            char *base = bx_smem + (size_t)(kBxPx * c) * plane_bytes + (size_t)padded(u) * 16;
+#pragma unroll
+            for (int i = 0; i < kBxPx; ++i) *reinterpret_cast<uint4 *>(base + (size_t)i * plane_bytes) = make_uint4(pc[0][i], pc[1][i], pc[2][i], pc[3][i]);
         }
     };
     auto store_window = [&]() {  // the prefetched window (branch-free: units beyond the window go to the dump row)
 #pragma unroll
         for (int h = 0; h < UPT; ++h) split_unit(reinterpret_cast<const float *>(&pre[h][0]), min(tid + 256 * h, nunits));
+    };
+    auto slow_max = [&](int64_t wdx) -> unsigned {   // the same window's largest magnitude
+        const int64_t g0 = window_g0(wdx);
+        unsigned m = 0;
+#pragma unroll 1
+        for (int u = tid; u < nunits; u += 256)
+#pragma unroll 1
+            for (int e = 0; e < 8; ++e) {
+                const int64_t g = g0 + 8 * (int64_t)u + e;
+                if (g >= -a.n_hist && g < a.n)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) m = max(m, __float_as_uint(x[g * C + c]) & 0x7fffffffu);
+            }
+        return m;
     };
     auto stage_window_slow = [&](int64_t wdx) {  // guarded scalar loads, zero outside [-n_hist, n)
         const int64_t g0 = window_g0(wdx);
@@ -181,14 +241,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     bool fast = interior(wdx);
     if (fast) load_window(wdx);  // first: the A operands below queue behind it
 
-    // A operands of this lane: [32-lag block][row tile][bf16 piece]
-    uint4 areg[KB][RT][3];
+    // A operands of this lane: [32-lag block][row tile][fp16 piece]
+    uint4 areg[KB][RT][kBxPh];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) areg[kb][rt][p] = At[(((kb0 + kb) * RTT + rt0 + rt) * 3 + p) * 64 + lane];
+            for (int p = 0; p < kBxPh; ++p) areg[kb][rt][p] = At[(((kb0 + kb) * RTT + rt0 + rt) * kBxPh + p) * 64 + lane];
 
     const int ncol = lane & 15, j = lane >> 4;
     const int ntiles = a.NS / 16;
@@ -199,12 +259,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < kBxPh; ++p)
                 asm volatile("" ::"v"(areg[kb][rt][p].x), "v"(areg[kb][rt][p].y), "v"(areg[kb][rt][p].z), "v"(areg[kb][rt][p].w) : "memory");
     // Iteration w:  MFMAs of window w (stores of all tiles but the wave's last) | barrier | split window w+1
     // into the planes | stores of the last tile | barrier | request window w+2.  The split is the only place
     // that waits on loads, and the only stores still in flight there are a whole tile old (vmcnt retires in
     // order: a wait behind fresh stores would also wait for their acknowledgement).
+    publish_max(fast ? pre_max() : slow_max(wdx));
+    __syncthreads();
+    fetch_scale();
+    float winv = winv_next;   // of the window in the planes
     if (fast) store_window();
     else stage_window_slow(wdx);
     __syncthreads();
@@ -234,34 +298,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // multiplied first, piece 3 last), so every LDS read has >= 3 products (192 cycles) of cover.
             // Small products (relative size 2^-9 .. 2^-18) go to their own accumulator; consecutive MFMAs
             // go to different accumulators (row tile x component).
-            uint4 b[C][3];
+            uint4 b[C][kBxPx];
             // (pad units in front of block kb0 + kb: wave-uniform)
             auto kpad = [&](int kb) -> int { return __builtin_amdgcn_readfirstlane((int)(((unsigned long long)(unsigned)(4 * (kb0 + kb)) * a.pad_magic) >> 32)); };
             auto read_b = [&](int kb, int p) {
 #pragma unroll
                 for (int c = 0; c < C; ++c)
-                    b[c][p] = *reinterpret_cast<const uint4 *>(bbase + (size_t)(3 * c + p) * plane_bytes + 64 * kb + 16 * kpad(kb));
+                    b[c][p] = *reinterpret_cast<const uint4 *>(bbase + (size_t)(kBxPx * c + p) * plane_bytes + 64 * kb + 16 * kpad(kb));
             };
-            read_b(0, 0);
-            read_b(0, 1);
-            read_b(0, 2);
+#pragma unroll
+            for (int p = 0; p < kBxPx; ++p) read_b(0, p);
 #define SK_BX(PA, PB, ACC)                                                                              \
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int c = 0; c < C; ++c)    \
         ACC[rt][c] = bx_mfma(b[c][PB], areg[kb][rt][PA], ACC[rt][c]);
+            // products: (tap piece, signal piece) = (1, 1) into `big`; (2, 1), (1, 2) [and (1, 3)] -- 2^-11 [2^-22] of it -- into `small`;
+            // (2, 2) and beyond are below 2^-22 of the leading product and are not formed
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                SK_BX(2, 0, small)
                 SK_BX(1, 0, small)
                 SK_BX(0, 0, big)
                 __builtin_amdgcn_sched_barrier(0);
                 if (kb + 1 < KB) read_b(kb + 1, 0);
-                SK_BX(1, 1, small)
                 SK_BX(0, 1, small)
                 __builtin_amdgcn_sched_barrier(0);
                 if (kb + 1 < KB) read_b(kb + 1, 1);
-                SK_BX(0, 2, small)
-                __builtin_amdgcn_sched_barrier(0);
-                if (kb + 1 < KB) read_b(kb + 1, 2);
+                if constexpr (kBxPx > 2) {
+                    SK_BX(0, 2, small)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kb + 1 < KB) read_b(kb + 1, 2);
+                }
             }
 #undef SK_BX
         };
@@ -283,10 +348,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             };
             auto put = [&](int rt, int i, int off) __attribute__((always_inline)) {
                 if (CPLX) {
-                    v2f_bx o = {sum(big[rt][0][i], small[rt][0][i]), sum(big[rt][C - 1][i], small[rt][C - 1][i])};
+                    v2f_bx o = {sum(big[rt][0][i], small[rt][0][i]) * winv, sum(big[rt][C - 1][i], small[rt][C - 1][i]) * winv};
                     __builtin_nontemporal_store(o, reinterpret_cast<v2f_bx *>(yb + 2 * off));
                 } else {
-                    __builtin_nontemporal_store(sum(big[rt][0][i], small[rt][0][i]), yb + off);
+                    __builtin_nontemporal_store(sum(big[rt][0][i], small[rt][0][i]) * winv, yb + off);
                 }
             };
             // whole tile inside the output and all 16 RT rows in use (uniform): no per-store guards
@@ -307,7 +372,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         if constexpr (KSP > 1) {
             // every wave multiplies its lags of every column tile; partial tiles [parity][wave][component, i][lane] behind the planes
-            float *red = reinterpret_cast<float *>(bx_smem + (size_t)(3 * C) * plane_bytes);
+            float *red = reinterpret_cast<float *>(bx_smem + (size_t)(kBxPx * C) * plane_bytes);
             const int cstep = a.eo ? 2 * a.RS : a.RS;
 #pragma unroll 1
             for (int ct = 0; ct < ntiles; ++ct) {
@@ -328,15 +393,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 const int64_t m = (int64_t)a.RS * (S0 + col_of(ct, 4 * j)) + ncol + (int64_t)wave * cstep;
                 if (ncol < a.RS && m < a.n_out) {
-                    if (CPLX) __builtin_nontemporal_store(v2f_bx{o[0], o[C - 1]}, reinterpret_cast<v2f_bx *>(y + 2 * m));
-                    else __builtin_nontemporal_store(o[0], y + m);
+                    if (CPLX) __builtin_nontemporal_store(v2f_bx{o[0] * winv, o[C - 1] * winv}, reinterpret_cast<v2f_bx *>(y + 2 * m));
+                    else __builtin_nontemporal_store(o[0] * winv, y + m);
                 }
             }
+            if (wnext < nwin) publish_max(fast ? pre_max() : slow_max(wnext));
             __syncthreads();  // everyone is done reading the planes
             if (wnext < nwin) {
+                fetch_scale();
                 if (fast) store_window();
                 else stage_window_slow(wnext);
             }
+            winv = winv_next;
             __syncthreads();  // the planes hold window w+1
             const int64_t wnext2 = wnext + gridDim.x;
             fast = wnext2 < nwin && interior(wnext2);
@@ -355,8 +423,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         const bool has_last = ct < ntiles;
         if (has_last) mma_tile(ct);
+        if (wnext < nwin) publish_max(fast ? pre_max() : slow_max(wnext));   // (the place that waits for the prefetched window)
         __syncthreads();  // everyone is done reading the planes
         if (wnext < nwin) {
+            fetch_scale();
             if (fast) {
                 store_window();
             } else {
@@ -364,8 +434,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         __builtin_amdgcn_s_setprio(3);
-        if (has_last) store_tile(ct);
+        if (has_last) store_tile(ct);   // (still window w: its own inverse scale)
         __builtin_amdgcn_s_setprio(0);
+        winv = winv_next;
         __syncthreads();  // the planes hold window w+1
         const int64_t wnext2 = wnext + gridDim.x;
         fast = wnext2 < nwin && interior(wnext2);
@@ -378,28 +449,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-static unsigned short bx_bf16_rne(double v)
+// nearest fp16 (ties to even) of a value inside the fp16 range, and back
+static unsigned short bx_f16_rne(double v)
 {
-    const float f = (float)v;  // (a piece need not be the nearest bf16: the next piece takes whatever is left)
-    unsigned u;
-    std::memcpy(&u, &f, 4);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+    const _Float16 hv = (_Float16)v;
+    unsigned short u;
+    std::memcpy(&u, &hv, 2);
+    return u;
 }
-static double bx_bf16_val(unsigned short h)
+static double bx_f16_val(unsigned short h)
 {
-    const unsigned u = (unsigned)h << 16;
-    float f;
-    std::memcpy(&f, &u, 4);
-    return (double)f;
+    _Float16 hv;
+    std::memcpy(&hv, &h, 2);
+    return (double)hv;
 }
 
-// does a wave's share fit its 256 VGPRs (2 waves per SIMD)?  A operands (12 per 32-lag block and row tile) + accumulators + B fragments +
-// 32 prefetch registers + ~52 others; kb, rt: blocks / row tiles PER WAVE.  Used by the geometry below and by the dispatch, so that only
-// kernels the geometry can pick are instantiated.
+// does a wave's share fit its 256 VGPRs (2 waves per SIMD)?  A operands (4 per tap piece, 32-lag block and row tile) + accumulators + B
+// fragments + 32 prefetch registers + ~60 others; kb, rt: blocks / row tiles PER WAVE.  Used by the geometry below and by the dispatch, so
+// that only kernels the geometry can pick are instantiated.
 static constexpr bool bx_fits(bool cplx, int kb, int rt)
 {
-    return kb * rt <= 12 && 12 * kb * rt + 8 * (cplx ? 2 : 1) * rt + 12 * (cplx ? 2 : 1) + 32 + 52 <= (cplx ? 276 : 256);
+    return kb * rt <= 16 && 4 * kBxPh * kb * rt + 8 * (cplx ? 2 : 1) * rt + 4 * kBxPx * (cplx ? 2 : 1) + 32 + 60 <= 252;
 }
 
 // geometry of one (L, M): false if the kernel family does not cover it
@@ -417,15 +487,23 @@ static bool bx_geometry(const FirHandle *h, int L, int M, FirHandle::BxTab *t)
         if (util > best_util + 1e-9) { best_util = util; best_k = k; }
     }
     if (best_k == 0 || best_util < 0.74) return false;
-    const int DS = ds0 * best_k, RS = Lp * DS, RT = (RS + 15) / 16;
-    int imax = 0;
-    for (int c = 0; c < Lp; ++c) imax = std::max(imax, (int)(((int64_t)c * M) / L));
-    int U0 = imax + q * (DS - 1);
-    // window element 0 is input q_ds S0 + U0 + 1 - 32 KB: a 16-byte boundary of x for U0 + 1 = 0 mod 4 (2 for complex)
-    const int al = dtype_complex(h->dtype) ? 2 : 4;
-    U0 += (al - (U0 + 1) % al) % al;
-    const int KB = (T + U0 + 31) / 32;
     const int comp = dtype_complex(h->dtype) ? 2 : 1;
+    const int al = comp == 2 ? 2 : 4;
+    const int cap = 8 * (comp == 2 ? kBxUnitsC : kBxUnitsR);
+    int DS, RS, RT, U0, KB;
+    for (;; best_k /= 2) {
+        DS = ds0 * best_k; RS = Lp * DS; RT = (RS + 15) / 16;
+        int imax = 0;
+        for (int c = 0; c < Lp; ++c) imax = std::max(imax, (int)(((int64_t)c * M) / L));
+        U0 = imax + q * (DS - 1);
+        // window element 0 is input q_ds S0 + U0 + 1 - 32 KB: a 16-byte boundary of x for U0 + 1 = 0 mod 4 (2 for complex)
+        U0 += (al - (U0 + 1) % al) % al;
+        KB = (T + U0 + 31) / 32;
+        // A decimator with a large M (one class, one row tile): 16 slots per column are 16 M inputs, and 16 columns of them may not fit the
+        // window (M = 24: 16 x 384 samples).  Fewer slots per column then -- half-empty row tiles cost matrix-pipe time these shapes do
+        // not lack (M = 24, 512 taps, complex64: 1.43 ms per 2^26 inputs on the kernels behind this one).
+        if (Lp > 1 || best_k % 2 || RS < 8 || cap >= q * DS * 15 + 32 * ((KB + 3) / 4 * 4)) break;
+    }
     // What does not fit one wave (bx_fits) is tried with the row tiles dealt to wave pairs (RSP = 2: see the kernel); four or more row tiles
     // always are (the same speed where both fit -- L = 8, 48 taps per phase: 0.1245 / 0.1259 ms -- and the one-wave forms of 4 x 2, 6 x 1 spilled)
     int RSP = 0;
@@ -439,11 +517,10 @@ static bool bx_geometry(const FirHandle *h, int L, int M, FirHandle::BxTab *t)
     // than one wave's registers take: the waves split the lags (KSP = 4: see the kernel); the table is padded to 4 equal shares.
     int KSP = 1, KBT = KB;
     if (RT == 1) {
-        const int cap = 8 * (comp == 2 ? kBxUnitsC : kBxUnitsR);
         const int ns_max = cap > 32 * KB ? (cap - 32 * KB) / (q * DS) + 1 : 0;
         if (!RSP || ns_max < 64) {
             const int kbw = (KB + 3) / 4;
-            if (kbw <= 8 && cap >= 32 * 4 * kbw + q * DS * 15) { KSP = 4; KBT = 4 * kbw; RSP = 1; }
+            if (kbw <= 12 && cap >= 32 * 4 * kbw + q * DS * 15) { KSP = 4; KBT = 4 * kbw; RSP = 1; }
         }
     }
     if (!RSP) return false;
@@ -488,8 +565,8 @@ int fir_bx_blocks(const FirHandle *h, int L, int M, int *row_tiles)
     return t.KB;
 }
 
-// A-operand table of one (L, M): At[((kb RT + rt) 3 + piece) 64 + lane] = 8 bf16 of row 16 rt + (lane & 15),
-// lags u = K - 1 - (32 kb + 8 (lane >> 4) + i)
+// A-operand table of one (L, M): At[((kb RT + rt) kBxPh + piece) 64 + lane] = 8 fp16 of row 16 rt + (lane & 15),
+// lags u = K - 1 - (32 kb + 8 (lane >> 4) + i); the taps are L b 2^te, te the power of two that puts the largest into [2^13, 2^14)
 static int get_bx_table(FirHandle *h, int L, int M, const FirHandle::BxTab **out)
 {
     for (auto &t : h->bx)
@@ -497,7 +574,16 @@ static int get_bx_table(FirHandle *h, int L, int M, const FirHandle::BxTab **out
     FirHandle::BxTab t;
     SK_CHECK(bx_geometry(h, L, M, &t), SKDSP_ERR_UNSUPPORTED, "fir_bx: L=%d M=%d not covered", L, M);
     const int P = h->ntaps, T = (P + L - 1) / L, K = 32 * t.KB;
-    std::vector<unsigned short> host((size_t)t.KB * t.RT * 3 * 64 * 8, 0);
+    double tmax = 0.0;
+    for (int k = 0; k < P; ++k) tmax = std::max(tmax, std::fabs((double)L * h->taps_host[k]));
+    int te = 0;
+    if (tmax > 0.0 && std::isfinite(tmax)) {
+        int ex;
+        std::frexp(tmax, &ex);        // tmax = m 2^ex, m in [0.5, 1)
+        te = std::min(std::max(14 - ex, -100), 100);
+    }
+    t.tap_inv = (float)std::ldexp(1.0, -te);
+    std::vector<unsigned short> host((size_t)t.KB * t.RT * kBxPh * 64 * 8, 0);
     for (int kb = 0; kb < t.KB; ++kb)
         for (int rt = 0; rt < t.RT; ++rt)
             for (int lane = 0; lane < 64; ++lane)
@@ -512,11 +598,11 @@ static int get_bx_table(FirHandle *h, int L, int M, const FirHandle::BxTab **out
                     if (tt < 0 || tt >= T) continue;
                     const int k = phi + L * tt;
                     if (k >= P) continue;
-                    double v = (double)L * h->taps_host[k];
-                    for (int p = 0; p < 3; ++p) {
-                        const unsigned short piece = bx_bf16_rne(v);
-                        host[((((size_t)kb * t.RT + rt) * 3 + p) * 64 + lane) * 8 + i] = piece;
-                        v -= bx_bf16_val(piece);
+                    double v = std::ldexp((double)L * h->taps_host[k], te);
+                    for (int p = 0; p < kBxPh; ++p) {
+                        const unsigned short piece = bx_f16_rne(v);
+                        host[((((size_t)kb * t.RT + rt) * kBxPh + p) * 64 + lane) * 8 + i] = piece;
+                        v -= bx_f16_val(piece);
                     }
                 }
     SK_HIP(hipMalloc(&t.At, host.size() * 2));
@@ -553,24 +639,26 @@ static bool bx_dispatch(int KB, int RT, int RSP, int KSP, unsigned grid, size_t 
 #define SK_BXK(kb) case (kb): return bx_launch_if<CPLX, kb, 1, 1, 4>(grid, lds, s, x, At, a, y);
     if (KSP == 4) {
         switch (KB) {
-            SK_BXK(1) SK_BXK(2) SK_BXK(3) SK_BXK(4) SK_BXK(5) SK_BXK(6) SK_BXK(7) SK_BXK(8)
+            SK_BXK(1) SK_BXK(2) SK_BXK(3) SK_BXK(4) SK_BXK(5) SK_BXK(6) SK_BXK(7) SK_BXK(8) SK_BXK(9) SK_BXK(10) SK_BXK(11) SK_BXK(12)
         default: return false;
         }
     }
+    // (the lists are what bx_fits can accept for either dtype; bx_launch_if instantiates only what fits)
     if (RSP == 1) {   // one, two, three, five or seven row tiles
         switch (KB * 16 + RT) {
             SK_BXC(1, 1) SK_BXC(2, 1) SK_BXC(3, 1) SK_BXC(4, 1) SK_BXC(5, 1) SK_BXC(6, 1) SK_BXC(7, 1) SK_BXC(8, 1) SK_BXC(9, 1) SK_BXC(10, 1) SK_BXC(11, 1) SK_BXC(12, 1)
-            SK_BXC(1, 2) SK_BXC(2, 2) SK_BXC(3, 2) SK_BXC(4, 2) SK_BXC(5, 2) SK_BXC(6, 2)
-            SK_BXC(1, 3) SK_BXC(2, 3) SK_BXC(3, 3) SK_BXC(4, 3)
+            SK_BXC(13, 1) SK_BXC(14, 1) SK_BXC(15, 1) SK_BXC(16, 1)
+            SK_BXC(1, 2) SK_BXC(2, 2) SK_BXC(3, 2) SK_BXC(4, 2) SK_BXC(5, 2) SK_BXC(6, 2) SK_BXC(7, 2) SK_BXC(8, 2)
+            SK_BXC(1, 3) SK_BXC(2, 3) SK_BXC(3, 3) SK_BXC(4, 3) SK_BXC(5, 3)
             SK_BXC(1, 5) SK_BXC(2, 5)
             SK_BXC(1, 7)
         default: return false;
         }
     }
     switch (KB * 16 + RT) {   // four, six or eight row tiles: half of them per wave
-        SK_BXR(1, 2) SK_BXR(2, 2) SK_BXR(3, 2) SK_BXR(4, 2) SK_BXR(5, 2) SK_BXR(6, 2)
-        SK_BXR(1, 3) SK_BXR(2, 3) SK_BXR(3, 3)
-        SK_BXR(1, 4) SK_BXR(2, 4)
+        SK_BXR(1, 2) SK_BXR(2, 2) SK_BXR(3, 2) SK_BXR(4, 2) SK_BXR(5, 2) SK_BXR(6, 2) SK_BXR(7, 2) SK_BXR(8, 2)
+        SK_BXR(1, 3) SK_BXR(2, 3) SK_BXR(3, 3) SK_BXR(4, 3) SK_BXR(5, 3)
+        SK_BXR(1, 4) SK_BXR(2, 4) SK_BXR(3, 4)
     default: return false;
     }
 #undef SK_BXC
@@ -596,8 +684,10 @@ int fir_bx_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L,
     a.pad_s = su % 4 == 0 ? su : 0;
     a.pad_magic = a.pad_s ? (unsigned)(((1ull << 32) + su - 1) / su) : 0u;
     const int units = a.win / 8;
-    size_t lds = (size_t)(cplx ? 6 : 3) * (size_t)(units + (a.pad_s ? units / su : 0) + 1) * 16;  // (+ a dump row per plane)
+    size_t lds = (size_t)(cplx ? 2 : 1) * kBxPx * (size_t)(units + (a.pad_s ? units / su : 0) + 1) * 16;  // (+ a dump row per plane)
     if (t->KSP > 1) lds += (size_t)2 * 4 * (cplx ? 8 : 4) * 64 * sizeof(float);   // the partial tiles of the lag split, two generations
+    lds += 16;                                                                      // the waves' window maxima
+    a.tap_inv = t->tap_inv;
     const int64_t ncols = (n_out + a.RS - 1) / a.RS;
     const int64_t nwin = (ncols + a.NS - 1) / a.NS;
     const unsigned grid = (unsigned)std::min<int64_t>(nwin, (int64_t)2 * ctx().num_cus);  // persistent: two per CU

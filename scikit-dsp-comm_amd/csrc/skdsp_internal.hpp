@@ -146,7 +146,7 @@ struct FirHandle : HandleBase {
     struct MmTab { int L, M, Lp, q, DS, RS, U0, K4; void *At; };
     std::vector<MmTab> mm;
     // bf16x3 Toeplitz-product A-operand tables, keyed by (L, M)  -- fir_bx.hip
-    struct BxTab { int L, M, Lp, q, DS, RS, RT, U0, KB, RSP, KSP; void *At; };   // RT / KB: row tiles / 32-lag blocks of the table; RSP / KSP: waves they are dealt to
+    struct BxTab { int L, M, Lp, q, DS, RS, RT, U0, KB, RSP, KSP; float tap_inv; void *At; };   // RT / KB: row tiles / 32-lag blocks of the table; RSP / KSP: waves they are dealt to
     std::vector<BxTab> bx;
     OlsPlan *ols = nullptr;
     struct OlsUp { int L; OlsPlan *plan; };   // overlap-save plans of multirate_FIR.up, keyed by L (fir_ols_up_launch)

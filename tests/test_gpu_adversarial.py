@@ -129,9 +129,10 @@ def test_filter_coherent_inputs(engine, algo, cplx, taps, kind):
     if stop:
         check_forward(y, orc.fir_filter(b, x), b, x, what)
     else:
-        # the direct form FORCED onto a 4097-tap filter (AUTO takes overlap-save from 82 / 146 taps on) is one float32
-        # chain of 128 products per partial sum in the sliding-window kernel: 8e-7 on DC, the only case above 6e-7
-        forced_long = engine == "direct" and len(b) > 2000
+        # the direct form FORCED onto a long filter (AUTO takes overlap-save from 82 / 146 taps on): 4097 taps are one float32 chain of
+        # 128 products per partial sum in the sliding-window kernel (8e-7 on DC); 1024 taps are 36 lag blocks of the matrix-pipe kernel,
+        # nine per wave (rel-L2 1.3e-7 like every engine, worst sample 8.2e-7 on the tones) -- the only cases above 6e-7
+        forced_long = engine == "direct" and len(b) > 1000
         check(y, orc.fir_filter(b, x), what, TOL32 if forced_long else TOL32_PASS)
 
 
@@ -176,6 +177,8 @@ def test_up_dn_updn_coherent_inputs(cplx, taps, kind):
         kk = _ffi.FirKernel(b, code)
         kk.set_algo(algo)
         verdict(kk.dn(x, 12), ref_dn, x, "dn12/%s %s" % (engine, tag))
+    # what AUTO takes for a decimator with a large M (the matrix-pipe kernel with its lags dealt to the four waves, up to 12 blocks each)
+    verdict(k.dn(x, 24), orc.fir_dn(b, x, 24), x, "dn24 " + tag)
     xs = signal_of("tone" if stop else kind, 12000, cplx, f0 * 4)
     verdict(k.updn(xs, 4, 3), orc.downsample(orc.fir_up(b, xs, 4), 3), xs, "updn43 " + tag, gain=phase_gain(4))
 
