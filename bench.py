@@ -261,8 +261,8 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
         w.step = lambda: k.filter_dev(w.xd, w.yd)
         w.alg_bytes = 8.0 * n
         w.kern = "fir_bx_kernel"
-        w.wl = ("multirate_FIR.filter: 127-tap lowpass, float32, %s samples, direct form on the BF16 matrix pipe "
-                "(3-way bf16 split = float32 precision)" % lg)
+        w.wl = ("multirate_FIR.filter: 127-tap lowpass, float32, %s samples, direct form on the fp16 matrix pipe "
+                "(two fp16 pieces per operand, three products per tap = float32 accuracy)" % lg)
         w.metric = "float32 MSamples/s (FIR-127 tap, %s samples)" % lg
     elif name == "updn43":
         b = firwin_lowpass(512, 0.225)
@@ -273,13 +273,13 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
         w.yd = _ffi.DeviceArray(n_out, w.dtype)
         w.step = lambda: k.updn_dev(w.xd, w.yd, 4, 3)
         w.alg_bytes = 8.0 * n + 8.0 * n_out                      # 18.67 B per input sample
-        # float32 arithmetic carried by 6 bf16 products per multiply: against the FP32 matrix / vector peak the useful
+        # float32 arithmetic carried by 3 fp16 products per multiply: against the FP32 matrix / vector peak the useful
         # flops may exceed 100 % -- that is the point of the split
-        w.compute = ("useful f32 flops vs the FP32 matrix-pipe peak (computed as 6 bf16 MFMA products per multiply)",
+        w.compute = ("useful f32 flops vs the FP32 matrix-pipe peak (computed as 3 fp16 MFMA products per multiply)",
                      157.3, 4.0 * 512 / 4 * n_out)               # 4*Ntaps/L flop per c64 output
         w.kern = "fir_bx_kernel"
         w.wl = ("downsample(multirate_FIR.up(x,4),3): 512-tap prototype, complex64, %s input samples, fused polyphase "
-                "(Toeplitz product on the BF16 matrix pipe, 3-way bf16 split = float32 precision)" % lg)
+                "(Toeplitz product on the fp16 matrix pipe, two fp16 pieces per operand = float32 accuracy)" % lg)
         w.metric = "complex64 input MSamples/s (polyphase L=4/M=3, 512 taps, %s samples)" % lg
     elif name == "fir1024c128":
         b = firwin_lowpass(1024, 0.2)

@@ -224,10 +224,10 @@ static int pick_fir_algo(const FirHandle *h, int64_t n)
     // float64 signals: the direct form costs 2 (4 for complex taps) FP64 FMA per tap and real sample; the float64
     // overlap-save tile is flat in the tap count (measured crossovers at 2^26 samples: see DESIGN.md 4.1b)
     if (ols64) return h->ntaps >= (h->dtype == SKDSP_C128 ? 24 : 128) && n >= 8192 ? SKDSP_FIR_OLS : SKDSP_FIR_DIRECT;
-    // measured crossover at 2^26 samples (same box, alternating runs): the bf16x3 matrix-pipe kernel (real taps) stays
-    // ahead of overlap-save up to 3 lag blocks for complex64 (0.21 vs 0.23 ms at 81 taps; 0.234 vs 0.227 at 96) and
-    // 5 for float32 (0.135 vs 0.138 ms at 145 taps)
-    const int ols_from = h->taps_complex ? 48 : (h->dtype == SKDSP_C64 ? 82 : 146);
+    // measured crossover at 2^26 samples (tools/time_fir_filter.py, profiles/r04/fir_filter.txt): the matrix-pipe kernel (real taps, fp16 pieces)
+    // stays ahead of overlap-save up to 6 lag blocks for complex64 (0.215 vs 0.229 ms at 145 taps; 0.221 vs 0.227 at 160; 0.241 vs 0.227 at 192)
+    // and for float32 (0.109 vs 0.125 ms at 145 taps; 0.125 vs 0.126 at 192; 0.133 vs 0.122 at 224)
+    const int ols_from = h->taps_complex ? 48 : (h->dtype == SKDSP_C64 ? 177 : 193);
     if (fir_ols_supported(h) && h->ntaps >= ols_from && n >= 4096) return SKDSP_FIR_OLS;
     return SKDSP_FIR_DIRECT;
 }
@@ -236,8 +236,7 @@ int fir_algo_for(const FirHandle *h, int64_t n) { return pick_fir_algo(h, n); }
 
 // .dn: long filters with a modest M go through the overlap-save engine with a decimating store, which
 // beats Ntaps/M direct taps per kept sample (2^24 complex64, 512 taps, M = 3: 0.163 -> 0.085 ms).  Where the
-// bf16x3 matrix-pipe kernel covers the geometry it is the faster one up to ~4 M lag blocks for complex64
-// (2^26: 0.14-0.20 ms against a flat 0.24) and always for float32 (0.07-0.15 against 0.26).
+// matrix-pipe kernel covers the geometry it is the faster one (profiles/r04/fir_dn.txt) except for the long filters of M <= 4: fir_dn_any.
 // ---- tap partitioning: filters longer than one launch takes ------------------------------------------------------
 // The reference accepts any tap count (lfilter(b,[1],x), multirate_helper.py:108).  One launch takes up to 4097 taps in
 // the overlap-save engine (float32 / complex64) and a few thousand in the float64 direct-form kernels (LDS window); a
@@ -353,7 +352,7 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
         // the matrix-pipe kernel where it covers the shape (profiles/r04/fir_dn.txt), except the long filters of M <= 4, whose kept outputs still
         // cost it a good part of the full-rate work: complex64 M = 3, 512 taps 0.256 ms against 0.215 in the frequency domain, float32 0.132 / 0.100
         const int kb = h->algo == SKDSP_FIR_OLS ? 0 : fir_bx_blocks(h, 1, M);
-        ols = kb == 0 || (M <= 4 && kb > 12) || (h->dtype == SKDSP_C64 && kb > 32);   // (complex64 M = 24, 1024 taps: 0.254 against 0.232)
+        ols = kb == 0 || (M <= 4 && kb > 12);
     }
     // M <= 4: the frequency-domain decimator (fir_dn4k.hip: M forward transforms accumulated, ONE inverse per tile of kept outputs) wherever
     // the decimating overlap-save store would run (which spends 2 M transforms on the same outputs); option fir_dn4k = 2: wherever it applies

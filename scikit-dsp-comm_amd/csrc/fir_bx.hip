@@ -1,10 +1,15 @@
-// fir_bx.hip -- direct / polyphase FIR of float32 or complex64 signals with real taps as a Toeplitz
-// matrix product on the BF16 matrix pipe, in float32 precision: every operand is split into three bf16
-// pieces (x = x1 + x2 + x3, 8 mantissa bits each, exact), and the six partial products down to 2^-18 of
-// the leading one are formed with v_mfma_f32_16x16x32_bf16 (fp32 accumulate; the five small products in
-// their own accumulator).  tools/ubench_bf16x3.hip: max error 1.9e-7 of max|y| over 160 lags, against
-// 5.2e-7 for one v_mfma_f32_16x16x4_f32 chain -- at 6/16 of its pipe time (the bf16 instruction does 8x
-// the lags in half the cycles).
+// fir_bx.hip -- direct / polyphase FIR of float32 or complex64 signals with real taps as a Toeplitz matrix product on the
+// fp16 matrix pipe, at float32 accuracy: every operand is split into TWO fp16 pieces (x = x1 + x2: 22 - 23 of float32's 24
+// mantissa bits, round-to-nearest pieces, residual <= 2^-23 |x|: half an ulp more than float32 itself carries), and the three
+// partial products down to 2^-11 of the leading one are formed with v_mfma_f32_16x16x32_f16 (fp32 accumulate; the two small
+// products in their own accumulator); x2 h2 (2^-22) is not formed.  fp16's exponent range is narrow, so every WINDOW of the signal
+// is multiplied by the power of two that puts its largest magnitude at 2^14 before it is split, its outputs by the inverse, and
+// the taps are scaled once on the host: exact, and scale-invariant over the whole float32 range
+// (tests/test_gpu_parity.py::test_matrix_pipe_path_is_scale_invariant).  A sample 2^-25 or more below its window's largest loses its
+// second piece to the fp16 floor (absolute error <= 2^-39 of the window's largest magnitude).
+// Until round 4 the pieces were three bf16 (exact 24 bits, 8-bit exponents, no scaling) and the products six: the kernels ran at the
+// board's power cap with the matrix pipe ~60 % busy, and half the products were half the joules -- config 3 0.313 -> 0.238 ms, 127 taps
+// float32 0.135 -> 0.111, same error statistics on the coherent-input suite (tests/test_gpu_adversarial.py; rel-L2 1.3e-7).
 //
 // Serves the same reference calls as fir_mm.hip / fir_direct.hip (multirate_helper.py:104-127 and
 // downsample(up(x,L),M)):   y[m] = L * sum_t b[phi_c + L t] * x[i_c + q s - t],
@@ -14,11 +19,11 @@
 // row tiles), a COLUMN N is a slot block, so   m = RS N + r   and the input index is
 //     q DS N + U0 - u,   lag u = t + U0 - i_c - q ds >= 0   (independent of N):
 //     Y[RS x N] = A[RS x K] * W[K x N],  A[r][u] = L b[phi_c + L (u - U0 + i_c + q ds)],  W[u][N] = x[q DS N + U0 - u].
-// The bf16 instruction wants 8 consecutive lags per lane.  With k' = K-1-u ascending in x, lane (column n,
-// group j) reads the 8 window elements  q DS n + 32 kb + 8 j + (0..7)  as ONE 16-byte LDS read per bf16
+// The instruction wants 8 consecutive lags per lane.  With k' = K-1-u ascending in x, lane (column n,
+// group j) reads the 8 window elements  q DS n + 32 kb + 8 j + (0..7)  as ONE 16-byte LDS read per fp16
 // piece -- aligned whenever q DS is a multiple of 8, which fixes DS (and with it RS: 32 rows for L/M = 4/3,
-// 16 for a plain filter, 96 for L = 12).  The taps (three bf16 pieces per row tile and 32-lag block) stay in
-// registers for the whole launch; the window is split once, while it is staged, into 3 (6: re, im) bf16
+// 16 for a plain filter, 96 for L = 12).  The taps (two fp16 pieces per row tile and 32-lag block) stay in
+// registers for the whole launch; the window is split once, while it is staged, into 2 (4: re, im) fp16
 // planes in LDS.  The MFMA is issued with the window fragment as its A operand and the taps as B, i.e. the
 // tile comes out transposed (col = lane & 15 = row of the tile, the four registers = four columns), so that
 // the 16 lanes of a group store 16 consecutive outputs.
@@ -37,6 +42,10 @@ typedef _Float16 v8h_bx __attribute__((ext_vector_type(8)));
 
 constexpr int kBxUnitsC = 512;   // 8-sample units of one complex64 window (2 per thread: 32 prefetch VGPRs)
 constexpr int kBxUnitsR = 1024;  // float32: 4 per thread, the same 32 VGPRs
+// ... of the lag-split kernels (KSP = 4): their registers and the smaller fp16 planes leave room for windows of several column tiles
+// where 16 columns are already thousands of samples (56 / 64 KiB of planes + the partial tiles: still two workgroups per CU)
+constexpr int kBxUnitsCK = 896, kBxUnitsRK = 2048;
+static constexpr int bx_units(bool cplx, bool ksp) { return ksp ? (cplx ? kBxUnitsCK : kBxUnitsRK) : (cplx ? kBxUnitsC : kBxUnitsR); }
 
 struct BxArgs {
     int64_t n, n_hist, n_out;
@@ -107,7 +116,7 @@ __device__ __forceinline__ v4f_bx bx_mfma(uint4 a, uint4 b, v4f_bx c)
 
 // Persistent 256-thread workgroups: window w+1 is requested into registers before window w is multiplied, so
 // its HBM latency hides behind the MFMAs of the same workgroup; the workgroups of a CU run out of phase with
-// each other, which is what overlaps the bf16 split / LDS writes / stores of one with the MFMAs of another.
+// each other, which is what overlaps the fp16 split / LDS writes / stores of one with the MFMAs of another.
 //
 // RSP = 2 (row split): the taps of a geometry with many row tiles do not fit one wave's registers (L = 12: 96 rows = 6 row tiles x 2
 // blocks = 144 VGPRs).  The waves of a workgroup then pair up: wave w takes the row tiles [RT (w & 1), RT (w & 1) + RT) of the column
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int C = CPLX ? 2 : 1;
     static_assert(KSP == 1 || (RT == 1 && RSP == 1), "the lag split serves one-row-tile geometries");
     constexpr int K = 32 * KB * KSP;
-    constexpr int UPT = (CPLX ? kBxUnitsC : kBxUnitsR) / 256;   // staged 8-sample units per thread
+    constexpr int UPT = (bx_units(CPLX, KSP > 1) + 255) / 256;   // staged 8-sample units per thread
     constexpr int F4 = 2 * C;             // 16-byte loads per unit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int RTT = RT * RSP;                                   // row tiles of the table
@@ -502,7 +511,7 @@ static bool bx_geometry(const FirHandle *h, int L, int M, FirHandle::BxTab *t)
         // A decimator with a large M (one class, one row tile): 16 slots per column are 16 M inputs, and 16 columns of them may not fit the
         // window (M = 24: 16 x 384 samples).  Fewer slots per column then -- half-empty row tiles cost matrix-pipe time these shapes do
         // not lack (M = 24, 512 taps, complex64: 1.43 ms per 2^26 inputs on the kernels behind this one).
-        if (Lp > 1 || best_k % 2 || RS < 8 || cap >= q * DS * 15 + 32 * ((KB + 3) / 4 * 4)) break;
+        if (Lp > 1 || best_k % 2 || RS < 8 || 8 * bx_units(comp == 2, true) >= q * DS * 15 + 32 * ((KB + 3) / 4 * 4)) break;
     }
     // What does not fit one wave (bx_fits) is tried with the row tiles dealt to wave pairs (RSP = 2: see the kernel); four or more row tiles
     // always are (the same speed where both fit -- L = 8, 48 taps per phase: 0.1245 / 0.1259 ms -- and the one-wave forms of 4 x 2, 6 x 1 spilled)
@@ -520,7 +529,7 @@ static bool bx_geometry(const FirHandle *h, int L, int M, FirHandle::BxTab *t)
         const int ns_max = cap > 32 * KB ? (cap - 32 * KB) / (q * DS) + 1 : 0;
         if (!RSP || ns_max < 64) {
             const int kbw = (KB + 3) / 4;
-            if (kbw <= 12 && cap >= 32 * 4 * kbw + q * DS * 15) { KSP = 4; KBT = 4 * kbw; RSP = 1; }
+            if (kbw <= 12 && 8 * bx_units(comp == 2, true) >= 32 * 4 * kbw + q * DS * 15) { KSP = 4; KBT = 4 * kbw; RSP = 1; }
         }
     }
     if (!RSP) return false;
@@ -532,10 +541,10 @@ static bool bx_geometry(const FirHandle *h, int L, int M, FirHandle::BxTab *t)
 
 static int bx_columns(const FirHandle::BxTab *t, int comp, int64_t n_out)
 {
-    // columns per workgroup: what a window of kBxUnitsC / kBxUnitsR 8-sample units holds (48 KiB of bf16 planes: 3
+    // columns per workgroup: what a window of kBxUnitsC / kBxUnitsR 8-sample units holds (32 KiB of fp16 planes: 3
     // workgroups per CU by LDS, 2 by registers), multiples of 64 (16 for wide strides), at most 512
     auto win_of = [&](int NS) { return ((t->q * t->DS * (NS - 1) + 32 * t->KB) + 7) / 8 * 8; };
-    const int cap = 8 * (comp == 2 ? kBxUnitsC : kBxUnitsR);
+    const int cap = 8 * bx_units(comp == 2, t->KSP > 1);
     int NS = 512;
     while (NS > 64 && win_of(NS) > cap) NS -= 64;
     while (NS > 16 && win_of(NS) > cap) NS -= 16;
