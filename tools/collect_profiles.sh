@@ -45,7 +45,10 @@ python tools/time_fir_c128.py > $OUT/fir_f64.txt 2>&1
 # multirate_FIR.up: every engine (polyphase, walk over (tile, phase) pairs, the input-tile interpolators) and the default dispatch; .dn likewise
 python tools/time_fir_up.py > $OUT/fir_up.txt 2>&1
 python tools/time_fir_updn.py > $OUT/fir_updn.txt 2>&1
+python tools/time_fir_filter.py > $OUT/fir_filter.txt 2>&1
+python tools/acc_probe.py > $OUT/acc_probe.txt 2>&1
 python tools/time_fir_dn.py > $OUT/fir_dn.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_strided_store.hip -o /tmp/ubss 2>/dev/null && /tmp/ubss > $OUT/ubench_strided_store.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_dp_pipes.hip -o /tmp/ubench_dp_pipes 2>/dev/null && /tmp/ubench_dp_pipes > $OUT/ubench_dp_pipes.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_mfma_f64_4x4.hip -o /tmp/ub44 2>/dev/null && /tmp/ub44 > $OUT/ubench_mfma_f64_4x4.txt 2>&1
 ls -la $OUT
