@@ -8,16 +8,19 @@ R=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$R
 PMC_ONLY=""
-if [ "${2:-}" = pmc ]; then shift 2; PMC_ONLY="$*"; mkdir -p $OUT; else rm -rf $OUT && mkdir -p $OUT; fi
+BENCH_ONLY=""
+if [ "${2:-}" = pmc ]; then shift 2; PMC_ONLY="$*"; mkdir -p $OUT;
+elif [ "${2:-}" = bench ]; then BENCH_ONLY=1; mkdir -p $OUT;   # only the un-profiled bench lines (taken again once the reduced counters of this collection are in the tree, so that each quotes its traffic)
+else rm -rf $OUT && mkdir -p $OUT; fi
 cd /tmp && export TMPDIR=/tmp
 RATE="upsample4 downsample3 firup12 firdn12 firup4 firdn4 rcup12 rcdn12 iirup2 iirdn3"
-[ -z "$PMC_ONLY" ] && for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE; do
+[ -z "$PMC_ONLY$BENCH_ONLY" ] && for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python $ROOT/bench.py --workload $w --no-cpu-baseline --no-other-configs --board-seconds 0 > /dev/null 2>&1
   cp $OUT/trace_$w/*/*kernel_stats.csv $OUT/kernel_stats_$w.csv
   rm -rf $OUT/trace_$w
 done
 # PMC passes, each counter group in its own run (never combined with other trace domains)
-for w in ${PMC_ONLY:-fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE}; do
+[ -z "$BENCH_ONLY" ] && for w in ${PMC_ONLY:-fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE}; do
   sets=("FETCH_SIZE" "WRITE_SIZE")
   [ $w = fir1024 ] && sets+=("SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES")
   # the issue / wait picture of config 4, before (cascade form) and after (parallel form)
@@ -36,6 +39,7 @@ for w in updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE; do
   python bench.py --workload $w --no-other-configs --no-cpu-baseline > $OUT/bench_$w.json 2>/dev/null
 done
 python bench.py --scaling strong --total-log2n 30 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_fir1024_2p30_one_gpu.json 2>/dev/null
+[ -n "$BENCH_ONLY" ] && { ls -la $OUT | tail -3; exit 0; }
 python tools/power_probe.py idle copy fir1024 fir1024f32 fir1024f64 fir1024c128 updn43 fir127 iir8 iir8cas iir8c64 iirlp8 > $OUT/power_probe.txt 2>&1
 python tools/ab_iir_par.py 26 > $OUT/ab_iir_par.txt 2>&1
 python tools/time_fir_shapes.py > $OUT/fir_shapes.txt 2>&1
