@@ -118,13 +118,13 @@ __device__ __forceinline__ v4f_bx bx_mfma(uint4 a, uint4 b, v4f_bx c)
 // its HBM latency hides behind the MFMAs of the same workgroup; the workgroups of a CU run out of phase with
 // each other, which is what overlaps the fp16 split / LDS writes / stores of one with the MFMAs of another.
 //
-// RSP = 2 (row split): the taps of a geometry with many row tiles do not fit one wave's registers (L = 12: 96 rows = 6 row tiles x 2
-// blocks = 144 VGPRs).  The waves of a workgroup then pair up: wave w takes the row tiles [RT (w & 1), RT (w & 1) + RT) of the column
+// RSP = 2 (row split): the taps and accumulators of a geometry with many row tiles do not fit one wave's registers (L = 12: 96 rows = 6 row
+// tiles x 2 blocks: 96 VGPRs of taps + 96 of accumulators).  The waves of a workgroup then pair up: wave w takes the row tiles [RT (w & 1), RT (w & 1) + RT) of the column
 // tiles w >> 1, w >> 1 + 2, ... -- RT is the per-wave count, the table holds RT RSP row tiles.  A window fragment is read from the planes
 // by both waves of a pair; a wave's 16 RT rows of a column are still one run of y (L = 12: 48 outputs = 384 bytes = three whole lines).
 //
 // KSP = 4 (lag split; RT = RSP = 1): a decimator with a large M spreads the 16 rows of its one row tile over 16 M input samples, so its lag
-// range is 16 M + Ntaps long (M = 12, 512 taps: 22 blocks = 264 VGPRs of taps) while a window holds one or two column tiles -- nothing for
+// range is 16 M + Ntaps long (M = 12, 512 taps: 22 blocks = 176 VGPRs of taps) while a window holds one or two column tiles -- nothing for
 // three of the four waves to do.  The waves then split the LAGS: wave w takes the blocks [KB w, KB w + KB) of every column tile (KB is
 // the per-wave count; the table holds 4 KB blocks, the last ones zero-padded), the four partial tiles meet in the LDS, and wave w
 // stores column 4 j + w of every lane's four.

@@ -339,6 +339,11 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
             }
         }
         dft16_g(v);   // v[a] = y[256 a + t]
+        // "these are the results, in these registers, now" (LABNOTES R4.3): without it hipcc carries the finished transform in a form of its own
+        // into the store section -- spilled VGPRs 66 -> 30 (complex, decimating), 22 -> 18 (complex), 4 -> 0 (real, decimating)
+#pragma unroll
+        for (int b = 0; b < 16; b += 4)
+            asm volatile("" : "+v"(v[b].x), "+v"(v[b].y), "+v"(v[b + 1].x), "+v"(v[b + 1].y), "+v"(v[b + 2].x), "+v"(v[b + 2].y), "+v"(v[b + 3].x), "+v"(v[b + 3].y));
         asm volatile("" : "+v"(ts));
         // ---- store the last V points ----
         // whole tile(s) inside the signal, no decimation: one copy of the 16 - a0 unguarded stores per possible a0
