@@ -2,7 +2,7 @@
 
 Every other float32 / complex64 check drives the kernels with Gaussian noise, where rounding errors
 average out.  The two engines with re-associated float32 arithmetic -- the 8192-point float32 FFT of the
-overlap-save tile (csrc/ols_core.hpp) and the 3-way bf16 split of the matrix-pipe direct form
+overlap-save tile (csrc/ols_core.hpp) and the fp16-piece split of the matrix-pipe direct form
 (csrc/fir_bx.hip) -- are driven here with inputs whose errors add up instead: DC, a pass-band tone, and a
 full-scale tone next to a -100 dB tone, through all-positive taps (sigsys.cic(64, 5), a 1024-tap boxcar,
 a 4097-tap boxcar) and the 1024-tap window-design lowpass; through .filter, .up(., 12), .dn(., 12) and the
@@ -117,7 +117,7 @@ ENGINES = [("ols", _ffi.FIR_OLS), ("direct", _ffi.FIR_DIRECT)]
 @pytest.mark.parametrize("engine,algo", ENGINES)
 def test_filter_coherent_inputs(engine, algo, cplx, taps, kind):
     """.filter: overlap-save (complex64 tile / two real tiles per complex tile) and the direct engines
-    (bf16x3 matrix pipe up to 12 lag blocks, FP32 matrix pipe / sliding-window kernels beyond)."""
+    (fp16-piece matrix pipe up to 16 lag blocks -- 48 with the lags dealt to the waves --, FP32 matrix pipe / sliding-window kernels beyond)."""
     b = TAPS[taps]()
     n = 3 * 8192 + 1234 if len(b) > 2000 else 6 * 8192 + 777
     stop = kind == "stop"

@@ -415,6 +415,46 @@ def test_updn_full_size_config3():
         assert_close(yd.to_host(m0, w), ref[skip:skip + w], TOL32, "updn window @%d" % s_in)
 
 
+@pytest.mark.parametrize("dt", [np.complex64, np.float32])
+def test_up_dn_full_size_reference_defaults(dt):
+    """multirate_FIR(512-tap prototype).up(x) / .dn(x) at the reference's defaults L_change = M_change = 12 (multirate_helper.py:112-127) on
+    2^26 samples of the high rate -- the matrix-pipe kernel with its row tiles dealt to wave pairs (.up) / its lags dealt to the four waves (.dn):
+    windows at the start, across window boundaries in the middle and at the end against the oracle."""
+    g = load("g6_fir512_updn.npz")
+    b = g["b"]
+    code = _ffi.code_of(dt)
+    k = _ffi.FirKernel(b, code)
+    n_hi = 2 ** 26
+    # .up: n_hi / 12 inputs -> n_in * 12 outputs
+    n_in = n_hi // 12
+    xd = _ffi.DeviceArray(n_in, dt).fill_noise(5)
+    yd = _ffi.DeviceArray(n_in * 12, dt)
+    k.up_dev(xd, yd, 12)
+    _ffi.sync()
+    for s_in in (0, 1_000_003, n_in // 2 + 77, n_in - 3000):
+        lo = max(0, s_in - 64)
+        xs = xd.to_host(lo, min(3000, n_in - lo))
+        ref = orc.fir_up(b, xs, 12)
+        skip = (s_in - lo) * 12
+        w = min(20000, len(ref) - skip)
+        assert_close(yd.to_host(s_in * 12, w), ref[skip:skip + w], TOL32, "up12 window @%d" % s_in)
+    xd.free(); yd.free()
+    # .dn: n_hi inputs -> n_hi / 12 outputs
+    xd = _ffi.DeviceArray(n_hi, dt).fill_noise(6)
+    yd = _ffi.DeviceArray(n_hi // 12, dt)
+    k.dn_dev(xd, yd, 12)
+    _ffi.sync()
+    for s_out in (0, 777_777, n_hi // 24 + 5, n_hi // 12 - 2500):
+        s_in = s_out * 12
+        lo = max(0, s_in - 12 * 50)   # (a multiple of 12: keeps the kept phase aligned)
+        xs = xd.to_host(lo, min(12 * 2600, n_hi - lo))
+        ref = orc.fir_dn(b, xs, 12)
+        skip = (s_in - lo) // 12
+        w = min(2000, len(ref) - skip, n_hi // 12 - s_out)
+        assert_close(yd.to_host(s_out, w), ref[skip:skip + w], TOL32, "dn12 window @%d" % s_out)
+    xd.free(); yd.free()
+
+
 # ------------------------------------------------------------- RCCL plumbing on one GPU
 def test_rccl_single_rank_communicator_p2p_and_allreduce():
     """The 8-GPU halo path cannot run on a 1-GPU box, but everything except the peer hop can:
@@ -987,7 +1027,7 @@ def test_fir_dn_overlap_save_decimating_store(M, ntaps, dt):
     n = 2 ** 20 + 12345
     esz = np.dtype(dt).itemsize
     k = _ffi.FirKernel(b, _ffi.code_of(dt))
-    k.set_algo(_ffi.FIR_OLS)  # (left to itself, .dn prefers the bf16x3 matrix-pipe kernel where that one is faster)
+    k.set_algo(_ffi.FIR_OLS)  # (left to itself, .dn prefers the matrix-pipe kernel where that one is faster)
     xd = _ffi.DeviceArray(n, dt, headroom=ntaps).fill_noise(31)
     xd.write(cnoise(rng, ntaps - 1) if dt == np.complex64 else rng.standard_normal(ntaps - 1).astype(np.float32), at=-(ntaps - 1))
     yd = _ffi.DeviceArray(n // M, dt)
@@ -1038,7 +1078,7 @@ def test_iir_up_dn_complex_vs_scipy(dt):
 
 @pytest.mark.parametrize("switch", ["SKDSP_FIR_MM", "SKDSP_FIR_BX"])
 def test_direct_fir_kernels_behind_the_default_path(switch):
-    """float32 / complex64 direct FIRs normally run as bf16x3 Toeplitz products on the BF16 matrix pipe
+    """float32 / complex64 direct FIRs normally run as Toeplitz products of fp16 pieces on the matrix pipe
     (fir_bx.hip).  Behind it sit the FP32 / FP64 matrix-pipe kernels (fir_mm.hip: float64, long lag ranges;
     SKDSP_FIR_BX=0 forces them) and the register sliding-window kernels (complex128, complex taps;
     SKDSP_FIR_MM=0 forces them): both are re-checked here on the same float32 / complex64 cases."""
@@ -1063,8 +1103,8 @@ def test_direct_fir_kernels_behind_the_default_path(switch):
                                    (512, 1, 12), (1000, 1, 12), (128, 1, 12), (300, 1, 16), (512, 1, 24), (77, 1, 20), (640, 1, 8),
                                    # ... with fewer slots per column where 16 of them do not fit the window
                                    (512, 1, 16), (1024, 1, 24), (256, 1, 32), (512, 1, 48), (200, 1, 100)])
-def test_bf16x3_matrix_pipe_geometries(dt, P, L, M):
-    """Row-tile / lag-block geometries of the bf16x3 Toeplitz kernel (1..7 row tiles, 1..10 lag blocks, shapes it
+def test_matrix_pipe_geometries(dt, P, L, M):
+    """Row-tile / lag-block geometries of the matrix-pipe Toeplitz kernel (1..8 row tiles, 1..48 lag blocks, shapes it
     hands on to the kernels behind it), ragged lengths, history: against the oracle at the float32 tolerance."""
     rng = np.random.default_rng(P + 13 * L + M)
     b = rng.standard_normal(P) / np.sqrt(P)
@@ -1212,7 +1252,7 @@ def test_iir_complex_interleaved_kernels(dt, nsec):
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_direct_fir_random_geometries(seed):
     """Randomised (dtype, taps, L, M, length, history) sweep of the direct / polyphase path -- whichever kernel
-    the dispatcher picks (bf16x3 or FP32 matrix pipe, sliding window) -- head and tail windows against the
+    the dispatcher picks (fp16-piece or FP32 matrix pipe, sliding window) -- head and tail windows against the
     oracle at the float32 tolerance."""
     rng = np.random.default_rng(seed)
     for _ in range(40):
