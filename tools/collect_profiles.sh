@@ -9,12 +9,15 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$R
 PMC_ONLY=""
 BENCH_ONLY=""
+ONLY=""
 if [ "${2:-}" = pmc ]; then shift 2; PMC_ONLY="$*"; mkdir -p $OUT;
+elif [ "${2:-}" = only ]; then shift 2; ONLY="$*"; mkdir -p $OUT;   # kernel trace + PMC passes + bench line of the workloads named (a kernel changed after the collection)
 elif [ "${2:-}" = bench ]; then BENCH_ONLY=1; mkdir -p $OUT;   # only the un-profiled bench lines (taken again once the reduced counters of this collection are in the tree, so that each quotes its traffic)
 else rm -rf $OUT && mkdir -p $OUT; fi
 cd /tmp && export TMPDIR=/tmp
 RATE="upsample4 downsample3 firup12 firdn12 firup4 firdn4 rcup12 rcdn12 iirup2 iirdn3"
-[ -z "$PMC_ONLY$BENCH_ONLY" ] && for w in fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE; do
+[ -n "$ONLY" ] && PMC_ONLY="$ONLY"
+[ -z "$PMC_ONLY$BENCH_ONLY" -o -n "$ONLY" ] && for w in ${ONLY:-fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python $ROOT/bench.py --workload $w --no-cpu-baseline --no-other-configs --board-seconds 0 > /dev/null 2>&1
   cp $OUT/trace_$w/*/*kernel_stats.csv $OUT/kernel_stats_$w.csv
   rm -rf $OUT/trace_$w
@@ -33,6 +36,13 @@ done
   done
 done
 cd $ROOT
+if [ -n "$ONLY" ]; then
+  for w in $ONLY; do
+    if [ $w = fir1024 ]; then python bench.py > $OUT/bench_fir1024.json 2>$OUT/bench_fir1024.err
+    else python bench.py --workload $w --no-other-configs --no-cpu-baseline > $OUT/bench_$w.json 2>/dev/null; fi
+  done
+  ls -la $OUT | tail -5; exit 0
+fi
 [ -n "$PMC_ONLY" ] && { ls -la $OUT | tail -5; exit 0; }
 python bench.py > $OUT/bench_fir1024.json 2>$OUT/bench_fir1024.err
 for w in updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE; do
