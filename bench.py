@@ -387,7 +387,7 @@ def make_rate_workload(w, name, n, lg, _ffi):
         w.kern = "upsample_kernel (resample.hip)"
     elif name == "downsample3":
         w.step = lambda: _ffi.check(L.skdsp_downsample_dev(xp, n_in, R, 0, code, yp))
-        w.kern = "downsample_kernel (resample.hip)"
+        w.kern = "downsample_tile_kernel (resample.hip)"
     elif name.startswith("fir"):
         b = firwin_lowpass(1024, 0.2 / 4) if name in ("firup4", "firdn4") else firwin_lowpass(512, 0.9 / 12)
         w.taps = b
