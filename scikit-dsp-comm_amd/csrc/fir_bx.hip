@@ -5,8 +5,9 @@
 // products in their own accumulator); x2 h2 (2^-22) is not formed.  fp16's exponent range is narrow, so every WINDOW of the signal
 // is multiplied by the power of two that puts its largest magnitude at 2^14 before it is split, its outputs by the inverse, and
 // the taps are scaled once on the host: exact, and scale-invariant over the whole float32 range
-// (tests/test_gpu_parity.py::test_matrix_pipe_path_is_scale_invariant).  A sample 2^-25 or more below its window's largest loses its
-// second piece to the fp16 floor (absolute error <= 2^-39 of the window's largest magnitude).
+// (tests/test_gpu_parity.py::test_matrix_pipe_path_is_scale_invariant).  The second piece of every operand is carried lifted by 2^11
+// (kBxLift), so a sample keeps its 22 bits down to 2^-29 of its window's largest magnitude and an absolute accuracy of 2^-51 of that
+// largest below it.
 // Until round 4 the pieces were three bf16 (exact 24 bits, 8-bit exponents, no scaling) and the products six: the kernels ran at the
 // board's power cap with the matrix pipe ~60 % busy, and half the products were half the joules -- config 3 0.313 -> 0.238 ms, 127 taps
 // float32 0.135 -> 0.111, same error statistics on the coherent-input suite (tests/test_gpu_adversarial.py; rel-L2 1.3e-7).
@@ -70,15 +71,17 @@ struct BxArgs {
     float tap_inv;        // 2^-te: the taps of the table are L b 2^te (scaled into the fp16 range on the host)
 };
 
-#ifndef SK_BX_PX
-#define SK_BX_PX 2
-#endif
-constexpr int kBxPx = SK_BX_PX;   // fp16 pieces of a signal sample (2: 22 bits; 3: all 24, one more product per tap piece pair)
+constexpr int kBxPx = 2;          // fp16 pieces of a signal sample
 constexpr int kBxPh = 2;          // fp16 pieces of a tap
+// The SECOND piece of every operand is the residual times 2^11 (kBxLift): fp16's floor is 2^-24, and a residual is 2^-11 of its first piece at
+// most, so unlifted it fell off that floor for every sample 2^-25 or more below its window's largest -- lifted, a sample keeps its full 22 bits
+// down to 2^-29 of the window's largest and something of itself down to 2^-50 (a 1e12 glitch leaves the rest of its window accurate to 5e-4
+// of ITS level, not zero).  Both small products (h2 x1, h1 x2) carry the same 2^11, so their accumulator is scaled back once, at the store.
+constexpr int kBxLift = 11;
 
-// (a, b), already scaled into the fp16 range -> kBxPx packed fp16 pairs, a in the low half: a = a1 + a2 (+ a3) to 2^-22 (exactly).
-// Round-to-nearest pieces (v_cvt_pk_f16_f32), so each residual is at most half an ulp of the piece before it.
-// The residuals are formed with SCALAR subtractions on purpose: v_pk_add_f32 runs on the datapath the matrix pipe uses, so while the
+// (a, b), already scaled into the fp16 range -> two packed fp16 pairs, a in the low half: a = a1 + 2^-11 a2 to 2^-23 |a|.
+// Round-to-nearest pieces (v_cvt_pk_f16_f32), so the residual is at most half an ulp of the first piece (<= 8 -> <= 2^14 lifted).
+// The residuals are formed with SCALAR instructions on purpose: v_pk_add_f32 runs on the datapath the matrix pipe uses, so while the
 // other workgroup of the CU is in its MFMA phase a packed split does not advance at all (round 3: the split of one workgroup ended
 // ~240 clocks after the partner's last MFMA, every window, which is what locked the two workgroups of a CU in phase).
 __device__ __forceinline__ void bx_split2(float a, float b, unsigned (&p)[kBxPx])
@@ -88,25 +91,24 @@ __device__ __forceinline__ void bx_split2(float a, float b, unsigned (&p)[kBxPx]
         asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
         return r;
     };
-    auto sub_lo = [](float x, unsigned piece) -> float {   // x - (float)piece.lo  (asm statements: hipcc's SLP vectoriser would pair the subtractions into v_pk_add_f32)
-        float f, r;
+    // (x - (float)piece.lo) 2^11  (asm statements: hipcc's SLP vectoriser would pair the subtractions into v_pk_add_f32)
+    auto res_lo = [](float x, unsigned piece) -> float {
+        float f, r, l;
         asm("v_cvt_f32_f16 %0, %1" : "=v"(f) : "v"(piece));
         asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(f));
-        return r;
+        asm("v_ldexp_f32 %0, %1, 11" : "=v"(l) : "v"(r));
+        return l;
     };
-    auto sub_hi = [](float x, unsigned piece) -> float {
-        float f, r;
+    auto res_hi = [](float x, unsigned piece) -> float {
+        float f, r, l;
         asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "v"(piece));
         asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(f));
-        return r;
+        asm("v_ldexp_f32 %0, %1, 11" : "=v"(l) : "v"(r));
+        return l;
     };
+    static_assert(kBxLift == 11 && kBxPx == 2, "the asm statements above carry the lift");
     p[0] = cvt(a, b);
-#pragma unroll
-    for (int i = 1; i < kBxPx; ++i) {
-        a = sub_lo(a, p[i - 1]);
-        b = sub_hi(b, p[i - 1]);
-        p[i] = cvt(a, b);
-    }
+    p[1] = cvt(res_lo(a, p[0]), res_hi(b, p[0]));
 }
 
 __device__ __forceinline__ v4f_bx bx_mfma(uint4 a, uint4 b, v4f_bx c)
@@ -320,8 +322,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define SK_BX(PA, PB, ACC)                                                                              \
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int c = 0; c < C; ++c)    \
         ACC[rt][c] = bx_mfma(b[c][PB], areg[kb][rt][PA], ACC[rt][c]);
-            // products: (tap piece, signal piece) = (1, 1) into `big`; (2, 1), (1, 2) [and (1, 3)] -- 2^-11 [2^-22] of it -- into `small`;
-            // (2, 2) and beyond are below 2^-22 of the leading product and are not formed
+            // products: (tap piece, signal piece) = (1, 1) into `big`; (2, 1), (1, 2) -- 2^-11 of it, both lifted by 2^11 -- into `small`;
+            // (2, 2) is below 2^-22 of the leading product and is not formed
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 SK_BX(1, 0, small)
@@ -331,11 +333,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 SK_BX(0, 1, small)
                 __builtin_amdgcn_sched_barrier(0);
                 if (kb + 1 < KB) read_b(kb + 1, 1);
-                if constexpr (kBxPx > 2) {
-                    SK_BX(0, 2, small)
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (kb + 1 < KB) read_b(kb + 1, 2);
-                }
             }
 #undef SK_BX
         };
@@ -349,18 +346,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float *yb = y + m_base * C;
             const int64_t left = a.n_out - m_base;
             const int rem = left > (int64_t)0x7fffffff ? 0x7fffffff : (left < 0 ? 0 : (int)left);
-            // (scalar adds through asm: hipcc pairs them into v_pk_add_f32, which waits for the matrix pipe -- see bx_split2)
-            auto sum = [](float u, float w) -> float {
-                float r;
-                asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(w));
+            // big winv + small (winv 2^-11)  (scalar instructions through asm: hipcc pairs them into v_pk_*_f32, which waits for the matrix pipe)
+            const float winv_s = winv * (1.0f / (float)(1 << kBxLift));
+            auto sum = [&](float u, float w) -> float {
+                float m, r;
+                asm("v_mul_f32 %0, %1, %2" : "=v"(m) : "v"(u), "v"(winv));
+                asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "v"(winv_s), "v"(m));
                 return r;
             };
             auto put = [&](int rt, int i, int off) __attribute__((always_inline)) {
                 if (CPLX) {
-                    v2f_bx o = {sum(big[rt][0][i], small[rt][0][i]) * winv, sum(big[rt][C - 1][i], small[rt][C - 1][i]) * winv};
+                    v2f_bx o = {sum(big[rt][0][i], small[rt][0][i]), sum(big[rt][C - 1][i], small[rt][C - 1][i])};
                     __builtin_nontemporal_store(o, reinterpret_cast<v2f_bx *>(yb + 2 * off));
                 } else {
-                    __builtin_nontemporal_store(sum(big[rt][0][i], small[rt][0][i]) * winv, yb + off);
+                    __builtin_nontemporal_store(sum(big[rt][0][i], small[rt][0][i]), yb + off);
                 }
             };
             // whole tile inside the output and all 16 RT rows in use (uniform): no per-store guards
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int c = 0; c < C; ++c)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) mine[(c * 4 + i) * 64] = big[0][c][i] + small[0][c][i];
+                    for (int i = 0; i < 4; ++i) mine[(c * 4 + i) * 64] = fmaf(small[0][c][i], 1.0f / (float)(1 << kBxLift), big[0][c][i]);
                 __syncthreads();
                 const float *all = red + ((size_t)((ct & 1) * 4) * (4 * C)) * 64 + lane;
                 float o[C];
@@ -608,10 +607,10 @@ static int get_bx_table(FirHandle *h, int L, int M, const FirHandle::BxTab **out
                     const int k = phi + L * tt;
                     if (k >= P) continue;
                     double v = std::ldexp((double)L * h->taps_host[k], te);
-                    for (int p = 0; p < kBxPh; ++p) {
+                    for (int p = 0; p < kBxPh; ++p) {   // (the second piece: the residual lifted by 2^11, see kBxLift)
                         const unsigned short piece = bx_f16_rne(v);
                         host[((((size_t)kb * t.RT + rt) * kBxPh + p) * 64 + lane) * 8 + i] = piece;
-                        v -= bx_f16_val(piece);
+                        v = std::ldexp(v - bx_f16_val(piece), kBxLift);
                     }
                 }
     SK_HIP(hipMalloc(&t.At, host.size() * 2));
