@@ -1327,6 +1327,38 @@ def test_matrix_pipe_path_is_scale_invariant(dt):
         assert err < bound, (lo_in, err)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_matrix_pipe_impulse_and_silence(dt):
+    """The matrix-pipe FIR on the two inputs that show its operand representation directly: an impulse returns the taps (two fp16 pieces each:
+    2^-23 of the largest tap at worst), also where the taps span 200 dB; silence returns exact zeros (a window without a largest magnitude is
+    not scaled); a window holding one tiny sample only is scaled by it."""
+    rng = np.random.default_rng(7)
+    cplx = np.dtype(dt).kind == "c"
+    for P, L, M in ((127, 1, 1), (512, 12, 1), (512, 1, 12), (512, 4, 3)):
+        b = rng.standard_normal(P) * np.logspace(0, -10, P)          # taps over 200 dB
+        k = _ffi.FirKernel(b, _ffi.code_of(dt))
+        k.set_algo(_ffi.FIR_DIRECT)
+        n = 60_000 - 60_000 % M
+        for amp in (1.0, 3e-33):
+            x = np.zeros(n, dtype=dt)
+            x[12345 - 12345 % M] = amp * ((0.6 - 0.8j) if cplx else 1.0)
+            xd = _ffi.DeviceArray.from_host(x)
+            yd = _ffi.DeviceArray(n * L // M, dt)
+            k.updn_dev(xd, yd, L, M)
+            _ffi.sync()
+            got = yd.to_host()
+            ref = orc.downsample(orc.fir_up(b, x, L), M) if L > 1 else orc.fir_dn(b, x, M)
+            err = np.max(np.abs(got - ref[:len(got)])) / np.max(np.abs(ref))
+            assert err < 3e-7, (P, L, M, amp, err)
+            xd.free(); yd.free()
+        xd = _ffi.DeviceArray.from_host(np.zeros(n, dtype=dt))
+        yd = _ffi.DeviceArray(n * L // M, dt)
+        k.updn_dev(xd, yd, L, M)
+        _ffi.sync()
+        assert not np.any(yd.to_host()), (P, L, M)
+        xd.free(); yd.free()
+
+
 @pytest.mark.parametrize("case", ["f32_direct_2p30", "c64_ols_2p29", "c64_updn43_2p29", "f32_ols_2p30"])
 def test_large_index_ranges(case):
     """4-8 GiB signals (sample and byte offsets beyond 2^31/2^32): windows at the head, the middle and the tail of
