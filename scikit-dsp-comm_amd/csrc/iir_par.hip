@@ -306,6 +306,10 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         }
     };
     const bool ld_fast = interior && a.up == 1;
+    // .up by 8 or more (from 4 on the unrolled column loop costs more than the zeros: rate_change(4).up 0.130 -> 0.140 ms): at most T / 8 + 1 samples of a chunk are not stuffed zeros, so V = G x is a handful of columns of G per chunk -- formed
+    // per lane on the vector ALU from the INPUT samples instead of multiplying the zeros on the matrix pipe (rate_change(12).up: 11 of 128 columns;
+    // the chunks of a wave start at different phases of the stuffing, so the columns differ from lane to lane and the matrix form cannot drop them)
+    const bool sparse = a.up >= 8;
 
     // ---- A: stream the segment in; chunk rows to registers; V = G x on the matrix pipe --------------------------------
     // (the chunk as 16-byte vectors: as a scalar array hipcc's SROA left half of it in scratch memory)
@@ -345,6 +349,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 #pragma unroll
         for (int sgi = 0; sgi < St::segs; ++sgi) xq[p * St::segs + sgi] = *reinterpret_cast<const xv_t *>(myrow + sgi * St::elems);
         const IO *xs = stage + c * St::pitch + j;
+        if (!sparse)
 #pragma unroll
         for (int s = 0; s < kPiece / 4; ++s) {
             if constexpr (G4) {
@@ -374,6 +379,40 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 
     // chunk end states from the accumulator layout (column = lane & 15, state row = (lane >> 4) + 4 reg) to one lane per chunk
     double v[D];
+    if (sparse) {
+        constexpr int JMAX = T / 8 + 1;
+        const unsigned v0 = up_r0 + (unsigned)((lane / LS) * T);          // this lane's chunk start, counted from the last multiple of up in front of the segment
+        const unsigned q = (unsigned)(((unsigned long long)v0 * a.up_magic) >> 32);
+        const unsigned rem = v0 - q * (unsigned)a.up;
+        const unsigned qa = q + (rem ? 1u : 0u), k0 = rem ? (unsigned)a.up - rem : 0u;   // first input sample of the chunk and its place in it
+        const unsigned last = in_lim ? in_lim - 1u : 0u;
+        const IO gain = (IO)a.up;
+        IO xin[JMAX];
+#pragma unroll
+        for (int jj = 0; jj < JMAX; ++jj) {
+            const unsigned qi = qa + (unsigned)jj;
+            xin[jj] = in_lim ? xup[(qi < last ? qi : last) * LS + lane % LS] : IO(0);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) v[d] = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < JMAX; ++jj) {
+            const unsigned k = k0 + (unsigned)jj * (unsigned)a.up;
+            const bool ok = k < (unsigned)T && qa + (unsigned)jj < in_lim;
+            const double xv = ok ? (double)(gain * xin[jj]) : 0.0;             // (the value the staging put into the chunk: rounded in the signal's type)
+            const unsigned kk = k < (unsigned)T ? k : (unsigned)(T - 1);
+            const double *gp = gl + (kk >> 2) * 64 + 16 * (kk & 3);             // column kk of G: its D state rows are consecutive
+#pragma unroll
+            for (int d = 0; d < D; d += 2) {
+                const v2d_t g2 = *reinterpret_cast<const v2d_t *>(gp + d);
+                v[d] = fma(g2[0], xv, v[d]);
+                v[d + 1] = fma(g2[1], xv, v[d + 1]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NSEC; ++k) *reinterpret_cast<v2d_t *>(E + (k * 64 + lane) * 2) = v2d_t{v[2 * k], v[2 * k + 1]};
+        wave_lds_sync();
+    } else {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -389,6 +428,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         const v2d_t t = *reinterpret_cast<const v2d_t *>(E + (k * 64 + lane) * 2);
         v[2 * k] = t[0];
         v[2 * k + 1] = t[1];
+    }
     }
 
     // ---- S: from-rest inclusive scan of the wave's 64 chunk states ------------------------------------------------------
