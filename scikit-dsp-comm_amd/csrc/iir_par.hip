@@ -309,7 +309,8 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     // .up by 8 or more (from 4 on the unrolled column loop costs more than the zeros: rate_change(4).up 0.130 -> 0.140 ms): at most T / 8 + 1 samples of a chunk are not stuffed zeros, so V = G x is a handful of columns of G per chunk -- formed
     // per lane on the vector ALU from the INPUT samples instead of multiplying the zeros on the matrix pipe (rate_change(12).up: 11 of 128 columns;
     // the chunks of a wave start at different phases of the stuffing, so the columns differ from lane to lane and the matrix form cannot drop them)
-    const bool sparse = a.up >= 8;
+    const bool sparse = !DEC && a.up >= 8;                         // (.up never comes with a decimating store: none of this in those kernels)
+    const int ust = !DEC && (a.up == 2 || a.up == 4) ? a.up : 1;   // .up by 2 / 4: the column step of V = G x (see phase A)
 
     // ---- A: stream the segment in; chunk rows to registers; V = G x on the matrix pipe --------------------------------
     // (the chunk as 16-byte vectors: as a scalar array hipcc's SROA left half of it in scratch memory)
@@ -349,7 +350,35 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 #pragma unroll
         for (int sgi = 0; sgi < St::segs; ++sgi) xq[p * St::segs + sgi] = *reinterpret_cast<const xv_t *>(myrow + sgi * St::elems);
         const IO *xs = stage + c * St::pitch + j;
-        if (!sparse)
+        if (ust > 1) {
+            // .up by 2 or 4: every chunk starts on a multiple of the factor, so the stuffed zeros are the same columns of G in every chunk --
+            // the product runs over the other columns only (column ust (4 st + k) of the table for step st, read with a per-lane address)
+            const IO *xu = stage + c * St::pitch + j * ust;
+            const int nst = (kPiece / 4) / ust;
+#pragma unroll
+            for (int s = 0; s < kPiece / 8; ++s) {
+                if (s < nst) {
+                    const int kcol = ust * (4 * (p * nst + s) + j);
+                    const double *ga_p = gl + ((kcol >> 2) << 6) + ((kcol & 3) << 4);
+                    if constexpr (G4) {
+                        constexpr int NG = (D + 3) / 4;
+                        double ga[NG];
+#pragma unroll
+                        for (int r = 0; r < NG; ++r) ga[r] = ga_p[4 * r + (lane & 3)];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const double b = (double)xu[g * 16 * St::pitch + 4 * ust * s];
+#pragma unroll
+                            for (int r = 0; r < NG; ++r) acc[g][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(ga[r], b, acc[g][r], 0, 0, 0);
+                        }
+                    } else {
+                        const double ga = ga_p[lane & 15];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, (double)xu[g * 16 * St::pitch + 4 * ust * s], acc[g], 0, 0, 0);
+                    }
+                }
+            }
+        } else if (!sparse)
 #pragma unroll
         for (int s = 0; s < kPiece / 4; ++s) {
             if constexpr (G4) {
