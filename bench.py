@@ -325,7 +325,7 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
         w.alg_bytes = 8.0 * n * cplx
         w.compute = ("FP64 vector (v_fma_f64)", 78.6, 72.0 * n * cplx)   # 9 flop per biquad per (real) sample
         if name in ("iir8", "iir8c64"):
-            # what actually bounds this kernel (DESIGN.md 4.3b): v_fma_f64 and v_mfma_f64 share ONE datapath on this chip
+            # what actually bounds this kernel (DESIGN.md 4.6): v_fma_f64 and v_mfma_f64 share ONE datapath on this chip
             # (tools/ubench_dp_pipes.hip), and a real sample costs 33 (recurrence + output taps) + 2 (conversions) + 16 (from-rest
             # end states on the matrix pipe) + ~3 (scan, correction) issue slots of 64 lanes x 4 cycles
             w.dp_slots = 54.0 * n * cplx
@@ -504,7 +504,7 @@ def board_state_of(w, seconds, _ffi):
     """Board power and shader clock (rocm-smi, a second thread) while the same step runs back to back for `seconds`,
     right after the timed region.  The streaming kernels here run AT the board power cap: the shader clock, and with it the
     time per step, is what the firmware leaves under that cap, which is why instruction-level changes that do not save
-    energy do not move these numbers (DESIGN.md 7c)."""
+    energy do not move these numbers (DESIGN.md 6)."""
     import threading
     samples, stop = [], threading.Event()
 
@@ -581,7 +581,7 @@ def roofline_of(w, ev_ms, K, log2n_for_traffic):
 def compute_of(w, ev_ms, K):
     if w.compute is None:
         return None
-    # these workloads are also priced against arithmetic (DESIGN.md 4.2 / 4.3): useful flops of the reference
+    # these workloads are also priced against arithmetic (DESIGN.md 4.5 / 4.6): useful flops of the reference
     # formulation against the peak of the unit that executes them
     tf = w.compute[2] / (ev_ms * 1e-3 / K) / 1e12
     out = {"unit": "TFLOP/s", "what": w.compute[0], "useful_flop_per_step": w.compute[2], "achieved": tf, "peak": w.compute[1]}

@@ -222,7 +222,7 @@ static int pick_fir_algo(const FirHandle *h, int64_t n)
     if (algo == SKDSP_FIR_OLS && !fir_ols_supported(h) && !ols64) algo = SKDSP_FIR_DIRECT;
     if (algo != SKDSP_FIR_AUTO) return algo;
     // float64 signals: the direct form costs 2 (4 for complex taps) FP64 FMA per tap and real sample; the float64
-    // overlap-save tile is flat in the tap count (measured crossovers at 2^26 samples: see DESIGN.md 4.1b)
+    // overlap-save tile is flat in the tap count (measured crossovers at 2^26 samples: see DESIGN.md 4.2, LABNOTES.md)
     if (ols64) return h->ntaps >= (h->dtype == SKDSP_C128 ? 24 : 128) && n >= 8192 ? SKDSP_FIR_OLS : SKDSP_FIR_DIRECT;
     // measured crossover at 2^26 samples (tools/time_fir_filter.py, profiles/r04/fir_filter.txt): the matrix-pipe kernel (real taps, fp16 pieces)
     // stays ahead of overlap-save up to 6 lag blocks for complex64 (0.215 vs 0.229 ms at 145 taps; 0.221 vs 0.227 at 160; 0.241 vs 0.227 at 192)
@@ -383,7 +383,7 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
 // matrix-pipe kernel covers the shape, 3-4x that where it does not -- the walk costs per (tile, phase) pair whatever the phase length,
 // plus what its stride-L stores cost, and runs in rounds of one pair per resident workgroup.
 // multirate_FIR.up through the overlap-save walk: from which L on the phases leave as rows of scratch and a second kernel weaves them
-// (measured crossovers of profiles/r03/fir_up.txt; 16-byte samples never: their strided stores are full-width requests already)
+// (measured crossovers of profiles/r03/fir_up.txt -- the walk serves float64 and > 1025 taps per phase today; 16-byte samples never: their strided stores are full-width requests already)
 static bool fir_up_rows(const FirHandle *h, int L, bool paired = false)
 {
     const int o = opt().fir_up_rows_min;
@@ -451,7 +451,7 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
     if (floor_t < 0) return true;
     if ((opt().fir_algo != SKDSP_FIR_AUTO ? opt().fir_algo : h->algo) == SKDSP_FIR_DIRECT) return false;
     if (fir_needs_parts(h, L)) return true;   // (longer than one polyphase launch takes)
-    // all figures: ms per 2^26 up-rate samples on this board (profiles/r03/fir_up.txt, fir_updn.txt)
+    // all figures: ms per 2^26 up-rate samples on this board (the walk and the float64 kernels: profiles/r03/fir_up.txt, fir_updn.txt; the matrix-pipe and tile kernels: profiles/r04)
     const double Lf = (double)L;
     const bool cplx = dtype_complex(h->dtype);
     double ols, base, poly, copy;   // base: the walk without what its stride-L stores cost

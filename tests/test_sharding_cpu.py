@@ -146,7 +146,7 @@ def test_sos_state_matrix_matches_sosfilt():
 
 def test_bench_reads_board_power_and_clock_from_rocm_smi(monkeypatch):
     """bench.py's board leg parses `rocm-smi --showpower --showmaxpower --showclocks`; the text below is what the tool prints on an MI355X box
-    (profiles/r03/power_probe.txt).  A box without the tool yields (None, None, None) and the leg reports itself as skipped."""
+    (profiles/r04/power_probe.txt).  A box without the tool yields (None, None, None) and the leg reports itself as skipped."""
     import types
     import bench
     text = ("============================ ROCm System Management Interface ============================\n"
