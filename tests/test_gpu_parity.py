@@ -1328,6 +1328,34 @@ def test_matrix_pipe_path_is_scale_invariant(dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_matrix_pipe_dispatch_sweep(dt):
+    """Every (taps, L, M) the direct path may be asked for must find a kernel -- the geometry test of the matrix-pipe kernel and the list of its
+    instantiations are separate pieces of code (a geometry without a kernel raised NotImplementedError once) -- and hold the float32 tolerance:
+    a sweep over tap counts x rate changes on short signals."""
+    rng = np.random.default_rng(11)
+    cplx = np.dtype(dt).kind == "c"
+    worst = 0.0
+    for P in (9, 40, 96, 130, 257, 400, 513, 700, 1025, 1500):
+        b = rng.standard_normal(P) / np.sqrt(P)
+        k = _ffi.FirKernel(b, _ffi.code_of(dt))
+        k.set_algo(_ffi.FIR_DIRECT)
+        for L, M in ((1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1), (12, 1), (16, 1), (24, 1), (1, 2), (1, 3), (1, 4), (1, 5), (1, 6),
+                     (1, 8), (1, 12), (1, 16), (1, 24), (1, 32), (1, 48), (1, 100), (4, 3), (3, 2), (12, 5), (5, 12), (7, 4), (16, 3)):
+            n = 30_000 - 30_000 % M
+            x = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(dt)
+            xd = _ffi.DeviceArray.from_host(x)
+            yd = _ffi.DeviceArray(n * L // M, dt)
+            k.updn_dev(xd, yd, L, M)
+            _ffi.sync()
+            got = yd.to_host()
+            ref = orc.downsample(orc.fir_up(b, x, L), M) if L > 1 else orc.fir_dn(b, x, M)
+            e = np.max(np.abs(got - ref[:len(got)])) / np.max(np.abs(ref))
+            worst = max(worst, e)
+            assert e < TOL32, (P, L, M, e)
+            xd.free(); yd.free()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
 def test_matrix_pipe_impulse_and_silence(dt):
     """The matrix-pipe FIR on the two inputs that show its operand representation directly: an impulse returns the taps (two fp16 pieces each:
     2^-23 of the largest tap at worst), also where the taps span 200 dB; silence returns exact zeros (a window without a largest magnitude is
