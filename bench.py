@@ -159,7 +159,15 @@ def config5_leg(args, rank, world, tr, _ffi, sharding):
     if total % world:
         return ({"skipped": "%d GPUs do not divide 2^%d samples" % (world, CONFIG5_TOTAL_LOG2N)} if rank == 0 else None), True
     n5 = total // world
-    w5 = make_workload("fir1024", n5, rank, world, tr, _ffi, sharding)
+    w5, err = None, None
+    try:
+        w5 = make_workload("fir1024", n5, rank, world, tr, _ffi, sharding)
+    except Exception as e:      # (e.g. out of memory on one rank: every rank must learn of it BEFORE the collectives below)
+        err = "%s: %s" % (type(e).__name__, e)
+    if tr.allreduce_max(1.0 if err else 0.0) > 0:
+        if w5 is not None:
+            free_workload(w5)
+        return ({"error": err or "another rank could not allocate its 2^%d / %d samples" % (CONFIG5_TOTAL_LOG2N, world)} if rank == 0 else None), False
     try:
         K5 = max(10, min(args.steps, 50))
         elapsed, ev_ms, _ = timed_steps(w5, K5, 10, 0.2, tr, _ffi)
@@ -344,7 +352,23 @@ def make_workload(name, n, rank, world, tr, _ffi, sharding):
         make_rate_workload(w, name, n, lg, _ffi)
     else:
         raise ValueError(name)
+    if w.check is None and world == 1:
+        w.check = lambda: head_check(w)
     return w
+
+
+def head_check(w, m=6000):
+    """The head of what a single-GPU workload just computed against the oracle (checker only): max-abs error / max-abs reference."""
+    from oracle import oracle as orc
+    x = w.xd.to_host(0, m)
+    if w.name == "updn43":
+        ref = orc.downsample(orc.fir_up(w.taps, x, 4), 3)
+    elif getattr(w, "sos", None) is not None:
+        ref = orc.sos_filter(w.sos, x)
+    else:
+        ref = orc.fir_filter(w.taps, x)
+    got = w.yd.to_host(0, ref.size)
+    return float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
 
 
 # The .up / .dn / resampling rows of SURVEY.md 8(a), each at the reference's defaults, sized by the HIGH rate (n samples on the fast side):
@@ -593,6 +617,14 @@ def compute_of(w, ev_ms, K):
     return out
 
 
+def compact_row(ms, frac, traffic, alg_bytes, err, board):
+    r = {"ms": round(ms, 4), "frac": round(frac, 3), "tr": round(traffic / alg_bytes, 3) if traffic else None,
+         "err": float("%.1e" % err) if err is not None else None}
+    if board and board.get("power_w") is not None:
+        r["W"], r["MHz"] = int(board["power_w"]), int(board["sclk_mhz"] or 0)
+    return r
+
+
 def dp_pipe_of(w, ev_ms, K, compute_units):
     """FP64-pipe utilisation of the parallel-form IIR kernel: executed FP64 issue slots (vector + matrix: one datapath) against
     what the chip can issue at its nominal 2.4 GHz (4 SIMDs x 16 lanes per CU and cycle; the part sustains 1.9-2.1 GHz here)."""
@@ -709,6 +741,9 @@ def main():
             "roofline": roofline_of(w, ev_ms, K, log2n),
             "kernel_source_sha256": source_hashes(args.workload),
         }
+        if info["compute_units"] < 200:   # an XCD partition of the card (CPX mode: 8 logical devices of 32 CUs on ONE MI355X)
+            out["config"]["logical_device"] = ("compute partition of one MI355X (%d CUs): the ranks share one HBM stack and one power "
+                                               "budget -- a FUNCTIONAL run of the RCCL path, not a scaling measurement" % info["compute_units"])
         c = compute_of(w, ev_ms, K)
         if c is not None:
             out["compute"] = c
@@ -758,8 +793,9 @@ def main():
                                 "steps": Ko, "ms": el * 1e3 / Ko, "kernel_ms": r["kernel_ms"], "achieved_GBps": r["achieved"],
                                 "frac": r["frac"], "traffic": r["traffic"],
                                 "algorithmic_bytes_per_launch": o.alg_bytes, "traffic_source": r["traffic_source"], "kernel": o.kern}
-                if getattr(o, "rate", None):   # a SURVEY 8(a) .up / .dn row: sizes at both rates, and the head of the result against the oracle
+                if getattr(o, "rate", None):   # a SURVEY 8(a) .up / .dn row: sizes at both rates
                     others[name]["rate"] = o.rate
+                if o.check is not None:            # the head of the result against the oracle
                     others[name]["parity_spot_check_max_err"] = o.check()
                 c = compute_of(o, ev, Ko)
                 if c is not None:
@@ -774,6 +810,17 @@ def main():
             except Exception as e:  # a broken side config must not take the headline line with it
                 others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["other_configs"] = others
+        # every row once more, compact: the driver's record keeps the scalar members of "roofline" and the last 2 KB of this line, so
+        # each row is a short string inside "roofline" AND the table is the LAST member of the line
+        rows = {"fir1024": compact_row(out["roofline"]["kernel_ms"], out["roofline"]["frac"], out["roofline"]["traffic"],
+                                       out["roofline"]["algorithmic_bytes_per_launch"], out.get("parity_spot_check_max_err"), out.get("board"))}
+        for name, o in others.items():
+            rows[name] = ({"error": o["error"][:60]} if "error" in o else
+                          compact_row(o["kernel_ms"], o["frac"], o["traffic"], o["algorithmic_bytes_per_launch"], o.get("parity_spot_check_max_err"), o.get("board")))
+        for name, r in rows.items():
+            out["roofline"]["row_" + name] = " ".join("%s=%s" % kv for kv in r.items())
+        out["rows_what"] = "per workload (2^26 samples): kernel ms, fraction of 8 TB/s, PMC traffic / algorithmic bytes, head max-abs error vs the oracle / max-abs reference, board W, shader MHz"
+        out["rows"] = rows
 
     # ------------------------------------------- N > 1: BASELINE config 5 (2^30 samples in total, strong scaling) behind the weak-scaling line
     c5_ok = True
@@ -781,8 +828,8 @@ def main():
         free_workload(w)
         try:
             rec, c5_ok = config5_leg(args, rank, world, tr, _ffi, sharding)
-        except Exception as e:   # (a failure here must not take the weak-scaling line with it -- but it must be visible)
-            rec, c5_ok = {"error": "%s: %s" % (type(e).__name__, e)}, True
+        except Exception as e:   # (a failure here must not take the weak-scaling line with it -- but the run exits 3)
+            rec, c5_ok = {"error": "%s: %s" % (type(e).__name__, e)}, False
         if rank == 0:
             out["config5"] = rec
 

@@ -794,7 +794,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     // 8 slots stay free: room for a concurrent kernel (the RCCL send/recv of a halo, another stream of the caller) at
     // no measurable cost (0.2375 vs 0.2375 ms at 2^26, alternating runs on one box)
     if (reserve_wgs < 0) reserve_wgs = opt().ols_reserve;
-    if (reserve_wgs > 0 && grid > 8 * (int64_t)reserve_wgs) grid -= reserve_wgs;
+    if (reserve_wgs > 0 && grid >= 4 * (int64_t)reserve_wgs) grid -= reserve_wgs;
     if (grid > ntiles) grid = ntiles;
     if (A.dec > 1) {
         if (real) hipLaunchKernelGGL((ols_tile_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
@@ -876,7 +876,7 @@ static int up_walk(FirHandle *h, int kind, const void *x, int64_t n, int64_t n_h
     A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     const int reserve_wgs = opt().ols_reserve;
-    if (reserve_wgs > 0 && grid > 8 * (int64_t)reserve_wgs) grid -= reserve_wgs;
+    if (reserve_wgs > 0 && grid >= 4 * (int64_t)reserve_wgs) grid -= reserve_wgs;
     if (grid > ntiles) grid = ntiles;
     if (xr) {
         // (L = 2 is one pair: "row 0" of the rows form IS the output, written with the plain complex filter's full-width stores.  The

@@ -381,7 +381,7 @@ int fir_up2k_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int 
     }
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     const int reserve_wgs = opt().ols_reserve;
-    if (reserve_wgs > 0 && grid > 8 * (int64_t)reserve_wgs) grid -= reserve_wgs;
+    if (reserve_wgs > 0 && grid >= 4 * (int64_t)reserve_wgs) grid -= reserve_wgs;
     if (grid > A.ntiles) grid = A.ntiles;
     const dim3 g((unsigned)grid), b(256);
     auto launch = [&](auto xr, auto ph) {
