@@ -67,6 +67,10 @@ int skdsp_shutdown(void);
 int skdsp_device_count(void);
 int skdsp_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes, int *clock_khz);
 const char *skdsp_last_error(void);
+/* Test / diagnostic aid (no reference counterpart): the comma-joined names of the kernels families the calling thread's API calls have
+ * launched since the last clear ("fir_ols", "fir_bx", "fir_up4k", "iir_par", ...), so that a parity test can assert that a shape
+ * reaches the engine it means to exercise.  clear != 0 empties the record. */
+int skdsp_debug_path(char *buf, int cap, int clear);
 const char *skdsp_version(void);
 /* Run-time switches (algorithm A/B selectors, pipeline chunk size, ...).  Each option NAME is read once from the
  * environment variable SKDSP_<NAME> when the library first needs it; afterwards only these calls change it, so no

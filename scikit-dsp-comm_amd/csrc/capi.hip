@@ -1183,9 +1183,28 @@ using namespace skdsp;
     }                                    \
     std::lock_guard<std::mutex> _ctxlk(ctx().mu)
 
+static thread_local char g_path[256];
+void skdsp::note_path(const char *engine)
+{
+    const size_t len = strlen(g_path), add = strlen(engine);
+    if (len >= add && strcmp(g_path + len - add, engine) == 0 && (len == add || g_path[len - add - 1] == ',')) return;   // (the same engine again)
+    if (len + add + 2 >= sizeof(g_path)) return;
+    if (len) g_path[len] = ',';
+    memcpy(g_path + len + (len ? 1 : 0), engine, add + 1);
+}
+
 extern "C" {
 
 const char *skdsp_last_error(void) { return g_err; }
+int skdsp_debug_path(char *buf, int cap, int clear)
+{
+    if (buf && cap > 0) {
+        strncpy(buf, g_path, (size_t)cap - 1);
+        buf[cap - 1] = 0;
+    }
+    if (clear) g_path[0] = 0;
+    return SKDSP_OK;
+}
 const char *skdsp_version(void) { return "skdsp-hip 0.1.0 (gfx950)"; }
 
 int skdsp_init(int device)

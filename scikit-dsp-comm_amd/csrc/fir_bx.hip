@@ -69,6 +69,8 @@ struct BxArgs {
     int pad_s;
     unsigned pad_magic;   // ceil(2^32 / s)
     float tap_inv;        // 2^-te: the taps of the table are L b 2^te (scaled into the fp16 range on the host)
+    int L, M;             // of the call (the exact path of a window this kernel cannot compute: careful.hpp)
+    CarefulFir cf;
 };
 
 constexpr int kBxPx = 2;          // fp16 pieces of a signal sample
@@ -114,6 +116,22 @@ __device__ __forceinline__ void bx_split2(float a, float b, unsigned (&p)[kBxPx]
 __device__ __forceinline__ v4f_bx bx_mfma(uint4 a, uint4 b, v4f_bx c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h_bx, a), __builtin_bit_cast(v8h_bx, b), c, 0, 0, 0);
+}
+
+// A window this kernel cannot compute: one that holds an inf / nan (0 x inf = nan on the zero-padded part of the lag blocks, and the
+// window's scale is taken from its largest magnitude), or one whose samples span more than 2^24 in magnitude (the fp16 pieces keep 22 bits
+// of a sample only down to 2^-29 of the window's largest: a 1e12 glitch would leave its unit-level neighbours 5e-4 of THEIR level).  The
+// window's outputs -- m in [RS S0, RS (S0 + NS)) -- are then recomputed by the reference's own float64 sum and overwrite what the tiles
+// stored (behind the barrier that ends the window).
+template <bool CPLX>
+__device__ __noinline__ void bx_careful_window(const float *x, float *y, int64_t n_hist, int64_t n_out, int64_t m0, int count, int L, int M, const CarefulFir cf, int tid)
+{
+#pragma unroll 1
+    for (int i = tid; i < count; i += 256) {
+        const int64_t m = m0 + i;
+        if (m >= n_out) break;
+        careful_fir_store<float, CPLX>(x, n_hist, cf, L, M, m, y + (CPLX ? 2 : 1) * m);
+    }
 }
 
 // Persistent 256-thread workgroups: window w+1 is requested into registers before window w is multiplied, so
@@ -173,15 +191,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // maxima of |x| as integer bit patterns (written in front of the barrier that frees the planes, read behind it).
     unsigned *wmax_sh = reinterpret_cast<unsigned *>(bx_smem + (size_t)(kBxPx * C) * plane_bytes + (KSP > 1 ? (size_t)2 * 4 * (4 * C) * 64 * 4 : 0));
     float wscale = 1.f, winv_next = 1.f;
+    bool wbad_next = false;   // the window being staged is one for the exact path (bx_careful_window)
     auto publish_max = [&](unsigned m) {   // m: this thread's maximum of |x| bits
+        unsigned lo = m ? m : 0xffffffffu;   // the smallest of the lanes' maxima (lanes that hold nothing but zeros aside: zeros are exact at any scale)
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-        if (lane == 0) wmax_sh[wave] = m;
+        for (int o = 32; o >= 1; o >>= 1) {
+            m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+            lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
+        }
+        if (lane == 0) { wmax_sh[wave] = m; wmax_sh[4 + wave] = lo; }
     };
     auto fetch_scale = [&]() {   // behind the barrier: wscale for the split, winv_next for this window's outputs
         const unsigned m = max(max(wmax_sh[0], wmax_sh[1]), max(wmax_sh[2], wmax_sh[3]));
+        const unsigned lo = min(min(wmax_sh[4], wmax_sh[5]), min(wmax_sh[6], wmax_sh[7]));
         int e = (int)(m >> 23);                       // biased exponent of the largest magnitude
-        if (e == 0 || e == 255) e = 141;              // all zero (or not finite: nothing sensible to do): scale 1
+        // not finite, or some lane's samples lie more than 2^24 below the largest: the exact path takes this window's outputs
+        wbad_next = e == 255 || (lo != 0xffffffffu && e - (int)(lo >> 23) > 24);
+        if (e == 0 || e == 255) e = 141;              // all zero (or not finite): scale 1
         e = e < 16 ? 16 : e;                          // (2^(141 - e) must stay a normal float)
         wscale = __uint_as_float((unsigned)(141 - e + 127) << 23);
         winv_next = __uint_as_float((unsigned)(e - 141 + 127) << 23) * a.tap_inv;
@@ -280,6 +306,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     fetch_scale();
     float winv = winv_next;   // of the window in the planes
+    bool wbad = wbad_next;
+    // windows for the exact path, by walk step of this workgroup (bit 63: "some step from 63 on"); they are recomputed BEHIND the loop
+    // (workgroup-uniform: the flag comes out of the LDS) -- a call inside it costs the 256-register instantiations spilled registers
+    unsigned long long bad = 0;
+    int step = 0;
+    const int64_t wdx_first = wdx;
     if (fast) store_window();
     else stage_window_slow(wdx);
     __syncthreads();
@@ -414,6 +446,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             winv = winv_next;
             __syncthreads();  // the planes hold window w+1
+            if (__builtin_expect(wbad, 0)) bad |= 1ull << (step < 63 ? step : 63);
+            wbad = wbad_next;
+            ++step;
             const int64_t wnext2 = wnext + gridDim.x;
             fast = wnext2 < nwin && interior(wnext2);
             if (fast) load_window(wnext2);
@@ -446,6 +481,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_s_setprio(0);
         winv = winv_next;
         __syncthreads();  // the planes hold window w+1
+        if (__builtin_expect(wbad, 0)) bad |= 1ull << (step < 63 ? step : 63);
+        wbad = wbad_next;
+        ++step;
         const int64_t wnext2 = wnext + gridDim.x;
         fast = wnext2 < nwin && interior(wnext2);
         __builtin_amdgcn_s_setprio(3);
@@ -453,6 +491,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_s_setprio(0);
         wdx = wnext;
         wnext = wnext2;
+    }
+    if (__builtin_expect(bad != 0, 0)) {
+        // (every store of the loop was issued in front of the barrier that ended its window: a second store to the same address, from
+        // whichever thread, follows it)
+        int k = 0;
+        for (int64_t w = wdx_first; w < nwin; w += gridDim.x, ++k)
+            if ((bad >> (k < 63 ? k : 63)) & 1)
+                bx_careful_window<CPLX>(x, y, a.n_hist, a.n_out, (int64_t)a.RS * a.NS * w, a.RS * a.NS, a.L, a.M, a.cf, tid);
     }
 }
 
@@ -676,6 +722,7 @@ static bool bx_dispatch(int KB, int RT, int RSP, int KSP, unsigned grid, size_t 
 
 int fir_bx_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, int M, int64_t n_out, void *y, hipStream_t s)
 {
+    note_path("fir_bx");
     if (n_out <= 0) return SKDSP_OK;
     const FirHandle::BxTab *t = nullptr;
     int rc = get_bx_table(h, L, M, &t);
@@ -694,8 +741,10 @@ int fir_bx_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L,
     const int units = a.win / 8;
     size_t lds = (size_t)(cplx ? 2 : 1) * kBxPx * (size_t)(units + (a.pad_s ? units / su : 0) + 1) * 16;  // (+ a dump row per plane)
     if (t->KSP > 1) lds += (size_t)2 * 4 * (cplx ? 8 : 4) * 64 * sizeof(float);   // the partial tiles of the lag split, two generations
-    lds += 16;                                                                      // the waves' window maxima
+    lds += 32;                                                                      // the waves' window maxima (and the smallest of their lanes' maxima)
     a.tap_inv = t->tap_inv;
+    a.L = L; a.M = M;
+    if ((rc = fir_careful(h, &a.cf))) return rc;
     const int64_t ncols = (n_out + a.RS - 1) / a.RS;
     const int64_t nwin = (ncols + a.NS - 1) / a.NS;
     const unsigned grid = (unsigned)std::min<int64_t>(nwin, (int64_t)2 * ctx().num_cus);  // persistent: two per CU

@@ -74,6 +74,7 @@ struct PolyArgs {
     int q;            // input stride per output within a class
     int s_tile;       // outputs per class per workgroup (<= 256*R)
     int win;          // staged window length in samples
+    CarefulFir cf;    // for the re-evaluation of non-finite results (careful.hpp)
 };
 
 template <typename X, typename B, int R>
@@ -158,6 +159,18 @@ __global__ __launch_bounds__(256) void fir_poly_kernel(const X *__restrict__ x, 
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = add_of(acc[r], part[r]);
         }
+        {   // a non-finite result: did a real tap meet the sample, or only the zero padding of the phase table?  (careful.hpp)
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) bad |= not_finite(acc[r]);
+            if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll 1
+                for (int r = 0; r < R; ++r) {
+                    const int64_t m = (int64_t)c + (int64_t)a.Lp * (s0 + tid + 256 * r);
+                    if (not_finite(acc[r]) && tid + 256 * r < a.s_tile && m < a.n_out) acc[r] = careful_fir_value<X>(x, a.n_hist, a.cf, a.L, a.M, m, 0);
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int sl = tid + 256 * r;
@@ -193,6 +206,8 @@ struct SwArgs {
     int half_last;  // taps 4..7 of the last block of every (class, residue) row are zero padding
     int out_tile;  // 1: out_off is ONE image of all Lp classes of the workgroup's slots (256*R*Lp elements)
     int out_off;  // byte offset of the four wave-private output transposition tiles (-1: store directly)
+    int M;        // of the call, for the re-evaluation of non-finite results (careful.hpp)
+    CarefulFir cf;
 };
 
 
@@ -462,10 +477,27 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
         }
     };
 
+    // a non-finite result: did a real tap meet the sample, or only the zero padding of the tap blocks?  (careful.hpp; the value without
+    // the gain L, which the stores below apply)
+    auto recheck = [&](const int c, const int lp, X (&acc)[R]) __attribute__((always_inline)) {
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) bad |= not_finite(acc[r]);
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll 1
+            for (int r = 0; r < R; ++r) {
+                const int64_t m = (int64_t)c + (int64_t)lp * (s0 + (int64_t)R * tid + r);
+                if (not_finite(acc[r]) && m < a.n_out) acc[r] = careful_fir_value<X>(x, a.n_hist, a.cf, a.L, a.M, m, 0);
+            }
+        }
+    };
     if constexpr (LPT > 0) {
         X accs[LPT][R];
 #pragma unroll
-        for (int c = 0; c < LPT; ++c) class_body(c, accs[c]);
+        for (int c = 0; c < LPT; ++c) {
+            class_body(c, accs[c]);
+            recheck(c, LPT, accs[c]);
+        }
         // element e of a wave's output run = LPT * slot + class; 16 lanes (16*LPT*R consecutive
         // elements) go through the wave-private tile per pass and leave as 512-byte rows
         static_assert(16 * (LPT * R + 1) <= 64 * (R + 1), "output tile too small");
@@ -495,6 +527,7 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
     for (int c = 0; c < a.Lp; ++c) {
         X acc[R];
         class_body(c, acc);
+        recheck(c, a.Lp, acc);
         const int64_t sb = s0 + (int64_t)R * tid;
         if (a.out_tile) {
             // every class of the workgroup's slots is parked in one LDS image laid out like the
@@ -571,6 +604,20 @@ FirHandle::~FirHandle()
     for (auto &u : ols64_up) fir_ols64_free(u.plan);
     for (FirHandle *p : parts) delete p;
     for (FirHandle *p : heads) delete p;
+    if (taps64_dev) (void)hipFree(taps64_dev);
+}
+
+int fir_careful(FirHandle *h, CarefulFir *out)
+{
+    if (!h->taps64_dev) {
+        const size_t bytes = h->taps_host.size() * sizeof(double);
+        SK_HIP(hipMalloc(&h->taps64_dev, bytes));
+        SK_HIP(hipMemcpy(h->taps64_dev, h->taps_host.data(), bytes, hipMemcpyHostToDevice));
+    }
+    out->taps = (const double *)h->taps64_dev;
+    out->ntaps = h->ntaps;
+    out->taps_complex = h->taps_complex ? 1 : 0;
+    return SKDSP_OK;
 }
 
 // polyphase bank for interpolation factor L in the compute precision
@@ -676,12 +723,14 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
     int T = 0;
     int rc = get_bank(h, L, &bank, &T);
     if (rc) return rc;
+    note_path("fir_direct");
 
     const int g = std::gcd(L, M);
     PolyArgs a;
     a.n = n; a.n_hist = n_hist; a.n_out = n_out;
     a.T = T; a.L = L; a.M = M; a.Lp = L / g; a.q = M / g;
     a.n_s = (n_out + a.Lp - 1) / a.Lp;
+    if ((rc = fir_careful(h, &a.cf))) return rc;
 
     const size_t esz = dtype_size(h->dtype);
     const size_t lds_cap = 80 * 1024;  // <= 2 workgroups per CU of the 160 KiB LDS
@@ -712,6 +761,7 @@ int fir_direct_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, in
             SwArgs w;
             w.n = n; w.n_hist = n_hist; w.n_out = n_out;
             w.L = L; w.Lp = a.Lp; w.q = q; w.G = G; w.nB = nB; w.win = (int)win;
+            w.M = M; w.cf = a.cf;
             w.half_last = (R == 8 && (Tq + 1) - (nB - 1) * R <= R / 2) ? 1 : 0;
             size_t lds = (size_t)phys * esz;
             w.tap_off = -1; w.tap_cnt = 0;

@@ -38,6 +38,7 @@ struct Dn4kArgs {
     int M;
     int aligned;             // x and y element-aligned
     int64_t ntiles;          // tiles (float32: pairs of tiles) of V outputs
+    CarefulFir cf;           // the filter as the exact path of a poisoned tile reads it (careful.hpp)
 };
 
 // first output of `tile` (float32: of the pair's tile A; tile B follows V outputs later), minus the overlap
@@ -192,6 +193,23 @@ __device__ __forceinline__ void dn4k_fwd_pass2(int t, const cf *T2, cf *img, cf 
     });
 }
 
+// A poisoned tile (one inf / nan among the M x 4096 inputs of a tile makes all of its outputs non-finite, where the reference confines the
+// sample to the kept ones among the Ntaps outputs that multiply it): the thread recomputes the outputs it stored by the reference's own sum
+// (careful.hpp) -- its own stores, in program order: no barrier.
+template <bool REAL> __device__ __noinline__ void dn4k_careful_outputs(const void *x, void *y, int64_t n_out, int64_t n_hist, const CarefulFir cf, int M, int64_t out0, int V, int a0, int t)
+{
+#pragma unroll 1
+    for (int a = a0; a < 16; ++a) {
+        const int64_t o = out0 + 256 * (a - a0) + t;
+        if (REAL) {
+            if (o < n_out) careful_fir_store<float, false>(reinterpret_cast<const float *>(x), n_hist, cf, 1, M, o, reinterpret_cast<float *>(y) + o);
+            if (o + V < n_out) careful_fir_store<float, false>(reinterpret_cast<const float *>(x), n_hist, cf, 1, M, o + V, reinterpret_cast<float *>(y) + o + V);
+        } else if (o < n_out) {
+            careful_fir_store<float, true>(reinterpret_cast<const float *>(x), n_hist, cf, 1, M, o, reinterpret_cast<float *>(y) + 2 * o);
+        }
+    }
+}
+
 // Persistent: 2 workgroups per CU walk the output tiles (XCD-contiguous runs per round: neighbouring tiles share their overlap
 // through that XCD's L2).  MS = M, a compile-time 2 ... 4: ONE load group holds all phases of a sample (32 contiguous bytes per
 // lane at M = 4), and with the phase count static every phase's registers are known dead where the next one starts -- the same
@@ -216,9 +234,12 @@ template <bool REAL, int MS> __global__ __launch_bounds__(256, 2) void dn4k_kern
     }
     __syncthreads();
     int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+    const int64_t tile_first = tile;
+    unsigned long long bad = 0;   // poisoned tiles of this wave's walk, by walk step (see fir_up4k.hip): recomputed behind the loop
+    int step = 0;
     cf in[MS * 16];         // the phase signals of the tile; each is transformed in place
     bool have_in = false;   // `in` holds the phase signals of `tile` (requested ahead: interior tiles only)
-    for (; tile < A.ntiles; tile += gridDim.x) {
+    for (; tile < A.ntiles; tile += gridDim.x, ++step) {
         const bool pre_next = tile + gridDim.x < A.ntiles && dn4k_interior<REAL>(A, tile + gridDim.x);
         if (!have_in) {
             if (dn4k_interior<REAL>(A, tile)) {
@@ -258,6 +279,13 @@ template <bool REAL, int MS> __global__ __launch_bounds__(256, 2) void dn4k_kern
         dn4k_pin(acc);
         if (pre_next) static_for<0, MS>([&](auto jc) __attribute__((always_inline)) { dn4k_pin(in + 16 * decltype(jc)::value); });   // (waited for in front of the stores)
         dn4k_store<REAL>(A, tile, t, acc);
+        if (__builtin_expect(__any(not_finite(acc[15].x) | not_finite(acc[15].y)), 0)) bad |= 1ull << (step < 63 ? step : 63);
+    }
+    if (__builtin_expect(bad != 0, 0)) {
+        int k = 0;
+        for (int64_t tl = tile_first; tl < A.ntiles; tl += gridDim.x, ++k)
+            if ((bad >> (k < 63 ? k : 63)) & 1)
+                dn4k_careful_outputs<REAL>(A.x, A.y, A.n_out, A.n_hist, A.cf, A.M, tl * (REAL ? 2 : 1) * (int64_t)A.V, A.V, A.a0, t);
     }
 }
 
@@ -323,6 +351,7 @@ static int dn4k_plan(FirHandle *h, int M, Dn4kPlan **out)
 
 int fir_dn4k_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int M, void *y, hipStream_t s)
 {
+    note_path("fir_dn4k");
     const int64_t n_out = n / M;
     if (n_out <= 0) return SKDSP_OK;
     SK_CHECK(fir_dn4k_supported(h, M), SKDSP_ERR_UNSUPPORTED, "fir_dn4k: needs complex64 (or float32 with real taps), 2 <= M <= 4, at most 2049 taps per phase");
@@ -339,6 +368,7 @@ int fir_dn4k_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int 
     A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & (esz - 1)) == 0;
     const int64_t per = (int64_t)p->V * (real ? 2 : 1);
     A.ntiles = (n_out + per - 1) / per;
+    if ((rc = fir_careful(h, &A.cf))) return rc;
     SK_CHECK(A.ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_dn4k: too many tiles");
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     const int reserve_wgs = opt().ols_reserve;

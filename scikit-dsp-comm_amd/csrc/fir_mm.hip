@@ -37,6 +37,8 @@ struct MmArgs {
     int U0;     // lag offset (see above)
     int NS;     // column blocks per workgroup (multiple of 64)
     int win;    // staged samples per workgroup = q_ds * (NS - 1) + 4 * K4
+    int L, M;   // of the call, for the re-evaluation of non-finite results (careful.hpp)
+    CarefulFir cf;
 };
 
 __device__ __forceinline__ int mm_phys(int e) { return e + (e >> 3); }
@@ -155,12 +157,26 @@ __global__ __launch_bounds__(256) void fir_mm_kernel(const X *__restrict__ x, co
                 ar[c] = ar[c] + ar[c + w];
                 ai[c] = ai[c] + ai[c + w];
             }
-        const V ar0 = ar[0];
-        const V ai0 = ai[0];
+        V ar0 = ar[0];
+        V ai0 = ai[0];
         // rows 4 (lane >> 4) + i of column N: outputs m = RS N + row
         const int64_t N = S0 + tile * 16 + ncol;
         const int row0 = 4 * klane;
         const int64_t m0 = (int64_t)a.RS * N + row0;
+        {   // a non-finite result: did a real tap meet the sample, or only the zero padding of the lag range?  (careful.hpp)
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bad |= not_finite((S)ar0[i]) || (CPLX && not_finite((S)ai0[i]));
+            if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll 1
+                for (int i = 0; i < 4; ++i)
+                    if ((not_finite((S)ar0[i]) || (CPLX && not_finite((S)ai0[i]))) && row0 + i < a.RS && m0 + i < a.n_out) {
+                        const X v = careful_fir_value<X>(x, a.n_hist, a.cf, a.L, a.M, m0 + i);
+                        ar0[i] = mm_re(v);
+                        if constexpr (CPLX) ai0[i] = mm_im(v);
+                    }
+            }
+        }
         if (a.RS == 16 && m0 + 4 <= a.n_out && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
             // 4 consecutive outputs per lane: 16-byte stores
             S buf[4 * MmIo<X>::C];
@@ -238,6 +254,7 @@ bool fir_mm_supported(const FirHandle *h, int L, int M, int64_t n_out)
 
 int fir_mm_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, int M, int64_t n_out, void *y, hipStream_t s)
 {
+    note_path("fir_mm");
     if (n_out <= 0) return SKDSP_OK;
     const FirHandle::MmTab *t = nullptr;
     int rc = get_mm_table(h, L, M, &t);
@@ -253,6 +270,8 @@ int fir_mm_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L,
     while (NS > 64 && (ncols + NS - 1) / NS < 2 * ctx().num_cus) NS -= 64;  // small problems: more workgroups
     a.NS = NS;
     a.win = a.q_ds * (NS - 1) + 4 * a.K4;
+    a.L = L; a.M = M;
+    if ((rc = fir_careful(h, &a.cf))) return rc;
     const size_t lds = ((((size_t)a.win + (size_t)a.win / 8 + 2) * esz + 15) & ~(size_t)15) + 64;
     const unsigned grid = (unsigned)((ncols + NS - 1) / NS);
 #define SK_MM(XT, KB)                                                                                              \

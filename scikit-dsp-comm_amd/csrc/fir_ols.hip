@@ -62,6 +62,7 @@ struct OlsArgs {
     const unsigned *halo_flag;
     unsigned halo_seq;
     unsigned *halo_err;  // host-mapped: set if the bounded wait gave up (the caller reports it; the launch never hangs)
+    CarefulFir cf;       // the filter as the exact path of a poisoned tile reads it (careful.hpp)
 };
 
 // The owner of tile 0 calls this (whole workgroup, uniform) before its first load of that tile: one lane polls with
@@ -486,6 +487,26 @@ template <bool DEC> __device__ __forceinline__ void store_tile_real_up(const Ols
     }
 }
 
+
+// ---- a poisoned tile ------------------------------------------------------------------------------------------------
+// One inf / nan among a tile's 8192 inputs makes EVERY result of that tile non-finite (each bin of the forward transform is a sum
+// over all inputs; no IEEE operation of the transforms turns a non-finite value back into a finite one), where the reference's
+// lfilter confines it to the Ntaps outputs that multiply it.  So a wave that finds a non-finite result recomputes the tile's outputs
+// by the reference's own sum (careful.hpp: careful_ols_tile) and overwrites what the tile just stored -- after the barrier that ends
+// the tile, which orders the two stores to an address whichever threads made them.  The hot path pays two compares per tile for this.
+__device__ __forceinline__ OlsCareful ols_careful_args(const OlsArgs &A, int ph, bool cx)
+{
+    OlsCareful c;
+    c.x = A.x; c.y = A.y; c.n = A.n; c.n_hist = A.n_hist; c.n_keep = A.n_keep; c.up_pitch = A.up_pitch;
+    c.V = A.V; c.dec = A.dec; c.up = A.up;
+    // .up: the interpolation factor and the first phase of this pass, from the byte strides of its store (see OlsArgs)
+    const int esz = cx ? 8 : 4;
+    c.L = A.up_sb / esz;
+    c.p0 = (A.up_pb0 + ph * A.up_pbs) / esz;
+    c.cf = A.cf;
+    return c;
+}
+
 // Persistent: gridDim.x = 2 workgroups per CU, each walks tiles blockIdx.x, +gridDim.x, ...
 // Per tile the only vector-memory traffic is [H: 16 loads at tile start, consumed after
 // the forward FFT] [next tile's x: 16 loads issued after the H multiply, consumed at the
@@ -627,9 +648,12 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
             store_any<REAL, DEC>(A, phys(tile), t, v, lds);
         }
         __builtin_amdgcn_s_setprio(0);
+        const bool poisoned = __any(not_finite(v[31].x) | not_finite(v[31].y));   // (wave-uniform; all results of a tile are, or none)
 #pragma unroll
         for (int i = 0; i < 32; ++i) v[i] = nx[i];
         __syncthreads();  // every wave is done reading the image before the next tile overwrites it
+        if (__builtin_expect(poisoned, 0))
+            careful_ols_tile<float, REAL, DEC, UP, XR>(ols_careful_args(A, UP ? phase_of(tile) : 0, !(REAL || XR)), phys(tile), UP ? phase_of(tile) : 0, t);
     }
 }
 
@@ -762,6 +786,7 @@ int fir_ols_publish_halo(unsigned *flag, unsigned seq, hipStream_t s)
 int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s, int dec, int reserve_wgs,
                    const unsigned *halo_flag, unsigned halo_seq, unsigned *halo_err)
 {
+    note_path("fir_ols");
     if (n <= 0) return SKDSP_OK;
     if (dec > 1) n = (n / dec) * dec;  // the dropped tail is never computed
     if (n <= 0) return SKDSP_OK;
@@ -789,6 +814,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.n_keep = n;
     A.up = 1; A.up_pitch = 0; A.up_sb = A.up_pbs = A.up_pb0 = 0;
     A.halo_flag = halo_flag; A.halo_seq = halo_seq; A.halo_err = halo_err;
+    if ((rc = fir_careful(h, &A.cf))) return rc;
     SK_CHECK(!(halo_flag && real), SKDSP_ERR_UNSUPPORTED, "fir_ols: halo flag wait is for complex64 shards");
     int64_t grid = 2 * (int64_t)ctx().num_cus;  // 2 resident workgroups per CU (76 KiB LDS each)
     // 8 slots stay free: room for a concurrent kernel (the RCCL send/recv of a halo, another stream of the caller) at
@@ -874,6 +900,7 @@ static int up_walk(FirHandle *h, int kind, const void *x, int64_t n, int64_t n_h
     A.up_pbs = xr ? 8 : esz;
     A.up_pb0 = kind == 2 ? (L - 1) * esz : 0;
     A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr;
+    if ((rc = fir_careful(h, &A.cf))) return rc;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     const int reserve_wgs = opt().ols_reserve;
     if (reserve_wgs > 0 && grid >= 4 * (int64_t)reserve_wgs) grid -= reserve_wgs;
@@ -896,6 +923,7 @@ static int up_walk(FirHandle *h, int kind, const void *x, int64_t n, int64_t n_h
 
 int fir_ols_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch, int paired)
 {
+    note_path("fir_ols_up");
     if (n <= 0) return SKDSP_OK;
     SK_CHECK(dec >= 1 && dec <= 4096 && (dec == 1 || L <= 64), SKDSP_ERR_UNSUPPORTED, "fir_ols_up: L / M = %d / %d (the fused L / M store takes L <= 64, M <= 4096)", L, dec);
     SK_CHECK(fir_ols_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols_up: needs complex64 (or float32 with real taps), 2 <= L <= 256, 2..4097 taps per phase");

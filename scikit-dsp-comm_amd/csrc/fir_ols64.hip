@@ -143,6 +143,7 @@ struct Ols64Args {
     // w / up filtered with phase w % up (Hp: up tables of 4096 bins), output i of the pair lands at y[i * up + phase]
     int up;
     int64_t up_pitch;   // > 0: the phases as rows, y[phase * up_pitch + i] (scratch; interleave_launch weaves them)
+    CarefulFir cf;      // the filter as the exact path of a poisoned tile reads it (careful.hpp)
 };
 
 // DEC: the decimating store (multirate_FIR.dn) is its own instantiation: the plain filter carries none of its code
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
         dft16_f(v);   // X[k1] at v[P16(k1)]
         {
             cdd w = w1;
+            asm volatile("" : "+v"(w.x), "+v"(w.y));   // (the running powers are recomputed per tile: hoisted out of the tile loop they are 60 spilled registers)
             img[0 * kPitch64 + hi4 * 17 + lo4] = v[0];
 #pragma unroll
             for (int k1 = 1; k1 < 16; ++k1) {
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
         dft16_f(v);
         {
             cdd w = w2;
+            asm volatile("" : "+v"(w.x), "+v"(w.y));
             img[hi4 * kPitch64 + 0 * 17 + lo4] = v[0];
 #pragma unroll
             for (int k2 = 1; k2 < 16; ++k2) {
@@ -317,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
         // thread (k1, c = lo4) reads over k2, applies conj W_256^(c k2), inverse DFT16 over k2 -> b
         {
             cdd w = w2;
+            asm volatile("" : "+v"(w.x), "+v"(w.y));
             v[0] = img[hi4 * kPitch64 + 0 * 17 + lo4];
 #pragma unroll
             for (int k2 = 1; k2 < 16; ++k2) {
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
         // thread t = (b = hi4, c = lo4) reads over k1, conj W_4096^(t k1), inverse DFT16 over k1 -> a
         {
             cdd w = w1;
+            asm volatile("" : "+v"(w.x), "+v"(w.y));   // (the running powers are recomputed per tile: hoisted out of the tile loop they are 60 spilled registers)
             v[0] = img[0 * kPitch64 + hi4 * 17 + lo4];
 #pragma unroll
             for (int k1 = 1; k1 < 16; ++k1) {
@@ -503,7 +508,17 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
                 }
             }
         }
+        // a non-finite input makes every result of the tile non-finite: such a tile is recomputed by the reference's own sum (careful.hpp)
+        const bool poisoned = __any(not_finite(v[15].x) || not_finite(v[15].y));
         __syncthreads();  // the image is free for the next tile
+        if (__builtin_expect(poisoned, 0)) {
+            OlsCareful c;
+            c.x = A.x; c.y = A.y; c.n = A.n; c.n_hist = A.n_hist; c.n_keep = A.n_keep; c.up_pitch = A.up_pitch;
+            c.V = A.V; c.dec = A.dec; c.up = A.up;
+            c.L = XR ? 2 * A.up : A.up; c.p0 = XR ? 2 * ph : ph;
+            c.cf = A.cf;
+            careful_ols_tile<double, REAL, DEC, UP, XR>(c, tin, ph, t);
+        }
     }
 }
 
@@ -601,6 +616,7 @@ static int ensure_plan64(FirHandle *h)
 
 int fir_ols64_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s, int dec)
 {
+    note_path("fir_ols64");
     if (n <= 0) return SKDSP_OK;
     if (dec > 1) n = (n / dec) * dec;
     if (n <= 0) return SKDSP_OK;
@@ -620,6 +636,7 @@ int fir_ols64_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, voi
     A.dec_magic = A.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + A.dec - 1) / A.dec) : 0u;
     A.n_keep = n;
     A.up = 1; A.up_pitch = 0;
+    if ((rc = fir_careful(h, &A.cf))) return rc;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     if (grid > ntiles) grid = ntiles;
     if (A.dec > 1) {
@@ -650,6 +667,7 @@ bool fir_ols64_up_pairs(const FirHandle *h, int L, int dec, const void *y)
 
 int fir_ols64_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s, int dec, int64_t rows_pitch, int paired_in)
 {
+    note_path("fir_ols64_up");
     if (n <= 0) return SKDSP_OK;
     SK_CHECK(dec >= 1 && dec <= 4096 && (dec == 1 || L <= 64), SKDSP_ERR_UNSUPPORTED, "fir_ols64_up: L / M = %d / %d (the fused L / M store takes L <= 64, M <= 4096)", L, dec);
     SK_CHECK(fir_ols64_up_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols64_up: needs complex128 (or float64 with real taps), 2 <= L <= 256, 2..2049 taps per phase");
@@ -680,6 +698,10 @@ int fir_ols64_up_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, 
     A.n_keep = dec > 1 ? (n * L) / dec : n;   // (L / M: the number of outputs)
     A.up = phases;
     A.up_pitch = dec > 1 ? 0 : rows_pitch;
+    {
+        int rc = fir_careful(h, &A.cf);
+        if (rc) return rc;
+    }
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     if (grid > ntiles) grid = ntiles;
     if (paired) {

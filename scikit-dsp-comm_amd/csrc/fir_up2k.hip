@@ -45,6 +45,7 @@ struct Up2kArgs {
     int staged;              // rows leave through the staging image (needs an even number of passes and no tail)
     unsigned upr_magic;      // staged: ceil(65536 / (row_bytes / 16)): lane / units-per-row by multiply-high
     int64_t ntiles;
+    CarefulFir cf;           // the filter as the exact path of a poisoned tile reads it (careful.hpp)
 };
 
 __device__ __forceinline__ bool up2k_interior(const Up2kArgs &A, int64_t tile)
@@ -186,6 +187,18 @@ template <int PH, bool TAIL> __device__ __forceinline__ void up2k_store_direct(c
     }
 }
 
+// A poisoned tile (see fir_up4k.hip): the thread recomputes the rows it stored -- tile-local rows 256 m + t - ov -- by the reference's own sum.
+template <bool XR> __device__ __noinline__ void up2k_careful_rows(const void *x, void *y, int64_t n, int64_t n_hist, const CarefulFir cf, int L, int64_t out0, int ov, int t)
+{
+#pragma unroll 1
+    for (int m = 0; m < 8; ++m) {
+        const int s = 256 * m + t - ov;
+        if (s < 0) continue;
+        if (out0 + s >= n) break;
+        careful_up_row<XR>(x, y, n_hist, cf, L, out0 + s);
+    }
+}
+
 // Persistent: 2 workgroups per CU walk the input tiles (XCD-contiguous runs per round, like ols_tile_kernel).  PH = passes whose
 // results a thread holds before it stores (its register budget: 16 per pass).  Every pass works in place in the registers of its
 // result: H product -> inverse pass 4 -> (LDS) -> inverse passes 3, 2 (arrays of their own, alive only while the result's
@@ -210,9 +223,12 @@ template <bool XR, int PH, bool STAGED> __global__ __launch_bounds__(256, 2) voi
     }
     __syncthreads();
     int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+    const int64_t tile_first = tile;
+    unsigned long long bad = 0;   // poisoned tiles of this wave's walk, by walk step (see fir_up4k.hip): recomputed behind the loop
+    int step = 0;
     cf Z[8];               // the tile's samples, then its spectrum, then (behind the last H product) the next tile's samples
     bool have_x = false;   // Z holds the samples of `tile` (requested a pass ahead: interior tiles only)
-    for (; tile < A.ntiles; tile += gridDim.x) {
+    for (; tile < A.ntiles; tile += gridDim.x, ++step) {
         const bool has_next = tile + gridDim.x < A.ntiles;
         const bool pre_next = !ZL && has_next && up2k_interior(A, tile + gridDim.x);
         if (!have_x) {   // the first tile of this workgroup, and tiles at the ends of the signal (guarded accesses)
@@ -239,6 +255,7 @@ template <bool XR, int PH, bool STAGED> __global__ __launch_bounds__(256, 2) voi
 #pragma unroll
             for (int k = 0; k < 8; ++k) zl[k * 256 + t] = Z[k];
         }
+        bool poisoned = false;
         for (int g0 = 0; g0 < A.passes; g0 += PH) {
             const int cnt = A.passes - g0 < PH ? A.passes - g0 : PH;
             const bool last_group = g0 + cnt == A.passes;
@@ -273,6 +290,7 @@ template <bool XR, int PH, bool STAGED> __global__ __launch_bounds__(256, 2) voi
                 }
             });
             if (!ZL && last_group && pre_next) up2k_settle_x<XR>(Z);
+            poisoned |= not_finite(out[7].x) | not_finite(out[7].y);
             if constexpr (STAGED) {
                 up2k_store_staged<PH>(A, tile, cnt, t, out, stage + Up2kStage<PH>::kWaveUnits * (t >> 6));
             } else if constexpr (XR) {
@@ -282,6 +300,12 @@ template <bool XR, int PH, bool STAGED> __global__ __launch_bounds__(256, 2) voi
                 up2k_store_direct<PH, false>(A, tile, g0, cnt, t, out);
             }
         }
+        if (__builtin_expect(__any(poisoned), 0)) bad |= 1ull << (step < 63 ? step : 63);
+    }
+    if (__builtin_expect(bad != 0, 0)) {
+        int k = 0;
+        for (int64_t tl = tile_first; tl < A.ntiles; tl += gridDim.x, ++k)
+            if ((bad >> (k < 63 ? k : 63)) & 1) up2k_careful_rows<XR>(A.x, A.y, A.n, A.n_hist, A.cf, A.row_bytes / (XR ? 4 : 8), tl * A.V, A.ov, t);
     }
 }
 
@@ -353,6 +377,7 @@ static int up2k_plan(FirHandle *h, int L, Up2kPlan **out)
 
 int fir_up2k_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s)
 {
+    note_path("fir_up2k");
     if (n <= 0) return SKDSP_OK;
     SK_CHECK(fir_up2k_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_up2k: needs complex64 (or float32 with real taps), 2 <= L <= 4096, at most 1025 taps per phase");
     Up2kPlan *p = nullptr;
@@ -368,6 +393,7 @@ int fir_up2k_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int 
     A.odd_tail = p->pairs && (L & 1);
     A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & (esz - 1)) == 0;
     A.ntiles = (n + p->V - 1) / p->V;
+    if ((rc = fir_careful(h, &A.cf))) return rc;
     SK_CHECK(A.ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_up2k: too many tiles");
     // passes held per thread: the smallest instantiation that takes the row in ONE group; longer rows go in groups of 12 (float32
     // and complex64 alike: 96-byte pieces)

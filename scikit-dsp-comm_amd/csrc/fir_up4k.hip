@@ -41,6 +41,7 @@ struct Up4kArgs {
     int aligned;             // x and y element-aligned
     int64_t ntiles;
     int staged;              // four-pass groups leave through the wave-private staging image (option fir_up4k_staged; 0 = as they lie, for A/B)
+    CarefulFir cf;           // the filter as the exact path of a poisoned tile reads it (careful.hpp)
 };
 
 // x[in0 + 256 a + t] -> v[a]; zero outside [-n_hist, n).  XR: a float32 signal into the real parts (the imaginary parts are
@@ -223,6 +224,20 @@ template <bool XR> __device__ __forceinline__ void up4k_settle_x(const cf *v)
     }
 }
 
+// A poisoned tile (one inf / nan among its 4096 inputs makes every result of every pass non-finite, where the reference confines the sample
+// to the Ntaps outputs that multiply it): the thread recomputes the rows it stored -- samples out0 + 256 (a - a0) + t, all L phases each -- by
+// the reference's own sum (careful.hpp).  Rows are written by their own thread or, through the wave-private staging image, by its own wave,
+// so the second store follows the first in program order: no barrier.
+template <bool XR> __device__ __noinline__ void up4k_careful_rows(const void *x, void *y, int64_t n, int64_t n_hist, const CarefulFir cf, int L, int64_t out0, int a0, int t)
+{
+#pragma unroll 1
+    for (int a = a0; a < 16; ++a) {
+        const int64_t i = out0 + 256 * (a - a0) + t;
+        if (i >= n) break;
+        careful_up_row<XR>(x, y, n_hist, cf, L, i);
+    }
+}
+
 // Persistent: 2 workgroups per CU walk the input tiles (XCD-contiguous runs per round, like ols_tile_kernel: neighbouring
 // tiles share their overlap through that XCD's L2).  G = passes whose results a thread holds before it stores.
 //
@@ -251,6 +266,11 @@ template <bool XR, int G> __global__ __launch_bounds__(256, 2) void up4k_kernel(
     }
     __syncthreads();
     int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+    const int64_t tile_first = tile;
+    // poisoned tiles of this wave's walk, by walk step (bit 63: "some step from 63 on"): they are recomputed BEHIND the loop -- a call inside it
+    // costs the loop 50 registers (140 - 194 spilled in the twelve-pass kernel of fir_up2k.hip)
+    unsigned long long bad = 0;
+    int step = 0;
     cf Z[16];          // the tile's samples, then its spectrum, then (behind the last H product) the next tile's samples
     float4 hh[G][8];   // the tables of the current group's passes
     bool have_x = false;   // Z holds the samples of `tile` (requested a pass ahead: interior tiles only)
@@ -259,7 +279,7 @@ template <bool XR, int G> __global__ __launch_bounds__(256, 2) void up4k_kernel(
     } else {
         up4k_no_H(hh[0]);
     }
-    for (; tile < A.ntiles; tile += gridDim.x) {
+    for (; tile < A.ntiles; tile += gridDim.x, ++step) {
         const bool has_next = tile + gridDim.x < A.ntiles;
         const bool pre_next = has_next && up4k_interior(A, tile + gridDim.x);
         if (!have_x) {   // the first tile of this workgroup, and tiles at the ends of the signal (guarded accesses)
@@ -281,6 +301,7 @@ template <bool XR, int G> __global__ __launch_bounds__(256, 2) void up4k_kernel(
         __syncthreads();
         fwd_pass2(t, T2f, img);
         fwd_pass3(t, img, Z);
+        bool poisoned = false;
         // (the first inverse pass writes the rows this thread's 16-lane group just read: wave-local, no barrier)
         for (int g0 = 0; g0 < A.passes; g0 += G) {
             const int cnt = A.passes - g0 < G ? A.passes - g0 : G;
@@ -309,6 +330,7 @@ template <bool XR, int G> __global__ __launch_bounds__(256, 2) void up4k_kernel(
             else up4k_no_H(hh[0]);
             up4k_settle(hh[0]);
             if (last_group && pre_next) up4k_settle_x<XR>(Z);
+            poisoned |= not_finite(out[15].x) | not_finite(out[15].y);
             const bool tail = A.odd_tail && last_group;
             auto store = [&](auto tc) __attribute__((always_inline)) {
                 constexpr bool TAIL = decltype(tc)::value;
@@ -329,6 +351,12 @@ template <bool XR, int G> __global__ __launch_bounds__(256, 2) void up4k_kernel(
                 store(std::false_type{});
             }
         }
+        if (__builtin_expect(__any(poisoned), 0)) bad |= 1ull << (step < 63 ? step : 63);
+    }
+    if (__builtin_expect(bad != 0, 0)) {
+        int k = 0;
+        for (int64_t tl = tile_first; tl < A.ntiles; tl += gridDim.x, ++k)
+            if ((bad >> (k < 63 ? k : 63)) & 1) up4k_careful_rows<XR>(A.x, A.y, A.n, A.n_hist, A.cf, A.row_bytes / (XR ? 4 : 8), tl * A.V, A.a0, t);
     }
 }
 
@@ -396,6 +424,7 @@ static int up4k_plan(FirHandle *h, int L, Up4kPlan **out)
 
 int fir_up4k_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s)
 {
+    note_path("fir_up4k");
     if (n <= 0) return SKDSP_OK;
     SK_CHECK(fir_up4k_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_up4k: needs complex64 (or float32 with real taps), 2 <= L <= 4096, at most 2049 taps per phase");
     Up4kPlan *p = nullptr;
@@ -412,6 +441,7 @@ int fir_up4k_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int 
     A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & (esz - 1)) == 0;
     A.ntiles = (n + p->V - 1) / p->V;
     A.staged = opt().fir_up4k_staged;
+    if ((rc = fir_careful(h, &A.cf))) return rc;
     SK_CHECK(A.ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_up4k: too many tiles");
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     const int reserve_wgs = opt().ols_reserve;

@@ -926,6 +926,7 @@ static int launch_fused(IirHandle *h, const void *x, int64_t n, int nbatch, int6
 int iir_fused_launch(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, const double *zi_dev,
                      double *zf_dev, hipStream_t s, int dec, int interleaved)
 {
+    note_path("iir_fused");
     return dtype_double(h->dtype) ? launch_fused<double>(h, x, n, nbatch, batch_stride, y, zi_dev, zf_dev, s, dec, interleaved)
                                   : launch_fused<float>(h, x, n, nbatch, batch_stride, y, zi_dev, zf_dev, s, dec, interleaved);
 }

@@ -1092,6 +1092,7 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
 int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y, hipStream_t s, int dec,
                    int interleaved, int up)
 {
+    note_path("iir_par");
     if (interleaved && nrow != 1) return 1;
     // .up: x holds n / up samples; one row, no decimation; the exact-division trick of the staging covers up <= 4096
     if (up > 1 && (dec > 1 || nrow != 1 || up > 4096 || n % up != 0)) return 1;

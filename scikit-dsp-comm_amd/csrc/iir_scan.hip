@@ -1198,6 +1198,7 @@ int iir_dispatch_shape_f64(IirHandle *h, IirArgs &a, int nbatch, int W, hipStrea
 int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, hipStream_t s,
                       const double *zi_host, double *zf_host, int interleaved, int dec)
 {
+    note_path("iir_scan");
     if (n <= 0) {
         if (zf_host) {
             if (zi_host) memcpy(zf_host, zi_host, (size_t)nbatch * h->nsec * h->order * 8);

@@ -7,6 +7,7 @@
 #include <vector>
 #include <mutex>
 #include "../../include/skdsp.h"
+#include "careful.hpp"
 
 namespace skdsp {
 
@@ -27,6 +28,10 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
             return (code);                   \
         }                                    \
     } while (0)
+
+// Which engines the calling thread's last API calls launched (tests assert that a shape reaches the engine they mean to exercise):
+// every *_launch appends its name once; skdsp_debug_path() reads and clears.  A few bytes of thread-local state, no device work.
+void note_path(const char *engine);
 
 // ------------------------------------------------------------------ options
 // Run-time switches.  Read from the environment ONCE (first use: SKDSP_<NAME>), changed afterwards only through
@@ -136,6 +141,7 @@ struct FirHandle : HandleBase {
     bool taps_complex = false;
     int algo = SKDSP_FIR_AUTO;
     std::vector<double> taps_host;  // ntaps (real) or 2*ntaps (complex, interleaved)
+    void *taps64_dev = nullptr;     // the same on the device, natural order (careful.hpp: the rare exact path of a poisoned tile); lazy
     // polyphase tap banks, keyed by L (lazy): bank[phase][t] = b[phase + L*t], T = ceil(P/L)
     struct Poly { int L; int T; void *dev; };
     std::vector<Poly> poly;
@@ -166,6 +172,9 @@ struct FirHandle : HandleBase {
     std::vector<FirHandle *> heads;
     ~FirHandle();
 };
+
+// the taps as the careful path reads them (uploaded on first use, under the handle's lock like every other table)
+int fir_careful(FirHandle *h, CarefulFir *out);
 
 // direct-form / polyphase launcher (fir_direct.hip).
 //   y[m] = L * sum_t b[phi + L t] * x[i - t],  j = m*M, phi = j mod L, i = j div L,  m in [0, n_out)

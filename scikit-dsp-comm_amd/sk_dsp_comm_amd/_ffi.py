@@ -22,7 +22,7 @@ _CODE_OF = {np.dtype(np.float32): F32, np.dtype(np.complex64): C64, np.dtype(np.
 
 # every symbol include/skdsp.h declares (tests check the built library exports all of them)
 SYMBOLS = [
-    "skdsp_init", "skdsp_shutdown", "skdsp_device_count", "skdsp_device_info", "skdsp_last_error", "skdsp_version",
+    "skdsp_init", "skdsp_shutdown", "skdsp_debug_path", "skdsp_device_count", "skdsp_device_info", "skdsp_last_error", "skdsp_version",
     "skdsp_set_option", "skdsp_get_option", "skdsp_init_devices", "skdsp_slot_count", "skdsp_host_chunk_plan",
     "skdsp_host_alloc", "skdsp_host_free", "skdsp_malloc", "skdsp_free", "skdsp_memcpy_h2d", "skdsp_memcpy_d2h", "skdsp_memcpy_d2d", "skdsp_memset",
     "skdsp_sync", "skdsp_timer_start", "skdsp_timer_stop", "skdsp_fill_noise_dev",
@@ -67,6 +67,7 @@ def load():
         L.skdsp_last_error.restype = ctypes.c_char_p
         L.skdsp_version.restype = ctypes.c_char_p
         L.skdsp_init.argtypes = [ci]
+        L.skdsp_debug_path.argtypes = [ctypes.c_char_p, ci, ci]
         L.skdsp_init_devices.argtypes = [ctypes.POINTER(ci), ci]
         p64 = ctypes.POINTER(i64)
         L.skdsp_host_chunk_plan.argtypes = [i64, ci, ci, i64, ci, i64, p64, p64, p64, p64, p64, p64]
@@ -205,6 +206,13 @@ class option:
     def __exit__(self, *exc):
         set_option(self.name, self.old)
         return False
+
+
+def debug_path(clear=True):
+    """Names of the kernel families this thread's calls launched since the last clear (tests: which engine did a shape reach?)."""
+    buf = ctypes.create_string_buffer(256)
+    check(load().skdsp_debug_path(buf, 256, 1 if clear else 0))
+    return buf.value.decode().split(",") if buf.value else []
 
 
 def device_info():

@@ -1,0 +1,159 @@
+"""Non-finite samples and glitches: the reference confines them, and so must every engine.
+
+scipy.signal.lfilter(b, [1], x) (multirate_helper.py:108, 117, 125) multiplies x[k] into the Ntaps outputs y[k .. k+Ntaps-1] and into
+no other: one inf / nan at x[k] leaves every output outside that range finite and correct.  The fast engines here work on tiles
+(a frequency-domain tile spreads a non-finite input over all of its outputs) and windows (the fp16 split of the matrix-pipe kernel
+scales a window by its largest magnitude), so each of them notices a tile / window it cannot have computed correctly and recomputes
+it by the reference's own sum (csrc/careful.hpp).  These tests drive one inf, one nan and one 1e12 glitch through .filter / .up / .dn
+on shapes that reach every engine AUTO picks, assert WHICH engine ran, and compare with the oracle sample by sample."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from sk_dsp_comm_amd import _ffi  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def lowpass(ntaps, cutoff):
+    m = np.arange(ntaps) - (ntaps - 1) / 2.0
+    h = cutoff * np.sinc(cutoff * m) * np.hamming(ntaps)
+    return h / np.sum(h)
+
+
+def signal_of(dt, n, seed=11):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(n)
+    if np.dtype(dt).kind == "c":
+        x = (x + 1j * rng.standard_normal(n)) / np.sqrt(2)
+    return x.astype(dt)
+
+
+# (name, dtype, taps, mode, L, M, n, engine expected in the launch record)
+CASES = [
+    ("ols_c64", np.complex64, lowpass(1024, 0.2), "filter", 1, 1, 150_001, "fir_ols"),
+    ("ols_f32", np.float32, lowpass(1024, 0.2), "filter", 1, 1, 150_001, "fir_ols"),
+    ("bx_c64", np.complex64, lowpass(127, 0.2), "filter", 1, 1, 150_001, "fir_bx"),
+    ("bx_f32", np.float32, lowpass(127, 0.2), "filter", 1, 1, 150_001, "fir_bx"),
+    ("ctaps_c64", np.complex64, lowpass(33, 0.2) * np.exp(0.3j * np.arange(33)), "filter", 1, 1, 100_001, None),
+    ("ols64_c128", np.complex128, lowpass(1024, 0.2), "filter", 1, 1, 100_001, "fir_ols64"),
+    ("ols64_f64", np.float64, lowpass(1024, 0.2), "filter", 1, 1, 100_001, "fir_ols64"),
+    ("direct_f64", np.float64, lowpass(48, 0.2), "filter", 1, 1, 100_001, None),
+    ("parts_c64", np.complex64, lowpass(5000, 0.05), "filter", 1, 1, 150_001, "fir_ols"),
+    ("up12_bx", np.complex64, lowpass(512, 0.9 / 12), "up", 12, 1, 20_001, "fir_bx"),
+    ("up4_4k", np.complex64, lowpass(1024, 0.2 / 4), "up", 4, 1, 500_001, "fir_up4k"),
+    ("up4_4k_f32", np.float32, lowpass(1024, 0.2 / 4), "up", 4, 1, 500_001, "fir_up4k"),
+    ("up12_2k", np.complex64, lowpass(3072, 0.9 / 12), "up", 12, 1, 150_001, "fir_up2k"),
+    ("up2_walk", np.complex64, lowpass(8001, 0.4), "up", 2, 1, 60_001, "fir_ols_up"),
+    ("up4_f64", np.float64, lowpass(1024, 0.2 / 4), "up", 4, 1, 40_001, None),
+    ("dn12_bx", np.complex64, lowpass(512, 0.9 / 12), "dn", 1, 12, 200_001, "fir_bx"),
+    ("dn4_ols", np.complex64, lowpass(1024, 0.2 / 4), "dn", 1, 4, 200_001, "fir_ols"),
+    ("dn4_4k_f32", np.float32, lowpass(1024, 0.2 / 4), "dn", 1, 4, 200_001, "fir_dn4k"),
+    ("dn2_4k_c64", np.complex64, lowpass(1024, 0.4), "dn", 1, 2, 200_001, "fir_dn4k"),
+    ("dn3_f64", np.float64, lowpass(512, 0.3), "dn", 1, 3, 100_001, None),
+    ("updn43_bx", np.complex64, lowpass(512, 0.225), "updn", 4, 3, 60_001, "fir_bx"),
+]
+
+
+def run(k, mode, x, L, M):
+    if mode == "filter":
+        return k.filter(x)
+    if mode == "up":
+        return k.up(x, L)
+    if mode == "dn":
+        return k.dn(x, M)
+    return k.updn(x, L, M)
+
+
+def reference(b, mode, x, L, M):
+    xw = x.astype(np.complex128 if np.iscomplexobj(x) else np.float64)
+    with np.errstate(all="ignore"):
+        if mode == "filter":
+            return orc.fir_filter(b, xw)
+        if mode == "up":
+            return orc.fir_up(b, xw, L)
+        if mode == "dn":
+            return orc.fir_dn(b, xw, M)
+        return orc.downsample(orc.fir_up(b, xw, L), M)
+
+
+def touched(n_out, ntaps, mode, L, M, ks):
+    """Outputs that multiply x[k] for some k in ks: high-rate indices [k L, k L + Ntaps), every M-th kept."""
+    t = np.zeros(n_out, bool)
+    for k in ks:
+        lo, hi = k * L, k * L + ntaps           # at the rate the filter runs on
+        m0, m1 = -(-lo // M), -(-hi // M)       # kept outputs m with lo <= m M < hi
+        t[max(m0, 0):min(m1, n_out)] = True
+    return t
+
+
+@pytest.mark.parametrize("poison", ["inf", "nan", "-inf"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_one_non_finite_sample_stays_inside_its_ntaps_outputs(case, poison):
+    name, dt, b, mode, L, M, n, engine = case
+    x = signal_of(dt, n)
+    ks = [n // 3 + 17, (2 * n) // 3 + 5]          # two samples, far apart, in different tiles
+    val = {"inf": np.inf, "nan": np.nan, "-inf": -np.inf}[poison]
+    x[ks[0]] = val
+    x[ks[1]] = val * (1j if np.dtype(dt).kind == "c" else 1)    # (complex: the second one in the imaginary part)
+    k = _ffi.FirKernel(b, _ffi.code_of(np.dtype(dt)))
+    _ffi.debug_path()
+    with np.errstate(all="ignore"):
+        got = run(k, mode, x, L, M)
+    path = _ffi.debug_path()
+    if engine is not None:
+        assert engine in path, (name, path)
+    ref = reference(b, mode, x, L, M)
+    assert got.shape == ref.shape
+    hit = touched(ref.size, len(b), mode, L, M, ks)
+    # the oracle itself confines the sample to those outputs (it is the reference's sum)
+    assert np.all(np.isfinite(ref[~hit])) and not np.any(np.isfinite(ref[hit]))
+    bad = np.flatnonzero(~np.isfinite(got[~hit]))
+    assert bad.size == 0, "%s (%s): %d outputs that never see the sample are not finite, first at %d (sample at %s)" % (
+        name, path, bad.size, np.flatnonzero(~hit)[bad[0]], [kk * L // M for kk in ks])
+    assert not np.any(np.isfinite(got[hit])), "%s: an output that multiplies the %s came out finite" % (name, poison)
+    tol = 1e-6 if np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4 else 1e-11
+    err = np.max(np.abs(got[~hit] - ref[~hit])) / np.max(np.abs(ref[~hit]))
+    assert err <= tol, (name, path, err)
+
+
+GLITCH_CASES = [c for c in CASES if c[0] in ("bx_c64", "bx_f32", "up12_bx", "dn12_bx", "updn43_bx")]
+
+
+@pytest.mark.parametrize("case", GLITCH_CASES, ids=[c[0] for c in GLITCH_CASES])
+def test_glitch_does_not_cost_its_neighbours_their_float32_accuracy(case):
+    """A 1e12 spike among unit-level samples: the matrix-pipe kernel's fp16 pieces are scaled by the window's largest magnitude, so
+    without a second look every sample of that window would keep ~2^-51 of the SPIKE, not 2^-23 of itself.  Outputs beyond the
+    filter's reach of the spike must be within 1e-6 of THEIR OWN level (the reference's float64 sum is exact to 1e-16 there)."""
+    name, dt, b, mode, L, M, n, engine = case
+    x = signal_of(dt, n, seed=5)
+    ks = [n // 2 + 3]
+    x[ks[0]] = 1e12
+    k = _ffi.FirKernel(b, _ffi.code_of(np.dtype(dt)))
+    _ffi.debug_path()
+    got = run(k, mode, x, L, M)
+    assert engine in _ffi.debug_path()
+    ref = reference(b, mode, x, L, M)
+    hit = touched(ref.size, len(b), mode, L, M, ks)
+    own = np.max(np.abs(ref[~hit]))
+    assert own < 100.0      # (unit-level: the comparison below is NOT relative to the spike)
+    err = np.max(np.abs(got[~hit] - ref[~hit])) / own
+    assert err <= 1e-6, (name, err)
+    # and the outputs that do see the spike: float32 accuracy relative to the spike
+    err_hit = np.max(np.abs(got[hit] - ref[hit])) / np.max(np.abs(ref[hit]))
+    assert err_hit <= 1e-6, (name, err_hit)
+
+
+def test_many_poisoned_tiles_still_finish():
+    """A nan every 3000 samples poisons every overlap-save tile: the exact path then carries the whole call (slowly) and the result
+    is still the reference's."""
+    n = 60_000
+    b = lowpass(1024, 0.2)
+    x = signal_of(np.complex64, n)
+    ks = list(range(1500, n, 3000))
+    x[ks] = np.nan
+    got = _ffi.FirKernel(b, _ffi.C64).filter(x)
+    ref = reference(b, "filter", x, 1, 1)
+    hit = touched(n, 1024, "filter", 1, 1, ks)
+    assert np.all(np.isfinite(got[~hit])) and not np.any(np.isfinite(got[hit]))
+    assert np.max(np.abs(got[~hit] - ref[~hit])) / np.max(np.abs(ref[~hit])) <= 1e-6
