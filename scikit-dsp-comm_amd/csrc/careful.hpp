@@ -8,6 +8,11 @@
 // direct-form sum in float64 -- y[m] = L sum_t b[phi + L t] x[i - t], j = m M, phi = j mod L, i = j div L -- straight from
 // global memory, with IEEE propagation (so the P outputs that do see the sample come out non-finite, like the reference's).
 // Slow (one thread per output, Ntaps / L loads each) and rare.
+//
+// Where it runs.  NOT inside the engines' loops, and not as a call: a call anywhere in a kernel reserves scalar registers for its
+// frame, and the loops of these kernels have none to spare (measured with the call: the headline + 3.8 %, the 127-tap kernel + 10 %,
+// 8 - 45 spilled SGPRs).  A kernel that notices a poisoned tile / window only sets a bit in a workgroup-shared word (careful_note); BEHIND
+// its loop, inline, it walks the noted steps again and recomputes them (careful_noted).  The hot loop keeps no state for this.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,7 +28,7 @@ struct CarefulFir {
 // T: float / double; CX: the signal is complex (interleaved).  Returns the output as (re, im).
 // gain = 0: without the factor L (kernels that apply it themselves behind this point)
 template <typename T, bool CX>
-__device__ __noinline__ void careful_fir_point(const T *__restrict__ x, int64_t n_hist, const CarefulFir c, int L, int M, int64_t m, double *re_out, double *im_out, int gain = 1)
+__device__ __forceinline__ void careful_fir_point(const T *__restrict__ x, int64_t n_hist, const CarefulFir c, int L, int M, int64_t m, double *re_out, double *im_out, int gain = 1)
 {
     const int64_t j = m * M;
     const int64_t i = j / L;
@@ -98,6 +103,60 @@ __device__ __forceinline__ void careful_up_row(const void *x, void *y, int64_t n
     }
 }
 
+// The poisoned steps of a persistent workgroup's walk: bit min(step, 63) of a workgroup-shared word (bit 63: "some step from 63 on",
+// every such step is then recomputed -- exact, only slow).  careful_note: by one lane of a wave that found one; careful_noted: after the
+// loop, by every thread (a barrier on both sides: the flags of all waves are in, and the loop's stores are ordered in front of the
+// recomputed ones whichever thread made them).
+__device__ __forceinline__ void careful_note(unsigned long long *word, int64_t step)
+{
+    if ((threadIdx.x & 63) == 0) atomicOr(word, 1ull << (step < 63 ? (int)step : 63));
+}
+__device__ __forceinline__ unsigned long long careful_noted(const unsigned long long *word)
+{
+    __syncthreads();
+    const unsigned long long w = *reinterpret_cast<const volatile unsigned long long *>(word);
+    return w;
+}
+__device__ __forceinline__ bool careful_step_noted(unsigned long long noted, int64_t step) { return (noted >> (step < 63 ? (int)step : 63)) & 1; }
+
+// a contiguous run of outputs [m0, m0 + count) of y (L / M as the call has them), every thread every 256th
+template <typename T, bool CX>
+__device__ __forceinline__ void careful_fir_range(const void *x, void *y, int64_t n_hist, int64_t n_out, int64_t m0, int64_t count, int L, int M, const CarefulFir &cf, int tid)
+{
+#pragma unroll 1
+    for (int64_t i = tid; i < count; i += 256) {
+        const int64_t m = m0 + i;
+        if (m >= n_out) break;
+        careful_fir_store<T, CX>(reinterpret_cast<const T *>(x), n_hist, cf, L, M, m, reinterpret_cast<T *>(y) + (CX ? 2 : 1) * m);
+    }
+}
+// the same run, but only the outputs that came out non-finite (direct-form engines: a non-finite result may be the sample meeting the ZERO
+// padding of a tap table -- 0 x inf = nan -- a few outputs past the reference's Ntaps; read back, re-evaluated, rewritten where so).
+// Behind a barrier and an agent-scope fence; the loads bypass the vector L1.
+template <typename T, bool CX>
+__device__ __forceinline__ void careful_fir_recheck(const void *x, void *y, int64_t n_hist, int64_t n_out, int64_t m0, int64_t count, int L, int M, const CarefulFir &cf, int tid)
+{
+    constexpr int W = CX ? 2 : 1;
+    T *yy = reinterpret_cast<T *>(y);
+#pragma unroll 1
+    for (int64_t i = tid; i < count; i += 256) {
+        const int64_t m = m0 + i;
+        if (m >= n_out) break;
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            if constexpr (sizeof(T) == 4) {
+                const unsigned u = __hip_atomic_load(reinterpret_cast<const unsigned *>(yy + W * m + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad |= (u & 0x7f800000u) == 0x7f800000u;
+            } else {
+                const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(yy + W * m + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad |= ((unsigned)(u >> 32) & 0x7ff00000u) == 0x7ff00000u;
+            }
+        }
+        if (bad) careful_fir_store<T, CX>(reinterpret_cast<const T *>(x), n_hist, cf, L, M, m, yy + W * m);
+    }
+}
+
 // ---- frequency-domain tiles (fir_ols.hip, fir_ols64.hip) -------------------------------------------------------------------------------
 // One non-finite input makes EVERY result of an overlap-save tile non-finite; the tile's outputs are then recomputed here, every thread
 // taking every 256th output position, and overwrite what the tile stored (the caller places this behind the barrier that ends the tile).
@@ -111,7 +170,7 @@ struct OlsCareful {   // (scalars by value: taking the address of a kernel's arg
 };
 // tile: the tile, or the pair of real tiles (REAL); ph: the pass's index among the launch's phases (UP)
 template <typename T, bool REAL, bool DEC, bool UP, bool XR>
-__device__ __noinline__ void careful_ols_tile(const OlsCareful c, int64_t tile, int ph, int t)
+__device__ __forceinline__ void careful_ols_tile(const OlsCareful c, int64_t tile, int ph, int t)
 {
     constexpr bool CX = !(REAL || XR);
     constexpr int W = CX ? 2 : 1;

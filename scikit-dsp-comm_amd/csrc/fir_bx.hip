@@ -113,6 +113,20 @@ __device__ __forceinline__ void bx_split2(float a, float b, unsigned (&p)[kBxPx]
     p[1] = cvt(res_lo(a, p[0]), res_hi(b, p[0]));
 }
 
+// max (MAX) / min of an unsigned value over the wave, valid in lane 63: four DPP steps inside the rows of 16 lanes (quad permutes, half-row and
+// row mirrors), then row_bcast15 into rows 1 and 3 and row_bcast31 into rows 2 and 3
+template <bool MAX> __device__ __forceinline__ unsigned bx_wave_reduce(unsigned v)
+{
+    auto op = [](unsigned a, unsigned b) -> unsigned { return MAX ? max(a, b) : min(a, b); };
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));   // row_mirror
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast15 -> rows 1, 3
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast31 -> rows 2, 3
+    return v;
+}
+
 __device__ __forceinline__ v4f_bx bx_mfma(uint4 a, uint4 b, v4f_bx c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h_bx, a), __builtin_bit_cast(v8h_bx, b), c, 0, 0, 0);
@@ -120,19 +134,9 @@ __device__ __forceinline__ v4f_bx bx_mfma(uint4 a, uint4 b, v4f_bx c)
 
 // A window this kernel cannot compute: one that holds an inf / nan (0 x inf = nan on the zero-padded part of the lag blocks, and the
 // window's scale is taken from its largest magnitude), or one whose samples span more than 2^24 in magnitude (the fp16 pieces keep 22 bits
-// of a sample only down to 2^-29 of the window's largest: a 1e12 glitch would leave its unit-level neighbours 5e-4 of THEIR level).  The
-// window's outputs -- m in [RS S0, RS (S0 + NS)) -- are then recomputed by the reference's own float64 sum and overwrite what the tiles
-// stored (behind the barrier that ends the window).
-template <bool CPLX>
-__device__ __noinline__ void bx_careful_window(const float *x, float *y, int64_t n_hist, int64_t n_out, int64_t m0, int count, int L, int M, const CarefulFir cf, int tid)
-{
-#pragma unroll 1
-    for (int i = tid; i < count; i += 256) {
-        const int64_t m = m0 + i;
-        if (m >= n_out) break;
-        careful_fir_store<float, CPLX>(x, n_hist, cf, L, M, m, y + (CPLX ? 2 : 1) * m);
-    }
-}
+// of a sample only down to 2^-29 of the window's largest: a 1e12 glitch would leave its unit-level neighbours 5e-4 of THEIR level).  Such a
+// window is noted (careful.hpp) and its outputs -- m in [RS NS w, RS NS (w + 1)) -- are recomputed behind the loop by the reference's own
+// float64 sum.
 
 // Persistent 256-thread workgroups: window w+1 is requested into registers before window w is multiplied, so
 // its HBM latency hides behind the MFMAs of the same workgroup; the workgroups of a CU run out of phase with
@@ -153,6 +157,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                      float *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) char bx_smem[];
+    __shared__ unsigned long long bx_noted;   // windows for the exact path, by walk step (careful.hpp)
+    if (threadIdx.x == 0) bx_noted = 0;       // (the first barrier of the kernel lies between this and any note)
     constexpr int C = CPLX ? 2 : 1;
     static_assert(KSP == 1 || (RT == 1 && RSP == 1), "the lag split serves one-row-tile geometries");
     constexpr int K = 32 * KB * KSP;
@@ -192,14 +198,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned *wmax_sh = reinterpret_cast<unsigned *>(bx_smem + (size_t)(kBxPx * C) * plane_bytes + (KSP > 1 ? (size_t)2 * 4 * (4 * C) * 64 * 4 : 0));
     float wscale = 1.f, winv_next = 1.f;
     bool wbad_next = false;   // the window being staged is one for the exact path (bx_careful_window)
+    // Two statistics of the window: its largest magnitude (the scale) and the smallest of the lanes' largest (non-zero) magnitudes -- a window
+    // whose samples span more than the fp16 pieces hold goes to the exact path.  Both reductions run on DPP row operations (no LDS round
+    // trips: the ds_bpermute chain this replaced was 6 dependent LDS operations per wave with the whole workgroup waiting behind it).
     auto publish_max = [&](unsigned m) {   // m: this thread's maximum of |x| bits
-        unsigned lo = m ? m : 0xffffffffu;   // the smallest of the lanes' maxima (lanes that hold nothing but zeros aside: zeros are exact at any scale)
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-            lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
-        }
-        if (lane == 0) { wmax_sh[wave] = m; wmax_sh[4 + wave] = lo; }
+        const unsigned hi = bx_wave_reduce<true>(m), lo = bx_wave_reduce<false>(m ? m : 0xffffffffu);   // (in lane 63)
+        if (lane == 63) { wmax_sh[wave] = hi; wmax_sh[4 + wave] = lo; }
     };
     auto fetch_scale = [&]() {   // behind the barrier: wscale for the split, winv_next for this window's outputs
         const unsigned m = max(max(wmax_sh[0], wmax_sh[1]), max(wmax_sh[2], wmax_sh[3]));
@@ -307,11 +311,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     fetch_scale();
     float winv = winv_next;   // of the window in the planes
     bool wbad = wbad_next;
-    // windows for the exact path, by walk step of this workgroup (bit 63: "some step from 63 on"); they are recomputed BEHIND the loop
-    // (workgroup-uniform: the flag comes out of the LDS) -- a call inside it costs the 256-register instantiations spilled registers
-    unsigned long long bad = 0;
-    int step = 0;
-    const int64_t wdx_first = wdx;
     if (fast) store_window();
     else stage_window_slow(wdx);
     __syncthreads();
@@ -446,9 +445,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             winv = winv_next;
             __syncthreads();  // the planes hold window w+1
-            if (__builtin_expect(wbad, 0)) bad |= 1ull << (step < 63 ? step : 63);
+            if (__builtin_expect(wbad, 0)) careful_note(&bx_noted, (wdx - blockIdx.x) / gridDim.x);
             wbad = wbad_next;
-            ++step;
             const int64_t wnext2 = wnext + gridDim.x;
             fast = wnext2 < nwin && interior(wnext2);
             if (fast) load_window(wnext2);
@@ -481,9 +479,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_s_setprio(0);
         winv = winv_next;
         __syncthreads();  // the planes hold window w+1
-        if (__builtin_expect(wbad, 0)) bad |= 1ull << (step < 63 ? step : 63);
+        if (__builtin_expect(wbad, 0)) careful_note(&bx_noted, (wdx - blockIdx.x) / gridDim.x);
         wbad = wbad_next;
-        ++step;
         const int64_t wnext2 = wnext + gridDim.x;
         fast = wnext2 < nwin && interior(wnext2);
         __builtin_amdgcn_s_setprio(3);
@@ -492,13 +489,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         wdx = wnext;
         wnext = wnext2;
     }
-    if (__builtin_expect(bad != 0, 0)) {
-        // (every store of the loop was issued in front of the barrier that ended its window: a second store to the same address, from
-        // whichever thread, follows it)
-        int k = 0;
-        for (int64_t w = wdx_first; w < nwin; w += gridDim.x, ++k)
-            if ((bad >> (k < 63 ? k : 63)) & 1)
-                bx_careful_window<CPLX>(x, y, a.n_hist, a.n_out, (int64_t)a.RS * a.NS * w, a.RS * a.NS, a.L, a.M, a.cf, tid);
+    const unsigned long long noted = careful_noted(&bx_noted);
+    if (__builtin_expect(noted != 0, 0)) {
+        int64_t k = 0;
+        for (int64_t w = blockIdx.x; w < nwin; w += gridDim.x, ++k)
+            if (careful_step_noted(noted, k))
+                careful_fir_range<float, CPLX>(x, y, a.n_hist, a.n_out, (int64_t)a.RS * a.NS * w, (int64_t)a.RS * a.NS, a.L, a.M, a.cf, tid);
     }
 }
 
@@ -741,7 +737,7 @@ int fir_bx_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L,
     const int units = a.win / 8;
     size_t lds = (size_t)(cplx ? 2 : 1) * kBxPx * (size_t)(units + (a.pad_s ? units / su : 0) + 1) * 16;  // (+ a dump row per plane)
     if (t->KSP > 1) lds += (size_t)2 * 4 * (cplx ? 8 : 4) * 64 * sizeof(float);   // the partial tiles of the lag split, two generations
-    lds += 32;                                                                      // the waves' window maxima (and the smallest of their lanes' maxima)
+    lds += 32;                                                                      // the waves' window statistics
     a.tap_inv = t->tap_inv;
     a.L = L; a.M = M;
     if ((rc = fir_careful(h, &a.cf))) return rc;

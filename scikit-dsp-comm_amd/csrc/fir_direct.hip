@@ -82,6 +82,8 @@ __global__ __launch_bounds__(256) void fir_poly_kernel(const X *__restrict__ x, 
                                                        X *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int poly_nf;   // some result of this workgroup came out non-finite (see the end of the kernel)
+    if (threadIdx.x == 0) poly_nf = 0;
     X *win = reinterpret_cast<X *>(smem_raw);
     using S = typename ScalarOf<X>::type;
 
@@ -159,17 +161,11 @@ __global__ __launch_bounds__(256) void fir_poly_kernel(const X *__restrict__ x, 
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = add_of(acc[r], part[r]);
         }
-        {   // a non-finite result: did a real tap meet the sample, or only the zero padding of the phase table?  (careful.hpp)
+        {   // a non-finite result: did a real tap meet the sample, or only the zero padding of the phase table?  Looked at behind the loop (careful.hpp)
             bool bad = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) bad |= not_finite(acc[r]);
-            if (__builtin_expect(__any(bad), 0)) {
-#pragma unroll 1
-                for (int r = 0; r < R; ++r) {
-                    const int64_t m = (int64_t)c + (int64_t)a.Lp * (s0 + tid + 256 * r);
-                    if (not_finite(acc[r]) && tid + 256 * r < a.s_tile && m < a.n_out) acc[r] = careful_fir_value<X>(x, a.n_hist, a.cf, a.L, a.M, m, 0);
-                }
-            }
+            if (__builtin_expect(__any(bad), 0)) poly_nf = 1;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -178,6 +174,11 @@ __global__ __launch_bounds__(256) void fir_poly_kernel(const X *__restrict__ x, 
             if (sl < a.s_tile && m < a.n_out) y[m] = (a.L == 1) ? acc[r] : scl(acc[r], gain);
         }
     }
+    // non-finite results among this workgroup's outputs m in [Lp s0, Lp (s0 + s_tile)): re-evaluated by the reference's sum (careful.hpp)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (__builtin_expect(*reinterpret_cast<volatile int *>(&poly_nf) != 0, 0))
+        careful_fir_recheck<typename CarefulOf<X>::T, CarefulOf<X>::CX>(x, y, a.n_hist, a.n_out, (int64_t)a.Lp * s0, (int64_t)a.Lp * a.s_tile, a.L, a.M, a.cf, tid);
 }
 
 // ------------------------------------------------------------------ sliding window
@@ -293,6 +294,8 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
                                                      const int *__restrict__ rho_tab, SwArgs a, X *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int sw_nf;   // some result of this workgroup came out non-finite (see recheck_outputs)
+    if (threadIdx.x == 0) sw_nf = 0;
     X *win = reinterpret_cast<X *>(smem_raw);
     using S = typename ScalarOf<X>::type;
     const int tid = threadIdx.x;
@@ -477,26 +480,26 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
         }
     };
 
-    // a non-finite result: did a real tap meet the sample, or only the zero padding of the tap blocks?  (careful.hpp; the value without
-    // the gain L, which the stores below apply)
-    auto recheck = [&](const int c, const int lp, X (&acc)[R]) __attribute__((always_inline)) {
+    // a non-finite result: did a real tap meet the sample, or only the zero padding of the tap blocks?  Looked at behind the stores (careful.hpp)
+    auto recheck = [&](X (&acc)[R]) __attribute__((always_inline)) {
         bool bad = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) bad |= not_finite(acc[r]);
-        if (__builtin_expect(__any(bad), 0)) {
-#pragma unroll 1
-            for (int r = 0; r < R; ++r) {
-                const int64_t m = (int64_t)c + (int64_t)lp * (s0 + (int64_t)R * tid + r);
-                if (not_finite(acc[r]) && m < a.n_out) acc[r] = careful_fir_value<X>(x, a.n_hist, a.cf, a.L, a.M, m, 0);
-            }
-        }
+        if (__builtin_expect(__any(bad), 0)) sw_nf = 1;
+    };
+    // ... of this workgroup's outputs m in [Lp s0, Lp (s0 + 256 R))
+    auto recheck_outputs = [&](int lp) __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (__builtin_expect(*reinterpret_cast<volatile int *>(&sw_nf) != 0, 0))
+            careful_fir_recheck<typename CarefulOf<X>::T, CarefulOf<X>::CX>(x, y, a.n_hist, a.n_out, (int64_t)lp * s0, (int64_t)lp * 256 * R, a.L, a.M, a.cf, tid);
     };
     if constexpr (LPT > 0) {
         X accs[LPT][R];
 #pragma unroll
         for (int c = 0; c < LPT; ++c) {
             class_body(c, accs[c]);
-            recheck(c, LPT, accs[c]);
+            recheck(accs[c]);
         }
         // element e of a wave's output run = LPT * slot + class; 16 lanes (16*LPT*R consecutive
         // elements) go through the wave-private tile per pass and leave as 512-byte rows
@@ -522,12 +525,13 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
                 if (m < a.n_out) y[m] = v;
             }
         }
+        recheck_outputs(LPT);
         return;
     }
     for (int c = 0; c < a.Lp; ++c) {
         X acc[R];
         class_body(c, acc);
-        recheck(c, a.Lp, acc);
+        recheck(acc);
         const int64_t sb = s0 + (int64_t)R * tid;
         if (a.out_tile) {
             // every class of the workgroup's slots is parked in one LDS image laid out like the
@@ -586,6 +590,7 @@ __global__ __launch_bounds__(256) void fir_sw_kernel(const X *__restrict__ x, co
                 if (m0 + i < a.n_out) y[m0 + i] = src[i];
         }
     }
+    recheck_outputs(a.Lp);
 }
 
 // ------------------------------------------------------------------ host side

@@ -196,7 +196,7 @@ __device__ __forceinline__ void dn4k_fwd_pass2(int t, const cf *T2, cf *img, cf 
 // A poisoned tile (one inf / nan among the M x 4096 inputs of a tile makes all of its outputs non-finite, where the reference confines the
 // sample to the kept ones among the Ntaps outputs that multiply it): the thread recomputes the outputs it stored by the reference's own sum
 // (careful.hpp) -- its own stores, in program order: no barrier.
-template <bool REAL> __device__ __noinline__ void dn4k_careful_outputs(const void *x, void *y, int64_t n_out, int64_t n_hist, const CarefulFir cf, int M, int64_t out0, int V, int a0, int t)
+template <bool REAL> __device__ __forceinline__ void dn4k_careful_outputs(const void *x, void *y, int64_t n_out, int64_t n_hist, const CarefulFir cf, int M, int64_t out0, int V, int a0, int t)
 {
 #pragma unroll 1
     for (int a = a0; a < 16; ++a) {
@@ -224,7 +224,9 @@ template <bool REAL, int MS> __global__ __launch_bounds__(256, 2) void dn4k_kern
     __shared__ cf img[kImgUnits];
     __shared__ cf T2f[kT2Units], T2t[kT2Units];
     __shared__ cf twl[kTwUnits];
+    __shared__ unsigned long long dn_noted;   // poisoned tiles, by walk step (careful.hpp)
     const int t = threadIdx.x;
+    if (t == 0) dn_noted = 0;
     {
         const cf w = A.T2[t];
         T2f[t] = w;
@@ -234,12 +236,10 @@ template <bool REAL, int MS> __global__ __launch_bounds__(256, 2) void dn4k_kern
     }
     __syncthreads();
     int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
-    const int64_t tile_first = tile;
-    unsigned long long bad = 0;   // poisoned tiles of this wave's walk, by walk step (see fir_up4k.hip): recomputed behind the loop
-    int step = 0;
+    auto tile_first = [&]() -> int64_t { return (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x; };
     cf in[MS * 16];         // the phase signals of the tile; each is transformed in place
     bool have_in = false;   // `in` holds the phase signals of `tile` (requested ahead: interior tiles only)
-    for (; tile < A.ntiles; tile += gridDim.x, ++step) {
+    for (; tile < A.ntiles; tile += gridDim.x) {
         const bool pre_next = tile + gridDim.x < A.ntiles && dn4k_interior<REAL>(A, tile + gridDim.x);
         if (!have_in) {
             if (dn4k_interior<REAL>(A, tile)) {
@@ -279,12 +279,13 @@ template <bool REAL, int MS> __global__ __launch_bounds__(256, 2) void dn4k_kern
         dn4k_pin(acc);
         if (pre_next) static_for<0, MS>([&](auto jc) __attribute__((always_inline)) { dn4k_pin(in + 16 * decltype(jc)::value); });   // (waited for in front of the stores)
         dn4k_store<REAL>(A, tile, t, acc);
-        if (__builtin_expect(__any(not_finite(acc[15].x) | not_finite(acc[15].y)), 0)) bad |= 1ull << (step < 63 ? step : 63);
+        if (__builtin_expect(__any(not_finite(acc[15].x) | not_finite(acc[15].y)), 0)) careful_note(&dn_noted, (tile - tile_first()) / gridDim.x);
     }
-    if (__builtin_expect(bad != 0, 0)) {
-        int k = 0;
-        for (int64_t tl = tile_first; tl < A.ntiles; tl += gridDim.x, ++k)
-            if ((bad >> (k < 63 ? k : 63)) & 1)
+    const unsigned long long noted = careful_noted(&dn_noted);
+    if (__builtin_expect(noted != 0, 0)) {
+        int64_t k = 0;
+        for (int64_t tl = tile_first(); tl < A.ntiles; tl += gridDim.x, ++k)
+            if (careful_step_noted(noted, k))
                 dn4k_careful_outputs<REAL>(A.x, A.y, A.n_out, A.n_hist, A.cf, A.M, tl * (REAL ? 2 : 1) * (int64_t)A.V, A.V, A.a0, t);
     }
 }

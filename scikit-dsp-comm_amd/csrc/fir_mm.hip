@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256) void fir_mm_kernel(const X *__restrict__ x, co
                                                      X *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int mm_nf;   // some result of this workgroup came out non-finite (see the end of the kernel)
+    if (threadIdx.x == 0) mm_nf = 0;
     X *win = reinterpret_cast<X *>(smem_raw);
     using S = typename MmIo<X>::S;
     using V = typename MmIo<X>::V;
@@ -157,25 +159,17 @@ __global__ __launch_bounds__(256) void fir_mm_kernel(const X *__restrict__ x, co
                 ar[c] = ar[c] + ar[c + w];
                 ai[c] = ai[c] + ai[c + w];
             }
-        V ar0 = ar[0];
-        V ai0 = ai[0];
+        const V ar0 = ar[0];
+        const V ai0 = ai[0];
         // rows 4 (lane >> 4) + i of column N: outputs m = RS N + row
         const int64_t N = S0 + tile * 16 + ncol;
         const int row0 = 4 * klane;
         const int64_t m0 = (int64_t)a.RS * N + row0;
-        {   // a non-finite result: did a real tap meet the sample, or only the zero padding of the lag range?  (careful.hpp)
+        {   // a non-finite result: did a real tap meet the sample, or only the zero padding of the lag range?  Looked at behind the loop (careful.hpp)
             bool bad = false;
 #pragma unroll
             for (int i = 0; i < 4; ++i) bad |= not_finite((S)ar0[i]) || (CPLX && not_finite((S)ai0[i]));
-            if (__builtin_expect(__any(bad), 0)) {
-#pragma unroll 1
-                for (int i = 0; i < 4; ++i)
-                    if ((not_finite((S)ar0[i]) || (CPLX && not_finite((S)ai0[i]))) && row0 + i < a.RS && m0 + i < a.n_out) {
-                        const X v = careful_fir_value<X>(x, a.n_hist, a.cf, a.L, a.M, m0 + i);
-                        ar0[i] = mm_re(v);
-                        if constexpr (CPLX) ai0[i] = mm_im(v);
-                    }
-            }
+            if (__builtin_expect(__any(bad), 0)) mm_nf = 1;
         }
         if (a.RS == 16 && m0 + 4 <= a.n_out && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
             // 4 consecutive outputs per lane: 16-byte stores
@@ -195,6 +189,11 @@ __global__ __launch_bounds__(256) void fir_mm_kernel(const X *__restrict__ x, co
                 if (row0 + i < a.RS && m0 + i < a.n_out) mm_put(y + m0 + i, (S)ar0[i], (S)ai0[i]);
         }
     }
+    // non-finite results of this workgroup's outputs m in [RS S0, RS (S0 + NS)): re-evaluated by the reference's sum (careful.hpp)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (__builtin_expect(*reinterpret_cast<volatile int *>(&mm_nf) != 0, 0))
+        careful_fir_recheck<S, CPLX>(x, y, a.n_hist, a.n_out, (int64_t)a.RS * S0, (int64_t)a.RS * a.NS, a.L, a.M, a.cf, tid);
 }
 
 // A-operand table of one (L, M): At[ks][lane] = A[row = lane & 15][u = 4 ks + (lane >> 4)]

@@ -522,6 +522,8 @@ template <bool REAL, bool DEC, bool UP = false, bool XR = false>   // XR: real s
 __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
 {
     __shared__ float4 lds[kLdsUnits + 2 * kT2Units];
+    __shared__ unsigned long long ols_noted;   // poisoned tiles, by walk step (careful.hpp)
+    if (threadIdx.x == 0) ols_noted = 0;       // (the barrier behind the table load lies between this and any note)
     // Decimating store (.dn): the last HS of the thread's 16 H registers are fetched per tile (HS x 4 KiB from L2, requested at the top of the
     // tile, used behind the forward transform).  With all 16 held across tiles hipcc spilled four of them and reloaded them from scratch INSIDE
     // the H multiply: four round trips per tile on the critical path.
@@ -648,12 +650,19 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
             store_any<REAL, DEC>(A, phys(tile), t, v, lds);
         }
         __builtin_amdgcn_s_setprio(0);
-        const bool poisoned = __any(not_finite(v[31].x) | not_finite(v[31].y));   // (wave-uniform; all results of a tile are, or none)
+        // (all results of a tile are non-finite, or none; noted by walk step and recomputed behind the loop: careful.hpp)
+        if (__builtin_expect(__any(not_finite(v[31].x) | not_finite(v[31].y)), 0)) careful_note(&ols_noted, it);
 #pragma unroll
         for (int i = 0; i < 32; ++i) v[i] = nx[i];
         __syncthreads();  // every wave is done reading the image before the next tile overwrites it
-        if (__builtin_expect(poisoned, 0))
-            careful_ols_tile<float, REAL, DEC, UP, XR>(ols_careful_args(A, UP ? phase_of(tile) : 0, !(REAL || XR)), phys(tile), UP ? phase_of(tile) : 0, t);
+    }
+    const unsigned long long noted = careful_noted(&ols_noted);
+    if (__builtin_expect(noted != 0, 0)) {
+        // (the walk again, as the loop made it)
+        int64_t w = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+        for (int64_t k = 0; w < A.ntiles; w += gridDim.x, ++k)
+            if (careful_step_noted(noted, k))
+                careful_ols_tile<float, REAL, DEC, UP, XR>(ols_careful_args(A, UP ? phase_of(w) : 0, !(REAL || XR)), phys(w), UP ? phase_of(w) : 0, t);
     }
 }
 

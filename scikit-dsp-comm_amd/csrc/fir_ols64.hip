@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
 {
     __shared__ cdd img[16 * kPitch64];
     __shared__ unsigned touch_lds[4 * 128];   // landing area of the next tile's cache-line touches (never read)
+    __shared__ unsigned long long ols_noted;  // poisoned tiles, by walk step (careful.hpp)
     const int t = threadIdx.x;
+    if (t == 0) ols_noted = 0;
     const int hi4 = t >> 4, lo4 = t & 15;
     const cdd w1 = A.W1[t];        // W_4096^t            (pass 1: t = 16 b + c)
     const cdd w2 = A.W2[lo4];      // W_256^c             (pass 2: thread (k1, c))
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
         }
     };
     int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+    auto tile_first = [&]() -> int64_t { return (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x; };
     for (; tile < A.ntiles; tile += gridDim.x) {
         // .up: pair index -> (input tile, phase); < 2^31 pairs (checked at launch)
         const int64_t tin = UP ? (int64_t)((unsigned)tile / (unsigned)A.up) : tile;
@@ -508,10 +511,17 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
                 }
             }
         }
-        // a non-finite input makes every result of the tile non-finite: such a tile is recomputed by the reference's own sum (careful.hpp)
-        const bool poisoned = __any(not_finite(v[15].x) || not_finite(v[15].y));
+        // a non-finite input makes every result of the tile non-finite: noted by walk step, recomputed behind the loop (careful.hpp)
+        if (__builtin_expect(__any(not_finite(v[15].x) || not_finite(v[15].y)), 0)) careful_note(&ols_noted, (tile - tile_first()) / gridDim.x);
         __syncthreads();  // the image is free for the next tile
-        if (__builtin_expect(poisoned, 0)) {
+    }
+    const unsigned long long noted = careful_noted(&ols_noted);
+    if (__builtin_expect(noted != 0, 0)) {
+        int64_t k = 0;
+        for (int64_t w = tile_first(); w < A.ntiles; w += gridDim.x, ++k) {
+            if (!careful_step_noted(noted, k)) continue;
+            const int64_t tin = UP ? (int64_t)((unsigned)w / (unsigned)A.up) : w;
+            const int ph = UP ? (int)((unsigned)w % (unsigned)A.up) : 0;
             OlsCareful c;
             c.x = A.x; c.y = A.y; c.n = A.n; c.n_hist = A.n_hist; c.n_keep = A.n_keep; c.up_pitch = A.up_pitch;
             c.V = A.V; c.dec = A.dec; c.up = A.up;

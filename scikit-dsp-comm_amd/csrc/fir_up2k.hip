@@ -188,7 +188,7 @@ template <int PH, bool TAIL> __device__ __forceinline__ void up2k_store_direct(c
 }
 
 // A poisoned tile (see fir_up4k.hip): the thread recomputes the rows it stored -- tile-local rows 256 m + t - ov -- by the reference's own sum.
-template <bool XR> __device__ __noinline__ void up2k_careful_rows(const void *x, void *y, int64_t n, int64_t n_hist, const CarefulFir cf, int L, int64_t out0, int ov, int t)
+template <bool XR> __device__ __forceinline__ void up2k_careful_rows(const void *x, void *y, int64_t n, int64_t n_hist, const CarefulFir cf, int L, int64_t out0, int ov, int t)
 {
 #pragma unroll 1
     for (int m = 0; m < 8; ++m) {
@@ -215,7 +215,9 @@ template <bool XR, int PH, bool STAGED> __global__ __launch_bounds__(256, 2) voi
     __shared__ cf tw1l[kTw1Units], tw2l[kTw2Units], tw3l[kTw3Units];
     __shared__ float4 stage[STAGED ? 4 * Up2kStage<PH>::kWaveUnits : 1];
     __shared__ cf zl[ZL ? 8 * 256 : 1];   // [slot][thread]
+    __shared__ unsigned long long up_noted;   // poisoned tiles, by walk step (careful.hpp)
     const int t = threadIdx.x;
+    if (t == 0) up_noted = 0;
     {
         tw1l[t] = A.tw1[t]; tw1l[256 + t] = A.tw1[256 + t]; tw1l[512 + t] = A.tw1[512 + t];
         tw2l[t] = A.tw2[t]; tw2l[256 + t] = A.tw2[256 + t];
@@ -223,12 +225,10 @@ template <bool XR, int PH, bool STAGED> __global__ __launch_bounds__(256, 2) voi
     }
     __syncthreads();
     int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
-    const int64_t tile_first = tile;
-    unsigned long long bad = 0;   // poisoned tiles of this wave's walk, by walk step (see fir_up4k.hip): recomputed behind the loop
-    int step = 0;
+    auto tile_first = [&]() -> int64_t { return (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x; };
     cf Z[8];               // the tile's samples, then its spectrum, then (behind the last H product) the next tile's samples
     bool have_x = false;   // Z holds the samples of `tile` (requested a pass ahead: interior tiles only)
-    for (; tile < A.ntiles; tile += gridDim.x, ++step) {
+    for (; tile < A.ntiles; tile += gridDim.x) {
         const bool has_next = tile + gridDim.x < A.ntiles;
         const bool pre_next = !ZL && has_next && up2k_interior(A, tile + gridDim.x);
         if (!have_x) {   // the first tile of this workgroup, and tiles at the ends of the signal (guarded accesses)
@@ -300,12 +300,13 @@ template <bool XR, int PH, bool STAGED> __global__ __launch_bounds__(256, 2) voi
                 up2k_store_direct<PH, false>(A, tile, g0, cnt, t, out);
             }
         }
-        if (__builtin_expect(__any(poisoned), 0)) bad |= 1ull << (step < 63 ? step : 63);
+        if (__builtin_expect(__any(poisoned), 0)) careful_note(&up_noted, (tile - tile_first()) / gridDim.x);
     }
-    if (__builtin_expect(bad != 0, 0)) {
-        int k = 0;
-        for (int64_t tl = tile_first; tl < A.ntiles; tl += gridDim.x, ++k)
-            if ((bad >> (k < 63 ? k : 63)) & 1) up2k_careful_rows<XR>(A.x, A.y, A.n, A.n_hist, A.cf, A.row_bytes / (XR ? 4 : 8), tl * A.V, A.ov, t);
+    const unsigned long long noted = careful_noted(&up_noted);
+    if (__builtin_expect(noted != 0, 0)) {
+        int64_t k = 0;
+        for (int64_t tl = tile_first(); tl < A.ntiles; tl += gridDim.x, ++k)
+            if (careful_step_noted(noted, k)) up2k_careful_rows<XR>(A.x, A.y, A.n, A.n_hist, A.cf, A.row_bytes / (XR ? 4 : 8), tl * A.V, A.ov, t);
     }
 }
 

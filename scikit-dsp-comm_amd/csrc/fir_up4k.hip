@@ -228,7 +228,7 @@ template <bool XR> __device__ __forceinline__ void up4k_settle_x(const cf *v)
 // to the Ntaps outputs that multiply it): the thread recomputes the rows it stored -- samples out0 + 256 (a - a0) + t, all L phases each -- by
 // the reference's own sum (careful.hpp).  Rows are written by their own thread or, through the wave-private staging image, by its own wave,
 // so the second store follows the first in program order: no barrier.
-template <bool XR> __device__ __noinline__ void up4k_careful_rows(const void *x, void *y, int64_t n, int64_t n_hist, const CarefulFir cf, int L, int64_t out0, int a0, int t)
+template <bool XR> __device__ __forceinline__ void up4k_careful_rows(const void *x, void *y, int64_t n, int64_t n_hist, const CarefulFir cf, int L, int64_t out0, int a0, int t)
 {
 #pragma unroll 1
     for (int a = a0; a < 16; ++a) {
@@ -256,7 +256,9 @@ template <bool XR, int G> __global__ __launch_bounds__(256, 2) void up4k_kernel(
     __shared__ cf T2f[kT2Units], T2t[kT2Units];
     __shared__ cf twl[kTwUnits];
     __shared__ float4 stage[G == 4 ? 4 * 128 : 1];   // 2 KiB per wave: up4k_store4_staged
+    __shared__ unsigned long long up_noted;          // poisoned tiles, by walk step (careful.hpp)
     const int t = threadIdx.x;
+    if (t == 0) up_noted = 0;
     {
         const cf w = A.T2[t];
         T2f[t] = w;
@@ -266,11 +268,7 @@ template <bool XR, int G> __global__ __launch_bounds__(256, 2) void up4k_kernel(
     }
     __syncthreads();
     int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
-    const int64_t tile_first = tile;
-    // poisoned tiles of this wave's walk, by walk step (bit 63: "some step from 63 on"): they are recomputed BEHIND the loop -- a call inside it
-    // costs the loop 50 registers (140 - 194 spilled in the twelve-pass kernel of fir_up2k.hip)
-    unsigned long long bad = 0;
-    int step = 0;
+    auto tile_first = [&]() -> int64_t { return (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x; };
     cf Z[16];          // the tile's samples, then its spectrum, then (behind the last H product) the next tile's samples
     float4 hh[G][8];   // the tables of the current group's passes
     bool have_x = false;   // Z holds the samples of `tile` (requested a pass ahead: interior tiles only)
@@ -279,7 +277,7 @@ template <bool XR, int G> __global__ __launch_bounds__(256, 2) void up4k_kernel(
     } else {
         up4k_no_H(hh[0]);
     }
-    for (; tile < A.ntiles; tile += gridDim.x, ++step) {
+    for (; tile < A.ntiles; tile += gridDim.x) {
         const bool has_next = tile + gridDim.x < A.ntiles;
         const bool pre_next = has_next && up4k_interior(A, tile + gridDim.x);
         if (!have_x) {   // the first tile of this workgroup, and tiles at the ends of the signal (guarded accesses)
@@ -351,12 +349,13 @@ template <bool XR, int G> __global__ __launch_bounds__(256, 2) void up4k_kernel(
                 store(std::false_type{});
             }
         }
-        if (__builtin_expect(__any(poisoned), 0)) bad |= 1ull << (step < 63 ? step : 63);
+        if (__builtin_expect(__any(poisoned), 0)) careful_note(&up_noted, (tile - tile_first()) / gridDim.x);
     }
-    if (__builtin_expect(bad != 0, 0)) {
-        int k = 0;
-        for (int64_t tl = tile_first; tl < A.ntiles; tl += gridDim.x, ++k)
-            if ((bad >> (k < 63 ? k : 63)) & 1) up4k_careful_rows<XR>(A.x, A.y, A.n, A.n_hist, A.cf, A.row_bytes / (XR ? 4 : 8), tl * A.V, A.a0, t);
+    const unsigned long long noted = careful_noted(&up_noted);
+    if (__builtin_expect(noted != 0, 0)) {
+        int64_t k = 0;
+        for (int64_t tl = tile_first(); tl < A.ntiles; tl += gridDim.x, ++k)
+            if (careful_step_noted(noted, k)) up4k_careful_rows<XR>(A.x, A.y, A.n, A.n_hist, A.cf, A.row_bytes / (XR ? 4 : 8), tl * A.V, A.a0, t);
     }
 }
 

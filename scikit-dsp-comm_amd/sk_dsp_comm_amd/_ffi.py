@@ -67,7 +67,8 @@ def load():
         L.skdsp_last_error.restype = ctypes.c_char_p
         L.skdsp_version.restype = ctypes.c_char_p
         L.skdsp_init.argtypes = [ci]
-        L.skdsp_debug_path.argtypes = [ctypes.c_char_p, ci, ci]
+        if hasattr(L, "skdsp_debug_path"):   # (absent from older builds of the library that SKDSP_LIB may point at for A/B timing)
+            L.skdsp_debug_path.argtypes = [ctypes.c_char_p, ci, ci]
         L.skdsp_init_devices.argtypes = [ctypes.POINTER(ci), ci]
         p64 = ctypes.POINTER(i64)
         L.skdsp_host_chunk_plan.argtypes = [i64, ci, ci, i64, ci, i64, p64, p64, p64, p64, p64, p64]
