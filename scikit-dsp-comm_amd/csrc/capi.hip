@@ -109,7 +109,7 @@ const OptEntry kOptTable[] = {
     {"device", &Options::device}, {"fir_algo", &Options::fir_algo}, {"dn_no_ols", &Options::dn_no_ols},
     {"fir_mm", &Options::fir_mm}, {"fir_bx", &Options::fir_bx}, 
     
-    {"ols_reserve", &Options::ols_reserve}, {"iir_planar", &Options::iir_planar}, 
+    {"ols_reserve", &Options::ols_reserve}, {"fir_dn_fold", &Options::fir_dn_fold}, {"iir_planar", &Options::iir_planar}, 
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, 
     {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up4k", &Options::fir_up4k}, {"fir_up4k_group", &Options::fir_up4k_group}, {"fir_up4k_staged", &Options::fir_up4k_staged}, {"fir_up2k", &Options::fir_up2k}, {"fir_dn4k", &Options::fir_dn4k}, {"fir_up_pair", &Options::fir_up_pair}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, 
     {"shard_two_launches", &Options::shard_two_launches},
@@ -348,19 +348,27 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
         return rc;
     }
     bool ols = M > 1 && fir_ols_supported(h) && pick_fir_algo(h, n) == SKDSP_FIR_OLS && !opt().dn_no_ols;
+    const bool fold = M % 2 == 0 && opt().fir_dn_fold;   // even M: the overlap-save tile transforms only the kept outputs back (ols_fold_kernel)
     if (ols) {
-        // the matrix-pipe kernel where it covers the shape (profiles/r04/fir_dn.txt), except the long filters of M <= 4, whose kept outputs still
-        // cost it a good part of the full-rate work: complex64 M = 3, 512 taps 0.256 ms against 0.215 in the frequency domain, float32 0.132 / 0.100
-        const int kb = h->algo == SKDSP_FIR_OLS ? 0 : fir_bx_blocks(h, 1, M);
-        ols = kb == 0 || (M <= 4 && kb > 12);
+        // Which engine (profiles/r05/fir_dn.txt, 2^26 inputs).  The matrix-pipe kernel computes kept outputs only and costs with the taps per kept
+        // output u = Ntaps / M; the overlap-save tile costs the same whatever the filter: with the folded inverse transform 0.155 - 0.19 ms
+        // (complex64; float32 0.085 - 0.105), with the decimating store (odd M) the plain filter's 0.21 - 0.23.  Measured crossovers: complex64
+        // M = 4 from the shortest filter overlap-save takes, M = 2 from u = 96, M = 8, 12, 16 from u = 64, M = 6, 10 from u = 128; float32 from
+        // u = 128 (M = 2: 192).  Where the matrix-pipe kernel does not cover the shape (complex taps, lag ranges beyond its 48 blocks) the
+        // register sliding-window kernel is the alternative, and cheaper below a few dozen taps per kept output.
+        const int kb = h->algo == SKDSP_FIR_OLS ? -1 : fir_bx_blocks(h, 1, M);
+        const int u = h->ntaps / M;
+        const bool f32 = h->dtype == SKDSP_F32;
+        if (kb < 0) ols = true;                                                  // (forced by the caller)
+        else if (kb == 0) ols = u >= (f32 ? 64 : 24);
+        else if (fold) ols = u >= (f32 ? (M == 2 ? 192 : 128) : (M == 4 ? 0 : (M == 2 ? 96 : (M % 4 == 0 ? 64 : 128))));
+        else ols = M <= 4 && kb > 12;                                            // (M = 3: complex64 512 taps 0.256 ms against 0.215, float32 0.132 / 0.100)
     }
-    // M <= 4: the frequency-domain decimator (fir_dn4k.hip: M forward transforms accumulated, ONE inverse per tile of kept outputs) wherever
-    // the decimating overlap-save store would run (which spends 2 M transforms on the same outputs); option fir_dn4k = 2: wherever it applies
-    // (measured, 2^26 inputs, round 4 -- tools/check_dn4k.py: float32 512 taps M = 3 0.125 -> 0.101 ms, 1024 taps M = 4 0.130 -> 0.119, 4096 taps
-    // 0.199 -> 0.129; complex64 1024 taps M = 2 0.231 -> 0.208, 4096 taps M = 4 0.356 -> 0.271, but 512 taps M = 3 and 1024 taps M = 4 a tie:
-    // its loads are the bulk of its traffic and wait where the interpolator's stores do not)
+    // M = 3: the frequency-domain decimator (fir_dn4k.hip: M forward transforms accumulated, ONE inverse per tile of kept outputs) wherever the
+    // decimating store would run; even M: the folded inverse is ahead of it everywhere (M = 2, 1024 taps: 0.189 against 0.219 ms; M = 4: 0.174 /
+    // 0.237; float32 0.097 / 0.116).  Option fir_dn4k = 2: wherever it applies (A/B timing, tests)
     if (M > 1 && opt().fir_dn4k && fir_dn4k_supported(h, M) && n / M >= 2048 &&
-        (opt().fir_dn4k >= 2 || (ols && (h->dtype == SKDSP_F32 || M == 2 || h->ntaps > 1536))))
+        (opt().fir_dn4k >= 2 || (ols && !fold && (h->dtype == SKDSP_F32 || h->ntaps > 1536))))
         return fir_dn4k_launch(h, x_dev, n, n_hist, M, y_dev, ctx().stream);
     if (ols) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
     int rc = fir_direct_launch(h, x_dev, n, n_hist, 1, M, n / M, y_dev, ctx().stream);

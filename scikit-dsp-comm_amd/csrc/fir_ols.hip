@@ -666,6 +666,121 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
     }
 }
 
+
+// ---- multirate_FIR.dn, even M: the decimating INVERSE transform ----------------------------------------------------------------------
+// The decimating store above computes every full-rate output and keeps one in M.  Here the spectrum is folded M-fold between the
+// registers of a thread and only the kept outputs are transformed back (ols_core.hpp: inv_pass32_fold) -- 1 forward + ~1/4 inverse
+// transform per tile instead of 2; loads, prefetch, H product and the walk are the plain filter's.  Thread (b, q) with q a multiple
+// of MF / 2 ends up with y[512 a + 32 b + 2 q], a = 0 .. 15: element (512 / MF) a + (32 / MF) b + 2 q / MF of the tile's MF-fold decimated
+// run, so for every a the workgroup's active lanes hold 512 / MF consecutive elements.  MF = the largest of 16, 8, 4, 2 that divides M;
+// what is left of M (A.dec / MF = 3 for the reference's default M = 12) is taken at the store: every (M / MF)-th element of the run
+// leaves.  REAL: two real tiles ride in one complex tile.
+template <bool REAL, int MF>
+__global__ __launch_bounds__(256, 2) void ols_fold_kernel(OlsArgs A)
+{
+    __shared__ float4 lds[kLdsUnits + 2 * kT2Units];
+    __shared__ unsigned long long ols_noted;   // poisoned tiles, by walk step (careful.hpp)
+    if (threadIdx.x == 0) ols_noted = 0;
+    float4 *T2f = lds + kLdsUnits, *T2t = lds + kLdsUnits + kT2Units;
+    const int t = threadIdx.x;
+    {
+        const float4 w = A.T2[t];
+        T2f[t] = w;
+        T2t[(t & 15) * 16 + (t >> 4)] = w;
+    }
+    cf tw[16];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) tw[k1] = lo(A.T1[k1 * 256 + t]);
+    tw[0] = make_float2(1.f, 0.f);
+    __syncthreads();
+    float4 hh[16];
+    auto first_tile = [&]() -> int64_t { return (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x; };
+    int64_t tile = first_tile();
+    load_H(t, A.Hp, hh);
+    cf v[32];
+    if (tile < A.ntiles) load_any<REAL, false>(A, tile, t, v);
+#pragma unroll
+    for (int i = 0; i < 32; i += 8)
+        asm volatile("" ::"v"(v[i].x), "v"(v[i].y), "v"(v[i + 1].x), "v"(v[i + 1].y), "v"(v[i + 2].x), "v"(v[i + 2].y),
+                     "v"(v[i + 3].x), "v"(v[i + 3].y), "v"(v[i + 4].x), "v"(v[i + 4].y), "v"(v[i + 5].x), "v"(v[i + 5].y),
+                     "v"(v[i + 6].x), "v"(v[i + 6].y), "v"(v[i + 7].x), "v"(v[i + 7].y));
+    constexpr int LS = MF / 2;
+    const int b = t >> 4, q = t & 15;
+    const bool active = q % LS == 0;
+    // this lane's first kept output inside a tile (a = 0), and how many kept outputs a step of a spans
+    const int j0 = (32 / MF) * b + q / LS;
+    constexpr int JA = 512 / MF;
+    for (int64_t step = 0; tile < A.ntiles; tile += gridDim.x, ++step) {
+        if (REAL) fwd_pass1_real(t, v, tw, lds); else fwd_pass1(t, v, tw, lds);
+        __syncthreads();
+        cf Z[32];
+        fwd_pass23(t, T2f, lds, Z);
+        mul_H(hh, Z);
+        const int64_t next = tile + gridDim.x;
+        cf nx[32];
+        __builtin_amdgcn_s_setprio(3);
+        if (next < A.ntiles) load_any<REAL, false>(A, next, t, nx);
+        __builtin_amdgcn_s_setprio(0);
+        inv_pass32_fold<MF>(t, T2t, lds, Z);
+        __syncthreads();
+        cf o[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) o[a] = make_float2(0.f, 0.f);
+        inv_pass1_fold<MF>(t, tw, lds, o);
+#pragma unroll
+        for (int i = 0; i < 32; i += 8)
+            asm volatile("" ::"v"(nx[i].x), "v"(nx[i].y), "v"(nx[i + 1].x), "v"(nx[i + 1].y), "v"(nx[i + 2].x), "v"(nx[i + 2].y),
+                         "v"(nx[i + 3].x), "v"(nx[i + 3].y), "v"(nx[i + 4].x), "v"(nx[i + 4].y), "v"(nx[i + 5].x), "v"(nx[i + 5].y),
+                         "v"(nx[i + 6].x), "v"(nx[i + 6].y), "v"(nx[i + 7].x), "v"(nx[i + 7].y)
+                         : "memory");
+        // ---- the kept outputs of the tile (pair of tiles): from block a0 on, V / MF elements of the decimated run per tile, every Mr-th kept ----
+        __builtin_amdgcn_s_setprio(3);
+        if (active) {
+            int a0 = A.a0;
+            asm volatile("" : "+s"(a0));
+            const int Mr = A.dec / MF;
+            const int64_t n_out = A.n_keep / A.dec;
+            const int VD = A.V / MF;                                       // elements of the decimated run per tile
+            // element e of the run is output e / Mr where Mr divides e: the tile's (pair's) first element = Mr q0 + r0
+            const int64_t e0 = (REAL ? 2 * tile : tile) * (int64_t)VD;
+            const int64_t q0 = Mr > 1 ? e0 / Mr : e0;
+            const unsigned r0 = Mr > 1 ? (unsigned)(e0 - q0 * Mr) : 0u;
+            auto put = [&](unsigned el, auto val, auto *yp) __attribute__((always_inline)) {   // el: element relative to e0
+                if (Mr > 1) {
+                    const unsigned g = r0 + el;
+                    const unsigned k = (unsigned)(((unsigned long long)g * A.dec_magic) >> 32);   // g / Mr (dec_magic = ceil(2^32 / Mr) here)
+                    if (k * (unsigned)Mr == g && q0 + k < n_out) __builtin_nontemporal_store(val, yp + (q0 + k));
+                } else if (q0 + el < n_out) {
+                    __builtin_nontemporal_store(val, yp + (q0 + el));
+                }
+            };
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                if (a < a0) continue;
+                const unsigned el = (unsigned)(j0 + JA * (a - a0));
+                if (REAL) {
+                    put(el, o[a].x, reinterpret_cast<float *>(A.y));
+                    put(el + (unsigned)VD, o[a].y, reinterpret_cast<float *>(A.y));
+                } else {
+                    put(el, v2f_t{o[a].x, o[a].y}, reinterpret_cast<v2f_t *>(A.y));
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // (all results of a tile are non-finite, or none; noted by walk step and recomputed behind the loop: careful.hpp)
+        if (__builtin_expect(__any(active && (not_finite(o[15].x) | not_finite(o[15].y))), 0)) careful_note(&ols_noted, step);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = nx[i];
+        __syncthreads();  // every wave is done reading the image before the next tile overwrites it
+    }
+    const unsigned long long noted = careful_noted(&ols_noted);
+    if (__builtin_expect(noted != 0, 0)) {
+        int64_t w = first_tile();
+        for (int64_t k = 0; w < A.ntiles; w += gridDim.x, ++k)
+            if (careful_step_noted(noted, k)) careful_ols_tile<float, REAL, true, false, false>(ols_careful_args(A, 0, !REAL), w, 0, t);
+    }
+}
+
 bool fir_ols_supported(const FirHandle *h)
 {
     // complex64 signal; overlap must leave at least half the tile as useful output
@@ -800,6 +915,8 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     if (dec > 1) n = (n / dec) * dec;  // the dropped tail is never computed
     if (n <= 0) return SKDSP_OK;
     SK_CHECK(fir_ols_supported(h), SKDSP_ERR_UNSUPPORTED, "fir_ols: needs complex64 (or float32 with real taps) and 2..4097 taps");
+    // (the decimating stores divide tile-local indices below M + 16384 by M through a multiply-high by ceil(2^32 / M): exact while (M + 16384) M < 2^32)
+    SK_CHECK(dec <= 32768, SKDSP_ERR_UNSUPPORTED, "fir_ols: decimation by %d (the decimating store takes M <= 32768)", dec);
     int rc = ensure_plan(h);
     if (rc) return rc;
     OlsPlan *p = h->ols;
@@ -831,7 +948,22 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     if (reserve_wgs < 0) reserve_wgs = opt().ols_reserve;
     if (reserve_wgs > 0 && grid >= 4 * (int64_t)reserve_wgs) grid -= reserve_wgs;
     if (grid > ntiles) grid = ntiles;
-    if (A.dec > 1) {
+    const int mf = A.dec % 16 == 0 ? 16 : (A.dec % 8 == 0 ? 8 : (A.dec % 4 == 0 ? 4 : (A.dec % 2 == 0 ? 2 : 1)));
+    const bool fold = opt().fir_dn_fold && !halo_flag && mf > 1;
+    if (fold) {   // the decimating inverse transform (ols_fold_kernel): M = mf x (what the store takes)
+        const int mr = A.dec / mf;
+        A.dec_magic = mr > 1 ? (unsigned)((((unsigned long long)1 << 32) + mr - 1) / mr) : 0u;   // (elements of the decimated run: below 2^14 + mr, exact for mr <= 4096)
+#define SK_FOLD(MF)                                                                                                  \
+    if (real) hipLaunchKernelGGL((ols_fold_kernel<true, MF>), dim3((unsigned)grid), dim3(256), 0, s, A);             \
+    else hipLaunchKernelGGL((ols_fold_kernel<false, MF>), dim3((unsigned)grid), dim3(256), 0, s, A)
+        switch (mf) {
+        case 2: SK_FOLD(2); break;
+        case 4: SK_FOLD(4); break;
+        case 8: SK_FOLD(8); break;
+        default: SK_FOLD(16); break;
+        }
+#undef SK_FOLD
+    } else if (A.dec > 1) {
         if (real) hipLaunchKernelGGL((ols_tile_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
         else hipLaunchKernelGGL((ols_tile_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
     } else {

@@ -231,22 +231,32 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
     };
     int64_t tile = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
     auto tile_first = [&]() -> int64_t { return (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x; };
+    // The next tile's samples are requested into registers behind the H product (with the running twiddle powers no longer hoisted the
+    // kernels use 154 - 174 of their 256 registers: room for the 64 of a tile) and have the whole inverse transform to arrive; interior tiles
+    // only.  Measured (2^26, 1024 taps, same box, alternating): float64 0.327 -> 0.308 ms (the round-4 build with its cache-line touches
+    // through global_load_lds: 0.315), complex128 0.512 -> 0.507 (round 4, with 18 spilled registers: 0.542).
+    constexpr bool PREF = true;
+    auto interior_of = [&](int64_t tn) -> bool {
+        const int64_t i0 = (REAL ? 2 * tn : tn) * A.V - A.ov;
+        return i0 >= -A.n_hist && i0 + (REAL ? A.V : 0) + kN64 <= A.n;
+    };
+    cdd v[16];
+    bool have = false;   // v holds the samples of `tile` (requested a tile ahead)
     for (; tile < A.ntiles; tile += gridDim.x) {
         // .up: pair index -> (input tile, phase); < 2^31 pairs (checked at launch)
         const int64_t tin = UP ? (int64_t)((unsigned)tile / (unsigned)A.up) : tile;
         const int ph = UP ? (int)((unsigned)tile % (unsigned)A.up) : 0;
         const cdd *Hq = UP ? A.Hp + (size_t)ph * kN64 : A.Hp;
-        cdd v[16];
         // opaque copies of the thread index: stop LICM from hoisting the 16 + 16 + 16 loop-invariant 64-bit addresses of the
         // loads, the H bins and the stores out of the tile loop (they were spilled and reloaded in front of every access)
         int tl = t, th = t, ts = t;
         asm volatile("" : "+v"(tl));
-        load_tile(tin, tl, v);
+        if (!PREF || !have) load_tile(tin, tl, v);
         // Two-real-tiles kernel: the next pair's 512 cache lines are pulled towards the L2 while this one is transformed: one
         // 4-byte load per line, two per thread, straight into a scratch corner of the LDS (global_load_lds_dword: no
         // destination VGPR -- a register prefetch of the 16 values spilled in every form tried, and so did two live "touch"
         // registers).  float64, 1024 taps, 2^26: 0.3895 -> 0.3596 ms.  The complex kernel loses with it (0.691 -> 0.809 ms).
-        if (REAL) {
+        if (REAL && !PREF) {
             const int64_t nw = tile + gridDim.x;
             const int64_t nt = UP ? (int64_t)((unsigned)nw / (unsigned)A.up) : nw;
             if (nw < A.ntiles) {
@@ -316,6 +326,18 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
         }
 #pragma unroll
         for (int k3 = 0; k3 < 16; ++k3) v[P16(k3)] = cmul(v[P16(k3)], HREG ? hh[HREG ? k3 : 0] : hs[HREG ? 0 : k3]);
+        cdd nx[PREF ? 16 : 1];
+        bool pre = false;
+        if constexpr (PREF) {
+            const int64_t nw = tile + gridDim.x;
+            const int64_t nt = UP ? (int64_t)((unsigned)nw / (unsigned)A.up) : nw;
+            pre = nw < A.ntiles && interior_of(nt);
+            if (pre) {
+                int tp = t;
+                asm volatile("" : "+v"(tp));
+                load_tile(nt, tp, nx);
+            }
+        }
         // ---- inverse pass 3: over k3 -> c (takes the spectrum where it lies); the conj twiddle W_256^(c k2) is applied by the reader ----
         dft16_g(v);   // v[c] for thread (k1, k2)
 #pragma unroll
@@ -353,6 +375,13 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
         for (int b = 0; b < 16; b += 4)
             asm volatile("" : "+v"(v[b].x), "+v"(v[b].y), "+v"(v[b + 1].x), "+v"(v[b + 1].y), "+v"(v[b + 2].x), "+v"(v[b + 2].y), "+v"(v[b + 3].x), "+v"(v[b + 3].y));
         asm volatile("" : "+v"(ts));
+        if constexpr (PREF) {   // (the wait for the prefetch HERE, in front of the stores: vmcnt retires in order)
+            if (pre) {
+#pragma unroll
+                for (int b = 0; b < 16; b += 4)
+                    asm volatile("" ::"v"(nx[b].x), "v"(nx[b].y), "v"(nx[b + 1].x), "v"(nx[b + 1].y), "v"(nx[b + 2].x), "v"(nx[b + 2].y), "v"(nx[b + 3].x), "v"(nx[b + 3].y) : "memory");
+            }
+        }
         // ---- store the last V points ----
         // whole tile(s) inside the signal, no decimation: one copy of the 16 - a0 unguarded stores per possible a0
         // (compile-time offsets, no predicates -- as in fir_ols.hip: a run-time a0 made hipcc keep sixteen (exec mask, 64-bit
@@ -513,6 +542,13 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
         }
         // a non-finite input makes every result of the tile non-finite: noted by walk step, recomputed behind the loop (careful.hpp)
         if (__builtin_expect(__any(not_finite(v[15].x) || not_finite(v[15].y)), 0)) careful_note(&ols_noted, (tile - tile_first()) / gridDim.x);
+        if constexpr (PREF) {
+            have = pre;
+            if (pre) {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) v[b] = nx[b];
+            }
+        }
         __syncthreads();  // the image is free for the next tile
     }
     const unsigned long long noted = careful_noted(&ols_noted);

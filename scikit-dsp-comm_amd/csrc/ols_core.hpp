@@ -451,5 +451,59 @@ SK_HD void inv_pass1(int t, const cf *tw, const float4 *lds, cf *v)
     }
 }
 
+// ----------------------------------------------------------------------------
+// The inverse transform of a DECIMATING filter (multirate_FIR.dn, M = MF in {2, 4, 8, 16}): only y[j MF] is wanted.
+// With n = 512 a + 32 b + c those are the outputs whose c is a multiple of MF, and a DFT32 over k3 evaluated at c = c' MF only is
+// the DFT of R = 32 / MF points of the FOLDED spectrum  F[k3'] = sum_m Z[k3' + R m]  -- adds between registers of ONE thread, because
+// k3 is the index a thread (k1, k2) holds.  What follows is the full-rate inverse restricted to the columns it still needs: c = 2 q + e
+// with e = 0 and q a multiple of MF / 2, i.e. ONE 16-point transform per lane and pass where the full inverse runs two, on every
+// (MF / 2)-th lane.  Forward transform, H product, loads: untouched.  Per tile: 1 forward + ~1/4 inverse transform instead of 2.
+// ----------------------------------------------------------------------------
+template <int MF> SK_HD void inv_pass32_fold(int t, const float4 *T2t /* LDS copy, transposed [qq][k2] */, float4 *lds, const cf *Z)
+{
+    constexpr int R = 32 / MF, LS = MF / 2;   // points of the folded transform; lane step of the columns in use
+    const int k1 = t >> 4, k2 = t & 15;
+    cf F[R], z[R];
+    SK_UNROLL
+    for (int k = 0; k < R; ++k) {
+        cf acc = Z[k];
+        SK_UNROLL
+        for (int m = 1; m < MF; ++m) acc = cadd(acc, Z[k + R * m]);
+        F[k] = acc;
+    }
+    Dft<R, 1, true>::run(F, z);   // z[c'] = the full inverse DFT32 at c = c' MF
+    cf *l2 = reinterpret_cast<cf *>(lds);   // (the first half of a float4 unit: column e = 0)
+    SK_UNROLL
+    for (int cp = 0; cp < R; ++cp) {
+        const int qq = cp * LS;
+        l2[2 * lds_unit(k1, k2, qq)] = cmulc(z[cp], lo(T2t[qq * 16 + k2]));
+    }
+    const int q = k2;  // now thread (k1, q): its column exists where LS divides q
+    if (q % LS == 0) {
+        cf in0[16], o0[16];
+        SK_UNROLL
+        for (int kk = 0; kk < 16; ++kk) in0[kk] = l2[2 * lds_unit(k1, kk, q)];
+        Dft<16, 1, true>::run(in0, o0);
+        SK_UNROLL
+        for (int b = 0; b < 16; ++b) l2[2 * lds_unit(k1, b, q)] = o0[b];
+    }
+}
+
+// exchange-1' read + conj twiddle + inverse pass 1 of the same: v[a] = y[512 a + 32 b + 2 q] out (threads whose q is a multiple of MF / 2)
+template <int MF> SK_HD void inv_pass1_fold(int t, const cf *tw, const float4 *lds, cf *v)
+{
+    constexpr int LS = MF / 2;
+    const int b = t >> 4, q = t & 15;
+    if (q % LS != 0) return;
+    const cf *l2 = reinterpret_cast<const cf *>(lds);
+    cf in0[16];
+    in0[0] = l2[2 * lds_unit(0, b, q)];
+    static_for<1, 16>([&](auto kc) {
+        constexpr int k1 = decltype(kc)::value;
+        in0[k1] = cmulc(l2[2 * lds_unit(k1, b, q)], tw[k1]);
+    });
+    Dft<16, 1, true>::run(in0, v);
+}
+
 }  // namespace ols
 }  // namespace skdsp

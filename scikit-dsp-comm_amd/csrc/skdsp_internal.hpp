@@ -56,6 +56,7 @@ struct Options {
     int fir_up_pair = 1;      // 0: float32 .up through the overlap-save walk never pairs its phases (A/B switch)
     int fir_up4k = 1;         // 0: multirate_FIR.up never through the one-workgroup-per-input-tile interpolator (fir_up4k.hip); the older engines instead (A/B switch)
     int fir_up2k = 1;         // the 2048-point tile with all phases per thread (fir_up2k.hip): 1 from five passes on (complex64: L >= 5, float32: L >= 9), 2 always, 0 never (A/B switch)
+    int fir_dn_fold = 1;      // multirate_FIR.dn through overlap-save, M = 2, 4, 8, 16: the folded spectrum's inverse transform (ols_fold_kernel); 0: the decimating store (A/B switch)
     int fir_dn4k = 1;         // multirate_FIR.dn through the frequency-domain decimator (fir_dn4k.hip): 1 where the cost model prefers it, 2 wherever it applies, 0 never (A/B switch)
     int fir_up4k_group = 4;   // phases (float32: pairs of phases) whose results a thread of that kernel holds before it stores: 4 (32 bytes per lane) or 2 (A/B switch)
     int fir_up4k_staged = 1;  // 0: four-pass groups of that kernel store each lane's own 32 bytes (A/B switch)

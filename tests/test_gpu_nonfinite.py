@@ -48,9 +48,15 @@ CASES = [
     ("up4_f64", np.float64, lowpass(1024, 0.2 / 4), "up", 4, 1, 40_001, None),
     ("dn12_bx", np.complex64, lowpass(512, 0.9 / 12), "dn", 1, 12, 200_001, "fir_bx"),
     ("dn4_ols", np.complex64, lowpass(1024, 0.2 / 4), "dn", 1, 4, 200_001, "fir_ols"),
-    ("dn4_4k_f32", np.float32, lowpass(1024, 0.2 / 4), "dn", 1, 4, 200_001, "fir_dn4k"),
-    ("dn2_4k_c64", np.complex64, lowpass(1024, 0.4), "dn", 1, 2, 200_001, "fir_dn4k"),
+    ("dn4_fold_f32", np.float32, lowpass(1024, 0.2 / 4), "dn", 1, 4, 200_001, "fir_ols"),
+    ("dn2_fold_c64", np.complex64, lowpass(1024, 0.4), "dn", 1, 2, 200_001, "fir_ols"),
+    ("dn3_4k_f32", np.float32, lowpass(512, 0.3), "dn", 1, 3, 200_001, "fir_dn4k"),
+    ("dn3_4k_c64", np.complex64, lowpass(2048, 0.3), "dn", 1, 3, 200_001, "fir_dn4k"),
     ("dn3_f64", np.float64, lowpass(512, 0.3), "dn", 1, 3, 100_001, None),
+    ("dn3_ols", np.complex64, lowpass(1024, 0.3), "dn", 1, 3, 200_001, None),            # (odd M: decimating store or fir_dn4k)
+    ("dn12_fold", np.complex64, lowpass(2048, 0.9 / 12), "dn", 1, 12, 300_001, "fir_ols"),  # (folded inverse, every 3rd element kept at the store)
+    ("dn6_fold_f32", np.float32, lowpass(1024, 0.9 / 6), "dn", 1, 6, 300_001, "fir_ols"),
+    ("dn16_fold", np.complex64, lowpass(2048, 0.9 / 16), "dn", 1, 16, 300_001, "fir_ols"),
     ("updn43_bx", np.complex64, lowpass(512, 0.225), "updn", 4, 3, 60_001, "fir_bx"),
 ]
 
