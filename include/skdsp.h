@@ -128,6 +128,14 @@ int skdsp_fir_dn_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t n_his
 int skdsp_fir_updn(skdsp_handle h, const void *x, int64_t n, int L, int M, void *y);
 int skdsp_fir_updn_dev(skdsp_handle h, const void *x_dev, int64_t n, int64_t n_hist, int L, int M, void *y_dev);
 
+/* Is this cascade one that runs the reference's own recursion, sample by sample (csrc/iir_seq.hip)?  scipy.signal.sosfilt
+ * (multirate_helper.py:173) evaluates a cascade section after section in float64; for ill-conditioned designs (a 40th-order Chebyshev)
+ * that result is itself good to ~1e-6 only, and a scan would add to it.  skdsp_sos_create probes every cascade of more than 8 sections
+ * (the reference's recursion with the sections as given and reversed, on a fixed pseudo-random input); *spread receives the relative
+ * difference it found (0 where no probe ran), *is_sequential whether the handle therefore runs sequentially (slow: the reference's own
+ * speed).  The Python layer logs a WARNING for such handles. */
+int skdsp_iir_sequential(skdsp_handle h, int *is_sequential, double *spread);
+
 /* ---- IIR: multirate_IIR (multirate_helper.py:159-192), rate_change (:54-83) - */
 /* sos: nsec x 6 float64, sos[:,3]==1 (scipy.signal.sosfilt contract); any number of sections up to 4096, as sosfilt takes them
  * (more than 8 run as consecutive groups of at most 8 on the device; a float32 cascade whose intermediate signals do not survive

@@ -109,7 +109,7 @@ const OptEntry kOptTable[] = {
     {"device", &Options::device}, {"fir_algo", &Options::fir_algo}, {"dn_no_ols", &Options::dn_no_ols},
     {"fir_mm", &Options::fir_mm}, {"fir_bx", &Options::fir_bx}, 
     
-    {"ols_reserve", &Options::ols_reserve}, {"fir_dn_fold", &Options::fir_dn_fold}, {"iir_planar", &Options::iir_planar}, 
+    {"ols_reserve", &Options::ols_reserve}, {"fir_dn_fold", &Options::fir_dn_fold}, {"iir_seq", &Options::iir_seq}, {"iir_dn_t96", &Options::iir_dn_t96}, {"iir_planar", &Options::iir_planar}, 
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, 
     {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up4k", &Options::fir_up4k}, {"fir_up4k_group", &Options::fir_up4k_group}, {"fir_up4k_staged", &Options::fir_up4k_staged}, {"fir_up2k", &Options::fir_up2k}, {"fir_dn4k", &Options::fir_dn4k}, {"fir_up_pair", &Options::fir_up_pair}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, 
     {"shard_two_launches", &Options::shard_two_launches},
@@ -1650,6 +1650,53 @@ static int iir_create_common(int nsec, int order, const std::vector<double> &coe
     h->nsec = nsec;
     h->order = order;
     h->coef = coef;
+    if (nsec > 8 && opt().iir_seq != 0) {
+        // How far apart do two float64 evaluations of THIS cascade lie -- the reference's recursion with the sections as given and in reverse
+        // order (equal in exact arithmetic)?  A 40th-order Chebyshev design shows 1e-7 .. 1e-6 of its output; the scans (which combine chunk
+        // transitions instead of running the recursion) add 30 - 400 x that on such cascades (profiles/r05/iir_illcond.txt), which would carry
+        // them past the contract (1e-6 of the output for float32 signals, 1e-10 for float64 ones).  Such a handle runs the recursion itself
+        // (iir_seq.hip): slow, and bit for bit the reference's result.  Cascades of up to 8 sections are not probed: the parallel form's own
+        // acceptance test covers them.
+        const int NH = 4096;
+        std::vector<double> u(NH), v(NH);
+        unsigned long long lcg = 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < NH; ++i) {   // (sum of four uniforms: bell-shaped, unit-level, reproducible)
+            double a = 0.0;
+            for (int k = 0; k < 4; ++k) {
+                lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                a += (double)(lcg >> 11) / 9007199254740992.0 - 0.5;
+            }
+            u[i] = v[i] = a * 1.7320508075688772;
+        }
+        auto run = [&](std::vector<double> &w, bool rev) {
+            for (int k = 0; k < nsec; ++k) {
+                const double *c = coef.data() + 5 * (rev ? nsec - 1 - k : k);
+                double z0 = 0.0, z1 = 0.0;
+                for (int i = 0; i < NH; ++i) {
+                    const double xn = w[i], xc = c[0] * xn + z0;
+                    z0 = c[1] * xn - c[3] * xc + z1;
+                    z1 = c[2] * xn - c[4] * xc;
+                    w[i] = xc;
+                }
+            }
+        };
+        run(u, false);
+        run(v, true);
+        double peak = 0.0, diff = 0.0;
+        for (int i = 0; i < NH; ++i) {
+            peak = std::max(peak, std::fabs(u[i]));
+            diff = std::max(diff, std::fabs(u[i] - v[i]));
+        }
+        const double spread = std::isfinite(diff) && peak > 0.0 ? diff / peak : 1.0;
+        h->seq_spread = spread;
+        const double limit = dtype_double(dtype) ? 2.5e-13 : 2.5e-9;   // (400 x spread stays inside the contract)
+        if (opt().iir_seq == 2 || !(spread <= limit)) {
+            h->seq = true;
+            h->seq_coef = coef;
+            *out = h.release();
+            return SKDSP_OK;
+        }
+    }
     if (nsec > 8) {
         // groups of at most 8 sections, as even as possible (10 -> 5 + 5): each a handle of its own, made from the CALLER's factorisation.
         // Between two groups the signal is stored in the handle's precision.  For float32 handles that rounding (6e-8 of the
@@ -1772,6 +1819,16 @@ int skdsp_sos_create(const double *sos, int nsec, int dtype, skdsp_handle *out)
         c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; c[3] = q[4]; c[4] = q[5];
     }
     return iir_create_common(nsec, 2, coef, dtype, out);
+}
+
+int skdsp_iir_sequential(skdsp_handle hh, int *is_sequential, double *spread)
+{
+    HandleBase *hb = static_cast<HandleBase *>(hh);
+    SK_CHECK(hb && hb->kind == H_IIR, SKDSP_ERR_BADARG, "iir_sequential: not an IIR handle");
+    IirHandle *h = static_cast<IirHandle *>(hb);
+    if (is_sequential) *is_sequential = h->seq ? 1 : 0;
+    if (spread) *spread = h->seq_spread;
+    return SKDSP_OK;
 }
 
 int skdsp_tf2sos(const double *b, int nb, const double *a, int na, double *sos_out, int *nsec_out)

@@ -107,15 +107,19 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 // DECM: 0 every output is stored; 1 .dn (the kept outputs gathered per piece, or picked out of the image); 2 .dn with dec = 2, 3 on 4-sample
 // units (gathered behind the recurrence in ranges of chunks) -- an instantiation of its own: inside the others its 64 predicated LDS
 // writes cost the 8-biquad kernels 450 spilled SGPRs and 2 % on every other M
-template <int NSEC, typename IO, int DECM, bool CPLX>
+// TT: samples per chunk (0: SK_PAR_T32 / its half for float64).  The decimating kernels of float32 / complex64 signals run on chunks of 96 where M divides 96
+// (M = 2, 3, 4, 6, 8, 12, 16, 24, ...): every chunk of every segment then starts on a kept sample, all lanes of a wave walk the SAME phase, and the 2 NSEC + 1
+// term output sum is formed for one sample in M -- with 128, M = 3 put the lanes on three phases and every sum was formed (M = 12: three in twelve).
+template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0>
 __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
                                                                  const double *__restrict__ lvl, const double *__restrict__ psi)
 {
     constexpr bool DEC = DECM != 0;
     constexpr int D = 2 * NSEC;
     constexpr bool G4 = D <= 12;   // V = G x by 4 x 4 x 4 products over the row groups in use (see phase A)
-    constexpr int T = SK_PAR_T32 * 4 / (int)sizeof(IO);
+    constexpr int T = TT ? TT : SK_PAR_T32 * 4 / (int)sizeof(IO);
     constexpr int NP = T / kPiece;
+    static_assert(T % kPiece == 0 && ((T / 4) * 64) % kIirThreads == 0, "chunk length: whole pieces, a table the workgroup loads evenly");
     using St = Stage<IO>;
     constexpr int kRowBytes = St::pitch * (int)sizeof(IO);
     constexpr int kWaveStage = 64 * kRowBytes;                    // 9216 (float) / 17408 (double) bytes: also holds the 8 KiB scan exchange
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     constexpr bool rounds = DECM == 2;
     int64_t dec_q0 = 0;
     unsigned dec_r0 = 0, dq = 0, dt = 0;
-    if (compact || rounds) {
+    if (DEC) {
         dec_q0 = m0 / a.dec;
         dec_r0 = (unsigned)(m0 - dec_q0 * a.dec);
         const unsigned v0 = dec_r0 + (unsigned)((lane / LS) * T);
@@ -603,10 +607,12 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
             if (DEC && e == 0) {
                 e0r = dtr == 0 ? 0u : (unsigned)a.dec - dtr;
                 dtr += kE;
-                if (dtr >= (unsigned)a.dec) dtr -= (unsigned)a.dec;
+                dtr = dtr >= (unsigned)a.dec ? dtr - (unsigned)a.dec : dtr;
+                dtr = dtr >= (unsigned)a.dec ? dtr - (unsigned)a.dec : dtr;   // (M = 2, 3: a 4-sample unit spans more than one period)
             }
             const double xd = (double)xq[(p * kPiece + k) / kE][e];
-            if (!DEC || !compact || e0r == (unsigned)e) {
+            // (the unit's kept samples: e0r and, with M below the samples of a unit, e0r + M)
+            if (!DEC || e0r == (unsigned)e || e0r + (unsigned)a.dec == (unsigned)e) {
                 double yv = gam * xd;
 #pragma unroll
                 for (int s = 0; s < NSEC; ++s) {
@@ -777,7 +783,7 @@ struct ParPlan {
     long double a1[8], a2[8], r0[8], r1[8], c0 = 0.0L;
     double na1[8], na2[8], al[8], be[8], gamma = 0.0;
     double kappa = 0.0, ir_err = 0.0;
-    ParTables tab[4];            // [0] float32 (T = 128), [1] float64 (T = 64), [2] complex64, [3] complex128 (32 chunks per segment)
+    ParTables tab[6];            // [0] float32 (T = 128), [1] float64 (T = 64), [2] complex64, [3] complex128 (32 chunks per segment), [4] / [5] float32 / complex64 with T = 96 (.dn)
     unsigned long long *lbg_dev = nullptr;
     size_t lbg_cap = 0;
     unsigned long long *ticket_dev = nullptr;
@@ -1009,7 +1015,7 @@ template <typename IO, bool CPLX> static bool par_dec_rounds(int dec)
     return sizeof(IO) == 4 && (dec == 2 || dec == 3) && opt().iir_dn_compact;
 }
 
-template <typename IO, bool CPLX>
+template <typename IO, bool CPLX, int TT = 0>
 static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
                       void *y, hipStream_t s, int dec, int up = 1)
 {
@@ -1068,12 +1074,12 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
         cf.gamma = p->gamma;                                                                                            \
         if (a.dec > 1 && a.dec_rounds > 1) {                                                                            \
             if constexpr (sizeof(IO) == 4)                                                                              \
-                hipLaunchKernelGGL((iir_par_kernel<N, IO, 2, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,        \
+                hipLaunchKernelGGL((iir_par_kernel<N, IO, 2, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,    \
                                    (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);  \
         } else if (a.dec > 1)                                                                                           \
-            hipLaunchKernelGGL((iir_par_kernel<N, IO, 1, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,            \
+            hipLaunchKernelGGL((iir_par_kernel<N, IO, 1, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,        \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);      \
-        else                                                                                                            \
+        else if constexpr (TT == 0)                                                                                     \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,            \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);      \
         break;                                                                                                          \
@@ -1105,7 +1111,19 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     ParPlan *p = h->par;
     if (p->state != 1) return 1;
     const bool dbl = dtype_double(h->dtype);
-    ParTables &tb = p->tab[(dbl ? 1 : 0) + (interleaved ? 2 : 0)];
+    // .dn of float32 / complex64 signals by a divisor of 96: chunks of 96 samples, so that all lanes of a wave walk the same phase (see the kernel)
+    // (measured, 2^26 inputs, profiles/r05/iir_dn.txt: 8-biquad elliptic M = 3 0.193 -> 0.173 ms, order-8 Butterworth M = 2 0.126 -> 0.114; from M = 4 on the
+    // shorter segments cost more than the aligned phases save -- M = 4 + 7 .. 9 %, M = 12 + 3 % -- and 128 is a multiple of the powers of two anyway)
+    bool t96 = !dbl && dec > 1 && ((opt().iir_dn_t96 == 1 && (dec == 2 || dec == 3 || dec == 6)) || (opt().iir_dn_t96 == 2 && 96 % dec == 0));
+    if (t96) {
+        ParTables &t9 = p->tab[4 + (interleaved ? 1 : 0)];
+        if (t9.T == 0) {
+            const int rc = par_tables(*p, t9, 96, interleaved ? 32 : 64, 1e-18L, par_max_k(false), s);
+            if (rc < 0) return rc;
+        }
+        if (t9.K == 0) t96 = false;   // (the filter remembers more segments of this length than the look-back serves: the 128-sample chunks, if they do)
+    }
+    ParTables &tb = t96 ? p->tab[4 + (interleaved ? 1 : 0)] : p->tab[(dbl ? 1 : 0) + (interleaved ? 2 : 0)];
     if (tb.T == 0) {
         // negligibility as in iir_scan.hip: 1e-30 for float64 signals, 1e-18 for float32 signals (a tenth of an ulp of the
         // float64 state the dropped term would be added to)
@@ -1116,6 +1134,9 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     // (interleaved signals have no decimating store here but the compact one)
     if (interleaved && dec > 1 && !(dbl ? par_dec_compact<double, true>(dec, (int64_t)32 * tb.T)
                                         : (par_dec_compact<float, true>(dec, (int64_t)32 * tb.T) || par_dec_rounds<float, true>(dec)))) return 1;
+    if (t96)
+        return interleaved ? launch_par<float, true, 96>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up)
+                           : launch_par<float, false, 96>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up);
     if (interleaved)
         return dbl ? launch_par<double, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up) : launch_par<float, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up);
     return dbl ? launch_par<double, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up)

@@ -918,6 +918,7 @@ IirHandle::~IirHandle()
     for (IirHandle *g : groups) delete g;
     if (group_tmp) (void)hipFree(group_tmp);
     delete twin64;
+    if (seq_coef_dev) (void)hipFree(seq_coef_dev);
     if (twin_in) (void)hipFree(twin_in);
     if (twin_out) (void)hipFree(twin_out);
 }
@@ -1205,6 +1206,10 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
             else memset(zf_host, 0, (size_t)nbatch * h->nsec * h->order * 8);
         }
         return SKDSP_OK;
+    }
+    if (h->seq) {   // an ill-conditioned cascade: the reference's own recursion (iir_seq.hip)
+        if (interleaved) return 1;
+        return iir_seq_launch(h, x, n, nbatch, batch_stride, batch_stride, y, s, zi_host, zf_host, dec);
     }
     if (h->twin64) {
         // the float64 detour (see IirHandle::twin64): planar float32 in, planar float32 out

@@ -48,6 +48,8 @@ struct Options {
     int iir_no_mfma = 0;      // recurrence K1 instead of the matrix-pipe K1
     int iir_two_pass = 0;     // 1: K1 + carries + K3 even where the single-pass scan applies; -1: single pass wherever it applies
     int iir_par = 1;          // 0: never the parallel-form scan (iir_par.hip); the cascade kernels everywhere
+    int iir_seq = 1;          // cascades of more than 8 sections whose float64 spread the scans would lift past the contract run the reference's recursion (iir_seq.hip): 1 probed, 2 always, 0 never
+    int iir_dn_t96 = 1;       // the parallel-form .dn of float32 / complex64 signals on 96-sample chunks: 1 for M = 2, 3, 6 (measured), 2 wherever M divides 96, 0 never (A/B switch)
     int iir_dn_compact = 1;   // 0: the parallel-form .dn keeps the image-and-pick store for every M (A/B switch)
     int fir_up_ols_min = 64;  // multirate_FIR.up: phases of at least this many taps MAY go through the overlap-save walk (the cost model
                               // of fir_up_prefers_ols decides); 0: never; -k: always from k taps per phase on (A/B switch)
@@ -254,6 +256,12 @@ struct IirHandle : HandleBase {
     IirHandle *twin64 = nullptr;
     void *twin_in = nullptr, *twin_out = nullptr;
     size_t twin_in_bytes = 0, twin_out_bytes = 0;
+    // Cascades whose float64 result is itself uncertain beyond what the scans may add to it (capi.hip: the probe at creation) run the reference's
+    // own recursion (iir_seq.hip): the caller's sections [nsec][5], the relative float64 spread the probe measured
+    bool seq = false;
+    double seq_spread = 0.0;
+    std::vector<double> seq_coef;
+    void *seq_coef_dev = nullptr;
     int group_first = 0;             // (a group: its first section in the parent's numbering)
     void *group_tmp = nullptr;       // full-rate intermediate of a decimating call
     size_t group_tmp_bytes = 0;
@@ -266,6 +274,9 @@ int iir_launch_planar(IirHandle *h, const void *x_dev, int64_t n, int nbatch, in
                       int interleaved = 0,   // 1: x / y interleaved complex, nbatch = 2; returns 1 if not applicable
                       int dec = 1);          // > 1 (real signals): y receives only every dec-th output (n / dec samples)
 void iir_free(IirPlan *p);
+// the reference's recursion, one wave per row (iir_seq.hip): handles with h->seq set
+int iir_seq_launch(IirHandle *h, const void *x_dev, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y_dev, hipStream_t s,
+                   const double *zi_host = nullptr, double *zf_host = nullptr, int dec = 1);
 // Parallel-form single-pass scan (iir_par.hip): real signals, <= 8 biquads with simple poles, zero initial state, no state
 // output; nrow rows x_stride / y_stride elements apart in one launch.  Returns 1 when it does not apply (nothing launched).
 int iir_par_launch(IirHandle *h, const void *x_dev, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y_dev, hipStream_t s,

@@ -31,7 +31,7 @@ SYMBOLS = [
     "skdsp_fir_up", "skdsp_fir_up_dev", "skdsp_fir_dn", "skdsp_fir_dn_dev", "skdsp_fir_updn", "skdsp_fir_updn_dev",
     "skdsp_sos_create", "skdsp_tf_create", "skdsp_tf2sos", "skdsp_iir_filter", "skdsp_iir_filter_dev", "skdsp_iir_up",
     "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev", "skdsp_iir_state_len", "skdsp_iir_filter_state_dev",
-    "skdsp_iir_filter_rows", "skdsp_iir_filter_rows_dev", "skdsp_sos_par_info",
+    "skdsp_iir_filter_rows", "skdsp_iir_filter_rows_dev", "skdsp_sos_par_info", "skdsp_iir_sequential",
     "skdsp_upsample", "skdsp_upsample_dev", "skdsp_downsample", "skdsp_downsample_dev", "skdsp_set_wide_output", "skdsp_destroy",
     "skdsp_dist_unique_id", "skdsp_dist_init", "skdsp_dist_shutdown", "skdsp_dist_comm_count", "skdsp_dist_barrier",
     "skdsp_dist_allreduce_max", "skdsp_dist_allreduce_sum", "skdsp_dist_sendrecv", "skdsp_dist_allgather", "skdsp_dist_halo_exchange", "skdsp_fir_filter_shard_dev",
@@ -108,6 +108,8 @@ def load():
         L.skdsp_iir_filter_rows.argtypes = [vp, vp, i64, i64, vp]
         L.skdsp_iir_filter_rows_dev.argtypes = [vp, vp, i64, i64, i64, i64, vp]
         L.skdsp_sos_par_info.argtypes = [vp, ci, vp, ctypes.POINTER(ci)]
+        if hasattr(L, "skdsp_iir_sequential"):
+            L.skdsp_iir_sequential.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_double)]
         L.skdsp_iir_up.argtypes = [vp, vp, i64, ci, vp]
         L.skdsp_iir_up_dev.argtypes = [vp, vp, i64, ci, vp]
         L.skdsp_iir_dn.argtypes = [vp, vp, i64, ci, vp]
@@ -561,6 +563,16 @@ class IirKernel(_HostCalls):
             check(L.skdsp_tf_create(_ptr(bb), bb.size, _ptr(aa), aa.size, code, ctypes.byref(h)))
         self.h = h.value
         self._fin = weakref.finalize(self, _destroy, self.h)
+        seq, spread = ctypes.c_int(0), ctypes.c_double(0.0)
+        if hasattr(L, "skdsp_iir_sequential"):
+            check(L.skdsp_iir_sequential(ctypes.c_void_p(self.h), ctypes.byref(seq), ctypes.byref(spread)))
+        self.sequential, self.spread = bool(seq.value), spread.value
+        if self.sequential:
+            import logging
+            logging.getLogger("sk_dsp_comm_amd").warning(
+                "IIR cascade of %d sections is ill-conditioned: two float64 evaluations of it (sections in another order) differ by %.1e of "
+                "the output; it runs the reference's own sample-by-sample recursion on the GPU (exact, but at a host core's speed)",
+                int(np.asarray(sos).shape[0]) if sos is not None else -1, self.spread)
 
     def filter(self, x, wide=False):
         return self._host(x.size, x.dtype, wide, lambda y: check(load().skdsp_iir_filter(ctypes.c_void_p(self.h), _ptr(x), x.size, _ptr(y))))

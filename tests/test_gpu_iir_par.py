@@ -759,3 +759,56 @@ def test_fir_up_default_dispatch_is_near_the_fastest_engine(dt, L, T):
     finally:
         xd.free()
         yd.free()
+
+
+# ---------------------------------------------------------------------------------------------------- ill-conditioned cascades
+def test_ill_conditioned_cascade_runs_the_reference_recursion(caplog):
+    """A 40th-order Chebyshev cascade is good to ~1e-6 of its output in float64 at best (two evaluations of the reference, sections in
+    another order, differ by that much), and a scan adds to it.  skdsp_sos_create probes for that and such a handle runs scipy.signal.sosfilt's
+    own recursion, sample by sample, in its operation order (csrc/iir_seq.hip): float64 results are BIT-IDENTICAL to the reference's
+    (multirate_helper.py:173, :181, :190), float32 ones the same rounded once; states (zi / zf) in scipy's coordinates."""
+    import logging
+    from scipy import signal
+    sos = signal.cheby1(40, 0.5, 0.3, output="sos")
+    rng = np.random.default_rng(8)
+    with caplog.at_level(logging.WARNING, logger="sk_dsp_comm_amd"):
+        k = _ffi.IirKernel(_ffi.F64, sos=sos)
+    assert k.sequential and k.spread > 2.5e-13
+    assert any("ill-conditioned" in r.getMessage() for r in caplog.records)
+    x = rng.standard_normal(20_001)
+    _ffi.debug_path()
+    y = k.filter(x)
+    assert "iir_seq" in _ffi.debug_path()
+    assert np.array_equal(y, signal.sosfilt(sos, x))
+    # .up / .dn: the same recursion over the zero-stuffed signal / with every M-th output kept
+    up = np.zeros(3 * 5000)
+    up[::3] = 3 * x[:5000]
+    assert np.array_equal(k.up(x[:5000], 3), signal.sosfilt(sos, up))
+    assert np.array_equal(np.asarray(k.dn(x, 3)), signal.sosfilt(sos, x)[::3][:x.size // 3])
+    # complex signals: two rows of the same recursion
+    kc = _ffi.IirKernel(_ffi.C128, sos=sos)
+    xc = x[:7000] + 1j * rng.standard_normal(7000)
+    assert np.array_equal(kc.filter(xc), signal.sosfilt(sos, xc))
+    # float32 signals: the float64 recursion on the widened samples, rounded once
+    k32 = _ffi.IirKernel(_ffi.F32, sos=sos)
+    assert k32.sequential
+    x32 = x.astype(np.float32)
+    assert np.array_equal(k32.filter(x32), signal.sosfilt(sos, x32.astype(np.float64)).astype(np.float32))
+    # states across calls, in scipy's coordinates
+    zi = rng.standard_normal((20, 2)) * 1e-3
+    y1, zf = k.filter_state(x[:6000], zi.ravel())
+    r1, rz = signal.sosfilt(sos, x[:6000], zi=zi)
+    assert np.array_equal(y1, r1) and np.array_equal(zf.reshape(20, 2), rz)
+    # more than 64 sections: pass after pass
+    sos80 = np.vstack([signal.butter(2, 0.3 + 0.002 * i, output="sos") for i in range(80)])
+    with _ffi.option("iir_seq", 2):
+        k80 = _ffi.IirKernel(_ffi.F64, sos=sos80)
+    assert k80.sequential
+    assert np.array_equal(k80.filter(x[:5000]), signal.sosfilt(sos80, x[:5000]))
+
+
+def test_well_conditioned_cascades_keep_the_scans():
+    from scipy import signal
+    for sos in (signal.butter(24, 0.2, output="sos"), signal.butter(40, 0.4, output="sos"), signal.ellip(8, 0.5, 60, 0.3, output="sos")):
+        k = _ffi.IirKernel(_ffi.F32, sos=sos)
+        assert not k.sequential, (sos.shape, k.spread)
