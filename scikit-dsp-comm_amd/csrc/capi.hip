@@ -109,7 +109,7 @@ const OptEntry kOptTable[] = {
     {"device", &Options::device}, {"fir_algo", &Options::fir_algo}, {"dn_no_ols", &Options::dn_no_ols},
     {"fir_mm", &Options::fir_mm}, {"fir_bx", &Options::fir_bx}, 
     
-    {"ols_reserve", &Options::ols_reserve}, {"fir_dn_fold", &Options::fir_dn_fold}, {"iir_seq", &Options::iir_seq}, {"iir_dn_t96", &Options::iir_dn_t96}, {"iir_planar", &Options::iir_planar}, 
+    {"ols_reserve", &Options::ols_reserve}, {"fir_dn_fold", &Options::fir_dn_fold}, {"fir_up_rep", &Options::fir_up_rep}, {"iir_seq", &Options::iir_seq}, {"iir_dn_t96", &Options::iir_dn_t96}, {"iir_planar", &Options::iir_planar}, 
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, 
     {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up4k", &Options::fir_up4k}, {"fir_up4k_group", &Options::fir_up4k_group}, {"fir_up4k_staged", &Options::fir_up4k_staged}, {"fir_up2k", &Options::fir_up2k}, {"fir_dn4k", &Options::fir_dn4k}, {"fir_up_pair", &Options::fir_up_pair}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, 
     {"shard_two_launches", &Options::shard_two_launches},
@@ -445,8 +445,21 @@ static double fir_up_tile_ms(const FirHandle *h, int L, int kind, int *V_out)
     return ms * (double)N / (double)(N - ov);
 }
 
-static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
+// multirate_FIR.up, even L, on tiles of the OUTPUT (fir_ols.hip: ols_rep_kernel): ms per 2^26 outputs (round-5 timings, profiles/r05/fir_up.txt: the plain
+// filter's tile with a quarter of its forward transform and 1 / L of its loads; the overlap is that of the WHOLE filter at the high rate)
+static double fir_up_rep_ms(const FirHandle *h, int L)
 {
+    const int ov = std::max(512, (h->ntaps - 1 + 511) / 512 * 512);
+    const bool cplx = h->dtype == SKDSP_C64;
+    const bool pow2 = (L & (L - 1)) == 0 && L <= 16;   // (else the decimated grid is itself zero-stuffed: the guarded loader, 4-byte samples feel it)
+    const double base = cplx ? (L == 2 ? 0.161 : 0.152) : (L == 2 ? 0.087 : (L == 4 ? 0.083 : 0.0885)) * (pow2 ? 1.0 : 1.18);
+    return base * 8192.0 / (8192.0 - ov);
+}
+
+// best: which frequency-domain engine the model found cheapest (1 the walk over (tile, phase) pairs, 2 an input-tile interpolator, 3 the output-tile one)
+static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1, int *best = nullptr)
+{
+    if (best) *best = 1;
     const int T = (h->ntaps + L - 1) / L;
     const int floor_t = opt().fir_up_ols_min;   // < 0: wherever supported from -floor_t taps per phase on, no cost model (tests, A/B timing)
     const bool dbl = dtype_double(h->dtype);
@@ -511,7 +524,12 @@ static bool fir_up_prefers_ols(const FirHandle *h, int L, int64_t n, int M = 1)
             int Vt = 0;
             const double ms = fir_up_tile_ms(h, L, kind, &Vt);
             const double tiles = (double)((n + Vt - 1) / Vt);
-            ols = std::min(ols, ms * std::ceil(tiles / slots) * slots * (double)Vt * Lf / 67108864.0);
+            const double tms = ms * std::ceil(tiles / slots) * slots * (double)Vt * Lf / 67108864.0;
+            if (tms < ols) { ols = tms; if (best) *best = 2; }
+        }
+        if (opt().fir_up_rep && fir_ols_rep_supported(h, L)) {
+            const double rms = fir_up_rep_ms(h, L) * (double)n * Lf / 67108864.0;
+            if (rms < ols) { ols = rms; if (best) *best = 3; }
         }
     }
     return ols < poly;
@@ -525,6 +543,12 @@ static int fir_updn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hi
         return dtype_double(h->dtype) ? fir_ols64_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream, dec)
                                       : fir_ols_up_launch(h, x_dev, n, n_hist, L, out, ctx().stream, dec);
     };
+    // even L: tiles of the OUTPUT, the zero-stuffed tile's spectrum from its non-zero columns (ols_rep_kernel); option fir_up_rep = 2: wherever it applies
+    if (M == 1 && n * L >= 8192 && fir_ols_rep_supported(h, L)) {
+        int best = 0;
+        if (opt().fir_up_rep >= 2 || (opt().fir_up4k < 2 && opt().fir_up_ols_min > 0 && fir_up_prefers_ols(h, L, n, 1, &best) && best == 3))   // (an engine forced by option stays forced)
+            return fir_ols_rep_launch(h, x_dev, n, n_hist, L, y_dev, ctx().stream);
+    }
     // one workgroup per input tile, all L phases from ONE forward transform (fir_up4k.hip / fir_up2k.hip); option fir_up4k: 0 never, 2
     // wherever one applies (tests, A/B timing), 1 where the cost model above prefers the frequency domain
     if (M == 1 && n >= 2048) {

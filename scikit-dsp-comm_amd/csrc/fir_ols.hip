@@ -63,6 +63,11 @@ struct OlsArgs {
     unsigned halo_seq;
     unsigned *halo_err;  // host-mapped: set if the bounded wait gave up (the caller reports it; the launch never hangs)
     CarefulFir cf;       // the filter as the exact path of a poisoned tile reads it (careful.hpp)
+    // ols_rep_kernel (multirate_FIR.up on the replicated spectrum): x holds n_in samples at the LOW rate (rep_hist of history in front), n = n_in L;
+    // rep_lr = L / LF, what is left of L beyond the power of two LF the kernel is compiled for (the zero-stuffed grid is itself stuffed rep_lr-fold)
+    int rep_L, rep_lr;
+    unsigned rep_magic;  // ceil(2^32 / rep_lr)
+    int64_t n_in, rep_hist;
 };
 
 // The owner of tile 0 calls this (whole workgroup, uniform) before its first load of that tile: one lane polls with
@@ -781,6 +786,139 @@ __global__ __launch_bounds__(256, 2) void ols_fold_kernel(OlsArgs A)
     }
 }
 
+
+// ---- multirate_FIR.up, even L: the forward transform of the zero-stuffed tile from its non-zero columns alone ---------------------------------
+// (ols_core.hpp: fwd_pass1_rep / fwd_pass23_rep.)  The tile is a tile of the OUTPUT: loads are a quarter (L = 4) of the plain filter's, the forward
+// transform about a quarter, H product, inverse transform and the full-width 16-byte stores the plain filter's own.  LF = the largest of 16, 8,
+// 4, 2 that divides L; with L = LF rep_lr (12 = 4 x 3) the LF-fold decimated grid is itself zero-stuffed: only every rep_lr-th of its samples is an
+// input.  Thread (b, q) with q a multiple of LF / 2 loads grid elements (512 / LF) a + (32 / LF) b + 2 q / LF of the tile, a = 0 .. 15.
+template <bool REAL, int LF>
+__device__ __forceinline__ void load_rep(const OlsArgs &A, int64_t tile, int t, cf *in)
+{
+    constexpr int LS = LF / 2, JA = 512 / LF;
+    const int b = t >> 4, q = t & 15;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) in[a] = make_float2(0.f, 0.f);
+    if (q % LS != 0) return;
+    const int j0 = (32 / LF) * b + q / LS;
+    const int Lr = A.rep_lr;
+    const int64_t in0 = (REAL ? 2 * tile : tile) * (int64_t)A.V - A.ov;    // up-rate index of the tile's first sample (a multiple of 512)
+    const int64_t e0 = in0 / LF;                                            // the same on the LF-fold decimated grid (exact)
+    // grid element e is input sample e / Lr where Lr divides e: e0 = Lr q0 + r0, 0 <= r0 < Lr (floor division: e0 is negative in the first tile)
+    int64_t q0 = e0, r0 = 0;
+    if (Lr > 1) {
+        q0 = e0 / Lr;
+        r0 = e0 - q0 * Lr;
+        if (r0 < 0) { r0 += Lr; q0 -= 1; }
+    }
+    const int VD = A.V / LF;                                                // grid elements between the pair's two tiles (REAL)
+    auto fetch = [&](unsigned d, int64_t &idx) -> bool {                    // grid element e0 + d -> input index; false: a stuffed zero
+        if (Lr == 1) { idx = q0 + d; return true; }
+        const unsigned g = (unsigned)r0 + d;
+        const unsigned k = (unsigned)(((unsigned long long)g * A.rep_magic) >> 32);
+        idx = q0 + k;
+        return k * (unsigned)Lr == g;
+    };
+    const bool interior = Lr == 1 && A.aligned && e0 >= -A.rep_hist && e0 + kN / LF + (REAL ? VD : 0) <= A.n_in;
+    int tt = j0;   // (opaque copy: the addresses are rebuilt per tile instead of living in registers across the tile loop)
+    asm volatile("" : "+v"(tt));
+    if (interior) {
+        if (REAL) {
+            const float *xa = reinterpret_cast<const float *>(A.x) + e0, *xb = xa + VD;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) in[a] = make_float2(__builtin_nontemporal_load(xa + (unsigned)(JA * a + tt)), __builtin_nontemporal_load(xb + (unsigned)(JA * a + tt)));
+        } else {
+            const v2f_t *xc = reinterpret_cast<const v2f_t *>(A.x) + e0;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                const v2f_t r = __builtin_nontemporal_load(xc + (unsigned)(JA * a + tt));
+                in[a] = make_float2(r.x, r.y);
+            }
+        }
+        return;
+    }
+#pragma unroll   // (unrolled: a run-time index into `in` would move the whole array to scratch memory)
+    for (int a = 0; a < 16; ++a) {
+        int64_t ia, ib;
+        if (REAL) {
+            const float *xr = reinterpret_cast<const float *>(A.x);
+            float va = 0.f, vb = 0.f;
+            if (fetch((unsigned)(JA * a + tt), ia) && ia >= -A.rep_hist && ia < A.n_in) va = xr[ia];
+            if (fetch((unsigned)(JA * a + tt + VD), ib) && ib >= -A.rep_hist && ib < A.n_in) vb = xr[ib];
+            in[a] = make_float2(va, vb);
+        } else if (fetch((unsigned)(JA * a + tt), ia) && ia >= -A.rep_hist && ia < A.n_in) {
+            in[a] = A.x[ia];
+        }
+    }
+}
+
+template <bool REAL, int LF>
+__global__ __launch_bounds__(256, 2) void ols_rep_kernel(OlsArgs A)
+{
+    __shared__ float4 lds[kLdsUnits + 2 * kT2Units];
+    __shared__ unsigned long long ols_noted;   // poisoned tiles, by walk step (careful.hpp)
+    if (threadIdx.x == 0) ols_noted = 0;
+    float4 *T2f = lds + kLdsUnits, *T2t = lds + kLdsUnits + kT2Units;
+    const int t = threadIdx.x;
+    {
+        const float4 w = A.T2[t];
+        T2f[t] = w;
+        T2t[(t & 15) * 16 + (t >> 4)] = w;
+    }
+    cf tw[16];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) tw[k1] = lo(A.T1[k1 * 256 + t]);
+    tw[0] = make_float2(1.f, 0.f);
+    __syncthreads();
+    float4 hh[16];
+    auto first_tile = [&]() -> int64_t { return (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x; };
+    int64_t tile = first_tile();
+    load_H(t, A.Hp, hh);
+    cf in[16];
+    if (tile < A.ntiles) load_rep<REAL, LF>(A, tile, t, in);
+#pragma unroll
+    for (int i = 0; i < 16; i += 8)
+        asm volatile("" ::"v"(in[i].x), "v"(in[i].y), "v"(in[i + 1].x), "v"(in[i + 1].y), "v"(in[i + 2].x), "v"(in[i + 2].y),
+                     "v"(in[i + 3].x), "v"(in[i + 3].y), "v"(in[i + 4].x), "v"(in[i + 4].y), "v"(in[i + 5].x), "v"(in[i + 5].y),
+                     "v"(in[i + 6].x), "v"(in[i + 6].y), "v"(in[i + 7].x), "v"(in[i + 7].y));
+    for (int64_t step = 0; tile < A.ntiles; tile += gridDim.x, ++step) {
+        fwd_pass1_rep<LF>(t, in, tw, lds);
+        __syncthreads();
+        cf Z[32];
+        fwd_pass23_rep<LF>(t, T2f, lds, Z);
+        mul_H(hh, Z);
+        const int64_t next = tile + gridDim.x;
+        cf nx[16];
+        __builtin_amdgcn_s_setprio(3);
+        if (next < A.ntiles) load_rep<REAL, LF>(A, next, t, nx);
+        __builtin_amdgcn_s_setprio(0);
+        inv_pass32(t, T2t, lds, Z);
+        __syncthreads();
+        cf v[32];
+        inv_pass1(t, tw, lds, v);
+#pragma unroll
+        for (int i = 0; i < 16; i += 8)
+            asm volatile("" ::"v"(nx[i].x), "v"(nx[i].y), "v"(nx[i + 1].x), "v"(nx[i + 1].y), "v"(nx[i + 2].x), "v"(nx[i + 2].y),
+                         "v"(nx[i + 3].x), "v"(nx[i + 3].y), "v"(nx[i + 4].x), "v"(nx[i + 4].y), "v"(nx[i + 5].x), "v"(nx[i + 5].y),
+                         "v"(nx[i + 6].x), "v"(nx[i + 6].y), "v"(nx[i + 7].x), "v"(nx[i + 7].y)
+                         : "memory");
+        __builtin_amdgcn_s_setprio(3);
+        store_any<REAL, false>(A, tile, t, v, lds);
+        __builtin_amdgcn_s_setprio(0);
+        if (__builtin_expect(__any(not_finite(v[31].x) | not_finite(v[31].y)), 0)) careful_note(&ols_noted, step);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) in[i] = nx[i];
+        __syncthreads();  // every wave is done reading the image before the next tile overwrites it
+    }
+    const unsigned long long noted = careful_noted(&ols_noted);
+    if (__builtin_expect(noted != 0, 0)) {
+        int64_t w = first_tile();
+        for (int64_t k = 0; w < A.ntiles; w += gridDim.x, ++k)
+            if (careful_step_noted(noted, k))
+                careful_fir_range<float, !REAL>(A.x, A.y, A.rep_hist, A.n, (REAL ? 2 * w : w) * (int64_t)A.V, (REAL ? 2 : 1) * (int64_t)A.V, A.rep_L, 1, A.cf, t);
+    }
+}
+
 bool fir_ols_supported(const FirHandle *h)
 {
     // complex64 signal; overlap must leave at least half the tile as useful output
@@ -829,7 +967,7 @@ static int build_plan(const FirHandle *h, int up, OlsPlan **out, int kind = 0)
         return SKDSP_OK;
     }
     const int comp = h->taps_complex ? 2 : 1;
-    const int T = (h->ntaps + up - 1) / up;
+    const int T = kind == 3 ? h->ntaps : (h->ntaps + up - 1) / up;   // (kind 3: the WHOLE filter at the high rate, with the gain L: ols_rep_kernel)
     const int q_first = kind == 2 ? up - 1 : 0;
     OlsPlan *p = new OlsPlan();
     p->ntaps = T;
@@ -841,6 +979,10 @@ static int build_plan(const FirHandle *h, int up, OlsPlan **out, int kind = 0)
     make_T2(T2);
     if (up == 1) {
         make_Hp(h->taps_host.data(), h->ntaps, comp, Hall);
+    } else if (kind == 3) {
+        std::vector<double> scaled(h->taps_host);
+        for (double &v : scaled) v *= (double)up;   // (the gain L of multirate_FIR.up)
+        make_Hp(scaled.data(), h->ntaps, comp, Hall);
     } else {
         std::vector<double> ph((size_t)T * comp);
         for (int q = q_first; q < up; ++q) {
@@ -940,6 +1082,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.n_keep = n;
     A.up = 1; A.up_pitch = 0; A.up_sb = A.up_pbs = A.up_pb0 = 0;
     A.halo_flag = halo_flag; A.halo_seq = halo_seq; A.halo_err = halo_err;
+    A.rep_L = 0; A.rep_lr = 1; A.rep_magic = 0; A.n_in = 0; A.rep_hist = 0;
     if ((rc = fir_careful(h, &A.cf))) return rc;
     SK_CHECK(!(halo_flag && real), SKDSP_ERR_UNSUPPORTED, "fir_ols: halo flag wait is for complex64 shards");
     int64_t grid = 2 * (int64_t)ctx().num_cus;  // 2 resident workgroups per CU (76 KiB LDS each)
@@ -1000,7 +1143,7 @@ bool fir_ols_up_pairs(const FirHandle *h, int L, int dec, const void *y)
 
 static int up_plan(FirHandle *h, int L, int kind, OlsPlan **out)
 {
-    const int key = kind == 1 ? -L : (kind == 2 ? 1000 + L : L);
+    const int key = kind == 1 ? -L : (kind == 2 ? 1000 + L : (kind == 3 ? 100000 + L : L));
     for (auto &u : h->ols_up)
         if (u.L == key) { *out = u.plan; return SKDSP_OK; }
     int rc = build_plan(h, L, out, kind);
@@ -1041,6 +1184,7 @@ static int up_walk(FirHandle *h, int kind, const void *x, int64_t n, int64_t n_h
     A.up_pbs = xr ? 8 : esz;
     A.up_pb0 = kind == 2 ? (L - 1) * esz : 0;
     A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr;
+    A.rep_L = 0; A.rep_lr = 1; A.rep_magic = 0; A.n_in = 0; A.rep_hist = 0;
     if ((rc = fir_careful(h, &A.cf))) return rc;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
     const int reserve_wgs = opt().ols_reserve;
@@ -1058,6 +1202,60 @@ static int up_walk(FirHandle *h, int kind, const void *x, int64_t n, int64_t n_h
         if (real) hipLaunchKernelGGL((ols_tile_kernel<true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
         else hipLaunchKernelGGL((ols_tile_kernel<false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, A);
     }
+    SK_HIP(hipGetLastError());
+    return SKDSP_OK;
+}
+
+// multirate_FIR.up, even L, at most 4097 taps in all: tiles of the OUTPUT, the zero-stuffed tile's spectrum from its non-zero columns (ols_rep_kernel)
+bool fir_ols_rep_supported(const FirHandle *h, int L)
+{
+    if (L < 2 || L % 2 || L > 4096 || !opt().fir_up_rep) return false;
+    return fir_ols_supported(h);
+}
+
+int fir_ols_rep_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, int L, void *y, hipStream_t s)
+{
+    note_path("fir_ols_rep");
+    if (n <= 0) return SKDSP_OK;
+    SK_CHECK(fir_ols_rep_supported(h, L), SKDSP_ERR_UNSUPPORTED, "fir_ols_rep: needs complex64 (or float32 with real taps), an even L and 2..4097 taps");
+    OlsPlan *p = nullptr;
+    int rc = up_plan(h, L, 3, &p);
+    if (rc) return rc;
+    const bool real = h->dtype == SKDSP_F32;
+    const int lf = L % 16 == 0 ? 16 : (L % 8 == 0 ? 8 : (L % 4 == 0 ? 4 : 2));
+    OlsArgs A;
+    A.x = (const cf *)x;
+    A.y = (cf *)y;
+    A.n = n * L;                  // (the rate the tiles live at)
+    A.n_hist = n_hist * L;
+    A.T1 = p->T1; A.T2 = p->T2; A.Hp = p->Hp;
+    A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512;
+    A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & (real ? 3 : 7)) == 0;
+    int64_t ntiles = (A.n + p->V - 1) / p->V;
+    if (real) ntiles = (ntiles + 1) / 2;
+    SK_CHECK(ntiles < (int64_t)1 << 31, SKDSP_ERR_BADARG, "fir_ols_rep: too many tiles");
+    A.ntiles = ntiles;
+    A.dec = 1; A.dec_magic = 0; A.n_keep = A.n;
+    A.up = 1; A.up_pitch = 0; A.up_sb = A.up_pbs = A.up_pb0 = 0;
+    A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr;
+    A.rep_L = L; A.rep_lr = L / lf;
+    A.rep_magic = A.rep_lr > 1 ? (unsigned)((((unsigned long long)1 << 32) + A.rep_lr - 1) / A.rep_lr) : 0u;
+    A.n_in = n; A.rep_hist = n_hist;
+    if ((rc = fir_careful(h, &A.cf))) return rc;
+    int64_t grid = 2 * (int64_t)ctx().num_cus;
+    const int reserve_wgs = opt().ols_reserve;
+    if (reserve_wgs > 0 && grid >= 4 * (int64_t)reserve_wgs) grid -= reserve_wgs;
+    if (grid > ntiles) grid = ntiles;
+#define SK_REP(LFV)                                                                                                  \
+    if (real) hipLaunchKernelGGL((ols_rep_kernel<true, LFV>), dim3((unsigned)grid), dim3(256), 0, s, A);             \
+    else hipLaunchKernelGGL((ols_rep_kernel<false, LFV>), dim3((unsigned)grid), dim3(256), 0, s, A)
+    switch (lf) {
+    case 2: SK_REP(2); break;
+    case 4: SK_REP(4); break;
+    case 8: SK_REP(8); break;
+    default: SK_REP(16); break;
+    }
+#undef SK_REP
     SK_HIP(hipGetLastError());
     return SKDSP_OK;
 }

@@ -58,6 +58,7 @@ struct Options {
     int fir_up_pair = 1;      // 0: float32 .up through the overlap-save walk never pairs its phases (A/B switch)
     int fir_up4k = 1;         // 0: multirate_FIR.up never through the one-workgroup-per-input-tile interpolator (fir_up4k.hip); the older engines instead (A/B switch)
     int fir_up2k = 1;         // the 2048-point tile with all phases per thread (fir_up2k.hip): 1 from five passes on (complex64: L >= 5, float32: L >= 9), 2 always, 0 never (A/B switch)
+    int fir_up_rep = 1;       // multirate_FIR.up, even L, through the replicated spectrum of the zero-stuffed tile (ols_rep_kernel): 1 where the cost model prefers it, 2 wherever it applies, 0 never (A/B switch)
     int fir_dn_fold = 1;      // multirate_FIR.dn through overlap-save, M = 2, 4, 8, 16: the folded spectrum's inverse transform (ols_fold_kernel); 0: the decimating store (A/B switch)
     int fir_dn4k = 1;         // multirate_FIR.dn through the frequency-domain decimator (fir_dn4k.hip): 1 where the cost model prefers it, 2 wherever it applies, 0 never (A/B switch)
     int fir_up4k_group = 4;   // phases (float32: pairs of phases) whose results a thread of that kernel holds before it stores: 4 (32 bytes per lane) or 2 (A/B switch)
@@ -210,6 +211,9 @@ bool fir_ols_up_pairs(const FirHandle *h, int L, int dec, const void *y_dev);   
 int fir_ols_up_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s, int dec = 1,
                       int64_t rows_pitch = 0, int paired = 0);  // dec = M: L / M, floor(n L / M) outputs; rows_pitch > 0: y[phase * rows_pitch + i] instead of
                                                                  // y[i L + phase]; paired: see fir_ols_up_pairs (rows then hold 8-byte pairs, L / 2 of them)
+// multirate_FIR.up, even L, tiles of the OUTPUT: the zero-stuffed tile's forward transform from its non-zero columns (fir_ols.hip: ols_rep_kernel)
+bool fir_ols_rep_supported(const FirHandle *h, int L);
+int fir_ols_rep_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, int L, void *y_dev, hipStream_t s);
 // multirate_FIR.up, one workgroup per input tile, all L phases from one forward transform (fir_up4k.hip): complex64, float32 with real
 // taps; at most 2049 taps per phase
 bool fir_up4k_supported(const FirHandle *h, int L);

@@ -723,18 +723,22 @@ def test_fir_from_rest_shorter_than_the_filter_runs_on_the_taps_it_reaches():
 
 @pytest.mark.parametrize("dt,L,T", [(np.complex64, 4, 256), (np.complex64, 12, 43), (np.complex64, 12, 256), (np.complex64, 8, 128), (np.complex64, 2, 96),
                                     (np.complex64, 4, 64), (np.complex64, 8, 48), (np.float32, 4, 256), (np.float32, 12, 43), (np.float32, 8, 64),
-                                    (np.float32, 2, 512), (np.float32, 16, 64)])
+                                    (np.float32, 2, 512), (np.float32, 16, 64), (np.complex64, 2, 512), (np.complex64, 6, 256), (np.complex64, 16, 256),
+                                    (np.complex64, 8, 256), (np.float32, 4, 512)])
 def test_fir_up_default_dispatch_is_near_the_fastest_engine(dt, L, T):
     """The cost model of capi.hip (fir_up_prefers_ols / fir_up_tile_ms) against a stopwatch: for the shapes of profiles/r04/fir_up.txt the engine
-    AUTO takes is within 12 % of the fastest of the three it chooses from -- the polyphase kernels, the walk over (tile, phase) pairs, the
-    one-workgroup-per-input-tile interpolators -- at 2^25 outputs with a settled clock.  (Round 3 flagged such rows by hand.)"""
+    AUTO takes is within 12 % of the fastest of the four it chooses from -- the polyphase kernels, the walk over (tile, phase) pairs, the
+    one-workgroup-per-input-tile interpolators, the output-tile interpolator (even L) -- at 2^25 outputs with a settled clock.  (Round 3 flagged such rows by hand.)"""
     import time
     import bench
     n = (1 << 25) // L
     k = _ffi.FirKernel(bench.firwin_lowpass(L * T, 0.8 / L), _ffi.code_of(dt))
     xd = _ffi.DeviceArray(n, dt).fill_noise(1)
     yd = _ffi.DeviceArray(n * L, dt)
-    engines = {"polyphase": {"fir_up_ols_min": 0}, "walk": {"fir_up_ols_min": -2, "fir_up4k": 0}, "tile": {"fir_up_ols_min": -2, "fir_up4k": 2}, "default": {}}
+    engines = {"polyphase": {"fir_up_ols_min": 0, "fir_up_rep": 0}, "walk": {"fir_up_ols_min": -2, "fir_up4k": 0, "fir_up_rep": 0},
+               "tile": {"fir_up_ols_min": -2, "fir_up4k": 2, "fir_up_rep": 0}, "default": {}}
+    if L % 2 == 0:
+        engines["output tile"] = {"fir_up_rep": 2}   # (round 5: the zero-stuffed tile's spectrum from its non-zero columns, fir_ols.hip: ols_rep_kernel)
     import contextlib
 
     def clock(opts, reps):

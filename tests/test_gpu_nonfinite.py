@@ -41,9 +41,12 @@ CASES = [
     ("direct_f64", np.float64, lowpass(48, 0.2), "filter", 1, 1, 100_001, None),
     ("parts_c64", np.complex64, lowpass(5000, 0.05), "filter", 1, 1, 150_001, "fir_ols"),
     ("up12_bx", np.complex64, lowpass(512, 0.9 / 12), "up", 12, 1, 20_001, "fir_bx"),
-    ("up4_4k", np.complex64, lowpass(1024, 0.2 / 4), "up", 4, 1, 500_001, "fir_up4k"),
-    ("up4_4k_f32", np.float32, lowpass(1024, 0.2 / 4), "up", 4, 1, 500_001, "fir_up4k"),
-    ("up12_2k", np.complex64, lowpass(3072, 0.9 / 12), "up", 12, 1, 150_001, "fir_up2k"),
+    ("up4_rep", np.complex64, lowpass(1024, 0.2 / 4), "up", 4, 1, 500_001, "fir_ols_rep"),
+    ("up2_rep_f32", np.float32, lowpass(1024, 0.2 / 2), "up", 2, 1, 500_001, "fir_ols_rep"),
+    ("up12_rep", np.complex64, lowpass(3072, 0.9 / 12), "up", 12, 1, 150_001, "fir_ols_rep"),
+    ("up3_4k", np.complex64, lowpass(768, 0.2 / 3), "up", 3, 1, 500_001, "fir_up4k"),
+    ("up3_4k_f32", np.float32, lowpass(768, 0.2 / 3), "up", 3, 1, 500_001, "fir_up4k"),
+    ("up9_2k", np.complex64, lowpass(2304, 0.9 / 9), "up", 9, 1, 600_001, "fir_up2k"),
     ("up2_walk", np.complex64, lowpass(8001, 0.4), "up", 2, 1, 60_001, "fir_ols_up"),
     ("up4_f64", np.float64, lowpass(1024, 0.2 / 4), "up", 4, 1, 40_001, None),
     ("dn12_bx", np.complex64, lowpass(512, 0.9 / 12), "dn", 1, 12, 200_001, "fir_bx"),

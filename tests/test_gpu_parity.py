@@ -1017,11 +1017,13 @@ def test_direct_fir_large_tiles_all_dtypes(dt, L, M):
 
 
 @pytest.mark.parametrize("dt", [np.complex64, np.float32])
-@pytest.mark.parametrize("M,ntaps", [(2, 512), (3, 512), (12, 768), (5, 1024), (7, 200)])
+@pytest.mark.parametrize("M,ntaps", [(2, 512), (3, 512), (12, 768), (5, 1024), (7, 200), (4, 1024), (6, 300), (8, 2048), (10, 1500), (16, 4097), (24, 777),
+                                     (32, 640), (48, 2000), (96, 3000)])
 def test_fir_dn_overlap_save_decimating_store(M, ntaps, dt):
-    """.dn of a long filter runs in the overlap-save engine and stores every M-th output: identical
-    (to float32 rounding) to the direct polyphase kernel, ragged length, with history; complex64 and
-    the float32 two-real-tiles variant."""
+    """.dn of a long filter runs in the overlap-save engine: odd M through the decimating store (every full-rate output computed, every M-th
+    kept), even M through the decimating INVERSE transform (the spectrum folded 2 / 4 / 8 / 16-fold between a thread's registers, what is left
+    of M taken at the store) -- identical (to float32 rounding) to the direct polyphase kernel and to the decimating store, ragged length,
+    with history; complex64 and the float32 two-real-tiles variant."""
     rng = np.random.default_rng(71)
     b = rng.standard_normal(ntaps) / np.sqrt(ntaps)
     n = 2 ** 20 + 12345
@@ -1038,6 +1040,12 @@ def test_fir_dn_overlap_save_decimating_store(M, ntaps, dt):
         k.dn_dev(xd, y2, M, n_hist=ntaps - 1)
         y_direct = y2.to_host()
     assert_close(y, y_direct, 2e-6, "ols-dn vs direct M=%d" % M)
+    if M % 2 == 0:   # the same call through the decimating store
+        with _ffi.option("fir_dn_fold", 0):
+            y3 = _ffi.DeviceArray(n // M, dt)
+            k.dn_dev(xd, y3, M, n_hist=ntaps - 1)
+            assert_close(y, y3.to_host(), 2e-6, "folded inverse vs decimating store M=%d" % M)
+            y3.free()
     # and against the oracle on windows (incl. the history at the start and the ragged end)
     hist = np.empty(ntaps - 1, dt)
     import ctypes
