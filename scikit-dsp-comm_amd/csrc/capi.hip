@@ -244,6 +244,18 @@ int fir_algo_for(const FirHandle *h, int64_t n) { return pick_fir_algo(h, n); }
 // launch over the input shortened by its delay (with as much of the caller's history as it can still see), and its
 // result is added onto y from output s seg on.  For .dn the segment length is a multiple of M, so every partial
 // result keeps decimation phase 0.
+// A handle over taps [t0, t0 + cnt) of `h` on slot `slot`: the ONE place that copies a FIR handle's fields (tap segments, the heads of short calls,
+// the per-slot clones of the multi-GPU host path), so that a field added to FirHandle cannot be forgotten in one of them.
+static FirHandle *fir_derive(const FirHandle *h, int t0, int cnt, int slot)
+{
+    const int comp = h->taps_complex ? 2 : 1;
+    FirHandle *d = new FirHandle();
+    d->kind = H_FIR; d->dtype = h->dtype; d->slot = slot; d->taps_complex = h->taps_complex; d->algo = h->algo; d->wide_out = h->wide_out;
+    d->ntaps = cnt;
+    d->taps_host.assign(h->taps_host.begin() + (size_t)t0 * comp, h->taps_host.begin() + (size_t)(t0 + cnt) * comp);
+    return d;
+}
+
 static int fir_part_len(const FirHandle *h)
 {
     return dtype_double(h->dtype) ? 2048 : 4096;
@@ -269,15 +281,7 @@ static int fir_parts_run(FirHandle *h, const void *x_dev, int64_t n, int64_t n_h
     if (h->part_seg != seg) {
         for (FirHandle *p : h->parts) delete p;
         h->parts.clear();
-        const int comp = h->taps_complex ? 2 : 1;
-        for (int t0 = 0; t0 < h->ntaps; t0 += seg) {
-            FirHandle *p = new FirHandle();
-            p->kind = H_FIR; p->dtype = h->dtype; p->slot = h->slot; p->taps_complex = h->taps_complex;
-            p->algo = h->algo;
-            p->ntaps = std::min(seg, h->ntaps - t0);
-            p->taps_host.assign(h->taps_host.begin() + (size_t)t0 * comp, h->taps_host.begin() + (size_t)(t0 + p->ntaps) * comp);
-            h->parts.push_back(p);
-        }
+        for (int t0 = 0; t0 < h->ntaps; t0 += seg) h->parts.push_back(fir_derive(h, t0, std::min(seg, h->ntaps - t0), h->slot));
         h->part_seg = seg;
     }
     for (FirHandle *p : h->parts) p->algo = h->algo;   // (skdsp_fir_set_algo after the parts were made)
@@ -609,11 +613,9 @@ static FirHandle *fir_head(FirHandle *h, int64_t n)
     if (keep >= h->ntaps) return h;
     for (FirHandle *t : h->heads)
         if (t->ntaps == keep) { t->algo = h->algo; return t; }
-    const int comp = h->taps_complex ? 2 : 1;
-    FirHandle *t = new FirHandle();
-    t->kind = H_FIR; t->dtype = h->dtype; t->slot = h->slot; t->taps_complex = h->taps_complex; t->algo = h->algo;
-    t->ntaps = keep;
-    t->taps_host.assign(h->taps_host.begin(), h->taps_host.begin() + (size_t)keep * comp);
+    // (at most log2(Ntaps) <= 13 heads per handle -- one per power of two below the tap count -- each with the tables of the engines it has run on: they
+    // live as long as the handle)
+    FirHandle *t = fir_derive(h, 0, keep, h->slot);
     h->heads.push_back(t);
     return t;
 }
@@ -1524,10 +1526,7 @@ static void *fir_job_on_slot(void *base, int slot)
     if (slot == h->slot) return &js->home;
     if ((int)h->clones.size() < kMaxSlots) h->clones.resize(kMaxSlots, nullptr);
     if (!h->clones[slot]) {
-        FirHandle *c = new FirHandle();
-        c->kind = H_FIR; c->dtype = h->dtype; c->slot = slot; c->ntaps = h->ntaps; c->taps_complex = h->taps_complex;
-        c->algo = h->algo; c->taps_host = h->taps_host;
-        h->clones[slot] = c;
+        h->clones[slot] = fir_derive(h, 0, h->ntaps, slot);
     }
     js->other[slot] = FirChunkJob{static_cast<FirHandle *>(h->clones[slot]), js->home.mode, js->home.L, js->home.M};
     return &js->other[slot];

@@ -155,7 +155,6 @@ template <bool REAL, bool DEC, bool UP = false, bool XR = false>
 __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
 {
     __shared__ cdd img[16 * kPitch64];
-    __shared__ unsigned touch_lds[4 * 128];   // landing area of the next tile's cache-line touches (never read)
     __shared__ unsigned long long ols_noted;  // poisoned tiles, by walk step (careful.hpp)
     const int t = threadIdx.x;
     if (t == 0) ols_noted = 0;
@@ -252,31 +251,6 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
         int tl = t, th = t, ts = t;
         asm volatile("" : "+v"(tl));
         if (!PREF || !have) load_tile(tin, tl, v);
-        // Two-real-tiles kernel: the next pair's 512 cache lines are pulled towards the L2 while this one is transformed: one
-        // 4-byte load per line, two per thread, straight into a scratch corner of the LDS (global_load_lds_dword: no
-        // destination VGPR -- a register prefetch of the 16 values spilled in every form tried, and so did two live "touch"
-        // registers).  float64, 1024 taps, 2^26: 0.3895 -> 0.3596 ms.  The complex kernel loses with it (0.691 -> 0.809 ms).
-        if (REAL && !PREF) {
-            const int64_t nw = tile + gridDim.x;
-            const int64_t nt = UP ? (int64_t)((unsigned)nw / (unsigned)A.up) : nw;
-            if (nw < A.ntiles) {
-                const char *xb = reinterpret_cast<const char *>(A.x);
-                int64_t o0 = -1, o1 = -1;   // byte offsets of this lane's two lines
-                if (REAL) {
-                    const int64_t inA = (2 * nt) * A.V - A.ov, inB = inA + A.V;
-                    if (inA >= -A.n_hist && inB + kN64 <= A.n) { o0 = (inA + 16 * tl) * 8; o1 = (inB + 16 * tl) * 8; }
-                } else {
-                    const int64_t in0 = nt * A.V - A.ov;
-                    if (in0 >= -A.n_hist && in0 + kN64 <= A.n) { o0 = (in0 + 16 * tl) * 16; o1 = o0 + 128; }
-                }
-                if (o0 >= 0) {
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xb + o0),
-                                                     (__attribute__((address_space(3))) void *)(touch_lds + (t >> 6) * 128), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xb + o1),
-                                                     (__attribute__((address_space(3))) void *)(touch_lds + (t >> 6) * 128 + 64), 4, 0, 0);
-                }
-            }
-        }
         // ---- pass 1: DFT16 over a, twiddle W_4096^(t k1) (running power), write [k1][b][c] ----
         dft16_f(v);   // X[k1] at v[P16(k1)]
         {

@@ -381,7 +381,9 @@ void fir_up4k_free(void *list)
 // complex64 (any taps) or float32 with real taps; per phase at most 2049 taps (half a tile of overlap)
 bool fir_up4k_supported(const FirHandle *h, int L)
 {
-    if (L < 2 || L > 4096) return false;
+    // (a plan holds one 32 / 16 KiB table per pass, built on first use under the handle's lock: 256 passes are 8 / 4 MiB and a few ms of host transforms;
+    // beyond that the walk over (tile, phase) pairs and the polyphase kernels serve the call)
+    if (L < 2 || L > 256) return false;
     const int T = up_taps_per_phase(h->ntaps, L);
     if (T - 1 > 2048) return false;
     return h->dtype == SKDSP_C64 || (h->dtype == SKDSP_F32 && !h->taps_complex);

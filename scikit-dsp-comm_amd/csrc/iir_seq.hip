@@ -79,32 +79,34 @@ __global__ __launch_bounds__(64) void iir_seq_kernel(SeqArgs a)
 #pragma unroll 1
     for (int64_t t0 = 0; t0 < steps; t0 += 64) {
         const double xnext = fetch(t0 / 64 + 1);
-#pragma unroll 1
-        for (int j = 0; j < 64; ++j) {
-            const int64_t t = t0 + j;
-            if (t >= steps) break;
+        // everything the 64 steps of this block test is worked out here, in 32 bits: this lane works on sample t0 - lane + j in steps
+        // j in [jlo, jhi); the last section finishes sample t0 - last + j in steps [llo, lhi) and a block of 64 outputs is complete at step jf
+        const int64_t i0 = t0 - lane, l0 = t0 - last;
+        const int jlo = i0 >= 0 ? 0 : (i0 < -64 ? 64 : (int)-i0), jhi = a.n - i0 >= 64 ? 64 : (a.n - i0 <= 0 ? 0 : (int)(a.n - i0));
+        const int llo = l0 >= 0 ? 0 : (l0 < -64 ? 64 : (int)-l0), lhi = a.n - l0 >= 64 ? 64 : (a.n - l0 <= 0 ? 0 : (int)(a.n - l0));
+        const int jf = (int)((63 - (l0 & 63)) & 63);                      // (l0 + jf) & 63 == 63
+        const int jend = a.n - 1 - l0 >= 0 && a.n - 1 - l0 < 64 ? (int)(a.n - 1 - l0) : -1;   // the row's last sample, if this block finishes it
+        const int slot0 = (int)(l0 & 63);
+        const int jmax = steps - t0 >= 64 ? 64 : (int)(steps - t0);
+#pragma unroll 2
+        for (int j = 0; j < jmax; ++j) {
             double in = lane_shr1(out);
             const double x0 = lane_bcast(xcur, j);
             if (lane == 0) in = x0;
-            const int64_t i = t - lane;
-            if (mine && i >= 0 && i < a.n) {
-                // (the reference's statement order and no contraction: x_c = b0 x_n + z0; z0 = b1 x_n - a1 x_c + z1; z1 = b2 x_n - a2 x_c)
-                // (plain operators under the pragma above: the __dmul_rn / __dadd_rn of the HIP headers are ordinary inline functions whose
-                // products and sums carry their own contraction licence and were fused all the same)
+            if (mine && j >= jlo && j < jhi) {
+                // (the reference's statement order: x_c = b0 x_n + z0; z0 = b1 x_n - a1 x_c + z1; z1 = b2 x_n - a2 x_c.  Plain operators under the pragma
+                // above: the __dmul_rn / __dadd_rn of the HIP headers are ordinary inline functions whose products and sums carry their own
+                // contraction licence and were fused all the same)
                 const double xc = b0 * in + z0;
                 z0 = b1 * in - a1 * xc + z1;
                 z1 = b2 * in - a2 * xc;
                 out = xc;
             }
-            // the last section has just finished sample il = t - last
-            const int64_t il = t - last;
-            if (il >= 0 && il < a.n) {
-                {
-                    const double fin = lane_bcast(out, last);
-                    yblk = lane == (int)(il & 63) ? fin : yblk;
-                }
-                if ((il & 63) == 63 || il == a.n - 1) {
-                    const int64_t o = (il & ~(int64_t)63) + lane;
+            if (j >= llo && j < lhi) {   // the last section has just finished sample l0 + j
+                const double fin = lane_bcast(out, last);
+                yblk = lane == ((slot0 + j) & 63) ? fin : yblk;
+                if (j == jf || j == jend) {
+                    const int64_t il = l0 + j, o = (il & ~(int64_t)63) + lane;
                     if (o <= il) {
                         if (a.dec > 1) {
                             if (o % a.dec == 0 && o / a.dec < a.n / a.dec) y[o / a.dec] = (IO)yblk;
