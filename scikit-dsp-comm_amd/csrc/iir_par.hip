@@ -110,9 +110,14 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 // TT: samples per chunk (0: SK_PAR_T32 / its half for float64).  The decimating kernels of float32 / complex64 signals run on chunks of 96 where M divides 96
 // (M = 2, 3, 4, 6, 8, 12, 16, 24, ...): every chunk of every segment then starts on a kept sample, all lanes of a wave walk the SAME phase, and the 2 NSEC + 1
 // term output sum is formed for one sample in M -- with 128, M = 3 put the lanes on three phases and every sum was formed (M = 12: three in twelve).
-template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0>
+// UPJ (.up by 4 or more, with TT = 96 and L a divisor of 96): between two input samples the filter runs on stuffed zeros, so the recurrence does not step
+// through them -- every output is a 2 NSEC term product of the state right behind the last input sample with a row of c A^j (a table, wave-uniform
+// because all chunks start on an input sample), and the state jumps by A^L per INPUT sample: 2 NSEC + 5 NSEC / L multiply-adds per output instead of
+// 4 NSEC + 1 (order-8 Butterworth, L = 12: 9.7 instead of 17).
+template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0, bool UPJ = false>
 __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
-                                                                 const double *__restrict__ lvl, const double *__restrict__ psi)
+                                                                 const double *__restrict__ lvl, const double *__restrict__ psi,
+                                                                 const double *__restrict__ upj = nullptr)   // UPJ: [up][2 nsec] rows c A^j, then [nsec][4] the blocks of A^up
 {
     constexpr bool DEC = DECM != 0;
     constexpr int D = 2 * NSEC;
@@ -598,6 +603,13 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     // walk different phases unless dec divides the chunk length, so a sample's sum is skipped only where NO lane keeps it: at dec = 12 the
     // 64 chunks of a segment start at three different phases (128 mod 12 = 8) and three of twelve samples pay for the sum instead of all.
     unsigned dtr = dt, e0r = 0;
+    int upj_cnt = 0;   // UPJ: (samples since the last input sample) - 1
+    constexpr bool UPJ_PRE = UPJ && NSEC <= 4;
+    double cjn[UPJ_PRE ? D : 1];   // UPJ: the row c A^cnt of the next sample
+    if constexpr (UPJ_PRE) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) cjn[d] = upj[d];
+    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
@@ -611,6 +623,47 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
                 dtr = dtr >= (unsigned)a.dec ? dtr - (unsigned)a.dec : dtr;   // (M = 2, 3: a 4-sample unit spans more than one period)
             }
             const double xd = (double)xq[(p * kPiece + k) / kE][e];
+            if constexpr (UPJ) {
+                if (p * kPiece + k > 0) {   // (the chunk's first sample is an input sample met with the state from the scan: the plain step below)
+                    // (up to 4 biquads the row c A^cnt of THIS sample was requested a sample ago -- scalar loads, wave-uniform -- and the next one goes
+                    // out first; longer rows would not leave the scalar registers for two of them)
+                    double cj[D];
+                    const bool is_input = upj_cnt == a.up - 1;
+                    if constexpr (UPJ_PRE) {
+#pragma unroll
+                        for (int d = 0; d < D; ++d) cj[d] = cjn[d];
+                        upj_cnt = is_input ? 0 : upj_cnt + 1;
+                        const double *nr = upj + (size_t)upj_cnt * D;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) cjn[d] = nr[d];
+                    } else {
+                        const double *nr = upj + (size_t)upj_cnt * D;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) cj[d] = nr[d];
+                        upj_cnt = is_input ? 0 : upj_cnt + 1;
+                    }
+                    double yv = cj[0] * z[0];
+                    yv = fma(cj[1], z[1], yv);
+#pragma unroll
+                    for (int s = 1; s < NSEC; ++s) {
+                        yv = fma(cj[2 * s], z[2 * s], yv);
+                        yv = fma(cj[2 * s + 1], z[2 * s + 1], yv);
+                    }
+                    if (is_input) {   // an input sample: its direct term, and the state jumps to right behind it (the blocks of A^up: one sample in `up`)
+                        yv = fma(gam, xd, yv);
+                        const double *Au = upj + (size_t)a.up * D;
+#pragma unroll
+                        for (int s = 0; s < NSEC; ++s) {
+                            const double n0 = fma(Au[4 * s + 1], z[2 * s + 1], fma(Au[4 * s], z[2 * s], xd));
+                            const double n1 = fma(Au[4 * s + 3], z[2 * s + 1], Au[4 * s + 2] * z[2 * s]);
+                            z[2 * s] = n0;
+                            z[2 * s + 1] = n1;
+                        }
+                    }
+                    xq[(p * kPiece + k) / kE][e] = (IO)yv;
+                    continue;
+                }
+            }
             // (the unit's kept samples: e0r and, with M below the samples of a unit, e0r + M)
             if (!DEC || e0r == (unsigned)e || e0r + (unsigned)a.dec == (unsigned)e) {
                 double yv = gam * xd;
@@ -784,6 +837,8 @@ struct ParPlan {
     double na1[8], na2[8], al[8], be[8], gamma = 0.0;
     double kappa = 0.0, ir_err = 0.0;
     ParTables tab[6];            // [0] float32 (T = 128), [1] float64 (T = 64), [2] complex64, [3] complex128 (32 chunks per segment), [4] / [5] float32 / complex64 with T = 96 (.dn)
+    struct UpJump { int up; double *dev; };
+    std::vector<UpJump> upj;     // per L: [L][2 nsec] rows c A^j + [nsec][4] blocks of A^L (UPJ kernels)
     unsigned long long *lbg_dev = nullptr;
     size_t lbg_cap = 0;
     unsigned long long *ticket_dev = nullptr;
@@ -799,6 +854,7 @@ void iir_par_free(ParPlan *p)
         if (t.lvl_dev) (void)hipFree(t.lvl_dev);
         if (t.psi_dev) (void)hipFree(t.psi_dev);
     }
+    for (auto &u : p->upj) if (u.dev) (void)hipFree(u.dev);
     if (p->lbg_dev) (void)hipFree(p->lbg_dev);
     if (p->ticket_dev) (void)hipFree(p->ticket_dev);
     delete p;
@@ -1015,7 +1071,37 @@ template <typename IO, bool CPLX> static bool par_dec_rounds(int dec)
     return sizeof(IO) == 4 && (dec == 2 || dec == 3) && opt().iir_dn_compact;
 }
 
-template <typename IO, bool CPLX, int TT = 0>
+
+// UPJ table of a plan for the factor L (see the kernel): rows c A^j, j = 0 .. L - 1, c = (al, be) of every section; then the 2 x 2 blocks of A^L
+static int par_upj_table(ParPlan &P, int L, const double **out)
+{
+    for (auto &u : P.upj)
+        if (u.up == L) { *out = u.dev; return SKDSP_OK; }
+    const int N = P.nsec, D = 2 * N;
+    std::vector<double> tab((size_t)L * D + (size_t)N * 4);
+    for (int k = 0; k < N; ++k) {
+        const long double A[4] = {-P.a1[k], -P.a2[k], 1.0L, 0.0L};   // (w[n-1], w[n-2]) -> (w[n], w[n-1]) without input
+        long double c0 = (long double)P.al[k], c1 = (long double)P.be[k];   // the row c A^j
+        long double M[4] = {1.0L, 0.0L, 0.0L, 1.0L};                  // A^j
+        for (int j = 0; j < L; ++j) {
+            tab[(size_t)j * D + 2 * k] = (double)c0;
+            tab[(size_t)j * D + 2 * k + 1] = (double)c1;
+            const long double n0 = c0 * A[0] + c1 * A[2], n1 = c0 * A[1] + c1 * A[3];
+            c0 = n0; c1 = n1;
+            const long double m0 = M[0] * A[0] + M[1] * A[2], m1 = M[0] * A[1] + M[1] * A[3], m2 = M[2] * A[0] + M[3] * A[2], m3 = M[2] * A[1] + M[3] * A[3];
+            M[0] = m0; M[1] = m1; M[2] = m2; M[3] = m3;
+        }
+        for (int i = 0; i < 4; ++i) tab[(size_t)L * D + 4 * k + i] = (double)M[i];   // A^L
+    }
+    double *dev = nullptr;
+    SK_HIP(hipMalloc((void **)&dev, tab.size() * 8));
+    SK_HIP(hipMemcpy(dev, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    P.upj.push_back(ParPlan::UpJump{L, dev});
+    *out = dev;
+    return SKDSP_OK;
+}
+
+template <typename IO, bool CPLX, int TT = 0, bool UPJ = false>
 static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
                       void *y, hipStream_t s, int dec, int up = 1)
 {
@@ -1058,6 +1144,11 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
     a.up_magic = a.up > 1 ? (unsigned)((((unsigned long long)1 << 32) + a.up - 1) / a.up) : 0u;
     a.n_in = a.up > 1 ? n / a.up : n;
     a.n_keep = (n / a.dec) * a.dec;
+    const double *upj_tab = nullptr;
+    if constexpr (UPJ) {
+        const int rc = par_upj_table(*p, a.up, &upj_tab);
+        if (rc) return rc;
+    }
     {
         const int64_t step = (int64_t)(64 / Stage<IO>::segs) * T;   // samples between a lane's staged segments
         a.dec_dq = (int)(step / a.dec);
@@ -1075,13 +1166,16 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
         if (a.dec > 1 && a.dec_rounds > 1) {                                                                            \
             if constexpr (sizeof(IO) == 4)                                                                              \
                 hipLaunchKernelGGL((iir_par_kernel<N, IO, 2, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,    \
-                                   (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);  \
+                                   (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, (const double *)nullptr);  \
         } else if (a.dec > 1)                                                                                           \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 1, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,        \
-                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);      \
+                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, (const double *)nullptr);      \
+        else if constexpr (UPJ)                                                                                         \
+            hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX, TT, true>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,  \
+                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, upj_tab); \
         else if constexpr (TT == 0)                                                                                     \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,            \
-                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev);      \
+                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, (const double *)nullptr);      \
         break;                                                                                                          \
     }
     switch (h->nsec) {
@@ -1115,6 +1209,11 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     // (measured, 2^26 inputs, profiles/r05/iir_dn.txt: 8-biquad elliptic M = 3 0.193 -> 0.173 ms, order-8 Butterworth M = 2 0.126 -> 0.114; from M = 4 on the
     // shorter segments cost more than the aligned phases save -- M = 4 + 7 .. 9 %, M = 12 + 3 % -- and 128 is a multiple of the powers of two anyway)
     bool t96 = !dbl && dec > 1 && ((opt().iir_dn_t96 == 1 && (dec == 2 || dec == 3 || dec == 6)) || (opt().iir_dn_t96 == 2 && 96 % dec == 0));
+    // .up by a divisor of 96 from 8 on, up to 4 biquads: the state jumps from input sample to input sample (UPJ kernels, chunks of 96 so that every chunk
+    // starts on one).  Measured (profiles/r05/iir_up.txt): rate_change(12).up float32 0.097 -> 0.085 ms, complex64 0.167 -> 0.156; by 4 a tie; 8 biquads
+    // by 4 lose 10 % (their rows of c A^j do not leave the scalar registers for a prefetched second one); option iir_up_jump = 2: wherever it applies
+    const bool upj = !dbl && dec <= 1 && up >= 4 && 96 % up == 0 && (opt().iir_up_jump >= 2 || (opt().iir_up_jump == 1 && up >= 8 && h->nsec <= 4));
+    t96 = t96 || upj;
     if (t96) {
         ParTables &t9 = p->tab[4 + (interleaved ? 1 : 0)];
         if (t9.T == 0) {
@@ -1123,6 +1222,10 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
         }
         if (t9.K == 0) t96 = false;   // (the filter remembers more segments of this length than the look-back serves: the 128-sample chunks, if they do)
     }
+    if (t96 && upj)
+        return interleaved ? launch_par<float, true, 96, true>(h, p, p->tab[5], x, n, 1, 0, 0, y, s, dec, up)
+                           : launch_par<float, false, 96, true>(h, p, p->tab[4], x, n, nrow, x_stride, y_stride, y, s, dec, up);
+    if (upj) t96 = false;
     ParTables &tb = t96 ? p->tab[4 + (interleaved ? 1 : 0)] : p->tab[(dbl ? 1 : 0) + (interleaved ? 2 : 0)];
     if (tb.T == 0) {
         // negligibility as in iir_scan.hip: 1e-30 for float64 signals, 1e-18 for float32 signals (a tenth of an ulp of the

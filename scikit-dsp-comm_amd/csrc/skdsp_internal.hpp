@@ -48,6 +48,7 @@ struct Options {
     int iir_no_mfma = 0;      // recurrence K1 instead of the matrix-pipe K1
     int iir_two_pass = 0;     // 1: K1 + carries + K3 even where the single-pass scan applies; -1: single pass wherever it applies
     int iir_par = 1;          // 0: never the parallel-form scan (iir_par.hip); the cascade kernels everywhere
+    int iir_up_jump = 1;      // the parallel-form .up of float32 / complex64 signals jumps its state from input sample to input sample: 1 for L >= 8 (a divisor of 96) and up to 4 biquads, 2 wherever it applies (L >= 4), 0 never (A/B switch)
     int iir_seq = 1;          // cascades of more than 8 sections whose float64 spread the scans would lift past the contract run the reference's recursion (iir_seq.hip): 1 probed, 2 always, 0 never
     int iir_dn_t96 = 1;       // the parallel-form .dn of float32 / complex64 signals on 96-sample chunks: 1 for M = 2, 3, 6 (measured), 2 wherever M divides 96, 0 never (A/B switch)
     int iir_dn_compact = 1;   // 0: the parallel-form .dn keeps the image-and-pick store for every M (A/B switch)

@@ -148,7 +148,7 @@ def test_parallel_form_decimating_store(dt, M):
                 yd.free()
 
 
-@pytest.mark.parametrize("L", [2, 3, 4, 5, 12, 13, 64, 100, 4096])
+@pytest.mark.parametrize("L", [2, 3, 4, 5, 8, 12, 13, 16, 24, 48, 64, 96, 100, 4096])
 @pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
 def test_parallel_form_up_zero_stuffs_while_staging(dt, L):
     """.up / rate_change.up (multirate_helper.py:69-75, 177-184: sosfilt(sos, L * upsample(x, L))): the parallel-form kernel builds the
@@ -158,7 +158,7 @@ def test_parallel_form_up_zero_stuffs_while_staging(dt, L):
     rng = np.random.default_rng(L)
     for name in ("ellip8", "butter8rc12", "butter3"):
         sos = designs()[name]
-        for n in (1, 7, 683, 8192 // L + 1, 8192 * 3 // L, 100_003 if L <= 13 else 2_003):
+        for n in (1, 7, 683, 8192 // L + 1, 8192 * 3 // L, 100_003 if L <= 13 else 2_003, 6144 * 2 // L + 5):
             x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if np.dtype(dt).kind == "c" else 0)
             x = x.astype(dt)
             outs = []
@@ -166,7 +166,10 @@ def test_parallel_form_up_zero_stuffs_while_staging(dt, L):
                 with _ffi.option("iir_up_fused", fused):
                     outs.append(_ffi.IirKernel(_ffi.code_of(dt), sos=sos).up(x, L))
             single = np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4
-            if np.dtype(dt).kind == "c":   # (the two-step path runs complex signals through other kernels: same arithmetic, other rounding)
+            # (float32 / complex64, L >= 8 a divisor of 96, up to 4 biquads: the fused kernel does not step through the stuffed zeros at all -- its state
+            # jumps from input sample to input sample: the same filter in another operation order)
+            jumps = single and L >= 8 and 96 % L == 0 and len(sos) <= 4
+            if np.dtype(dt).kind == "c" or jumps:   # (the two-step path runs complex signals through other kernels: same arithmetic, other rounding)
                 assert max(rel_err(outs[1], outs[0])) <= (2e-7 if single else 1e-13), (name, L, n)
             else:
                 assert np.array_equal(outs[0], outs[1]), (name, L, n)
