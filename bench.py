@@ -378,8 +378,8 @@ RATE_WORKLOADS = {
     "downsample3": ("sigsys.downsample(x, 3), complex64", "sigsys.py:3056-3083"),
     "firup12": ("multirate_FIR(512-tap lowpass).up(x) at the default L_change = 12, complex64", "multirate_helper.py:112-118"),
     "firdn12": ("multirate_FIR(512-tap lowpass).dn(x) at the default M_change = 12, complex64", "multirate_helper.py:121-127"),
-    "firup4": ("multirate_FIR(1024-tap lowpass).up(x, 4), complex64 (256 taps per phase: frequency-domain interpolator)", "multirate_helper.py:112-118"),
-    "firdn4": ("multirate_FIR(1024-tap lowpass).dn(x, 4), complex64 (overlap-save, decimating store)", "multirate_helper.py:121-127"),
+    "firup4": ("multirate_FIR(1024-tap lowpass).up(x, 4), complex64 (overlap-save on tiles of the output: the zero-stuffed tile's spectrum from its non-zero columns)", "multirate_helper.py:112-118"),
+    "firdn4": ("multirate_FIR(1024-tap lowpass).dn(x, 4), complex64 (overlap-save, decimating inverse transform: the spectrum folded 4-fold)", "multirate_helper.py:121-127"),
     "rcup12": ("rate_change(12).up(x): order-8 Butterworth, float32", "multirate_helper.py:69-75"),
     "rcdn12": ("rate_change(12).dn(x): order-8 Butterworth, float32", "multirate_helper.py:77-83"),
     "iirup2": ("multirate_IIR(8-biquad elliptic bandpass).up(x, 2), float32", "multirate_helper.py:177-184"),
@@ -845,12 +845,12 @@ OTHER_RATE_WORKLOADS = ("upsample4", "downsample3", "firup12", "firdn12", "firup
 
 # kernel sources whose change makes a committed PMC measurement stale (workload -> files under scikit-dsp-comm_amd/csrc)
 TRAFFIC_SOURCES = {
-    "fir1024": ["fir_ols.hip", "ols_core.hpp"], "fir127": ["fir_bx.hip"], "updn43": ["fir_bx.hip"],
-    "fir1024c128": ["fir_ols64.hip"], "iir8": ["iir_par.hip"], "iirlp8": ["iir_par.hip"], "iir8c64": ["iir_par.hip"],
+    "fir1024": ["fir_ols.hip", "ols_core.hpp", "careful.hpp"], "fir127": ["fir_bx.hip", "careful.hpp"], "updn43": ["fir_bx.hip", "careful.hpp"],
+    "fir1024c128": ["fir_ols64.hip", "careful.hpp"], "iir8": ["iir_par.hip"], "iirlp8": ["iir_par.hip"], "iir8c64": ["iir_par.hip"],
     "iir8cas": ["iir_fused.hip", "iir_common.hpp"], "iir8tp": ["iir_scan.hip", "iir_common.hpp"],
     "upsample4": ["resample.hip"], "downsample3": ["resample.hip"],
-    "firup12": ["fir_up2k.hip", "ols2k_core.hpp", "fir_bx.hip"], "firup4": ["fir_up4k.hip", "ols4k_core.hpp"],
-    "firdn12": ["fir_bx.hip", "fir_direct.hip"], "firdn4": ["fir_ols.hip", "ols_core.hpp", "fir_dn4k.hip", "ols4k_core.hpp"],
+    "firup12": ["fir_bx.hip", "careful.hpp"], "firup4": ["fir_ols.hip", "ols_core.hpp", "careful.hpp"],
+    "firdn12": ["fir_bx.hip", "careful.hpp"], "firdn4": ["fir_ols.hip", "ols_core.hpp", "careful.hpp"],
     "rcup12": ["iir_par.hip"], "rcdn12": ["iir_par.hip"], "iirup2": ["iir_par.hip"], "iirdn3": ["iir_par.hip"],
 }
 

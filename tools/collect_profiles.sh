@@ -4,7 +4,7 @@
 #   gpurun --timeout 600 -- 'bash tools/collect_profiles.sh r03 pmc iir8 iirlp8'    (only the PMC passes of the workloads named, added to an existing collection)
 # Writes gpurun_out/profiles_<round>/ ; copy what should be judged into profiles/<round>/.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$R
 PMC_ONLY=""

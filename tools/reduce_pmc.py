@@ -37,7 +37,7 @@ WORK = {  # workload -> (substring of every kernel of a step, substring of the k
 }
 # the .up / .dn rows of SURVEY.md 8(a) (bench.RATE_WORKLOADS, 2^26 samples at the high rate): every library kernel of a step counts (one launch
 # per step, whatever engine AUTO takes), algorithmic bytes as bench.py counts them
-_LIB = ("up2k_kernel", "up4k_kernel", "dn4k_kernel", "skdsp::fir_", "ols_tile_kernel", "interleave_kernel", "skdsp::iir_par", "upsample_kernel", "downsample_kernel", "downsample_tile_kernel")
+_LIB = ("up2k_kernel", "up4k_kernel", "dn4k_kernel", "skdsp::fir_", "ols_tile_kernel", "ols_fold_kernel", "ols_rep_kernel", "interleave_kernel", "skdsp::iir_par", "upsample_kernel", "downsample_kernel", "downsample_tile_kernel")
 for _w in bench.OTHER_RATE_WORKLOADS:
     _R = {"upsample4": 4, "downsample3": 3, "firup12": 12, "firdn12": 12, "firup4": 4, "firdn4": 4, "rcup12": 12, "rcdn12": 12, "iirup2": 2, "iirdn3": 3}[_w]
     _up = _w in ("upsample4", "firup12", "firup4", "rcup12", "iirup2")
