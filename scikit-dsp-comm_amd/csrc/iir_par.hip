@@ -52,6 +52,7 @@ constexpr int SK_PAR_T32 = 128;   // samples per lane (float32 signals); float64
 constexpr int SK_PAR_PRIO = 3;      // wave priority in front of the recurrence (float32 signals, 6 - 8 biquads: DESIGN.md)
 constexpr int SK_PAR_PRIO_ST = 1;   // ... and on a piece's way out through the image
 constexpr int SK_PAR_OCC = 2;     // waves per SIMD the register budget is set for
+constexpr int SK_PAR_OCC_UPL = 3;   // ... of the lean .up kernels (UPJ, up to 4 biquads: no input image, no table in LDS)
 
 template <int NSEC> struct ParCoef {
     double na1[NSEC], na2[NSEC];   // -a1, -a2
@@ -115,12 +116,24 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 // because all chunks start on an input sample), and the state jumps by A^L per INPUT sample: 2 NSEC + 5 NSEC / L multiply-adds per output instead of
 // 4 NSEC + 1 (order-8 Butterworth, L = 12: 9.7 instead of 17).
 template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0, bool UPJ = false>
-__global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
+__global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
                                                                  const double *__restrict__ lvl, const double *__restrict__ psi,
                                                                  const double *__restrict__ upj = nullptr)   // UPJ: [up][2 nsec] rows c A^j, then [nsec][4] the blocks of A^up
 {
     constexpr bool DEC = DECM != 0;
     constexpr int D = 2 * NSEC;
+    // UPL, the lean form of UPJ (up to 4 biquads): a chunk of 96 outputs holds 96 / up <= 12 input samples and starts on one, so the zero-stuffed chunk
+    // never exists, not even in the wave's image: a lane loads ITS inputs (adjacent lanes adjacent runs: whole lines per wave), forms its from-rest end
+    // state from the 96 / up columns of G those meet (wave-uniform columns: scalar loads, no table in LDS) and hands the recurrence the next input as a
+    // register.  The zero-stuffing through the image (two magic divisions, a dozen selects and an LDS round trip per 16-byte unit of OUTPUT-rate
+    // samples) was two thirds of the kernel's 3000 vector instructions per segment (profiles/r05/pmc_rcup12.json: SQ_INSTS_VALU) -- the FP64 work is 1000.
+    constexpr bool UPL = UPJ && NSEC <= 4;
+    // DNL, the lean form of the compact decimating store (TT = 96, M a divisor of 96 from 4 on): every chunk of every segment starts on a kept sample,
+    // so WHICH samples are kept is wave-uniform -- a scalar counter and a scalar branch instead of the per-lane phase arithmetic (a compare and an exec
+    // mask per sample, the unit bookkeeping per 16 bytes, the pick out of the unit at the gathering: 2000 of the 3700 vector instructions per segment of
+    // rate_change(12).dn, profiles/r05/pmc_rcdn12.json).  A kept output goes straight from the sum into its slot of the wave's idle image.
+    constexpr bool DNL = DECM == 1 && TT == 96;
+    constexpr bool UNI = DEC && TT == 96;   // (M = 2, 3 on 96-sample chunks keep their gathering in ranges but test for kept samples the same way)
     constexpr bool G4 = D <= 12;   // V = G x by 4 x 4 x 4 products over the row groups in use (see phase A)
     constexpr int T = TT ? TT : SK_PAR_T32 * 4 / (int)sizeof(IO);
     constexpr int NP = T / kPiece;
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     constexpr int KMAX = par_max_k(sizeof(IO) == 8);
     static_assert(kWaveStage >= 64 * 16 * 8 + KMAX * 64 * 4, "scan exchange + look-back words must fit the wave's stage image");
     __shared__ __attribute__((aligned(16))) char lds_raw[4 * kWaveStage];
-    __shared__ double gl[(T / 4) * 64];
+    __shared__ double gl[UPL ? 64 : (T / 4) * 64];
     __shared__ int base_sh;
     // CPLX: an interleaved complex signal.  Lane L owns component L & 1 (re / im) of complex chunk L >> 1: T complex samples
     // per chunk, 32 chunks per wave segment.  The two components are independent real signals through the same real
@@ -163,12 +176,16 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     // before it asked for its share of the table, and the barrier for thread 0)
     constexpr int kTabPer = (T / 4) * 64 / kIirThreads;
     double tab[kTabPer];
+    if constexpr (!UPL) {
 #pragma unroll
-    for (int i = 0; i < kTabPer; ++i) tab[i] = gtab[tid + i * kIirThreads];
+        for (int i = 0; i < kTabPer; ++i) tab[i] = gtab[tid + i * kIirThreads];
+    }
     unsigned long long drawn = 0;
     if (tid == 0) drawn = atomicAdd(a.ticket + blockIdx.x % kParTickets, 1ull);
+    if constexpr (!UPL) {
 #pragma unroll
-    for (int i = 0; i < kTabPer; ++i) gl[tid + i * kIirThreads] = tab[i];
+        for (int i = 0; i < kTabPer; ++i) gl[tid + i * kIirThreads] = tab[i];
+    }
     if (tid == 0) base_sh = 4 * (int)((unsigned)(drawn - a.ticket_base) * kParTickets + blockIdx.x % kParTickets);
     __syncthreads();   // the only workgroup barrier
     const int tk = __builtin_amdgcn_readfirstlane(base_sh) + wave;
@@ -330,6 +347,24 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
     for (int g = 0; g < 4; ++g) acc[g] = v4d_t{0.0, 0.0, 0.0, 0.0};
     const int c = lane & 15, j = lane >> 4;
     IO *myrow = stage + lane * St::pitch;
+    constexpr int NIN = UPL ? T / 8 : 1;   // UPL: input samples a chunk can hold
+    IO xs[NIN];                            // ... this lane's, times the gain, rounded in the signal's type as the staging rounds them
+    const int nin = UPL ? T / a.up : 0;    // ... and how many there are
+    if constexpr (UPL) {
+        const unsigned qa = (unsigned)((lane / LS) * nin);   // the chunk's first input sample, counted from the segment's
+        const unsigned last = in_lim ? in_lim - 1u : 0u;
+        const IO gain = (IO)a.up;
+#pragma unroll
+        for (int jj = 0; jj < NIN; ++jj) {
+            IO val = IO(0);
+            if (jj < nin && in_lim) {
+                const unsigned qi = qa + (unsigned)jj;
+                const IO got = xup[(qi < last ? qi : last) * LS + lane % LS];
+                val = qi < in_lim ? gain * got : IO(0);
+            }
+            xs[jj] = val;
+        }
+    } else {
     // (every piece of the segment is requested up front: the landing registers are the ones the chunk will occupy anyway)
     if (ld_fast) {
 #pragma unroll
@@ -414,10 +449,27 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
         }
         wave_lds_sync();
     }
+    }
 
     // chunk end states from the accumulator layout (column = lane & 15, state row = (lane >> 4) + 4 reg) to one lane per chunk
     double v[D];
-    if (sparse) {
+    if constexpr (UPL) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) v[d] = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < NIN; ++jj) {
+            if (jj < nin) {
+                const int kk = jj * a.up;                                      // column of G: the same for every chunk
+                const double *gp = gtab + (kk >> 2) * 64 + 16 * (kk & 3);     // (its D state rows are consecutive in the operand order of the table)
+                const double xv = (double)xs[jj];
+#pragma unroll
+                for (int d = 0; d < D; ++d) v[d] = fma(gp[d], xv, v[d]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NSEC; ++k) *reinterpret_cast<v2d_t *>(E + (k * 64 + lane) * 2) = v2d_t{v[2 * k], v[2 * k + 1]};
+        wave_lds_sync();
+    } else if (sparse) {
         constexpr int JMAX = T / 8 + 1;
         const unsigned v0 = up_r0 + (unsigned)((lane / LS) * T);          // this lane's chunk start, counted from the last multiple of up in front of the segment
         const unsigned q = (unsigned)(((unsigned long long)v0 * a.up_magic) >> 32);
@@ -610,19 +662,25 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
 #pragma unroll
         for (int d = 0; d < D; ++d) cjn[d] = upj[d];
     }
+    int dnl_cnt = 0;                                  // DNL: samples since the last kept one
+    unsigned dnl_o = (unsigned)(lane / LS) * (unsigned)(T / (DNL ? a.dec : 1));   // DNL: this lane's next output, counted from the segment's first
+    int upl_ji = 1;                                   // UPL: the next input sample of the chunk
+    double upl_next = UPL ? (double)xs[NIN > 1 ? 1 : 0] : 0.0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
         for (int k = 0; k < kPiece; ++k) {
             constexpr int kE = St::elems;
             const int e = (p * kPiece + k) % kE;
-            if (DEC && e == 0) {
+            if (DEC && !UNI && e == 0) {
                 e0r = dtr == 0 ? 0u : (unsigned)a.dec - dtr;
                 dtr += kE;
                 dtr = dtr >= (unsigned)a.dec ? dtr - (unsigned)a.dec : dtr;
                 dtr = dtr >= (unsigned)a.dec ? dtr - (unsigned)a.dec : dtr;   // (M = 2, 3: a 4-sample unit spans more than one period)
             }
-            const double xd = (double)xq[(p * kPiece + k) / kE][e];
+            double xd;
+            if constexpr (UPL) xd = p * kPiece + k == 0 ? (double)xs[0] : upl_next;   // (read at input samples only)
+            else xd = (double)xq[(p * kPiece + k) / kE][e];
             if constexpr (UPJ) {
                 if (p * kPiece + k > 0) {   // (the chunk's first sample is an input sample met with the state from the scan: the plain step below)
                     // (up to 4 biquads the row c A^cnt of THIS sample was requested a sample ago -- scalar loads, wave-uniform -- and the next one goes
@@ -659,13 +717,34 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
                             z[2 * s] = n0;
                             z[2 * s + 1] = n1;
                         }
+                        if constexpr (UPL) {
+                            upl_ji = upl_ji + 1 < NIN ? upl_ji + 1 : NIN - 1;
+                            upl_next = (double)xs[upl_ji];   // (a wave-uniform index into registers)
+                        }
                     }
                     xq[(p * kPiece + k) / kE][e] = (IO)yv;
                     continue;
                 }
             }
-            // (the unit's kept samples: e0r and, with M below the samples of a unit, e0r + M)
-            if (!DEC || e0r == (unsigned)e || e0r + (unsigned)a.dec == (unsigned)e) {
+            bool keep;
+            if constexpr (UNI) keep = dnl_cnt == 0;
+            else keep = !DEC || e0r == (unsigned)e || e0r + (unsigned)a.dec == (unsigned)e;   // (the unit's kept samples: e0r and, with M below the samples of a unit, e0r + M)
+            if constexpr (UNI) dnl_cnt = dnl_cnt + 1 == a.dec ? 0 : dnl_cnt + 1;
+            if constexpr (DNL) {
+                if (keep) {
+                    double yv = gam * xd;
+#pragma unroll
+                    for (int s = 0; s < NSEC; ++s) {
+                        yv = fma(al[s], z[2 * s], yv);
+                        yv = fma(be[s], z[2 * s + 1], yv);
+                    }
+                    if (dnl_o < olim) {
+                        const unsigned slot = dnl_o * LS + (unsigned)(lane % LS);
+                        stage[slot + (slot >> 5)] = (IO)yv;
+                    }
+                    ++dnl_o;
+                }
+            } else if (keep) {
                 double yv = gam * xd;
 #pragma unroll
                 for (int s = 0; s < NSEC; ++s) {
@@ -681,6 +760,7 @@ __global__ __launch_bounds__(kIirThreads, SK_PAR_OCC) void iir_par_kernel(ParArg
                 z[2 * s] = w0;
             }
         }
+        if constexpr (DNL) continue;   // (the kept outputs are in the image already)
         if (compact) {
 #pragma unroll
             for (int sgi = 0; sgi < St::segs; ++sgi) {
@@ -1205,14 +1285,21 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     ParPlan *p = h->par;
     if (p->state != 1) return 1;
     const bool dbl = dtype_double(h->dtype);
-    // .dn of float32 / complex64 signals by a divisor of 96: chunks of 96 samples, so that all lanes of a wave walk the same phase (see the kernel)
-    // (measured, 2^26 inputs, profiles/r05/iir_dn.txt: 8-biquad elliptic M = 3 0.193 -> 0.173 ms, order-8 Butterworth M = 2 0.126 -> 0.114; from M = 4 on the
-    // shorter segments cost more than the aligned phases save -- M = 4 + 7 .. 9 %, M = 12 + 3 % -- and 128 is a multiple of the powers of two anyway)
-    bool t96 = !dbl && dec > 1 && ((opt().iir_dn_t96 == 1 && (dec == 2 || dec == 3 || dec == 6)) || (opt().iir_dn_t96 == 2 && 96 % dec == 0));
+    // .dn of float32 / complex64 signals by a divisor of 96: chunks of 96 samples, so that all lanes of a wave walk the same phase (see the kernel).
+    // From M = 4 on the 96-sample kernel is the compact store in its lean form (DNL in the kernel: which samples are kept is wave-uniform).  Measured, 2^26 inputs
+    // (_var/dn_t96.py, profiles/r05/iir_dn_lean.txt): order-8 Butterworth M = 4 .. 96 float32 0.105 - 0.122 -> 0.086 - 0.099 ms, complex64 0.198 - 0.223 -> 0.172 - 0.196;
+    // 8 biquads: float32 - 3 .. - 6 %, complex64 - 3 % where 3 divides M (128-sample chunks then start on three phases) and + 4 .. + 7 % elsewhere.
+    // Before the lean form: M = 2, 3, 6 only (M = 3 0.193 -> 0.173 ms, M = 4 + 7 .. 9 %).  Option iir_dn_t96 = 2: every divisor of 96; 0: never.
+    const bool t96_pays = dec == 2 || dec == 3 || dec == 6 || (96 % dec == 0 && (h->nsec <= 4 || !interleaved || dec % 3 == 0));
+    bool t96 = !dbl && dec > 1 && ((opt().iir_dn_t96 == 1 && t96_pays) || (opt().iir_dn_t96 == 2 && 96 % dec == 0));
+    // (the 96-sample kernels have no store but the gathering ones: ranges of chunks for M = 2, 3, the lean compact store from 4 on)
+    if (t96 && !(dec < 4 ? (interleaved ? par_dec_rounds<float, true>(dec) : par_dec_rounds<float, false>(dec))
+                         : (interleaved ? par_dec_compact<float, true>(dec, (int64_t)32 * 96) : par_dec_compact<float, false>(dec, (int64_t)64 * 96))))
+        t96 = false;
     // .up by a divisor of 96 from 8 on, up to 4 biquads: the state jumps from input sample to input sample (UPJ kernels, chunks of 96 so that every chunk
     // starts on one).  Measured (profiles/r05/iir_up.txt): rate_change(12).up float32 0.097 -> 0.085 ms, complex64 0.167 -> 0.156; by 4 a tie; 8 biquads
     // by 4 lose 10 % (their rows of c A^j do not leave the scalar registers for a prefetched second one); option iir_up_jump = 2: wherever it applies
-    const bool upj = !dbl && dec <= 1 && up >= 4 && 96 % up == 0 && (opt().iir_up_jump >= 2 || (opt().iir_up_jump == 1 && up >= 8 && h->nsec <= 4));
+    const bool upj = !dbl && dec <= 1 && up >= 8 && 96 % up == 0 && (opt().iir_up_jump >= 2 || (opt().iir_up_jump == 1 && h->nsec <= 4));
     t96 = t96 || upj;
     if (t96) {
         ParTables &t9 = p->tab[4 + (interleaved ? 1 : 0)];

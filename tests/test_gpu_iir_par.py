@@ -139,7 +139,9 @@ def test_parallel_form_decimating_store(dt, M):
                 if n // M:
                     if n >= 4099:
                         assert_close(got[0], ref, TOL32 if single else TOL64, "%s dn M=%d n=%d" % (name, M, n))
-                    if not cplx:
+                    # (float32 signals with M | 96 run their gathering store on 96-sample chunks and the picking store on 128-sample ones: the same
+                    # outputs from different chunk scans, equal to the rounding of the float64 scan)
+                    if not cplx and not (single and 96 % M == 0):
                         assert np.array_equal(got[0], got[1]), (name, M, n)
                     else:
                         assert max(rel_err(got[0], got[1])) <= (2e-7 if single else 1e-13), (name, M, n)
