@@ -52,7 +52,7 @@ constexpr int SK_PAR_T32 = 128;   // samples per lane (float32 signals); float64
 constexpr int SK_PAR_PRIO = 3;      // wave priority in front of the recurrence (float32 signals, 6 - 8 biquads: DESIGN.md)
 constexpr int SK_PAR_PRIO_ST = 1;   // ... and on a piece's way out through the image
 constexpr int SK_PAR_OCC = 2;     // waves per SIMD the register budget is set for
-constexpr int SK_PAR_OCC_UPL = 3;   // ... of the lean .up kernels (UPJ, up to 4 biquads: no input image, no table in LDS)
+constexpr int SK_PAR_OCC_UPL = 4;   // ... of the lean .up kernels (UPJ, up to 4 biquads: no input image, no table in LDS)
 
 template <int NSEC> struct ParCoef {
     double na1[NSEC], na2[NSEC];   // -a1, -a2
@@ -118,6 +118,7 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0, bool UPJ = false>
 __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
                                                                  const double *__restrict__ lvl, const double *__restrict__ psi,
+                                                                 unsigned long long,   // (keeps upj out of the register tuple the three pointers above arrive in: that tuple was spilled as a whole, upj with it, and restored -- eight registers -- in front of every pair of row loads)
                                                                  const double *__restrict__ upj = nullptr)   // UPJ: [up][2 nsec] rows c A^j, then [nsec][4] the blocks of A^up
 {
     constexpr bool DEC = DECM != 0;
@@ -128,12 +129,12 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
     // register.  The zero-stuffing through the image (two magic divisions, a dozen selects and an LDS round trip per 16-byte unit of OUTPUT-rate
     // samples) was two thirds of the kernel's 3000 vector instructions per segment (profiles/r05/pmc_rcup12.json: SQ_INSTS_VALU) -- the FP64 work is 1000.
     constexpr bool UPL = UPJ && NSEC <= 4;
-    // DNL, the lean form of the compact decimating store (TT = 96, M a divisor of 96 from 4 on): every chunk of every segment starts on a kept sample,
+    // DNL, the lean form of the compact decimating store (TT = 96, M a divisor of 96 from 3 on: a segment's kept outputs fit the image): every chunk of every segment starts on a kept sample,
     // so WHICH samples are kept is wave-uniform -- a scalar counter and a scalar branch instead of the per-lane phase arithmetic (a compare and an exec
     // mask per sample, the unit bookkeeping per 16 bytes, the pick out of the unit at the gathering: 2000 of the 3700 vector instructions per segment of
     // rate_change(12).dn, profiles/r05/pmc_rcdn12.json).  A kept output goes straight from the sum into its slot of the wave's idle image.
     constexpr bool DNL = DECM == 1 && TT == 96;
-    constexpr bool UNI = DEC && TT == 96;   // (M = 2, 3 on 96-sample chunks keep their gathering in ranges but test for kept samples the same way)
+    constexpr bool UNI = DEC && TT == 96;   // (M = 2 on 96-sample chunks keeps its gathering in ranges but tests for kept samples the same way)
     constexpr bool G4 = D <= 12;   // V = G x by 4 x 4 x 4 products over the row groups in use (see phase A)
     constexpr int T = TT ? TT : SK_PAR_T32 * 4 / (int)sizeof(IO);
     constexpr int NP = T / kPiece;
@@ -180,6 +181,16 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
 #pragma unroll
         for (int i = 0; i < kTabPer; ++i) tab[i] = gtab[tid + i * kIirThreads];
     }
+    // UPL: the blocks of A^up in vector registers (used once in `up` samples: not worth 32 scalar registers).  Vector loads of one address -- a lane offset
+    // the compiler cannot see through: as scalar loads they were 4 NSEC round trips one after the other, each waited for before its value could move over
+    double AuV[UPL ? 4 * NSEC : 1];
+    if constexpr (UPL) {
+        int vz = 0;
+        asm volatile("" : "+v"(vz));
+        const double *Ap = upj + (size_t)(a.up + 1) * D + vz;
+#pragma unroll
+        for (int i = 0; i < 4 * NSEC; ++i) AuV[i] = Ap[i];
+    }
     unsigned long long drawn = 0;
     if (tid == 0) drawn = atomicAdd(a.ticket + blockIdx.x % kParTickets, 1ull);
     if constexpr (!UPL) {
@@ -188,6 +199,10 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
     }
     if (tid == 0) base_sh = 4 * (int)((unsigned)(drawn - a.ticket_base) * kParTickets + blockIdx.x % kParTickets);
     __syncthreads();   // the only workgroup barrier
+    // (UPL, measured and not kept: PERSISTENT waves that draw their own tickets and ask for the next one before they start on a segment -- 0.072 -> 0.135 ms:
+    // a ticket held early is a segment whose from-rest state appears a segment's time late, and its successor, drawn by another wave a moment later,
+    // waits for it in the look-back.  The draw itself is 8 % of rate_change(12).up (ticket replaced by blockIdx: 0.0755 -> 0.0695 ms), which needs the
+    // dispatch order the hardware happens to follow and promises nowhere.)
     const int tk = __builtin_amdgcn_readfirstlane(base_sh) + wave;
     if (tk >= a.total) return;
     const int row = a.nseg == a.total ? 0 : __builtin_amdgcn_readfirstlane(tk / a.nseg), seg = tk - row * a.nseg;
@@ -626,11 +641,13 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
     // (the output taps live in VGPRs: 33 double coefficients next to the addresses do not fit a wave's 102 SGPRs, and
     // hipcc then shuffles them through v_readlane / re-reads them from the kernel arguments inside the body)
     double al[NSEC], be[NSEC], gam = cf.gamma;
+    if constexpr (!UPL) {   // (UPL: the taps are row 0 of its table, and that arrives by scalar loads)
 #pragma unroll
-    for (int s = 0; s < NSEC; ++s) {
-        al[s] = cf.al[s];
-        be[s] = cf.be[s];
-        asm volatile("" : "+v"(be[s]));
+        for (int s = 0; s < NSEC; ++s) {
+            al[s] = cf.al[s];
+            be[s] = cf.be[s];
+            asm volatile("" : "+v"(be[s]));
+        }
     }
     // .dn, compact form: this lane's sample stream (T samples of chunk cj, component lane % LS) walks the positions
     // v = R0 + cj T + c of the segment, R0 = (first sample of the segment) mod dec; sample v is kept iff dec divides v, as
@@ -657,10 +674,22 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
     unsigned dtr = dt, e0r = 0;
     int upj_cnt = 0;   // UPJ: (samples since the last input sample) - 1
     constexpr bool UPJ_PRE = UPJ && NSEC <= 4;
-    double cjn[UPJ_PRE ? D : 1];   // UPJ: the row c A^cnt of the next sample
+    // UPJ, up to 4 biquads: the rows c A^cnt arrive by scalar loads, wave-uniform, in PAIRS (rows cnt, cnt + 1 are adjacent in the table, row `up` repeats
+    // row 0), requested a pair ahead.  Scalar loads return in no order, so a wave can only wait for ALL of them: with one row requested per sample the wait
+    // for this sample's row was also the wait for the next one's, one sample old -- 200 clocks of scalar-cache latency against 40 of arithmetic, and four
+    // waves per SIMD do not cover that (SQ_WAIT_ANY: half of every wave's life).  Pairs halve the waits and double the distance.
+    double cjn[UPJ_PRE ? 2 * D : 1];   // the pair requested last: rows of the next two samples once the current pair is used up
+    double cjc[UPJ_PRE ? 2 * D : 1];   // the pair in use
+    int upj_c2 = 2;                    // first row of the pair to request next
     if constexpr (UPJ_PRE) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) cjn[d] = upj[d];
+        for (int d = 0; d < 2 * D; ++d) cjn[d] = upj[d];
+#pragma unroll
+        for (int d = 0; d < 2 * D; ++d) cjc[d] = 0.0;
+        // (the blocks of A^up, requested at the top of the kernel, have arrived: said HERE, so that no wait for them -- which would also be a wait for the
+        // wave's own stores -- appears at the input samples inside the loop)
+#pragma unroll
+        for (int i = 0; i < 4 * NSEC; ++i) asm volatile("" : "+v"(AuV[i]));
     }
     int dnl_cnt = 0;                                  // DNL: samples since the last kept one
     unsigned dnl_o = (unsigned)(lane / LS) * (unsigned)(T / (DNL ? a.dec : 1));   // DNL: this lane's next output, counted from the segment's first
@@ -668,6 +697,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
     double upl_next = UPL ? (double)xs[NIN > 1 ? 1 : 0] : 0.0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
+        if constexpr (UPL) wave_lds_sync();   // (the wave's rows are free: UPL hands every 16-byte unit to the image as it completes)
 #pragma unroll
         for (int k = 0; k < kPiece; ++k) {
             constexpr int kE = St::elems;
@@ -688,12 +718,20 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
                     double cj[D];
                     const bool is_input = upj_cnt == a.up - 1;
                     if constexpr (UPJ_PRE) {
+                        const int half = (p * kPiece + k - 1) & 1;   // samples 1, 2 are the first pair
+                        if (half == 0) {
 #pragma unroll
-                        for (int d = 0; d < D; ++d) cj[d] = cjn[d];
+                            for (int d = 0; d < 2 * D; ++d) cjc[d] = cjn[d];
+                            asm volatile("" : "+s"(upj_c2));   // (one address at a time: hipcc otherwise works out the addresses of many pairs ahead and spills them)
+                            const double *nr = upj + (size_t)upj_c2 * D;
+#pragma unroll
+                            for (int d = 0; d < 2 * D; ++d) cjn[d] = nr[d];
+                            upj_c2 += 2;                                   // (rows c2, c2 + 1; the pair behind row up - 1 or up starts over)
+                            upj_c2 = upj_c2 >= a.up ? upj_c2 - a.up : upj_c2;
+                        }
+#pragma unroll
+                        for (int d = 0; d < D; ++d) cj[d] = cjc[half * D + d];
                         upj_cnt = is_input ? 0 : upj_cnt + 1;
-                        const double *nr = upj + (size_t)upj_cnt * D;
-#pragma unroll
-                        for (int d = 0; d < D; ++d) cjn[d] = nr[d];
                     } else {
                         const double *nr = upj + (size_t)upj_cnt * D;
 #pragma unroll
@@ -709,7 +747,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
                     }
                     if (is_input) {   // an input sample: its direct term, and the state jumps to right behind it (the blocks of A^up: one sample in `up`)
                         yv = fma(gam, xd, yv);
-                        const double *Au = upj + (size_t)a.up * D;
+                        const double *Au = UPJ_PRE ? AuV : upj + (size_t)a.up * D;
 #pragma unroll
                         for (int s = 0; s < NSEC; ++s) {
                             const double n0 = fma(Au[4 * s + 1], z[2 * s + 1], fma(Au[4 * s], z[2 * s], xd));
@@ -723,6 +761,22 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
                         }
                     }
                     xq[(p * kPiece + k) / kE][e] = (IO)yv;
+                    if constexpr (UPL) {
+                        if (e == kE - 1) *reinterpret_cast<xv_t *>(myrow + (k / kE) * kE) = xq[(p * kPiece + k) / kE];
+                    }
+                    continue;
+                }
+                if constexpr (UPL) {   // the chunk's first sample: an input sample met with the state from the scan -- the taps are row 0, the step the plain one
+                    double yv = gam * xd;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) yv = fma(cjn[d], z[d], yv);   // (the first pair, requested above, starts with row 0)
+                    xq[0][0] = (IO)yv;
+#pragma unroll
+                    for (int s = 0; s < NSEC; ++s) {
+                        const double w0 = fma(cf.na2[s], z[2 * s + 1], fma(cf.na1[s], z[2 * s], xd));
+                        z[2 * s + 1] = z[2 * s];
+                        z[2 * s] = w0;
+                    }
                     continue;
                 }
             }
@@ -781,9 +835,11 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
         }
         if (rounds) continue;   // (the outputs stay in the registers of the chunk until the gathering below)
         if (PRIO && SK_PAR_PRIO_ST) __builtin_amdgcn_s_setprio(SK_PAR_PRIO);   // (the piece's way out through the image: -2.7 %)
-        wave_lds_sync();  // the wave's rows are free (its previous piece's stores have read them)
+        if constexpr (!UPL) {
+            wave_lds_sync();  // the wave's rows are free (its previous piece's stores have read them)
 #pragma unroll
-        for (int sgi = 0; sgi < St::segs; ++sgi) *reinterpret_cast<xv_t *>(myrow + sgi * St::elems) = xq[p * St::segs + sgi];
+            for (int sgi = 0; sgi < St::segs; ++sgi) *reinterpret_cast<xv_t *>(myrow + sgi * St::elems) = xq[p * St::segs + sgi];
+        }
         wave_lds_sync();
         if (!DEC && interior) {
             {
@@ -1137,12 +1193,13 @@ int iir_par_expand_host(const double *coef, int nsec, double *out, int *accepted
 }
 
 // .dn: can a segment's kept outputs be gathered in the wave's stage image (see ParArgs::dec_compact)?
-template <typename IO, bool CPLX> static bool par_dec_compact(int dec, int64_t seg_samples)
+// (lean: the 96-sample kernels put a kept output into its slot straight from the sum -- no unit to pick it from, so M may be below the samples of a unit)
+template <typename IO, bool CPLX> static bool par_dec_compact(int dec, int64_t seg_samples, bool lean = false)
 {
     constexpr int elems = 16 / (int)sizeof(IO), ls = CPLX ? 2 : 1;
     const int64_t slots = (seg_samples / dec + 2) * ls;
     const int64_t bytes = (slots + slots / 32 + 2) * (int64_t)sizeof(IO);
-    return dec >= elems && bytes <= (int64_t)64 * Stage<IO>::pitch * (int64_t)sizeof(IO) && opt().iir_dn_compact;
+    return (lean || dec >= elems) && bytes <= (int64_t)64 * Stage<IO>::pitch * (int64_t)sizeof(IO) && opt().iir_dn_compact;
 }
 
 // .dn with dec below the samples of a 16-byte unit (float32 / complex64, dec = 2, 3): gathered in two ranges of chunks behind the recurrence
@@ -1158,7 +1215,9 @@ static int par_upj_table(ParPlan &P, int L, const double **out)
     for (auto &u : P.upj)
         if (u.up == L) { *out = u.dev; return SKDSP_OK; }
     const int N = P.nsec, D = 2 * N;
-    std::vector<double> tab((size_t)L * D + (size_t)N * 4);
+    // layout: rows 0 .. L - 1; up to 4 biquads (the kernels that read rows in pairs) row 0 once more; the blocks of A^L
+    const size_t rows = (size_t)L + (N <= 4 ? 1 : 0);
+    std::vector<double> tab(rows * D + (size_t)N * 4);
     for (int k = 0; k < N; ++k) {
         const long double A[4] = {-P.a1[k], -P.a2[k], 1.0L, 0.0L};   // (w[n-1], w[n-2]) -> (w[n], w[n-1]) without input
         long double c0 = (long double)P.al[k], c1 = (long double)P.be[k];   // the row c A^j
@@ -1171,7 +1230,11 @@ static int par_upj_table(ParPlan &P, int L, const double **out)
             const long double m0 = M[0] * A[0] + M[1] * A[2], m1 = M[0] * A[1] + M[1] * A[3], m2 = M[2] * A[0] + M[3] * A[2], m3 = M[2] * A[1] + M[3] * A[3];
             M[0] = m0; M[1] = m1; M[2] = m2; M[3] = m3;
         }
-        for (int i = 0; i < 4; ++i) tab[(size_t)L * D + 4 * k + i] = (double)M[i];   // A^L
+        if (N <= 4) {
+            tab[(size_t)L * D + 2 * k] = tab[2 * k];
+            tab[(size_t)L * D + 2 * k + 1] = tab[2 * k + 1];
+        }
+        for (int i = 0; i < 4; ++i) tab[rows * D + 4 * k + i] = (double)M[i];   // A^L
     }
     double *dev = nullptr;
     SK_HIP(hipMalloc((void **)&dev, tab.size() * 8));
@@ -1218,7 +1281,7 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
     a.aligned = ((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (nrow == 1 || ((x_stride * sizeof(IO)) % 16 == 0 && (y_stride * sizeof(IO)) % 16 == 0))) ? 1 : 0;
     a.dec = dec > 1 ? dec : 1;
     a.dec_magic = a.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + a.dec - 1) / a.dec) : 0u;
-    a.dec_compact = a.dec > 1 && par_dec_compact<IO, CPLX>(a.dec, S) ? 1 : 0;
+    a.dec_compact = a.dec > 1 && par_dec_compact<IO, CPLX>(a.dec, S, TT == 96) ? 1 : 0;
     a.dec_rounds = !a.dec_compact && par_dec_rounds<IO, CPLX>(a.dec) ? 2 : 1;
     a.up = up > 1 ? up : 1;
     a.up_magic = a.up > 1 ? (unsigned)((((unsigned long long)1 << 32) + a.up - 1) / a.up) : 0u;
@@ -1246,16 +1309,16 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
         if (a.dec > 1 && a.dec_rounds > 1) {                                                                            \
             if constexpr (sizeof(IO) == 4)                                                                              \
                 hipLaunchKernelGGL((iir_par_kernel<N, IO, 2, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,    \
-                                   (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, (const double *)nullptr);  \
+                                   (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr);  \
         } else if (a.dec > 1)                                                                                           \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 1, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,        \
-                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, (const double *)nullptr);      \
+                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr);      \
         else if constexpr (UPJ)                                                                                         \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX, TT, true>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,  \
-                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, upj_tab); \
+                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, upj_tab); \
         else if constexpr (TT == 0)                                                                                     \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,            \
-                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, (const double *)nullptr);      \
+                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr);      \
         break;                                                                                                          \
     }
     switch (h->nsec) {
@@ -1292,9 +1355,9 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     // Before the lean form: M = 2, 3, 6 only (M = 3 0.193 -> 0.173 ms, M = 4 + 7 .. 9 %).  Option iir_dn_t96 = 2: every divisor of 96; 0: never.
     const bool t96_pays = dec == 2 || dec == 3 || dec == 6 || (96 % dec == 0 && (h->nsec <= 4 || !interleaved || dec % 3 == 0));
     bool t96 = !dbl && dec > 1 && ((opt().iir_dn_t96 == 1 && t96_pays) || (opt().iir_dn_t96 == 2 && 96 % dec == 0));
-    // (the 96-sample kernels have no store but the gathering ones: ranges of chunks for M = 2, 3, the lean compact store from 4 on)
-    if (t96 && !(dec < 4 ? (interleaved ? par_dec_rounds<float, true>(dec) : par_dec_rounds<float, false>(dec))
-                         : (interleaved ? par_dec_compact<float, true>(dec, (int64_t)32 * 96) : par_dec_compact<float, false>(dec, (int64_t)64 * 96))))
+    // (the 96-sample kernels have no store but the gathering ones: the lean compact store where a segment's kept outputs fit the image -- from M = 3 on --, ranges of chunks for M = 2)
+    if (t96 && !(interleaved ? par_dec_compact<float, true>(dec, (int64_t)32 * 96, true) || par_dec_rounds<float, true>(dec)
+                             : par_dec_compact<float, false>(dec, (int64_t)64 * 96, true) || par_dec_rounds<float, false>(dec)))
         t96 = false;
     // .up by a divisor of 96 from 8 on, up to 4 biquads: the state jumps from input sample to input sample (UPJ kernels, chunks of 96 so that every chunk
     // starts on one).  Measured (profiles/r05/iir_up.txt): rate_change(12).up float32 0.097 -> 0.085 ms, complex64 0.167 -> 0.156; by 4 a tie; 8 biquads
