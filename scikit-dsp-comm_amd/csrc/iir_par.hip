@@ -115,7 +115,7 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 // through them -- every output is a 2 NSEC term product of the state right behind the last input sample with a row of c A^j (a table, wave-uniform
 // because all chunks start on an input sample), and the state jumps by A^L per INPUT sample: 2 NSEC + 5 NSEC / L multiply-adds per output instead of
 // 4 NSEC + 1 (order-8 Butterworth, L = 12: 9.7 instead of 17).
-template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0, bool UPJ = false>
+template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0, bool UPJ = false, bool UP2 = false>
 __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
                                                                  const double *__restrict__ lvl, const double *__restrict__ psi,
                                                                  unsigned long long,   // (keeps upj out of the register tuple the three pointers above arrive in: that tuple was spilled as a whole, upj with it, and restored -- eight registers -- in front of every pair of row loads)
@@ -129,6 +129,12 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
     // register.  The zero-stuffing through the image (two magic divisions, a dozen selects and an LDS round trip per 16-byte unit of OUTPUT-rate
     // samples) was two thirds of the kernel's 3000 vector instructions per segment (profiles/r05/pmc_rcup12.json: SQ_INSTS_VALU) -- the FP64 work is 1000.
     constexpr bool UPL = UPJ && NSEC <= 4;
+    // UP2 (.up by 2, the reference default of multirate_IIR.up): every chunk starts on an input sample and every second sample is a stuffed zero -- known when
+    // the kernel is compiled.  The segment is staged at the INPUT rate (the plain filter's loads over chunks of T / 2 samples: whole lines, no division, no
+    // select), V = G x runs over the even columns of G, and the recurrence reads input k / 2 at even k and a literal zero at odd k.  Building the
+    // zero-stuffed image unit by unit (two magic divisions, two loads, a dozen selects per 16 bytes of OUTPUT) was 2600 of the 7200 vector instructions per
+    // segment of multirate_IIR(8 biquads).up(x, 2) -- the arithmetic is 4500 (SQ_INSTS_VALU, LABNOTES R5.8).
+    static_assert(!UP2 || (DECM == 0 && TT == 0 && !UPJ), "UP2: the plain store, the default chunk length");
     // DNL, the lean form of the compact decimating store (TT = 96, M a divisor of 96 from 3 on: a segment's kept outputs fit the image): every chunk of every segment starts on a kept sample,
     // so WHICH samples are kept is wave-uniform -- a scalar counter and a scalar branch instead of the per-lane phase arithmetic (a compare and an exec
     // mask per sample, the unit bookkeeping per 16 bytes, the pick out of the unit at the gathering: 2000 of the 3700 vector instructions per segment of
@@ -138,6 +144,9 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
     constexpr bool G4 = D <= 12;   // V = G x by 4 x 4 x 4 products over the row groups in use (see phase A)
     constexpr int T = TT ? TT : SK_PAR_T32 * 4 / (int)sizeof(IO);
     constexpr int NP = T / kPiece;
+    constexpr int TI = UP2 ? T / 2 : T;   // samples per chunk at the rate the signal is READ at
+    constexpr int NPI = TI / kPiece;
+    static_assert(TI % kPiece == 0, "UP2: whole pieces at the input rate");
     static_assert(T % kPiece == 0 && ((T / 4) * 64) % kIirThreads == 0, "chunk length: whole pieces, a table the workgroup loads evenly");
     using St = Stage<IO>;
     constexpr int kRowBytes = St::pitch * (int)sizeof(IO);
@@ -217,16 +226,18 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
     pre_t pre[NP][St::per_thread];
     // (uniform segment base + one 32-bit lane offset + constants: hipcc then addresses every access of the segment as
     // SGPR base + VGPR offset + immediate instead of keeping a 64-bit address pair per access alive)
-    const IO *xseg = x + row0 * T * LS;          // (IO scalars: an interleaved complex sample is two)
+    const IO *xseg = x + row0 * TI * LS;         // (IO scalars: an interleaved complex sample is two)
     IO *yseg = y + row0 * T * LS;
     // a 16-byte unit of a chunk's piece: St::segs units per real chunk piece, 2 x St::segs per complex one (re/im interleaved)
     constexpr int USEG = St::segs * LS;
     const unsigned loff = (unsigned)((lane / USEG) * T * LS + (lane % USEG) * St::elems);
     constexpr unsigned kRowStep = (64 / USEG) * T * LS;   // IO scalars between a lane's consecutive staged units
+    const unsigned loff_in = UP2 ? (unsigned)((lane / USEG) * TI * LS + (lane % USEG) * St::elems) : loff;   // (the same on the way in, at the rate read at)
+    constexpr unsigned kRowStepIn = (64 / USEG) * TI * LS;
     auto load_piece = [&](int p) {  // interior segments only
 #pragma unroll
         for (int i = 0; i < St::per_thread; ++i)
-            pre[p][i] = __builtin_nontemporal_load(reinterpret_cast<const pre_t *>(xseg + (loff + i * kRowStep + p * kPiece * LS)));
+            pre[p][i] = __builtin_nontemporal_load(reinterpret_cast<const pre_t *>(xseg + (loff_in + i * kRowStepIn + p * kPiece * LS)));
     };
     // image position of staged unit (i, lane): real: 16 bytes of row idx / segs; complex: the unit holds elems / 2 complex
     // samples of chunk idx / USEG -- their re parts go to row 2 chunk, their im parts to row 2 chunk + 1
@@ -270,11 +281,12 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
             const int idx = i * 64 + lane;
             const int r = idx / USEG, sg = idx % USEG;
             // g: index of the unit's first sample (a complex sample for CPLX) in the row
-            const int64_t g = (row0 + r) * T + (int64_t)p * kPiece + (int64_t)sg * (St::elems / LS);
+            const int64_t g = (row0 + r) * TI + (int64_t)p * kPiece + (int64_t)sg * (St::elems / LS);
+            const int64_t nlim = UP2 ? a.n_in : a.n;
             pre_t val;
             IO *e4 = reinterpret_cast<IO *>(&val);
 #pragma unroll
-            for (int e = 0; e < St::elems; ++e) e4[e] = (g + e / LS < a.n) ? x[g * LS + e] : IO(0);
+            for (int e = 0; e < St::elems; ++e) e4[e] = (g + e / LS < nlim) ? x[g * LS + e] : IO(0);
             image_put(i, val);
         }
     };
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
             image_put(i, val);
         }
     };
-    const bool ld_fast = interior && a.up == 1;
+    const bool ld_fast = interior && (a.up == 1 || UP2);
     // .up by 8 or more (from 4 on the unrolled column loop costs more than the zeros: rate_change(4).up 0.130 -> 0.140 ms): at most T / 8 + 1 samples of a chunk are not stuffed zeros, so V = G x is a handful of columns of G per chunk -- formed
     // per lane on the vector ALU from the INPUT samples instead of multiplying the zeros on the matrix pipe (rate_change(12).up: 11 of 128 columns;
     // the chunks of a wave start at different phases of the stuffing, so the columns differ from lane to lane and the matrix form cannot drop them)
@@ -379,7 +391,51 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
             }
             xs[jj] = val;
         }
-    } else {
+    }
+    xv_t xin[UP2 ? TI / St::elems : 1];   // UP2: the chunk's input samples
+    if constexpr (UP2) {
+        if (ld_fast) {
+#pragma unroll
+            for (int p = 0; p < NPI; ++p) load_piece(p);
+        }
+#pragma unroll
+        for (int p = 0; p < NPI; ++p) {
+            if (ld_fast) {
+#pragma unroll
+                for (int i = 0; i < St::per_thread; ++i) image_put(i, pre[p][i]);
+            } else {
+                stage_slow(p);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int sgi = 0; sgi < St::segs; ++sgi) xin[p * St::segs + sgi] = *reinterpret_cast<const xv_t *>(myrow + sgi * St::elems);
+            // V = G x over the even columns of G: input 4 s + j of the piece meets column 2 (4 (8 p + s) + j) -- read with a per-lane address, as the
+            // zero-stuffed image's .up by 2 / 4 below reads it
+            const IO *xu = stage + c * St::pitch + j;
+#pragma unroll
+            for (int s = 0; s < kPiece / 4; ++s) {
+                const int kcol = 2 * (4 * (p * (kPiece / 4) + s) + j);
+                const double *ga_p = gl + ((kcol >> 2) << 6) + ((kcol & 3) << 4);
+                if constexpr (G4) {
+                    constexpr int NG = (D + 3) / 4;
+                    double ga[NG];
+#pragma unroll
+                    for (int r = 0; r < NG; ++r) ga[r] = ga_p[4 * r + (lane & 3)];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const double b = (double)xu[g * 16 * St::pitch + 4 * s];
+#pragma unroll
+                        for (int r = 0; r < NG; ++r) acc[g][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(ga[r], b, acc[g][r], 0, 0, 0);
+                    }
+                } else {
+                    const double ga = ga_p[lane & 15];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, (double)xu[g * 16 * St::pitch + 4 * s], acc[g], 0, 0, 0);
+                }
+            }
+            wave_lds_sync();
+        }
+    } else if constexpr (!UPL) {
     // (every piece of the segment is requested up front: the landing registers are the ones the chunk will occupy anyway)
     if (ld_fast) {
 #pragma unroll
@@ -524,7 +580,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
         for (int r = 0; r < 4; ++r) {
             const int d = j + 4 * r;   // state row: section d >> 1, component d & 1
             if (4 * r < D) {
-                if (d < D) E[(((d >> 1) * 64) + 16 * g + c) * 2 + (d & 1)] = acc[g][r];
+                if (d < D) E[(((d >> 1) * 64) + 16 * g + c) * 2 + (d & 1)] = UP2 ? 2.0 * acc[g][r] : acc[g][r];   // (UP2: the gain the zero-stuffed image would have carried)
             }
         }
     wave_lds_sync();
@@ -697,7 +753,8 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
     double upl_next = UPL ? (double)xs[NIN > 1 ? 1 : 0] : 0.0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        if constexpr (UPL) wave_lds_sync();   // (the wave's rows are free: UPL hands every 16-byte unit to the image as it completes)
+        if constexpr (UPL || UP2) wave_lds_sync();   // (the wave's rows are free: UPL / UP2 hand every 16-byte unit to the image as it completes)
+        xv_t ou = xv_t(0);   // UP2: the unit being completed
 #pragma unroll
         for (int k = 0; k < kPiece; ++k) {
             constexpr int kE = St::elems;
@@ -709,7 +766,9 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
                 dtr = dtr >= (unsigned)a.dec ? dtr - (unsigned)a.dec : dtr;   // (M = 2, 3: a 4-sample unit spans more than one period)
             }
             double xd;
+            const bool zero_in = UP2 && ((p * kPiece + k) & 1);   // UP2: a stuffed zero (known here, not tested)
             if constexpr (UPL) xd = p * kPiece + k == 0 ? (double)xs[0] : upl_next;   // (read at input samples only)
+            else if constexpr (UP2) xd = zero_in ? 0.0 : 2.0 * (double)xin[((p * kPiece + k) / 2) / kE][((p * kPiece + k) / 2) % kE];
             else xd = (double)xq[(p * kPiece + k) / kE][e];
             if constexpr (UPJ) {
                 if (p * kPiece + k > 0) {   // (the chunk's first sample is an input sample met with the state from the scan: the plain step below)
@@ -799,17 +858,23 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
                     ++dnl_o;
                 }
             } else if (keep) {
-                double yv = gam * xd;
+                double yv = zero_in ? al[0] * z[0] : fma(al[0], z[0], gam * xd);
+                yv = fma(be[0], z[1], yv);
 #pragma unroll
-                for (int s = 0; s < NSEC; ++s) {
+                for (int s = 1; s < NSEC; ++s) {
                     yv = fma(al[s], z[2 * s], yv);
                     yv = fma(be[s], z[2 * s + 1], yv);
                 }
-                xq[(p * kPiece + k) / kE][e] = (IO)yv;
+                if constexpr (UP2) {
+                    ou[e] = (IO)yv;
+                    if (e == kE - 1) *reinterpret_cast<xv_t *>(myrow + (k / kE) * kE) = ou;
+                } else {
+                    xq[(p * kPiece + k) / kE][e] = (IO)yv;
+                }
             }
 #pragma unroll
             for (int s = 0; s < NSEC; ++s) {
-                const double w0 = fma(cf.na2[s], z[2 * s + 1], fma(cf.na1[s], z[2 * s], xd));
+                const double w0 = fma(cf.na2[s], z[2 * s + 1], zero_in ? cf.na1[s] * z[2 * s] : fma(cf.na1[s], z[2 * s], xd));
                 z[2 * s + 1] = z[2 * s];
                 z[2 * s] = w0;
             }
@@ -835,7 +900,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
         }
         if (rounds) continue;   // (the outputs stay in the registers of the chunk until the gathering below)
         if (PRIO && SK_PAR_PRIO_ST) __builtin_amdgcn_s_setprio(SK_PAR_PRIO);   // (the piece's way out through the image: -2.7 %)
-        if constexpr (!UPL) {
+        if constexpr (!UPL && !UP2) {
             wave_lds_sync();  // the wave's rows are free (its previous piece's stores have read them)
 #pragma unroll
             for (int sgi = 0; sgi < St::segs; ++sgi) *reinterpret_cast<xv_t *>(myrow + sgi * St::elems) = xq[p * St::segs + sgi];
@@ -1244,7 +1309,7 @@ static int par_upj_table(ParPlan &P, int L, const double **out)
     return SKDSP_OK;
 }
 
-template <typename IO, bool CPLX, int TT = 0, bool UPJ = false>
+template <typename IO, bool CPLX, int TT = 0, bool UPJ = false, bool UP2 = false>
 static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
                       void *y, hipStream_t s, int dec, int up = 1)
 {
@@ -1316,6 +1381,9 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
         else if constexpr (UPJ)                                                                                         \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX, TT, true>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,  \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, upj_tab); \
+        else if constexpr (UP2)                                                                                         \
+            hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX, 0, false, true>), dim3(grid), dim3(kIirThreads), 0, s, a, cf, \
+                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr); \
         else if constexpr (TT == 0)                                                                                     \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,            \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr);      \
@@ -1390,6 +1458,15 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     if (t96)
         return interleaved ? launch_par<float, true, 96>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up)
                            : launch_par<float, false, 96>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up);
+    // .up by 2 (the reference default of multirate_IIR.up): staged at the input rate, the stuffed zeros known to the compiler (UP2 in the kernel).  Measured
+    // (profiles/r05/iir_up_lean.txt); option iir_up_lean = 0: the zero-stuffed image as for every other factor
+    if (up == 2 && dec <= 1 && opt().iir_up_lean) {
+        if (interleaved)
+            return dbl ? launch_par<double, true, 0, false, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up)
+                       : launch_par<float, true, 0, false, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up);
+        return dbl ? launch_par<double, false, 0, false, true>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up)
+                   : launch_par<float, false, 0, false, true>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up);
+    }
     if (interleaved)
         return dbl ? launch_par<double, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up) : launch_par<float, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up);
     return dbl ? launch_par<double, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up)
