@@ -108,7 +108,7 @@ def test_parallel_form_is_what_config4_runs():
         y2.free()
 
 
-@pytest.mark.parametrize("M", [2, 3, 4, 5, 12, 13, 64, 127, 4096, 5000])
+@pytest.mark.parametrize("M", [2, 3, 4, 5, 6, 8, 12, 13, 24, 64, 96, 127, 4096, 5000])
 @pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
 def test_parallel_form_decimating_store(dt, M):
     """.dn: only every M-th output is stored (multirate_helper.py:186-192: downsample(sosfilt(sos, x), M)).  Where M is at least the

@@ -3,7 +3,7 @@
 profiles/<round>/pmc_<workload>.json: per-dispatch means per kernel plus the HBM bytes of ONE
 bench step (what bench.py reports as roofline.traffic).
 
-    python tools/reduce_pmc.py gpurun_out/profiles_r01 profiles/r01
+    python tools/reduce_pmc.py gpurun_out/profiles_r01 profiles/r01 [workload ...]
 
 FETCH_SIZE / WRITE_SIZE are in KiB; the read side is doubled per the gfx950 correction of
 MI355X_MICROARCH.md (HBM section); every counter group comes from its own rocprofv3 run.
@@ -16,6 +16,7 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+ONLY = set(sys.argv[3:])   # (workloads re-collected after a kernel changed: only their files are reduced and stamped -- the stamp is the tree's at reduce time)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import subprocess
@@ -52,6 +53,8 @@ def _has(pat, name):
 
 
 for w, (pat, marker, alg) in WORK.items():
+    if ONLY and w not in ONLY:
+        continue
     out = {}
     for tag in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_INSTS_MFMA"):
         f = os.path.join(src, "pmc_%s_%s.csv" % (w, tag))
@@ -85,6 +88,11 @@ for w, (pat, marker, alg) in WORK.items():
 for f in sorted(os.listdir(src)):
     if f.startswith("kernel_stats_") and f.endswith(".csv"):
         w = f[len("kernel_stats_"):-4]
+        if ONLY and w not in ONLY:
+            continue
+        if os.path.abspath(src) != os.path.abspath(dst):
+            import shutil
+            shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
         meta = {"workload": w, "source_sha256": bench.source_hashes(w), "collected_at_commit": COMMIT,
                 "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload %s --no-cpu-baseline --no-other-configs --board-seconds 0" % w}
         json.dump(meta, open(os.path.join(dst, "kernel_stats_%s.meta.json" % w), "w"), indent=1)
