@@ -111,7 +111,7 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 // TT: samples per chunk (0: SK_PAR_T32 / its half for float64).  The decimating kernels of float32 / complex64 signals run on chunks of 96 where M divides 96
 // (M = 2, 3, 4, 6, 8, 12, 16, 24, ...): every chunk of every segment then starts on a kept sample, all lanes of a wave walk the SAME phase, and the 2 NSEC + 1
 // term output sum is formed for one sample in M -- with 128, M = 3 put the lanes on three phases and every sum was formed (M = 12: three in twelve).
-// UPJ (.up by 4 or more, with TT = 96 and L a divisor of 96): between two input samples the filter runs on stuffed zeros, so the recurrence does not step
+// UPJ (.up by 8 or more, with TT = 96 and L a divisor of 96): between two input samples the filter runs on stuffed zeros, so the recurrence does not step
 // through them -- every output is a 2 NSEC term product of the state right behind the last input sample with a row of c A^j (a table, wave-uniform
 // because all chunks start on an input sample), and the state jumps by A^L per INPUT sample: 2 NSEC + 5 NSEC / L multiply-adds per output instead of
 // 4 NSEC + 1 (order-8 Butterworth, L = 12: 9.7 instead of 17).
@@ -123,13 +123,13 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
 {
     constexpr bool DEC = DECM != 0;
     constexpr int D = 2 * NSEC;
-    // UPL, the lean form of UPJ (up to 4 biquads): a chunk of 96 outputs holds 96 / up <= 12 input samples and starts on one, so the zero-stuffed chunk
+    // UPL, the lean form UPJ kernels take: a chunk of 96 outputs holds 96 / up <= 12 input samples and starts on one, so the zero-stuffed chunk
     // never exists, not even in the wave's image: a lane loads ITS inputs (adjacent lanes adjacent runs: whole lines per wave), forms its from-rest end
     // state from the 96 / up columns of G those meet (wave-uniform columns: scalar loads, no table in LDS) and hands the recurrence the next input as a
     // register.  The zero-stuffing through the image (two magic divisions, a dozen selects and an LDS round trip per 16-byte unit of OUTPUT-rate
     // samples) was two thirds of the kernel's 3000 vector instructions per segment (profiles/r05/pmc_rcup12.json: SQ_INSTS_VALU) -- the FP64 work is 1000.
-    constexpr bool UPL = UPJ && NSEC <= 4;
-    // UP2 (.up by 2, the reference default of multirate_IIR.up): every chunk starts on an input sample and every second sample is a stuffed zero -- known when
+    constexpr bool UPL = UPJ;   // (every UPJ kernel is lean; what differs by the number of biquads is how the rows of c A^j are requested)
+    // UP2 (.up by 2 -- the smallest factor: one sample in two carries input and the state jump would cost more than it saves): every chunk starts on an input sample and every second sample is a stuffed zero -- known when
     // the kernel is compiled.  The segment is staged at the INPUT rate (the plain filter's loads over chunks of T / 2 samples: whole lines, no division, no
     // select), V = G x runs over the even columns of G, and the recurrence reads input k / 2 at even k and a literal zero at odd k.  Building the
     // zero-stuffed image unit by unit (two magic divisions, two loads, a dozen selects per 16 bytes of OUTPUT) was 2600 of the 7200 vector instructions per
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
     if constexpr (UPL) {
         int vz = 0;
         asm volatile("" : "+v"(vz));
-        const double *Ap = upj + (size_t)(a.up + 1) * D + vz;
+        const double *Ap = upj + (size_t)(a.up + (NSEC <= 4 ? 1 : 0)) * D + vz;   // (up to 4 biquads the table repeats row 0 behind row up - 1)
 #pragma unroll
         for (int i = 0; i < 4 * NSEC; ++i) AuV[i] = Ap[i];
     }
@@ -737,11 +737,19 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
     double cjn[UPJ_PRE ? 2 * D : 1];   // the pair requested last: rows of the next two samples once the current pair is used up
     double cjc[UPJ_PRE ? 2 * D : 1];   // the pair in use
     int upj_c2 = 2;                    // first row of the pair to request next
+    // more than 4 biquads: a row is 2 NSEC doubles = up to 32 scalar registers, a pair in use and a pair in flight would be all there are: one row, a sample ahead
+    double cj1[(UPJ && !UPJ_PRE) ? D : 1];
+    if constexpr (UPJ && !UPJ_PRE) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) cj1[d] = upj[d];
+    }
     if constexpr (UPJ_PRE) {
 #pragma unroll
         for (int d = 0; d < 2 * D; ++d) cjn[d] = upj[d];
 #pragma unroll
         for (int d = 0; d < 2 * D; ++d) cjc[d] = 0.0;
+    }
+    if constexpr (UPL) {
         // (the blocks of A^up, requested at the top of the kernel, have arrived: said HERE, so that no wait for them -- which would also be a wait for the
         // wave's own stores -- appears at the input samples inside the loop)
 #pragma unroll
@@ -792,10 +800,12 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
                         for (int d = 0; d < D; ++d) cj[d] = cjc[half * D + d];
                         upj_cnt = is_input ? 0 : upj_cnt + 1;
                     } else {
+#pragma unroll
+                        for (int d = 0; d < D; ++d) cj[d] = cj1[d];
+                        upj_cnt = is_input ? 0 : upj_cnt + 1;
                         const double *nr = upj + (size_t)upj_cnt * D;
 #pragma unroll
-                        for (int d = 0; d < D; ++d) cj[d] = nr[d];
-                        upj_cnt = is_input ? 0 : upj_cnt + 1;
+                        for (int d = 0; d < D; ++d) cj1[d] = nr[d];
                     }
                     double yv = cj[0] * z[0];
                     yv = fma(cj[1], z[1], yv);
@@ -806,7 +816,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
                     }
                     if (is_input) {   // an input sample: its direct term, and the state jumps to right behind it (the blocks of A^up: one sample in `up`)
                         yv = fma(gam, xd, yv);
-                        const double *Au = UPJ_PRE ? AuV : upj + (size_t)a.up * D;
+                        const double *Au = AuV;
 #pragma unroll
                         for (int s = 0; s < NSEC; ++s) {
                             const double n0 = fma(Au[4 * s + 1], z[2 * s + 1], fma(Au[4 * s], z[2 * s], xd));
@@ -828,7 +838,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : 
                 if constexpr (UPL) {   // the chunk's first sample: an input sample met with the state from the scan -- the taps are row 0, the step the plain one
                     double yv = gam * xd;
 #pragma unroll
-                    for (int d = 0; d < D; ++d) yv = fma(cjn[d], z[d], yv);   // (the first pair, requested above, starts with row 0)
+                    for (int d = 0; d < D; ++d) yv = fma(UPJ_PRE ? cjn[d] : cj1[d], z[d], yv);   // (the first pair / row, requested above, is or starts with row 0)
                     xq[0][0] = (IO)yv;
 #pragma unroll
                     for (int s = 0; s < NSEC; ++s) {
@@ -1427,10 +1437,10 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     if (t96 && !(interleaved ? par_dec_compact<float, true>(dec, (int64_t)32 * 96, true) || par_dec_rounds<float, true>(dec)
                              : par_dec_compact<float, false>(dec, (int64_t)64 * 96, true) || par_dec_rounds<float, false>(dec)))
         t96 = false;
-    // .up by a divisor of 96 from 8 on, up to 4 biquads: the state jumps from input sample to input sample (UPJ kernels, chunks of 96 so that every chunk
-    // starts on one).  Measured (profiles/r05/iir_up.txt): rate_change(12).up float32 0.097 -> 0.085 ms, complex64 0.167 -> 0.156; by 4 a tie; 8 biquads
-    // by 4 lose 10 % (their rows of c A^j do not leave the scalar registers for a prefetched second one); option iir_up_jump = 2: wherever it applies
-    const bool upj = !dbl && dec <= 1 && up >= 8 && 96 % up == 0 && (opt().iir_up_jump >= 2 || (opt().iir_up_jump == 1 && h->nsec <= 4));
+    // .up by a divisor of 96 from 8 on (the reference default 12): the lean kernels whose state jumps from input sample to input sample (UPJ, chunks of 96 so
+    // that every chunk starts on one).  Measured, same box (profiles/r05/iir_up_lean.txt): rate_change(12).up float32 0.101 -> 0.072 ms per 2^26 outputs; 8-biquad
+    // elliptic by 12 0.113 -> 0.092 per 5e7 (complex64 0.216 -> 0.183); 5 biquads by 8 0.132 -> 0.096 (0.231 -> 0.164).  Option iir_up_jump = 0: never
+    const bool upj = !dbl && dec <= 1 && up >= 8 && 96 % up == 0 && opt().iir_up_jump >= 1;
     t96 = t96 || upj;
     if (t96) {
         ParTables &t9 = p->tab[4 + (interleaved ? 1 : 0)];
@@ -1458,7 +1468,7 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     if (t96)
         return interleaved ? launch_par<float, true, 96>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up)
                            : launch_par<float, false, 96>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up);
-    // .up by 2 (the reference default of multirate_IIR.up): staged at the input rate, the stuffed zeros known to the compiler (UP2 in the kernel).  Measured
+    // .up by 2 (where the state jump does not pay): staged at the input rate, the stuffed zeros known to the compiler (UP2 in the kernel).  Measured
     // (profiles/r05/iir_up_lean.txt); option iir_up_lean = 0: the zero-stuffed image as for every other factor
     if (up == 2 && dec <= 1 && opt().iir_up_lean) {
         if (interleaved)

@@ -48,7 +48,7 @@ struct Options {
     int iir_no_mfma = 0;      // recurrence K1 instead of the matrix-pipe K1
     int iir_two_pass = 0;     // 1: K1 + carries + K3 even where the single-pass scan applies; -1: single pass wherever it applies
     int iir_par = 1;          // 0: never the parallel-form scan (iir_par.hip); the cascade kernels everywhere
-    int iir_up_jump = 1;      // the parallel-form .up of float32 / complex64 signals jumps its state from input sample to input sample: 1 for L >= 8 (a divisor of 96) and up to 4 biquads, 2 wherever it applies (L >= 4), 0 never (A/B switch)
+    int iir_up_jump = 1;      // the parallel-form .up of float32 / complex64 signals by L >= 8, a divisor of 96: lean kernels whose state jumps from input sample to input sample; 0 never (A/B switch)
     int iir_seq = 1;          // cascades of more than 8 sections whose float64 spread the scans would lift past the contract run the reference's recursion (iir_seq.hip): 1 probed, 2 always, 0 never
     int iir_up_lean = 1;      // multirate_IIR.up by 2 staged at the input rate with the stuffed zeros known at compile time (A/B switch; 0: the zero-stuffed image)
     int iir_dn_t96 = 1;       // the parallel-form .dn of float32 / complex64 signals on 96-sample chunks: 1 for M = 2, 3, 6 (measured), 2 wherever M divides 96, 0 never (A/B switch)
