@@ -116,7 +116,7 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 // because all chunks start on an input sample), and the state jumps by A^L per INPUT sample: 2 NSEC + 5 NSEC / L multiply-adds per output instead of
 // 4 NSEC + 1 (order-8 Butterworth, L = 12: 9.7 instead of 17).
 template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0, bool UPJ = false, bool UP2 = false>
-__global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4) ? SK_PAR_OCC_UPL : SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
+__global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) ? SK_PAR_OCC_UPL : SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
                                                                  const double *__restrict__ lvl, const double *__restrict__ psi,
                                                                  unsigned long long,   // (keeps upj out of the register tuple the three pointers above arrive in: that tuple was spilled as a whole, upj with it, and restored -- eight registers -- in front of every pair of row loads)
                                                                  const double *__restrict__ upj = nullptr)   // UPJ: [up][2 nsec] rows c A^j, then [nsec][4] the blocks of A^up
@@ -1047,7 +1047,7 @@ struct ParPlan {
     long double a1[8], a2[8], r0[8], r1[8], c0 = 0.0L;
     double na1[8], na2[8], al[8], be[8], gamma = 0.0;
     double kappa = 0.0, ir_err = 0.0;
-    ParTables tab[6];            // [0] float32 (T = 128), [1] float64 (T = 64), [2] complex64, [3] complex128 (32 chunks per segment), [4] / [5] float32 / complex64 with T = 96 (.dn)
+    ParTables tab[8];            // [0] float32 (T = 128), [1] float64 (T = 64), [2] complex64, [3] complex128 (32 chunks per segment), [4] / [5] float32 / complex64 with T = 96 (.dn, .up), [6] / [7] float64 / complex128 with T = 96 (.up)
     struct UpJump { int up; double *dev; };
     std::vector<UpJump> upj;     // per L: [L][2 nsec] rows c A^j + [nsec][4] blocks of A^L (UPJ kernels)
     unsigned long long *lbg_dev = nullptr;
@@ -1440,19 +1440,23 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     // .up by a divisor of 96 from 8 on (the reference default 12): the lean kernels whose state jumps from input sample to input sample (UPJ, chunks of 96 so
     // that every chunk starts on one).  Measured, same box (profiles/r05/iir_up_lean.txt): rate_change(12).up float32 0.101 -> 0.072 ms per 2^26 outputs; 8-biquad
     // elliptic by 12 0.113 -> 0.092 per 5e7 (complex64 0.216 -> 0.183); 5 biquads by 8 0.132 -> 0.096 (0.231 -> 0.164).  Option iir_up_jump = 0: never
-    const bool upj = !dbl && dec <= 1 && up >= 8 && 96 % up == 0 && opt().iir_up_jump >= 1;
+    const bool upj = dec <= 1 && up >= 8 && 96 % up == 0 && opt().iir_up_jump >= 1;
     t96 = t96 || upj;
     if (t96) {
-        ParTables &t9 = p->tab[4 + (interleaved ? 1 : 0)];
+        ParTables &t9 = p->tab[(dbl ? 6 : 4) + (interleaved ? 1 : 0)];
         if (t9.T == 0) {
-            const int rc = par_tables(*p, t9, 96, interleaved ? 32 : 64, 1e-18L, par_max_k(false), s);
+            const int rc = par_tables(*p, t9, 96, interleaved ? 32 : 64, dbl ? 1e-30L : 1e-18L, par_max_k(dbl), s);
             if (rc < 0) return rc;
         }
         if (t9.K == 0) t96 = false;   // (the filter remembers more segments of this length than the look-back serves: the 128-sample chunks, if they do)
     }
-    if (t96 && upj)
+    if (t96 && upj) {
+        if (dbl)
+            return interleaved ? launch_par<double, true, 96, true>(h, p, p->tab[7], x, n, 1, 0, 0, y, s, dec, up)
+                               : launch_par<double, false, 96, true>(h, p, p->tab[6], x, n, nrow, x_stride, y_stride, y, s, dec, up);
         return interleaved ? launch_par<float, true, 96, true>(h, p, p->tab[5], x, n, 1, 0, 0, y, s, dec, up)
                            : launch_par<float, false, 96, true>(h, p, p->tab[4], x, n, nrow, x_stride, y_stride, y, s, dec, up);
+    }
     if (upj) t96 = false;
     ParTables &tb = t96 ? p->tab[4 + (interleaved ? 1 : 0)] : p->tab[(dbl ? 1 : 0) + (interleaved ? 2 : 0)];
     if (tb.T == 0) {

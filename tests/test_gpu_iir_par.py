@@ -168,11 +168,13 @@ def test_parallel_form_up_zero_stuffs_while_staging(dt, L):
                 with _ffi.option("iir_up_fused", fused):
                     outs.append(_ffi.IirKernel(_ffi.code_of(dt), sos=sos).up(x, L))
             single = np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4
-            # (float32 / complex64, L >= 8 a divisor of 96: the fused kernel does not step through the stuffed zeros at all -- its state
+            # (L >= 8 a divisor of 96: the fused kernel does not step through the stuffed zeros at all -- its state
             # jumps from input sample to input sample: the same filter in another operation order)
-            jumps = single and L >= 8 and 96 % L == 0
+            jumps = L >= 8 and 96 % L == 0
             if np.dtype(dt).kind == "c" or jumps:   # (the two-step path runs complex signals through other kernels: same arithmetic, other rounding)
-                assert max(rel_err(outs[1], outs[0])) <= (2e-7 if single else 1e-13), (name, L, n)
+                # (float64 with the state jump: a one-sample input shows the head of the impulse response, where the partial-fraction branches cancel to 1e-5 of
+                # their own size -- the two operation orders then differ by 1e-12 of that small head, 1e-15 of the states)
+                assert max(rel_err(outs[1], outs[0])) <= (2e-7 if single else (5e-12 if jumps else 1e-13)), (name, L, n)
             else:
                 assert np.array_equal(outs[0], outs[1]), (name, L, n)
             if n >= 683:

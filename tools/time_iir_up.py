@@ -20,7 +20,7 @@ cases = [("rate_change(12).up: butter(8, 0.075)", signal.butter(8, 0.9 / 12, out
          ("multirate_IIR(ellip lowpass, 6 biquads).up(x) [12]", signal.ellip(12, 0.5, 70, 0.9 / 12, output="sos"), 12, 1 << 22),
          ("multirate_IIR(butter lowpass, 5 biquads).up(x, 8)", signal.butter(10, 0.9 / 8, output="sos"), 8, 1 << 23)]
 for name, sos, L, n in cases:
-    for dt in (np.float32, np.complex64):
+    for dt in ((np.float64, np.complex128) if os.environ.get("TIME_F64") else (np.float32, np.complex64)):
         k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
         xd = _ffi.DeviceArray(n, dt).fill_noise(5); yd = _ffi.DeviceArray(n * L, dt)
         for _ in range(20): k.up_dev(xd, yd, L)
