@@ -114,12 +114,15 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 // UPJ (.up by 8 or more, with TT = 96 and L a divisor of 96): between two input samples the filter runs on stuffed zeros, so the recurrence does not step
 // through them -- every output is a 2 NSEC term product of the state right behind the last input sample with a row of c A^j (a table, wave-uniform
 // because all chunks start on an input sample), and the state jumps by A^L per INPUT sample: 2 NSEC + 5 NSEC / L multiply-adds per output instead of
-// 4 NSEC + 1 (order-8 Butterworth, L = 12: 9.7 instead of 17).
+// 4 NSEC + 1 (order-8 Butterworth, L = 12: 9.7 instead of 17).  float64 / complex128 signals too (they never hold the chunk in registers).
+// UP2 (.up by 2): the stuffed zeros are compile-time facts; staged at the input rate.
+// The rate forms are LEAN: the bookkeeping of the general kernel (zero-stuffing unit by unit, per-lane phase tests, the pick of kept samples) was two
+// thirds of their instructions -- see UPL / DNL / UP2 at the top of the kernel and LABNOTES R5.8.
 template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0, bool UPJ = false, bool UP2 = false>
 __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) ? SK_PAR_OCC_UPL : SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
                                                                  const double *__restrict__ lvl, const double *__restrict__ psi,
                                                                  unsigned long long,   // (keeps upj out of the register tuple the three pointers above arrive in: that tuple was spilled as a whole, upj with it, and restored -- eight registers -- in front of every pair of row loads)
-                                                                 const double *__restrict__ upj = nullptr)   // UPJ: [up][2 nsec] rows c A^j, then [nsec][4] the blocks of A^up
+                                                                 const double *__restrict__ upj = nullptr)   // UPJ: [up][2 nsec] rows c A^j (up to 4 biquads: row 0 once more), then [nsec][4] the blocks of A^up
 {
     constexpr bool DEC = DECM != 0;
     constexpr int D = 2 * NSEC;
