@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
     for (int g = 0; g < 4; ++g) acc[g] = v4d_t{0.0, 0.0, 0.0, 0.0};
     const int c = lane & 15, j = lane >> 4;
     IO *myrow = stage + lane * St::pitch;
-    constexpr int NIN = UPL ? T / 3 : 1;   // UPL: input samples a chunk can hold (L >= 3)
+    constexpr int NIN = UPL ? T / 8 : 1;   // UPL: input samples a chunk can hold
     IO xs[NIN];                            // ... this lane's, times the gain, rounded in the signal's type as the staging rounds them
     const int nin = UPL ? T / a.up : 0;    // ... and how many there are
     if constexpr (UPL) {
@@ -1443,7 +1443,7 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     // .up by a divisor of 96 from 8 on (the reference default 12): the lean kernels whose state jumps from input sample to input sample (UPJ, chunks of 96 so
     // that every chunk starts on one).  Measured, same box (profiles/r05/iir_up_lean.txt): rate_change(12).up float32 0.101 -> 0.072 ms per 2^26 outputs; 8-biquad
     // elliptic by 12 0.113 -> 0.092 per 5e7 (complex64 0.216 -> 0.183); 5 biquads by 8 0.132 -> 0.096 (0.231 -> 0.164).  Option iir_up_jump = 0: never
-    const bool upj = dec <= 1 && up >= (opt().iir_up_jump >= 2 ? 3 : 8) && 96 % up == 0 && opt().iir_up_jump >= 1;
+    const bool upj = dec <= 1 && up >= 8 && 96 % up == 0 && opt().iir_up_jump >= 1;
     t96 = t96 || upj;
     if (t96) {
         ParTables &t9 = p->tab[(dbl ? 6 : 4) + (interleaved ? 1 : 0)];
