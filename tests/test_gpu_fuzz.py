@@ -104,7 +104,7 @@ def test_fuzz_iir(seed):
         else:
             sos = signal.ellip(min(order, 8), 0.5, 60, wn, output="sos")
         op = rng.choice(["filter", "up", "dn"])
-        f = int(rng.choice([1, 2, 3, 4, 5, 12, 17]))
+        f = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 16, 17, 24, 48, 96]))   # (the divisors of 96 have kernels of their own: state jump / wave-uniform kept samples)
         x = _signal(rng, n, dt)
         xw = x.astype(np.complex128 if np.dtype(dt).kind == "c" else np.float64)
         iir = mrh.multirate_IIR(sos)
