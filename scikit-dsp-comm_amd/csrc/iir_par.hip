@@ -115,10 +115,10 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 // through them -- every output is a 2 NSEC term product of the state right behind the last input sample with a row of c A^j (a table, wave-uniform
 // because all chunks start on an input sample), and the state jumps by A^L per INPUT sample: 2 NSEC + 5 NSEC / L multiply-adds per output instead of
 // 4 NSEC + 1 (order-8 Butterworth, L = 12: 9.7 instead of 17).  float64 / complex128 signals too (they never hold the chunk in registers).
-// UP2 (.up by 2): the stuffed zeros are compile-time facts; staged at the input rate.
+// UPS (.up by 2, 3, 4 -- the factors of sigsys.interp24's stages): the stuffed zeros are compile-time facts; staged at the input rate (UP2 in the kernel).
 // The rate forms are LEAN: the bookkeeping of the general kernel (zero-stuffing unit by unit, per-lane phase tests, the pick of kept samples) was two
 // thirds of their instructions -- see UPL / DNL / UP2 at the top of the kernel and LABNOTES R5.8.
-template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0, bool UPJ = false, bool UP2 = false>
+template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0, bool UPJ = false, int UPS = 0>
 __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) ? SK_PAR_OCC_UPL : SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
                                                                  const double *__restrict__ lvl, const double *__restrict__ psi,
                                                                  unsigned long long,   // (keeps upj out of the register tuple the three pointers above arrive in: that tuple was spilled as a whole, upj with it, and restored -- eight registers -- in front of every pair of row loads)
@@ -131,13 +131,16 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
     // state from the 96 / up columns of G those meet (wave-uniform columns: scalar loads, no table in LDS) and hands the recurrence the next input as a
     // register.  The zero-stuffing through the image (two magic divisions, a dozen selects and an LDS round trip per 16-byte unit of OUTPUT-rate
     // samples) was two thirds of the kernel's 3000 vector instructions per segment (profiles/r05/pmc_rcup12.json: SQ_INSTS_VALU) -- the FP64 work is 1000.
+    constexpr bool UP2 = UPS != 0;   // (named after the first of its factors)
+    constexpr int UL = UPS ? UPS : 1;
     constexpr bool UPL = UPJ;   // (every UPJ kernel is lean; what differs by the number of biquads is how the rows of c A^j are requested)
     // UP2 (.up by 2 -- the smallest factor: one sample in two carries input and the state jump would cost more than it saves): every chunk starts on an input sample and every second sample is a stuffed zero -- known when
     // the kernel is compiled.  The segment is staged at the INPUT rate (the plain filter's loads over chunks of T / 2 samples: whole lines, no division, no
     // select), V = G x runs over the even columns of G, and the recurrence reads input k / 2 at even k and a literal zero at odd k.  Building the
     // zero-stuffed image unit by unit (two magic divisions, two loads, a dozen selects per 16 bytes of OUTPUT) was 2600 of the 7200 vector instructions per
     // segment of multirate_IIR(8 biquads).up(x, 2) -- the arithmetic is 4500 (SQ_INSTS_VALU, LABNOTES R5.8).
-    static_assert(!UP2 || (DECM == 0 && TT == 0 && !UPJ), "UP2: the plain store, the default chunk length");
+    // The same for 3 (chunks of 96) and 4 (float32 / complex64: a float64 chunk of 64 holds 16 inputs, half a staging piece).
+    static_assert(!UP2 || (DECM == 0 && !UPJ && (UPS == 3 ? TT == 96 : TT == 0) && (UPS == 2 || UPS == 3 || UPS == 4)), "UPS: the plain store; by 3 on chunks of 96");
     // DNL, the lean form of the compact decimating store (TT = 96, M a divisor of 96 from 3 on: a segment's kept outputs fit the image): every chunk of every segment starts on a kept sample,
     // so WHICH samples are kept is wave-uniform -- a scalar counter and a scalar branch instead of the per-lane phase arithmetic (a compare and an exec
     // mask per sample, the unit bookkeeping per 16 bytes, the pick out of the unit at the gathering: 2000 of the 3700 vector instructions per segment of
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
     constexpr bool G4 = D <= 12;   // V = G x by 4 x 4 x 4 products over the row groups in use (see phase A)
     constexpr int T = TT ? TT : SK_PAR_T32 * 4 / (int)sizeof(IO);
     constexpr int NP = T / kPiece;
-    constexpr int TI = UP2 ? T / 2 : T;   // samples per chunk at the rate the signal is READ at
+    constexpr int TI = T / UL;   // samples per chunk at the rate the signal is READ at
     constexpr int NPI = TI / kPiece;
     static_assert(TI % kPiece == 0, "UP2: whole pieces at the input rate");
     static_assert(T % kPiece == 0 && ((T / 4) * 64) % kIirThreads == 0, "chunk length: whole pieces, a table the workgroup loads evenly");
@@ -412,12 +415,12 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
             wave_lds_sync();
 #pragma unroll
             for (int sgi = 0; sgi < St::segs; ++sgi) xin[p * St::segs + sgi] = *reinterpret_cast<const xv_t *>(myrow + sgi * St::elems);
-            // V = G x over the even columns of G: input 4 s + j of the piece meets column 2 (4 (8 p + s) + j) -- read with a per-lane address, as the
+            // V = G x over every UL-th column of G: input 4 s + j of the piece meets column UL (4 (8 p + s) + j) -- read with a per-lane address, as the
             // zero-stuffed image's .up by 2 / 4 below reads it
             const IO *xu = stage + c * St::pitch + j;
 #pragma unroll
             for (int s = 0; s < kPiece / 4; ++s) {
-                const int kcol = 2 * (4 * (p * (kPiece / 4) + s) + j);
+                const int kcol = UL * (4 * (p * (kPiece / 4) + s) + j);
                 const double *ga_p = gl + ((kcol >> 2) << 6) + ((kcol & 3) << 4);
                 if constexpr (G4) {
                     constexpr int NG = (D + 3) / 4;
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
         for (int r = 0; r < 4; ++r) {
             const int d = j + 4 * r;   // state row: section d >> 1, component d & 1
             if (4 * r < D) {
-                if (d < D) E[(((d >> 1) * 64) + 16 * g + c) * 2 + (d & 1)] = UP2 ? 2.0 * acc[g][r] : acc[g][r];   // (UP2: the gain the zero-stuffed image would have carried)
+                if (d < D) E[(((d >> 1) * 64) + 16 * g + c) * 2 + (d & 1)] = UP2 ? (double)UL * acc[g][r] : acc[g][r];   // (UP2: the gain the zero-stuffed image would have carried)
             }
         }
     wave_lds_sync();
@@ -777,9 +780,9 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
                 dtr = dtr >= (unsigned)a.dec ? dtr - (unsigned)a.dec : dtr;   // (M = 2, 3: a 4-sample unit spans more than one period)
             }
             double xd;
-            const bool zero_in = UP2 && ((p * kPiece + k) & 1);   // UP2: a stuffed zero (known here, not tested)
+            const bool zero_in = UP2 && ((p * kPiece + k) % UL) != 0;   // UP2: a stuffed zero (known here, not tested)
             if constexpr (UPL) xd = p * kPiece + k == 0 ? (double)xs[0] : upl_next;   // (read at input samples only)
-            else if constexpr (UP2) xd = zero_in ? 0.0 : 2.0 * (double)xin[((p * kPiece + k) / 2) / kE][((p * kPiece + k) / 2) % kE];
+            else if constexpr (UP2) xd = zero_in ? 0.0 : (double)UL * (double)xin[((p * kPiece + k) / UL) / kE][((p * kPiece + k) / UL) % kE];
             else xd = (double)xq[(p * kPiece + k) / kE][e];
             if constexpr (UPJ) {
                 if (p * kPiece + k > 0) {   // (the chunk's first sample is an input sample met with the state from the scan: the plain step below)
@@ -1322,7 +1325,7 @@ static int par_upj_table(ParPlan &P, int L, const double **out)
     return SKDSP_OK;
 }
 
-template <typename IO, bool CPLX, int TT = 0, bool UPJ = false, bool UP2 = false>
+template <typename IO, bool CPLX, int TT = 0, bool UPJ = false, int UPS = 0>
 static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
                       void *y, hipStream_t s, int dec, int up = 1)
 {
@@ -1385,17 +1388,18 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
         for (int k = 0; k < N; ++k) { cf.na1[k] = p->na1[k]; cf.na2[k] = p->na2[k]; cf.al[k] = p->al[k]; cf.be[k] = p->be[k]; } \
         cf.gamma = p->gamma;                                                                                            \
         if (a.dec > 1 && a.dec_rounds > 1) {                                                                            \
-            if constexpr (sizeof(IO) == 4)                                                                              \
+            if constexpr (sizeof(IO) == 4 && !UPJ && UPS == 0)   /* (the .up launchers never decimate: no decimating kernels on their account) */ \
                 hipLaunchKernelGGL((iir_par_kernel<N, IO, 2, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,    \
                                    (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr);  \
-        } else if (a.dec > 1)                                                                                           \
-            hipLaunchKernelGGL((iir_par_kernel<N, IO, 1, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,        \
-                               (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr);      \
-        else if constexpr (UPJ)                                                                                         \
+        } else if (a.dec > 1) {                                                                                         \
+            if constexpr (!UPJ && UPS == 0)                                                                             \
+                hipLaunchKernelGGL((iir_par_kernel<N, IO, 1, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,    \
+                                   (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr);  \
+        } else if constexpr (UPJ)                                                                                         \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX, TT, true>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,  \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, upj_tab); \
-        else if constexpr (UP2)                                                                                         \
-            hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX, 0, false, true>), dim3(grid), dim3(kIirThreads), 0, s, a, cf, \
+        else if constexpr (UPS != 0)                                                                                    \
+            hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX, TT, false, UPS>), dim3(grid), dim3(kIirThreads), 0, s, a, cf, \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr); \
         else if constexpr (TT == 0)                                                                                     \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,            \
@@ -1444,7 +1448,9 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     // that every chunk starts on one).  Measured, same box (profiles/r05/iir_up_lean.txt): rate_change(12).up float32 0.101 -> 0.072 ms per 2^26 outputs; 8-biquad
     // elliptic by 12 0.113 -> 0.092 per 5e7 (complex64 0.216 -> 0.183); 5 biquads by 8 0.132 -> 0.096 (0.231 -> 0.164).  Option iir_up_jump = 0: never
     const bool upj = dec <= 1 && up >= 8 && 96 % up == 0 && opt().iir_up_jump >= 1;
-    t96 = t96 || upj;
+    // .up by 3 (a stage of sigsys.interp24): the lean staging at the input rate (UPS in the kernel), on chunks of 96
+    const bool ups3 = !dbl && dec <= 1 && up == 3 && opt().iir_up_lean;   // (float64: four images of 96 doubles per row and the table leave room for ONE workgroup per CU)
+    t96 = t96 || upj || ups3;
     if (t96) {
         ParTables &t9 = p->tab[(dbl ? 6 : 4) + (interleaved ? 1 : 0)];
         if (t9.T == 0) {
@@ -1460,7 +1466,12 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
         return interleaved ? launch_par<float, true, 96, true>(h, p, p->tab[5], x, n, 1, 0, 0, y, s, dec, up)
                            : launch_par<float, false, 96, true>(h, p, p->tab[4], x, n, nrow, x_stride, y_stride, y, s, dec, up);
     }
-    if (upj) t96 = false;
+    if (t96 && ups3) {
+        ParTables &t3 = p->tab[4 + (interleaved ? 1 : 0)];
+        return interleaved ? launch_par<float, true, 96, false, 3>(h, p, t3, x, n, 1, 0, 0, y, s, dec, up)
+                           : launch_par<float, false, 96, false, 3>(h, p, t3, x, n, nrow, x_stride, y_stride, y, s, dec, up);
+    }
+    if (upj || ups3) t96 = false;
     ParTables &tb = t96 ? p->tab[4 + (interleaved ? 1 : 0)] : p->tab[(dbl ? 1 : 0) + (interleaved ? 2 : 0)];
     if (tb.T == 0) {
         // negligibility as in iir_scan.hip: 1e-30 for float64 signals, 1e-18 for float32 signals (a tenth of an ulp of the
@@ -1475,15 +1486,18 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     if (t96)
         return interleaved ? launch_par<float, true, 96>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up)
                            : launch_par<float, false, 96>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up);
-    // .up by 2 (where the state jump does not pay): staged at the input rate, the stuffed zeros known to the compiler (UP2 in the kernel).  Measured
-    // (profiles/r05/iir_up_lean.txt); option iir_up_lean = 0: the zero-stuffed image as for every other factor
+    // .up by 2 / 4 (where the state jump does not pay; with 3 above, the stages of sigsys.interp24): staged at the input rate, the stuffed zeros known to the
+    // compiler (UPS in the kernel).  Measured (profiles/r05/iir_up_lean.txt); option iir_up_lean = 0: the zero-stuffed image as for every other factor
     if (up == 2 && dec <= 1 && opt().iir_up_lean) {
         if (interleaved)
-            return dbl ? launch_par<double, true, 0, false, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up)
-                       : launch_par<float, true, 0, false, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up);
-        return dbl ? launch_par<double, false, 0, false, true>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up)
-                   : launch_par<float, false, 0, false, true>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up);
+            return dbl ? launch_par<double, true, 0, false, 2>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up)
+                       : launch_par<float, true, 0, false, 2>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up);
+        return dbl ? launch_par<double, false, 0, false, 2>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up)
+                   : launch_par<float, false, 0, false, 2>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up);
     }
+    if (up == 4 && dec <= 1 && !dbl && opt().iir_up_lean)   // (a float64 chunk of 64 holds 16 inputs: half a staging piece)
+        return interleaved ? launch_par<float, true, 0, false, 4>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up)
+                           : launch_par<float, false, 0, false, 4>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up);
     if (interleaved)
         return dbl ? launch_par<double, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up) : launch_par<float, true>(h, p, tb, x, n, 1, 0, 0, y, s, dec, up);
     return dbl ? launch_par<double, false>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up)

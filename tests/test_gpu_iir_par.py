@@ -171,7 +171,8 @@ def test_parallel_form_up_zero_stuffs_while_staging(dt, L):
             # (L >= 8 a divisor of 96: the fused kernel does not step through the stuffed zeros at all -- its state
             # jumps from input sample to input sample: the same filter in another operation order)
             jumps = L >= 8 and 96 % L == 0
-            if np.dtype(dt).kind == "c" or jumps:   # (the two-step path runs complex signals through other kernels: same arithmetic, other rounding)
+            rechunked = single and L == 3   # (by 3 the fused kernel of float32 / complex64 signals runs on chunks of 96 samples, the two-step path on 128: another scan tree)
+            if np.dtype(dt).kind == "c" or jumps or rechunked:   # (the two-step path runs complex signals through other kernels: same arithmetic, other rounding)
                 # (float64 with the state jump: a one-sample input shows the head of the impulse response, where the partial-fraction branches cancel to 1e-5 of
                 # their own size -- the two operation orders then differ by 1e-12 of that small head, 1e-15 of the states)
                 assert max(rel_err(outs[1], outs[0])) <= (2e-7 if single else (5e-12 if jumps else 1e-13)), (name, L, n)

@@ -18,7 +18,9 @@ cases = [("rate_change(12).up: butter(8, 0.075)", signal.butter(8, 0.9 / 12, out
          ("multirate_IIR(ellip bandpass, 8 biquads).up(x, 2)", sos8, 2, 1 << 25),
          ("multirate_IIR(ellip bandpass, 8 biquads).up(x) [12]", sos8, 12, 1 << 22),
          ("multirate_IIR(ellip lowpass, 6 biquads).up(x) [12]", signal.ellip(12, 0.5, 70, 0.9 / 12, output="sos"), 12, 1 << 22),
-         ("multirate_IIR(butter lowpass, 5 biquads).up(x, 8)", signal.butter(10, 0.9 / 8, output="sos"), 8, 1 << 23)]
+         ("multirate_IIR(butter lowpass, 5 biquads).up(x, 8)", signal.butter(10, 0.9 / 8, output="sos"), 8, 1 << 23),
+         ("interp24 stage 2: butter(10, 1/3).up(x, 3)", signal.butter(10, 1 / 3., output="sos"), 3, 22369621),
+         ("interp24 stage 3: butter(10, 1/4).up(x, 4)", signal.butter(10, 1 / 4., output="sos"), 4, 1 << 24)]
 for name, sos, L, n in cases:
     for dt in ((np.float64, np.complex128) if os.environ.get("TIME_F64") else (np.float32, np.complex64)):
         k = _ffi.IirKernel(_ffi.code_of(dt), sos=sos)
