@@ -52,6 +52,7 @@ constexpr int SK_PAR_T32 = 128;   // samples per lane (float32 signals); float64
 constexpr int SK_PAR_PRIO = 3;      // wave priority in front of the recurrence (float32 signals, 6 - 8 biquads: DESIGN.md)
 constexpr int SK_PAR_PRIO_ST = 1;   // ... and on a piece's way out through the image
 constexpr int SK_PAR_OCC = 2;     // waves per SIMD the register budget is set for
+constexpr int kParStageM2 = 13312;  // bytes of a wave's stage image in the DECM = 3 kernels (3072 + 3072 / 32 + 2 slots of 4 bytes, rounded up)
 constexpr int SK_PAR_OCC_UPL = 4;   // ... of the lean .up kernels (UPJ, up to 4 biquads: no input image, no table in LDS)
 
 template <int NSEC> struct ParCoef {
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
     // so WHICH samples are kept is wave-uniform -- a scalar counter and a scalar branch instead of the per-lane phase arithmetic (a compare and an exec
     // mask per sample, the unit bookkeeping per 16 bytes, the pick out of the unit at the gathering: 2000 of the 3700 vector instructions per segment of
     // rate_change(12).dn, profiles/r05/pmc_rcdn12.json).  A kept output goes straight from the sum into its slot of the wave's idle image.
-    constexpr bool DNL = DECM == 1 && TT == 96;
+    constexpr bool DNL = (DECM == 1 || DECM == 3) && TT == 96;   // (3: M = 2, whose 3072 kept outputs per segment need a larger image -- see kWaveStage)
     constexpr bool UNI = DEC && TT == 96;   // (M = 2 on 96-sample chunks keeps its gathering in ranges but tests for kept samples the same way)
     constexpr bool G4 = D <= 12;   // V = G x by 4 x 4 x 4 products over the row groups in use (see phase A)
     constexpr int T = TT ? TT : SK_PAR_T32 * 4 / (int)sizeof(IO);
@@ -156,7 +157,9 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
     static_assert(T % kPiece == 0 && ((T / 4) * 64) % kIirThreads == 0, "chunk length: whole pieces, a table the workgroup loads evenly");
     using St = Stage<IO>;
     constexpr int kRowBytes = St::pitch * (int)sizeof(IO);
-    constexpr int kWaveStage = 64 * kRowBytes;                    // 9216 (float) / 17408 (double) bytes: also holds the 8 KiB scan exchange
+    // 9216 (float) / 17408 (double) bytes: also holds the 8 KiB scan exchange.  DECM = 3 (the lean compact store at M = 2, float32 / complex64, more than 4
+    // biquads -- kernels that run two workgroups per CU anyway): room for the 3072 kept outputs of a segment and their padding
+    constexpr int kWaveStage = DECM == 3 ? kParStageM2 : 64 * kRowBytes;
     constexpr int KMAX = par_max_k(sizeof(IO) == 8);
     static_assert(kWaveStage >= 64 * 16 * 8 + KMAX * 64 * 4, "scan exchange + look-back words must fit the wave's stage image");
     __shared__ __attribute__((aligned(16))) char lds_raw[4 * kWaveStage];
@@ -1275,12 +1278,12 @@ int iir_par_expand_host(const double *coef, int nsec, double *out, int *accepted
 
 // .dn: can a segment's kept outputs be gathered in the wave's stage image (see ParArgs::dec_compact)?
 // (lean: the 96-sample kernels put a kept output into its slot straight from the sum -- no unit to pick it from, so M may be below the samples of a unit)
-template <typename IO, bool CPLX> static bool par_dec_compact(int dec, int64_t seg_samples, bool lean = false)
+template <typename IO, bool CPLX> static bool par_dec_compact(int dec, int64_t seg_samples, bool lean = false, int64_t image_bytes = 0)
 {
     constexpr int elems = 16 / (int)sizeof(IO), ls = CPLX ? 2 : 1;
     const int64_t slots = (seg_samples / dec + 2) * ls;
     const int64_t bytes = (slots + slots / 32 + 2) * (int64_t)sizeof(IO);
-    return (lean || dec >= elems) && bytes <= (int64_t)64 * Stage<IO>::pitch * (int64_t)sizeof(IO) && opt().iir_dn_compact;
+    return (lean || dec >= elems) && bytes <= (image_bytes ? image_bytes : (int64_t)64 * Stage<IO>::pitch * (int64_t)sizeof(IO)) && opt().iir_dn_compact;
 }
 
 // .dn with dec below the samples of a 16-byte unit (float32 / complex64, dec = 2, 3): gathered in two ranges of chunks behind the recurrence
@@ -1362,7 +1365,9 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
     a.aligned = ((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (nrow == 1 || ((x_stride * sizeof(IO)) % 16 == 0 && (y_stride * sizeof(IO)) % 16 == 0))) ? 1 : 0;
     a.dec = dec > 1 ? dec : 1;
     a.dec_magic = a.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + a.dec - 1) / a.dec) : 0u;
-    a.dec_compact = a.dec > 1 && par_dec_compact<IO, CPLX>(a.dec, S, TT == 96) ? 1 : 0;
+    // (M = 2 on 96-sample chunks, more than 4 biquads, float32 / complex64: the DECM = 3 kernels with their larger image)
+    const bool big_m2 = TT == 96 && sizeof(IO) == 4 && !UPJ && UPS == 0 && a.dec == 2 && h->nsec > 4 && opt().iir_dn_t96 != 3;
+    a.dec_compact = a.dec > 1 && par_dec_compact<IO, CPLX>(a.dec, S, TT == 96, big_m2 ? kParStageM2 : 0) ? 1 : 0;
     a.dec_rounds = !a.dec_compact && par_dec_rounds<IO, CPLX>(a.dec) ? 2 : 1;
     a.up = up > 1 ? up : 1;
     a.up_magic = a.up > 1 ? (unsigned)((((unsigned long long)1 << 32) + a.up - 1) / a.up) : 0u;
@@ -1390,6 +1395,10 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
         if (a.dec > 1 && a.dec_rounds > 1) {                                                                            \
             if constexpr (sizeof(IO) == 4 && !UPJ && UPS == 0)   /* (the .up launchers never decimate: no decimating kernels on their account) */ \
                 hipLaunchKernelGGL((iir_par_kernel<N, IO, 2, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,    \
+                                   (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr);  \
+        } else if (a.dec > 1 && big_m2 && a.dec_compact) {                                                              \
+            if constexpr (TT == 96 && sizeof(IO) == 4 && N > 4 && !UPJ && UPS == 0)                                     \
+                hipLaunchKernelGGL((iir_par_kernel<N, IO, 3, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,    \
                                    (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr);  \
         } else if (a.dec > 1) {                                                                                         \
             if constexpr (!UPJ && UPS == 0)                                                                             \
@@ -1439,7 +1448,7 @@ int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     // 8 biquads: float32 - 3 .. - 6 %, complex64 - 3 % where 3 divides M (128-sample chunks then start on three phases) and + 4 .. + 7 % elsewhere.
     // Before the lean form: M = 2, 3, 6 only (M = 3 0.193 -> 0.173 ms, M = 4 + 7 .. 9 %).  Option iir_dn_t96 = 2: every divisor of 96; 0: never.
     const bool t96_pays = dec == 2 || dec == 3 || dec == 6 || (96 % dec == 0 && (h->nsec <= 4 || !interleaved || dec % 3 == 0));
-    bool t96 = !dbl && dec > 1 && ((opt().iir_dn_t96 == 1 && t96_pays) || (opt().iir_dn_t96 == 2 && 96 % dec == 0));
+    bool t96 = !dbl && dec > 1 && (((opt().iir_dn_t96 == 1 || opt().iir_dn_t96 == 3) && t96_pays) || (opt().iir_dn_t96 == 2 && 96 % dec == 0));
     // (the 96-sample kernels have no store but the gathering ones: the lean compact store where a segment's kept outputs fit the image -- from M = 3 on --, ranges of chunks for M = 2)
     if (t96 && !(interleaved ? par_dec_compact<float, true>(dec, (int64_t)32 * 96, true) || par_dec_rounds<float, true>(dec)
                              : par_dec_compact<float, false>(dec, (int64_t)64 * 96, true) || par_dec_rounds<float, false>(dec)))

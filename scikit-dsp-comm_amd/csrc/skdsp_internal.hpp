@@ -51,7 +51,7 @@ struct Options {
     int iir_up_jump = 1;      // the parallel-form .up of float32 / complex64 signals by L >= 8, a divisor of 96: lean kernels whose state jumps from input sample to input sample; 0 never (A/B switch)
     int iir_seq = 1;          // cascades of more than 8 sections whose float64 spread the scans would lift past the contract run the reference's recursion (iir_seq.hip): 1 probed, 2 always, 0 never
     int iir_up_lean = 1;      // multirate_IIR.up by 2 staged at the input rate with the stuffed zeros known at compile time (A/B switch; 0: the zero-stuffed image)
-    int iir_dn_t96 = 1;       // the parallel-form .dn of float32 / complex64 signals on 96-sample chunks: 1 for M = 2, 3, 6 (measured), 2 wherever M divides 96, 0 never (A/B switch)
+    int iir_dn_t96 = 1;       // the parallel-form .dn of float32 / complex64 signals on 96-sample chunks: 1 where measured to pay (see iir_par_launch), 2 wherever M divides 96, 3 as 1 but M = 2 keeps its gathering in ranges for every cascade, 0 never (A/B switch)
     int iir_dn_compact = 1;   // 0: the parallel-form .dn keeps the image-and-pick store for every M (A/B switch)
     int fir_up_ols_min = 64;  // multirate_FIR.up: phases of at least this many taps MAY go through the overlap-save walk (the cost model
                               // of fir_up_prefers_ols decides); 0: never; -k: always from k taps per phase on (A/B switch)
