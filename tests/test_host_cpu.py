@@ -278,6 +278,9 @@ def test_options_table_without_gpu():
     """skdsp_set_option / skdsp_get_option work without a device; unknown names are BADARG -> ValueError."""
     from sk_dsp_comm_amd import _ffi
     assert _ffi.get_option("ols_reserve") == 8
+    # the A/B switches of the round-5 kernels and their defaults (DESIGN 4.8): on
+    for name, default in (("fir_dn_fold", 1), ("fir_up_rep", 1), ("iir_up_jump", 1), ("iir_up_lean", 1), ("iir_dn_t96", 1), ("iir_seq", 1)):
+        assert _ffi.get_option(name) == default, name
     with _ffi.option("iir_planar", 1):
         assert _ffi.get_option("iir_planar") == 1
     assert _ffi.get_option("iir_planar") == 0
