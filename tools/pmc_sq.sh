@@ -1,0 +1,23 @@
+# Issue / wait picture of bench workloads from SQ counters, each counter group in its own rocprofv3 pass (never combined with other trace domains):
+#   gpurun --timeout 900 -- 'bash tools/pmc_sq.sh rcup12 rcdn12 iir8'
+# prints per-wave means (SQ_INSTS_VALU / SQ_WAVES and friends; the *_CYCLES of a wave are in quad-cycles).  What LABNOTES R5.8 is built on.
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/pmc2; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+for W in "$@"; do i=0
+for set in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SMEM"; do
+  i=$((i+1))
+  timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python $ROOT/bench.py --workload $W --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs --board-seconds 0 > /dev/null 2>$OUT/err_$i.txt
+  cp $OUT/p$i/*/*counter_collection.csv $OUT/${W}_set$i.csv 2>/dev/null; rm -rf $OUT/p$i
+done
+python - $OUT $W <<'P'
+import sys,csv,glob,collections
+out,w=sys.argv[1:3]
+res={}
+for f in sorted(glob.glob(out+'/'+w+'_set*.csv')):
+    acc=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if 'skdsp::' in r['Kernel_Name'] and 'fill' not in r['Kernel_Name'] and 'noise' not in r['Kernel_Name']: acc[r['Counter_Name']].append(float(r['Counter_Value']))
+    for k,v in acc.items(): res[k]=sum(v)/len(v)
+wv=res.get('SQ_WAVES',1)
+print(w, 'waves %d' % wv, ' '.join('%s/wave %.0f' % (k[3:], v/wv) for k,v in res.items() if k!='SQ_WAVES'), 'busy_us %.1f' % (res.get('SQ_BUSY_CYCLES',0)/32/2400), flush=True)
+P
+done
