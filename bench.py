@@ -22,10 +22,15 @@ ranks filtered / max-over-ranks time.
 The product path uses no PyTorch; the ranks rendezvous through a file
 (sk_dsp_comm_amd.sharding.FileRendezvous) and barrier / max-reduce through RCCL.
 
-Rank 0 prints ONE JSON line: the driver contract's fields + "roofline" and "cpu_baseline"
-(the C port of the reference's arithmetic) + "cpu_baseline_scipy" (literally the reference's
-scipy.signal call) + "other_configs" (BASELINE.json configs 3, 4 and the 127-tap shape, timed
-in the same process after the headline) + per-rank kernel / step times for N > 1.
+Rank 0 prints ONE JSON line on stdout, the LAST thing it writes and kept under FINAL_LINE_MAX_BYTES
+(final_line(); tests/test_host_cpu.py checks the bound on a recorded run and on the worst case): the
+driver contract's fields + "roofline" + "cpu_baseline" (the C port of the reference's arithmetic) +
+"cpu_baseline_scipy" (literally the reference's scipy.signal call) + "rows" (one compact entry per
+other workload timed in the same process behind the headline: BASELINE.json configs 3, 4, the
+127-tap shape, the SURVEY 8(a) rate rows) + for N > 1 the RCCL rank count, the halo form used, the
+per-rank parity and the config-5 leg.  Everything longer (each other workload's full record, the
+provenance of the PMC traffic, the device-copy reference) goes to stderr, one JSON line per workload
+prefixed "bench.py detail: ", and to gpurun_out/bench_detail_n<N>.json -- never to stdout.
 --workload updn43|iir8|fir127 runs one of the other configs as the main line instead.
 """
 import argparse
@@ -98,12 +103,17 @@ def shard_parity(kind, coeffs, n_local, rank, get_x, get_y):
     return halo_err, rel(get_y(s0, m), orc.sos_filter(sos, get_x(g_start + s0 - h2, h2 + m))[h2:])
 
 
-def reduce_parity(tr, halo_err, interior_err, fallback_used):
-    """All ranks -> (max halo error, max interior error, per-rank fallback flags, ok)."""
-    tab = tr.allgather_state(np.array([halo_err, interior_err, float(fallback_used)]))
+HALO_FORMS = {0: "none yet", 1: "two launches (first step)", 2: "overlapped (probation passed)", 3: "two launches (probation failed)"}
+
+
+def reduce_parity(tr, halo_err, interior_err, fallback_used, halo_state=0):
+    """All ranks -> (max halo error, max interior error, per-rank fallback flags, ok, per-rank halo form).  The halo form is the
+    state of the library's probation (dist.hip): a process's first sharded step runs two launches, its second the overlapped launch on
+    probation, and only a passed probation makes the overlapped form the steady state."""
+    tab = tr.allgather_state(np.array([halo_err, interior_err, float(fallback_used), float(halo_state)]))
     hmax, imax = float(np.max(tab[:, 0])), float(np.max(tab[:, 1]))
     ok = bool(np.isfinite(hmax) and np.isfinite(imax) and hmax <= PARITY_TOL and imax <= PARITY_TOL)
-    return hmax, imax, [int(v) for v in tab[:, 2]], ok
+    return hmax, imax, [int(v) for v in tab[:, 2]], ok, [int(v) for v in tab[:, 3]]
 
 
 # ------------------------------------------------------------------------------ BASELINE config 5 inside an N > 1 run
@@ -147,7 +157,7 @@ def config5_summary(total, world, step_ms, kernel_ms, parity, n1):
            "frac_per_gpu": 16.0 * (total // world) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
            "n1_reference": n1, "speedup_vs_n1": (n1["ms"] / step_ms) if n1.get("ms") else None}
     if parity is not None:
-        out["parity_halo_max_err"], out["parity_interior_max_err"], out["halo_fallback_used"], out["parity_ok"] = parity
+        out["parity_halo_max_err"], out["parity_interior_max_err"], out["halo_fallback_used"], out["parity_ok"], out["halo_state"] = parity
     return out
 
 
@@ -180,7 +190,7 @@ def config5_leg(args, rank, world, tr, _ffi, sharding):
             finally:
                 t.free()
         herr, ierr = shard_parity(kind, coeffs, n5, rank, get_x, lambda i0, c: w5.yd.to_host(i0, c))
-        parity = reduce_parity(tr, herr, ierr, _ffi.get_option("shard_two_launches"))
+        parity = reduce_parity(tr, herr, ierr, _ffi.get_option("shard_two_launches"), _ffi.get_option("shard_halo_state"))
     finally:
         free_workload(w5)
     rec = None
@@ -638,6 +648,116 @@ def dp_pipe_of(w, ev_ms, K, compute_units):
             "frac": slots / t / peak}
 
 
+# ------------------------------------------------------------------------------ what rank 0 prints
+FINAL_LINE_MAX_BYTES = 8000   # the driver parses the LAST stdout line out of a bounded tail (a 22.9 KB line was not kept: BENCH_r05.json)
+ROWS_WHAT = "per workload (2^26 samples): kernel ms, fraction of 8 TB/s, PMC traffic / algorithmic bytes, head error vs the oracle, board W, shader MHz"
+
+
+def _clip(v, n):
+    v = str(v)
+    return v if len(v) <= n else v[: n - 3] + "..."
+
+
+def _sig(v, digits=6):
+    if isinstance(v, float) and np.isfinite(v) and v != int(v):     # (whole numbers -- byte and sample counts -- stay exact)
+        return float("%.*g" % (digits, v))
+    return v
+
+
+def _pick(d, keys, clip=None):
+    out = {}
+    for k in keys:
+        if isinstance(d, dict) and k in d:
+            v = d[k]
+            out[k] = _clip(v, clip) if (clip and isinstance(v, str)) else _sig(v) if isinstance(v, float) else v
+    return out
+
+
+def final_line(out):
+    """The full record of a run -> the ONE line that goes to stdout: the driver contract's fields, `roofline`, `cpu_baseline`,
+    `cpu_baseline_scipy`, the compact `rows` table and, for N > 1, what a scaling record needs (RCCL rank count, which halo form ran,
+    per-rank parity, per-rank times, the config-5 leg with its N = 1 cross-check) -- at most FINAL_LINE_MAX_BYTES bytes whatever the
+    run recorded.  Pure (no device, no clock): tests/test_host_cpu.py runs it on a recorded line and on the worst case."""
+    fl = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                  "scaling", "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    fl["config"] = _pick(cfg, ("workload", "samples_per_gpu", "total_samples", "clock_settle_s", "sharding", "n_ranks_rccl",
+                               "device", "compute_units", "logical_device"), clip=200)
+    r = out.get("roofline") or {}
+    fl["roofline"] = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
+                               "algorithmic_bytes_per_launch", "frac_of_device_copy", "frac_of_fastest_copy"), clip=120)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):          # the members the contract names are always there
+        fl["roofline"].setdefault(k, None)
+    src = r.get("traffic_source") or {}
+    if src:
+        fl["roofline"]["traffic_profile"] = _clip(src.get("stale") or src.get("profile"), 100)
+    for k in ("cpu_baseline", "cpu_baseline_scipy"):
+        if k in out:
+            fl[k] = _pick(out[k], ("value", "unit", "cores", "kind", "sample", "skipped", "cores_available"), clip=230) if out[k] else None
+    if "parity_spot_check_max_err" in out:
+        fl["parity_spot_check_max_err"] = _sig(out["parity_spot_check_max_err"], 3)
+    if isinstance(out.get("board"), dict):
+        fl["board"] = _pick(out["board"], ("power_w", "power_cap_w", "sclk_mhz", "skipped"), clip=80)
+    if isinstance(out.get("device_copy"), dict):
+        fl["device_copy"] = _pick(out["device_copy"], ("GBps", "own_copy_GBps", "skipped"), clip=80)
+    for k in ("compute", "fp64_pipe"):
+        if isinstance(out.get(k), dict):
+            fl[k] = _pick(out[k], ("unit", "achieved", "peak", "frac", "slots_per_real_sample"))
+    # ---- N > 1 (a future SCALE record must parse at every N): which communicator, which halo form, parity of every rank
+    fl["n_ranks_rccl"] = cfg.get("n_ranks_rccl")
+    for k in ("halo_fallback_used", "halo_state", "halo_form", "parity_halo_max_err", "parity_interior_max_err", "parity_ok"):
+        if k in out:
+            fl[k] = _sig(out[k], 3) if isinstance(out[k], float) else out[k]
+    if isinstance(out.get("per_rank"), dict):
+        fl["per_rank"] = {k: [round(float(v), 4) for v in vs][:64] for k, vs in out["per_rank"].items()}
+    c5 = out.get("config5")
+    if isinstance(c5, dict):
+        f5 = _pick(c5, ("total_samples", "samples_per_gpu", "n_gpus", "steps", "ms", "kernel_ms_max", "value", "unit", "frac_per_gpu",
+                        "speedup_vs_n1", "parity_halo_max_err", "parity_interior_max_err", "halo_fallback_used", "halo_state", "parity_ok",
+                        "error", "skipped"), clip=160)
+        n1 = c5.get("n1_reference") or {}
+        f5["n1_cross_check"] = _pick(n1, ("profile", "ms", "value", "stale", "why"), clip=120)   # the committed 1-GPU run of the same 2^30 samples
+        fl["config5"] = f5
+    if "rows" in out:
+        fl["rows_what"] = ROWS_WHAT
+        fl["rows"] = out["rows"]
+    if out.get("detail"):
+        fl["detail"] = out["detail"]
+    # ---- the bound, whatever was recorded: shed the least important members first
+    for drop in ("rows_what", "device_copy", "compute", "fp64_pipe", "per_rank", "detail"):
+        if len(json.dumps(fl)) <= FINAL_LINE_MAX_BYTES:
+            break
+        fl.pop(drop, None)
+    if len(json.dumps(fl)) > FINAL_LINE_MAX_BYTES and "rows" in fl:   # rows as [ms, frac] pairs
+        fl["rows"] = {k: ([v.get("ms"), v.get("frac")] if "ms" in v else "error") for k, v in list(fl["rows"].items())[:40]}
+    for drop in ("rows", "config5", "cpu_baseline_scipy"):
+        if len(json.dumps(fl)) <= FINAL_LINE_MAX_BYTES:
+            break
+        fl.pop(drop, None)
+    assert len(json.dumps(fl)) <= FINAL_LINE_MAX_BYTES, len(json.dumps(fl))
+    return fl
+
+
+def emit(out):
+    """Rank 0, once: the long records to stderr and to a side file, then the one line on stdout."""
+    n = out.get("n_gpus", 1)
+    for name, o in (out.get("other_configs") or {}).items():
+        print("bench.py detail: " + json.dumps(dict(o, name=name)), file=sys.stderr)
+    rest = {k: v for k, v in out.items() if k not in ("other_configs", "rows", "rows_what")}
+    print("bench.py detail: " + json.dumps(dict(rest, name="headline")), file=sys.stderr)
+    sys.stderr.flush()
+    try:   # gpurun merges gpurun_out/ back; elsewhere the file simply stays beside the repo's other scratch
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "bench_detail_n%d.json" % n)
+        with open(path, "w") as f:
+            json.dump(out, f)
+        out["detail"] = os.path.relpath(path, ROOT)
+    except OSError:
+        pass
+    print(json.dumps(final_line(out)), flush=True)
+
+
 # ------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -711,7 +831,7 @@ def main():
             finally:
                 t.free()
         herr, ierr = shard_parity(kind, coeffs, n, rank, get_x, lambda i0, c: w.yd.to_host(i0, c))
-        parity = reduce_parity(tr, herr, ierr, _ffi.get_option("shard_two_launches"))
+        parity = reduce_parity(tr, herr, ierr, _ffi.get_option("shard_two_launches"), _ffi.get_option("shard_halo_state"))
 
     out = None
     if rank == 0:
@@ -757,7 +877,8 @@ def main():
         if check is not None:
             out["parity_spot_check_max_err"] = check
         if parity is not None:
-            out["parity_halo_max_err"], out["parity_interior_max_err"], out["halo_fallback_used"], out["parity_ok"] = parity
+            out["parity_halo_max_err"], out["parity_interior_max_err"], out["halo_fallback_used"], out["parity_ok"], out["halo_state"] = parity
+            out["halo_form"] = HALO_FORMS.get(max(out["halo_state"]) if w.shard[0] == "fir" else -1, "state hand-off (no halo)")
             out["parity_what"] = ("every rank: first 2048 outputs of its shard (they consume the %s from rank r-1) and one interior "
                                   "window vs the CPU oracle on inputs regenerated by global index; max over ranks; tolerance %g"
                                   % ("Ntaps-1 halo" if w.shard[0] == "fir" else "handed-over filter state", PARITY_TOL))
@@ -810,16 +931,12 @@ def main():
             except Exception as e:  # a broken side config must not take the headline line with it
                 others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["other_configs"] = others
-        # every row once more, compact: the driver's record keeps the scalar members of "roofline" and the last 2 KB of this line, so
-        # each row is a short string inside "roofline" AND the table is the LAST member of the line
         rows = {"fir1024": compact_row(out["roofline"]["kernel_ms"], out["roofline"]["frac"], out["roofline"]["traffic"],
                                        out["roofline"]["algorithmic_bytes_per_launch"], out.get("parity_spot_check_max_err"), out.get("board"))}
         for name, o in others.items():
             rows[name] = ({"error": o["error"][:60]} if "error" in o else
                           compact_row(o["kernel_ms"], o["frac"], o["traffic"], o["algorithmic_bytes_per_launch"], o.get("parity_spot_check_max_err"), o.get("board")))
-        for name, r in rows.items():
-            out["roofline"]["row_" + name] = " ".join("%s=%s" % kv for kv in r.items())
-        out["rows_what"] = "per workload (2^26 samples): kernel ms, fraction of 8 TB/s, PMC traffic / algorithmic bytes, head max-abs error vs the oracle / max-abs reference, board W, shader MHz"
+        out["rows_what"] = ROWS_WHAT
         out["rows"] = rows
 
     # ------------------------------------------- N > 1: BASELINE config 5 (2^30 samples in total, strong scaling) behind the weak-scaling line
@@ -834,7 +951,7 @@ def main():
             out["config5"] = rec
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     tr.close()
     if (parity is not None and not parity[3]) or not c5_ok:
         sys.exit(3)   # a wrong halo / state hand-off must not look like a result

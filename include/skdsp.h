@@ -93,6 +93,8 @@ int skdsp_sync(void);                      /* wait for the library stream */
 /* HIP-event stopwatch on the library stream (bench.py times kernels with it) */
 int skdsp_timer_start(void);
 int skdsp_timer_stop(float *elapsed_ms);   /* synchronises on the stop event */
+/* what the last skdsp_timer_stop of the calling thread's slot measured, in ms (SURVEY.md 8(b)'s name for it); -1 before the first */
+double skdsp_last_kernel_ms(void);
 /* fill a device buffer with counter-based N(0,1)/sqrt(2) complex (or N(0,1) real)
  * noise keyed by (seed, global sample index): any window can be regenerated. */
 int skdsp_fill_noise_dev(void *x_dev, int64_t n, int dtype, uint64_t seed, int64_t first_index);
@@ -175,6 +177,11 @@ int skdsp_iir_up_dev(skdsp_handle h, const void *x_dev, int64_t n, int L, void *
 /* .dn: downsample(filter(x), M) (:77-83, :186-192); y has n/M samples */
 int skdsp_iir_dn(skdsp_handle h, const void *x, int64_t n, int M, void *y);
 int skdsp_iir_dn_dev(skdsp_handle h, const void *x_dev, int64_t n, int M, void *y_dev);
+/* The names SURVEY.md 8(b) sketched for the three calls above on handles made by skdsp_sos_create: the same functions
+ * (multirate_IIR.filter / .up / .dn, multirate_helper.py:169-192), kept so that a binding written from that table links. */
+int skdsp_sos_filter(skdsp_handle h, const void *x, int64_t n, void *y);
+int skdsp_sos_up(skdsp_handle h, const void *x, int64_t n, int L, void *y);
+int skdsp_sos_dn(skdsp_handle h, const void *x, int64_t n, int M, void *y);
 
 /* ---- rate-change primitives (sigsys.py:3031-3083) -------------------------- */
 /* upsample: y[k*L] = x[k], zeros elsewhere (sigsys.py:3050-3053). y has n*L samples. */

@@ -112,7 +112,7 @@ const OptEntry kOptTable[] = {
     {"ols_reserve", &Options::ols_reserve}, {"fir_dn_fold", &Options::fir_dn_fold}, {"fir_up_rep", &Options::fir_up_rep}, {"iir_seq", &Options::iir_seq}, {"iir_up_jump", &Options::iir_up_jump}, {"iir_dn_t96", &Options::iir_dn_t96}, {"iir_up_lean", &Options::iir_up_lean}, {"iir_planar", &Options::iir_planar}, 
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, 
     {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up4k", &Options::fir_up4k}, {"fir_up4k_group", &Options::fir_up4k_group}, {"fir_up4k_staged", &Options::fir_up4k_staged}, {"fir_up2k", &Options::fir_up2k}, {"fir_dn4k", &Options::fir_dn4k}, {"fir_up_pair", &Options::fir_up_pair}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, 
-    {"shard_two_launches", &Options::shard_two_launches},
+    {"shard_two_launches", &Options::shard_two_launches}, {"shard_probe", &Options::shard_probe}, {"shard_halo_state", &Options::shard_halo_state},
     {"shard_self_halo", &Options::shard_self_halo}, {"dist_force_comm", &Options::dist_force_comm},
     {"host_chunk_log2", &Options::host_chunk_log2}, {"host_pipeline", &Options::host_pipeline}, {"host_multi_slot", &Options::host_multi_slot},
 };
@@ -379,7 +379,8 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
     if (rc == SKDSP_ERR_UNSUPPORTED && M > 1) {
         // a stride the polyphase kernels' LDS window does not hold (a few hundred taps and M in the thousands): the decimating
         // overlap-save store takes any M; without that engine, the full-rate filter and a strided copy
-        if (fir_ols_supported(h) && !opt().dn_no_ols) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
+        // (that store's index arithmetic is exact up to M = 32768 -- fir_ols_launch checks it --: beyond, the full-rate filter and the strided copy)
+        if (fir_ols_supported(h) && !opt().dn_no_ols && M <= 32768) return fir_ols_launch(h, x_dev, n, n_hist, y_dev, ctx().stream, M);
         void *full = nullptr;
         const int64_t nk = (n / M) * M;
         if ((rc = ws_reserve(full_slot, (size_t)nk * dtype_size(h->dtype) + 256, &full))) return rc;
@@ -888,7 +889,7 @@ static int run_on_slots(const ChunkPlan &p, const char *x, char *y, chunk_kernel
         if (!selfs[i]) return SKDSP_ERR_NOMEM;
     }
     std::vector<int> rcs((size_t)nslots, SKDSP_OK);
-    std::vector<std::string> errs((size_t)nslots);
+    std::vector<std::string> errs((size_t)nslots), paths((size_t)nslots);   // (paths: the engines each worker thread launched -- the record is thread-local)
     std::vector<std::thread> workers;
     auto range = [&](int i, int64_t &a, int64_t &b) {
         a = p.nchunks * i / nslots;
@@ -905,6 +906,9 @@ static int run_on_slots(const ChunkPlan &p, const char *x, char *y, chunk_kernel
             }
             rcs[i] = r;
             if (r) errs[i] = skdsp_last_error();
+            char pb[256];
+            skdsp_debug_path(pb, (int)sizeof(pb), 1);
+            paths[i] = pb;
         });
     }
     {
@@ -913,6 +917,15 @@ static int run_on_slots(const ChunkPlan &p, const char *x, char *y, chunk_kernel
         rcs[0] = run_pipeline(p, a, b, x, y, kern, selfs[0]);
     }
     for (auto &w : workers) w.join();
+    for (int i = 1; i < nslots; ++i) {   // what the workers launched belongs to the caller's record: engine by engine, through the same de-duplication
+        size_t at = 0;
+        while (at < paths[i].size()) {
+            size_t e = paths[i].find(',', at);
+            if (e == std::string::npos) e = paths[i].size();
+            if (e > at) note_path(paths[i].substr(at, e - at).c_str());
+            at = e + 1;
+        }
+    }
     for (int i = 0; i < nslots; ++i)
         if (rcs[i]) {
             if (i > 0) set_error("%s", errs[i].c_str());
@@ -1222,6 +1235,7 @@ void skdsp::note_path(const char *engine)
 {
     const size_t len = strlen(g_path), add = strlen(engine);
     if (len >= add && strcmp(g_path + len - add, engine) == 0 && (len == add || g_path[len - add - 1] == ',')) return;   // (the same engine again)
+    if (add == 0) return;
     if (len + add + 2 >= sizeof(g_path)) return;
     if (len) g_path[len] = ',';
     memcpy(g_path + len + (len ? 1 : 0), engine, add + 1);
@@ -1416,8 +1430,10 @@ int skdsp_timer_stop(float *ms)
     float t = 0.f;
     SK_HIP(hipEventElapsedTime(&t, ctx().ev_start, ctx().ev_stop));
     if (ms) *ms = t;
+    ctx().last_timer_ms = (double)t;
     return async_err_check(ctx());
 }
+double skdsp_last_kernel_ms(void) { return ctx().ready ? ctx().last_timer_ms : -1.0; }
 int skdsp_fill_noise_dev(void *x_dev, int64_t n, int dtype, uint64_t seed, int64_t first_index)
 {
     API_BEGIN;
@@ -1661,7 +1677,10 @@ int skdsp_fir_dn(skdsp_handle h, const void *x, int64_t n, int M, void *y) { ret
 int skdsp_fir_updn(skdsp_handle h, const void *x, int64_t n, int L, int M, void *y) { return fir_host_call(h, x, n, L, M, 1, y); }
 
 // ------------------------------------------------------------------------ IIR
-static int iir_create_common(int nsec, int order, const std::vector<double> &coef, int dtype, skdsp_handle *out)
+// seq_limit > 0: the spread above which the handle runs the reference's recursion, given by the caller instead of derived from `dtype` -- the
+// float64 twin of a float32 handle serves the float32 contract, so it is probed against the float32 limit its parent just passed (with the
+// float64 limit a cheby1(26) cascade, spread 3.7e-11, would have run sample by sample although 1e-6 never needed it)
+static int iir_create_common(int nsec, int order, const std::vector<double> &coef, int dtype, skdsp_handle *out, double seq_limit = 0.0)
 {
     SK_CHECK(out, SKDSP_ERR_BADARG, "iir_create: null out");
     SK_CHECK(dtype_valid(dtype), SKDSP_ERR_BADARG, "iir_create: bad dtype %d", dtype);
@@ -1712,7 +1731,7 @@ static int iir_create_common(int nsec, int order, const std::vector<double> &coe
         }
         const double spread = std::isfinite(diff) && peak > 0.0 ? diff / peak : 1.0;
         h->seq_spread = spread;
-        const double limit = dtype_double(dtype) ? 2.5e-13 : 2.5e-9;   // (400 x spread stays inside the contract)
+        const double limit = seq_limit > 0.0 ? seq_limit : dtype_double(dtype) ? 2.5e-13 : 2.5e-9;   // (400 x spread stays inside the contract)
         if (opt().iir_seq == 2 || !(spread <= limit)) {
             h->seq = true;
             h->seq_coef = coef;
@@ -1772,7 +1791,7 @@ static int iir_create_common(int nsec, int order, const std::vector<double> &coe
                 if (nsec <= 12) goto single_group;      // one launch sequence of the cascade kernels: float64 between ALL sections
                 // too many sections for that, and no float32 boundary is safe: the same cascade in float64 (widen, filter, narrow)
                 skdsp_handle th = nullptr;
-                const int rc = iir_create_common(nsec, 2, coef, dtype == SKDSP_C64 ? SKDSP_C128 : SKDSP_F64, &th);
+                const int rc = iir_create_common(nsec, 2, coef, dtype == SKDSP_C64 ? SKDSP_C128 : SKDSP_F64, &th, 2.5e-9);
                 if (rc) return rc;
                 h->twin64 = static_cast<IirHandle *>(th);
                 h->twin64->slot = ctx().slot;
@@ -1849,7 +1868,7 @@ int skdsp_iir_sequential(skdsp_handle hh, int *is_sequential, double *spread)
     HandleBase *hb = static_cast<HandleBase *>(hh);
     SK_CHECK(hb && hb->kind == H_IIR, SKDSP_ERR_BADARG, "iir_sequential: not an IIR handle");
     IirHandle *h = static_cast<IirHandle *>(hb);
-    if (is_sequential) *is_sequential = h->seq ? 1 : 0;
+    if (is_sequential) *is_sequential = (h->seq || (h->twin64 && h->twin64->seq)) ? 1 : 0;   // (what actually runs: a float32 handle may filter through its float64 twin)
     if (spread) *spread = h->seq_spread;
     return SKDSP_OK;
 }
@@ -1916,6 +1935,8 @@ static int iir_rows_dev(IirHandle *h, const void *x_dev, int64_t n, int64_t nrow
     SK_CHECK(x_stride >= n && y_stride >= n, SKDSP_ERR_BADARG, "iir_filter_rows: row stride below the row length");
     SK_CHECK(nrow < (1 << 24), SKDSP_ERR_BADARG, "iir_filter_rows: too many rows");
     const size_t esz = dtype_size(h->dtype);
+    // the reference's recursion takes all rows in ONE launch (one wave per row), not one single-wave kernel per row in stream order
+    if (h->seq && !dtype_complex(h->dtype)) return iir_seq_launch(h, x_dev, n, (int)nrow, x_stride, y_stride, y_dev, ctx().stream);
     if (!h->groups.empty() && !dtype_complex(h->dtype) && opt().iir_par > 0) {
         // groups of sections (more than 8 biquads): every group over all rows in one launch where its parallel form applies, in place behind the first
         for (size_t gi = 0; gi < h->groups.size(); ++gi) {
@@ -2078,6 +2099,10 @@ static int iir_host_call(skdsp_handle hh, const void *x, int64_t n, int L, int M
 int skdsp_iir_filter(skdsp_handle h, const void *x, int64_t n, void *y) { return iir_host_call(h, x, n, 1, 1, y); }
 int skdsp_iir_up(skdsp_handle h, const void *x, int64_t n, int L, void *y) { return iir_host_call(h, x, n, L, 1, y); }
 int skdsp_iir_dn(skdsp_handle h, const void *x, int64_t n, int M, void *y) { return iir_host_call(h, x, n, 1, M, y); }
+// (SURVEY.md 8(b)'s names for the same three calls)
+int skdsp_sos_filter(skdsp_handle h, const void *x, int64_t n, void *y) { return skdsp_iir_filter(h, x, n, y); }
+int skdsp_sos_up(skdsp_handle h, const void *x, int64_t n, int L, void *y) { return skdsp_iir_up(h, x, n, L, y); }
+int skdsp_sos_dn(skdsp_handle h, const void *x, int64_t n, int M, void *y) { return skdsp_iir_dn(h, x, n, M, y); }
 
 // ---------------------------------------------------------------- resamplers
 int skdsp_upsample_dev(const void *x_dev, int64_t n, int L, int dtype, double scale, void *y_dev)

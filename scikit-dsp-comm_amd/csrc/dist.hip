@@ -316,12 +316,47 @@ int skdsp_fir_filter_shard_dev(skdsp_handle hh, void *x_dev, int64_t n_local, vo
             // RCCL receive is complete -- no second launch, no 1-workgroup tail (option shard_two_launches restores
             // that form: interior tiles, stream wait on the halo event, tile 0 as its own launch).
             const int reserve = 8;   // workgroup slots the persistent launch leaves to the RCCL send / recv kernel
-            if (opt().shard_two_launches) {
+            // Whether the RCCL kernel really starts beside a persistent launch is a property of the system (free workgroup slots, queue
+            // priorities, the RCCL build) that no 1-GPU box can show.  So the overlapped form is EARNED, per process:
+            //   step 1   two launches (cannot wait on anything inside a kernel),
+            //   step 2   the overlapped launch ON PROBATION -- the poll gives up after a few milliseconds instead of seconds, tile 0 is
+            //            computed once more behind the halo event (so the step is valid whatever the poll did), the step is synchronised and
+            //            the verdict read: passed -> overlapped from now on; gave up -> two launches for good, nothing to repeat,
+            //   step 3.. the proven form.  A first-ever multi-GPU run therefore cannot lose seconds (or a step) to the bounded poll.
+            const int probe = opt().shard_probe;
+            const bool two = opt().shard_two_launches || (probe && c.halo_state == 0);
+            if (two) {
                 SK_HIP(hipEventRecord(c.ev_halo, c.comm_stream));
                 r1 = fir_ols_launch(h, (char *)x_dev + (size_t)V * esz, n_local - V, V, (char *)y_dev + (size_t)V * esz, c.stream, 1, reserve);
                 if (r1) return r1;
                 SK_HIP(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
-                return fir_ols_launch(h, x_dev, V, first ? 0 : halo, y_dev, c.stream);
+                r1 = fir_ols_launch(h, x_dev, V, first ? 0 : halo, y_dev, c.stream);
+                if (r1) return r1;
+                if (c.halo_state == 0) opt().shard_halo_state = c.halo_state = 1;
+                return SKDSP_OK;
+            }
+            if (probe && c.halo_state == 1) {
+                const unsigned seq = ++c.halo_seq;
+                if (!first && probe != 2) {
+                    r1 = fir_ols_publish_halo(c.halo_flag, seq, c.comm_stream);
+                    if (r1) return r1;
+                }
+                SK_HIP(hipEventRecord(c.ev_halo, c.comm_stream));
+                r1 = fir_ols_launch(h, x_dev, n_local, first ? 0 : halo, y_dev, c.stream, 1, reserve, first ? nullptr : c.halo_flag, seq, err_dev,
+                                    4096 /* ~5 ms */);
+                if (r1) return r1;
+                SK_HIP(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
+                r1 = fir_ols_launch(h, x_dev, V, first ? 0 : halo, y_dev, c.stream);   // tile 0 again, from a halo that HAS landed
+                if (r1) return r1;
+                SK_HIP(hipStreamSynchronize(c.stream));
+                if (c.async_err[kAsyncErrHalo] != 0) {   // the receive did not run beside the launch here: not an error, a finding
+                    c.async_err[kAsyncErrHalo] = 0;
+                    opt().shard_two_launches = 1;
+                    opt().shard_halo_state = c.halo_state = 3;
+                } else {
+                    opt().shard_halo_state = c.halo_state = 2;
+                }
+                return SKDSP_OK;
             }
             const unsigned seq = ++c.halo_seq;
             if (!first) {

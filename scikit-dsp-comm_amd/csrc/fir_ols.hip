@@ -62,6 +62,7 @@ struct OlsArgs {
     const unsigned *halo_flag;
     unsigned halo_seq;
     unsigned *halo_err;  // host-mapped: set if the bounded wait gave up (the caller reports it; the launch never hangs)
+    int halo_spins;      // polls (~1 us each) before giving up: ~2^21 = seconds in steady state, a few thousand in the probation step of dist.hip
     CarefulFir cf;       // the filter as the exact path of a poisoned tile reads it (careful.hpp)
     // ols_rep_kernel (multirate_FIR.up on the replicated spectrum): x holds n_in samples at the LOW rate (rep_hist of history in front), n = n_in L;
     // rep_lr = L / LF, what is left of L beyond the power of two LF the kernel is compiled for (the zero-stuffed grid is itself stuffed rep_lr-fold)
@@ -79,7 +80,7 @@ __device__ __forceinline__ void wait_halo(const OlsArgs &A)
     if (threadIdx.x == 0) {
         int spins = 0;
         while ((int)(__hip_atomic_load(A.halo_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.halo_seq) < 0) {
-            if (++spins > (1 << 21)) {  // seconds of polling: report instead of hanging the GPU
+            if (++spins > A.halo_spins) {  // report instead of hanging the GPU
                 *A.halo_err = 1u;
                 break;
             }
@@ -1050,7 +1051,7 @@ int fir_ols_publish_halo(unsigned *flag, unsigned seq, hipStream_t s)
 }
 
 int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void *y, hipStream_t s, int dec, int reserve_wgs,
-                   const unsigned *halo_flag, unsigned halo_seq, unsigned *halo_err)
+                   const unsigned *halo_flag, unsigned halo_seq, unsigned *halo_err, int halo_spins)
 {
     note_path("fir_ols");
     if (n <= 0) return SKDSP_OK;
@@ -1081,7 +1082,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.dec_magic = A.dec > 1 ? (unsigned)((((unsigned long long)1 << 32) + A.dec - 1) / A.dec) : 0u;
     A.n_keep = n;
     A.up = 1; A.up_pitch = 0; A.up_sb = A.up_pbs = A.up_pb0 = 0;
-    A.halo_flag = halo_flag; A.halo_seq = halo_seq; A.halo_err = halo_err;
+    A.halo_flag = halo_flag; A.halo_seq = halo_seq; A.halo_err = halo_err; A.halo_spins = halo_spins > 0 ? halo_spins : (1 << 21);
     A.rep_L = 0; A.rep_lr = 1; A.rep_magic = 0; A.n_in = 0; A.rep_hist = 0;
     if ((rc = fir_careful(h, &A.cf))) return rc;
     SK_CHECK(!(halo_flag && real), SKDSP_ERR_UNSUPPORTED, "fir_ols: halo flag wait is for complex64 shards");
@@ -1183,7 +1184,7 @@ static int up_walk(FirHandle *h, int kind, const void *x, int64_t n, int64_t n_h
     A.up_sb = L * esz;
     A.up_pbs = xr ? 8 : esz;
     A.up_pb0 = kind == 2 ? (L - 1) * esz : 0;
-    A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr;
+    A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr; A.halo_spins = 0;
     A.rep_L = 0; A.rep_lr = 1; A.rep_magic = 0; A.n_in = 0; A.rep_hist = 0;
     if ((rc = fir_careful(h, &A.cf))) return rc;
     int64_t grid = 2 * (int64_t)ctx().num_cus;
@@ -1237,7 +1238,7 @@ int fir_ols_rep_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, i
     A.ntiles = ntiles;
     A.dec = 1; A.dec_magic = 0; A.n_keep = A.n;
     A.up = 1; A.up_pitch = 0; A.up_sb = A.up_pbs = A.up_pb0 = 0;
-    A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr;
+    A.halo_flag = nullptr; A.halo_seq = 0; A.halo_err = nullptr; A.halo_spins = 0;
     A.rep_L = L; A.rep_lr = L / lf;
     A.rep_magic = A.rep_lr > 1 ? (unsigned)((((unsigned long long)1 << 32) + A.rep_lr - 1) / A.rep_lr) : 0u;
     A.n_in = n; A.rep_hist = n_hist;

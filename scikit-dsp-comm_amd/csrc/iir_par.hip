@@ -1332,6 +1332,7 @@ template <typename IO, bool CPLX, int TT = 0, bool UPJ = false, int UPS = 0>
 static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
                       void *y, hipStream_t s, int dec, int up = 1)
 {
+    note_path("iir_par");   // (here, not in iir_par_launch: that function returns 1 -- nothing launched -- for every call the parallel form does not take)
     const int T = tb.T;
     const int64_t S = (int64_t)(CPLX ? 32 : 64) * T;   // samples per wave segment
     const int64_t nseg = (n + S - 1) / S;
@@ -1429,7 +1430,6 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
 int iir_par_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y, hipStream_t s, int dec,
                    int interleaved, int up)
 {
-    note_path("iir_par");
     if (interleaved && nrow != 1) return 1;
     // .up: x holds n / up samples; one row, no decimation; the exact-division trick of the staging covers up <= 4096
     if (up > 1 && (dec > 1 || nrow != 1 || up > 4096 || n % up != 0)) return 1;

@@ -1199,7 +1199,6 @@ int iir_dispatch_shape_f64(IirHandle *h, IirArgs &a, int nbatch, int W, hipStrea
 int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_t batch_stride, void *y, hipStream_t s,
                       const double *zi_host, double *zf_host, int interleaved, int dec)
 {
-    note_path("iir_scan");
     if (n <= 0) {
         if (zf_host) {
             if (zi_host) memcpy(zf_host, zi_host, (size_t)nbatch * h->nsec * h->order * 8);
@@ -1376,11 +1375,13 @@ int iir_launch_planar(IirHandle *h, const void *x, int64_t n, int nbatch, int64_
     }
     if (zf_host) a.zf = p->state_dev + 2 * D;
     SK_CHECK(nbatch >= 1 && nbatch <= 2, SKDSP_ERR_BADARG, "iir: batch must be 1 or 2");
-    if (fused)
+    if (fused) {
         rc = iir_fused_launch(h, x, n, nbatch, batch_stride, y, a.zi, a.zf, s, dec, interleaved);
-    else
+    } else {
         rc = dtype_double(h->dtype) ? iir_dispatch_shape_f64(h, a, nbatch, W, s) : dispatch_shape<float>(h, a, nbatch, W, s);
+    }
     if (rc) return rc;  // (1 = interleaved path not applicable, nothing was launched)
+    if (!fused) note_path("iir_scan");   // (recorded once the two-pass kernels WERE launched: iir_seq, the twin, the groups, iir_par and iir_fused note themselves)
     if (zf_host) {
         SK_HIP(hipMemcpyAsync(zf_host, p->state_dev + 2 * D, (size_t)nbatch * D * 8, hipMemcpyDeviceToHost, s));
         SK_HIP(hipStreamSynchronize(s));

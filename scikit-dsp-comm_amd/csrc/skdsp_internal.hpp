@@ -68,6 +68,12 @@ struct Options {
     int fir_updn_fused = 1;   // 0: L / M through the overlap-save walk writes all n L outputs to scratch and copies every M-th (A/B switch)
     int iir_up_fused = 1;     // 0: multirate_IIR.up / rate_change.up write the zero-stuffed signal first (A/B switch)
     int shard_two_launches = 0; // sharded FIR: tile 0 as its own launch behind the halo event (instead of the in-kernel flag wait)
+    int shard_probe = 1;        // 1: a process's FIRST sharded step runs the two-launch form, its second the overlapped form on probation (short
+                                // poll, tile 0 repeated behind the halo event, one sync) and only a passed probation makes the overlapped form
+                                // the steady state (dist.hip); 0: overlapped from the first step; 2 (test hook): the probation step's flag is
+                                // never published, i.e. the probation fails
+    int shard_halo_state = 0;   // read-only mirror of that state machine: 0 no sharded step yet, 1 first step done (probation next), 2 overlapped form
+                                // proven, 3 probation failed (two-launch form for good)
     int shard_self_halo = 0;    // test hook: a 1-rank communicator sends its tail to ITSELF (exercises the whole halo path on one GPU)
     int dist_force_comm = 0;  // build an RCCL communicator for a 1-rank job too (exercises the plumbing on one GPU)
     int host_chunk_log2 = 22; // host-pointer entry points: samples per pipelined chunk (pinned double buffers)
@@ -97,6 +103,8 @@ struct Context {
     unsigned *halo_flag = nullptr;       // device word the halo stream bumps when a shard's history has landed
     unsigned *async_err = nullptr;       // host-mapped [kAsyncErrWords]: kernels of this slot report here (async_err_check)
     unsigned halo_seq = 0;
+    double last_timer_ms = -1.0;         // skdsp_last_kernel_ms
+    int halo_state = 0;                  // the probation state machine of the sharded FIR step (Options::shard_halo_state mirrors it)
     void *ws[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t ws_bytes[4] = {0, 0, 0, 0};
     std::mutex mu;
@@ -204,7 +212,8 @@ int fir_ols_launch(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist, v
                    int reserve_wgs = -1,  // persistent grid smaller by this many workgroups (multiple of 8; -1: default 8)
                    // sharded launches: tile 0 is walked last and waits until *halo_flag >= halo_seq (the history in front
                    // of x is being received on another stream); halo_err (host-mapped) is set if that wait gives up
-                   const unsigned *halo_flag = nullptr, unsigned halo_seq = 0, unsigned *halo_err = nullptr);
+                   const unsigned *halo_flag = nullptr, unsigned halo_seq = 0, unsigned *halo_err = nullptr,
+                   int halo_spins = 0);   // polls of ~1 us before that wait gives up (0: the steady-state bound, seconds)
 int fir_ols_publish_halo(unsigned *flag, unsigned seq, hipStream_t s);  // one-thread kernel: *flag = seq (agent-scope release)
 void fir_ols_free(OlsPlan *p);
 // multirate_FIR.up as an overlap-save walk over (tile, phase) pairs: complex64, float32 with real taps; 2..4097 taps per phase

@@ -25,13 +25,14 @@ SYMBOLS = [
     "skdsp_init", "skdsp_shutdown", "skdsp_debug_path", "skdsp_device_count", "skdsp_device_info", "skdsp_last_error", "skdsp_version",
     "skdsp_set_option", "skdsp_get_option", "skdsp_init_devices", "skdsp_slot_count", "skdsp_host_chunk_plan",
     "skdsp_host_alloc", "skdsp_host_free", "skdsp_malloc", "skdsp_free", "skdsp_memcpy_h2d", "skdsp_memcpy_d2h", "skdsp_memcpy_d2d", "skdsp_memset",
-    "skdsp_sync", "skdsp_timer_start", "skdsp_timer_stop", "skdsp_fill_noise_dev",
+    "skdsp_sync", "skdsp_timer_start", "skdsp_timer_stop", "skdsp_last_kernel_ms", "skdsp_fill_noise_dev",
     "skdsp_fir_create", "skdsp_fir_set_algo", "skdsp_fir_get_algo", "skdsp_fir_filter", "skdsp_fir_filter_dev",
     "skdsp_fir_filter_rows", "skdsp_fir_filter_rows_dev", "skdsp_fir_filter_sharded",
     "skdsp_fir_up", "skdsp_fir_up_dev", "skdsp_fir_dn", "skdsp_fir_dn_dev", "skdsp_fir_updn", "skdsp_fir_updn_dev",
     "skdsp_sos_create", "skdsp_tf_create", "skdsp_tf2sos", "skdsp_iir_filter", "skdsp_iir_filter_dev", "skdsp_iir_up",
     "skdsp_iir_up_dev", "skdsp_iir_dn", "skdsp_iir_dn_dev", "skdsp_iir_state_len", "skdsp_iir_filter_state_dev",
     "skdsp_iir_filter_rows", "skdsp_iir_filter_rows_dev", "skdsp_sos_par_info", "skdsp_iir_sequential",
+    "skdsp_sos_filter", "skdsp_sos_up", "skdsp_sos_dn",
     "skdsp_upsample", "skdsp_upsample_dev", "skdsp_downsample", "skdsp_downsample_dev", "skdsp_set_wide_output", "skdsp_destroy",
     "skdsp_dist_unique_id", "skdsp_dist_init", "skdsp_dist_shutdown", "skdsp_dist_comm_count", "skdsp_dist_barrier",
     "skdsp_dist_allreduce_max", "skdsp_dist_allreduce_sum", "skdsp_dist_sendrecv", "skdsp_dist_allgather", "skdsp_dist_halo_exchange", "skdsp_fir_filter_shard_dev",
@@ -114,6 +115,10 @@ def load():
         L.skdsp_iir_up_dev.argtypes = [vp, vp, i64, ci, vp]
         L.skdsp_iir_dn.argtypes = [vp, vp, i64, ci, vp]
         L.skdsp_iir_dn_dev.argtypes = [vp, vp, i64, ci, vp]
+        L.skdsp_sos_filter.argtypes = [vp, vp, i64, vp]
+        L.skdsp_sos_up.argtypes = [vp, vp, i64, ci, vp]
+        L.skdsp_sos_dn.argtypes = [vp, vp, i64, ci, vp]
+        L.skdsp_last_kernel_ms.restype = ctypes.c_double
         L.skdsp_upsample.argtypes = [vp, i64, ci, ci, vp]
         L.skdsp_upsample_dev.argtypes = [vp, i64, ci, ci, ctypes.c_double, vp]
         L.skdsp_downsample.argtypes = [vp, i64, ci, ci, ci, vp]

@@ -10,8 +10,8 @@ precision (default "input"): which arithmetic the filters run in.
               inputs to float64, so a result typed float64 by strict_dtype still carries float32 accuracy);
               float64 / complex128 / integer arrays are filtered in float64.
     "double"  everything in float64, like the reference: 1e-12 agreement, also for attenuated (stop-band) outputs
-              where float32 arithmetic only holds a bound relative to the INPUT.  Long FIRs are
-              several times slower than in float32 (no float64 overlap-save tile).
+              where float32 arithmetic only holds a bound relative to the INPUT.  Long FIRs run
+              on the float64 overlap-save tile (csrc/fir_ols64.hip): about twice the time of float32, as their bytes are.
     "single"  everything in float32, also float64 inputs: the fast kernels for NumPy's default dtype when 1e-6 is enough.
 """
 import os

@@ -559,6 +559,68 @@ print('RCCL_OK')
     print(out.stdout.decode()[-300:])
 
 
+@pytest.mark.parametrize("probe", [1, 2])
+def test_sharded_step_earns_the_overlapped_form(probe):
+    """dist.hip's probation: a process's first sharded step runs two launches, its second the overlapped launch on probation (short
+    poll, tile 0 repeated behind the halo event, one sync), and only a passed probation (state 2) makes the overlapped form the steady
+    state; a failed one (probe = 2: the test hook never publishes the probation step's flag) switches to two launches for good
+    (state 3) -- and EVERY step's result is right whatever the poll did: a first-ever multi-GPU run loses neither seconds nor a step."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, ctypes, time, numpy as np
+sys.path.insert(0, os.path.join(%r, 'scikit-dsp-comm_amd'))
+sys.path.insert(0, %r)
+os.environ['SKDSP_DIST_FORCE_COMM'] = '1'
+os.environ['SKDSP_SHARD_SELF_HALO'] = '1'      # the one rank is its own left neighbour: a REAL halo from the first step on
+os.environ['SKDSP_SHARD_PROBE'] = '%d'
+from sk_dsp_comm_amd import _ffi, sharding
+from oracle import oracle as orc
+_ffi.init(0)
+L = _ffi.load()
+buf = ctypes.create_string_buffer(128)
+_ffi.check(L.skdsp_dist_unique_id(buf))
+_ffi.check(L.skdsp_dist_init(0, 1, ctypes.c_char_p(buf.raw)))
+tr = sharding.RcclTransport.__new__(sharding.RcclTransport)
+tr.rank, tr.world, tr._rdzv = 0, 1, None
+rng = np.random.default_rng(3)
+bl = np.hanning(1024) / 512
+ns = 1 << 21
+xs = (rng.standard_normal(ns) + 1j * rng.standard_normal(ns)).astype(np.complex64)
+fir = sharding.ShardedFIR(bl, tr, dtype=np.complex64)
+xsd = fir.new_shard_buffer(ns); xsd.write(xs)
+ysd = _ffi.DeviceArray(ns, np.complex64)
+assert _ffi.get_option('shard_halo_state') == 0
+states, walls = [], []
+for it in range(5):
+    tail = (rng.standard_normal(1023) + 1j * rng.standard_normal(1023)).astype(np.complex64)
+    xsd.write(tail, at=ns - 1023)
+    xs[ns - 1023:] = tail
+    _ffi.sync()
+    t0 = time.perf_counter()
+    fir.filter_local_dev(xsd, ysd)
+    _ffi.sync()
+    walls.append(time.perf_counter() - t0)
+    states.append((_ffi.get_option('shard_halo_state'), _ffi.get_option('shard_two_launches')))
+    got = ysd.to_host(0, 9000)
+    ref = orc.fir_filter(bl, xs[:9000], hist=tail)
+    e = np.max(np.abs(got - ref)) / np.max(np.abs(ref))
+    assert e < 1e-6, ('head (consumes the halo)', it, e, states)
+    got = ysd.to_host(ns - 9000, 9000)
+    ref = orc.fir_filter(bl, xs[ns - 9000 - 1023:])[1023:]
+    assert np.max(np.abs(got - ref)) / np.max(np.abs(ref)) < 1e-6, ('tail', it)
+print('states', states, 'wall ms', [round(w * 1e3, 2) for w in walls])
+want = [(1, 0), (2, 0), (2, 0), (2, 0), (2, 0)] if %d == 1 else [(1, 0), (3, 1), (3, 1), (3, 1), (3, 1)]
+assert states == want, states
+assert max(walls[1:]) < 0.25, walls      # the failed probation costs milliseconds, not the seconds of the steady-state poll bound
+_ffi.check(L.skdsp_dist_shutdown())
+print('PROBATION_OK')
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), probe, probe)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert b"PROBATION_OK" in out.stdout, out.stdout.decode()[-3000:]
+    print(out.stdout.decode()[-400:])
+
+
 def test_sharded_fir_eight_shards_emulated_on_one_gpu():
     """BASELINE config 5 semantics on one GPU: the 8-way sample-block sharding of
     sk_dsp_comm_amd.sharding (shard_bounds, headroom layout, Ntaps-1 halo in front of the

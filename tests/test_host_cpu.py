@@ -8,6 +8,7 @@ import json
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -366,3 +367,89 @@ def test_parallel_form_refuses_what_it_cannot_expand():
     assert not _ffi.sos_par_info(fir_heavy)["accepted"]
     unstable_ok = np.array([[1.0, 0.0, 0.0, 1.0, -1.0, 0.0]])   # an integrator expands (one real pole); the launcher refuses it by its decay test
     assert _ffi.sos_par_info(unstable_ok)["accepted"]
+
+
+# ---- bench.py's stdout contract: ONE line the driver can keep (BENCH_r05.json: a 22.9 KB line came back parsed = null) ----------
+def _bench_module():
+    import importlib
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+def _recorded_full_record():
+    """The full record of a real run: round 5's line (profiles/r05/bench_fir1024.json: headline + 18 other workloads, 22.9 KB)."""
+    txt = open(os.path.join(ROOT, "profiles", "r05", "bench_fir1024.json")).read().strip().splitlines()[-1]
+    return json.loads(txt)
+
+
+def test_bench_final_line_of_a_recorded_run_is_small_and_complete():
+    bench = _bench_module()
+    rec = _recorded_full_record()
+    assert len(json.dumps(rec)) > 20000                       # (the record that was not kept)
+    fl = bench.final_line(rec)
+    line = json.dumps(fl)
+    assert len(line) < bench.FINAL_LINE_MAX_BYTES <= 8000
+    back = json.loads(line)
+    assert back == fl and "\n" not in line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert back["value"] == rec["value"] and back["ms_per_step"] == rec["ms_per_step"]      # the contract's numbers are not rounded
+    r = back["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - rec["roofline"]["frac"]) < 1e-5 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-5
+    assert r["algorithmic_bytes_per_launch"] == 16 * 2 ** 26                                # byte counts stay exact
+    assert abs(r["traffic"] - rec["roofline"]["traffic"]) <= 1e-5 * r["traffic"]
+    c = back["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c and c["unit"] == "MSamples/s"
+    assert back["cpu_baseline_scipy"]["kind"] == "scipy"
+    assert back["config"]["workload"].startswith("multirate_FIR.filter: 1024-tap") and "model" not in back["config"]
+    assert len(back["rows"]) == 19 and all("frac" in v and "ms" in v for v in back["rows"].values())
+    assert "other_configs" not in back and not any(k.startswith("row_") for k in r)
+
+
+def test_bench_final_line_worst_case_still_fits():
+    """Every string at its longest, 64 ranks, a failed config-5 leg, forty rows of errors: the line sheds members rather than grow."""
+    bench = _bench_module()
+    rec = _recorded_full_record()
+    rec["n_gpus"] = 64
+    rec["config"]["sharding"] = "s" * 5000
+    rec["config"]["logical_device"] = "d" * 5000
+    rec["config"]["n_ranks_rccl"] = 64
+    rec["roofline"]["kernel"] = "k" * 5000
+    rec["cpu_baseline"]["sample"] = "c" * 5000
+    rec["per_rank"] = {"step_ms": [0.23456789] * 64, "kernel_ms": [0.23456789] * 64}
+    rec["halo_fallback_used"], rec["halo_state"], rec["halo_form"] = [0] * 64, [2] * 64, "overlapped (probation passed)"
+    rec["parity_halo_max_err"], rec["parity_interior_max_err"], rec["parity_ok"] = 2.5e-7, 2.4e-7, True
+    rec["config5"] = {"what": "w" * 3000, "total_samples": 1 << 30, "samples_per_gpu": 1 << 24, "n_gpus": 64, "ms": 0.07, "kernel_ms_max": 0.06,
+                      "value": 1.5e7, "unit": "MSamples/s", "frac_per_gpu": 0.5, "speedup_vs_n1": 54.2, "steps": 50,
+                      "n1_reference": {"profile": "p" * 400, "ms": 3.8, "value": 282000.0, "kernel_source_sha256": {"a": "b" * 64}},
+                      "parity_halo_max_err": 2.5e-7, "parity_interior_max_err": 2.4e-7, "halo_fallback_used": [0] * 64, "halo_state": [2] * 64,
+                      "parity_ok": True, "error": "e" * 3000}
+    rec["rows"] = {"row%02d" % i: {"error": "x" * 60} for i in range(40)}
+    fl = bench.final_line(rec)
+    line = json.dumps(fl)
+    assert len(line) <= bench.FINAL_LINE_MAX_BYTES
+    back = json.loads(line)
+    for k in ("metric", "value", "roofline", "cpu_baseline", "config", "n_ranks_rccl", "halo_fallback_used", "parity_ok"):
+        assert k in back, k
+    assert back["n_ranks_rccl"] == 64 and back["config5"]["n1_cross_check"]["ms"] == 3.8 and back["config5"]["speedup_vs_n1"] == 54.2
+
+
+def test_bench_emit_prints_exactly_one_stdout_line(tmp_path, monkeypatch, capsys):
+    bench = _bench_module()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    rec = _recorded_full_record()
+    bench.emit(rec)
+    cap = capsys.readouterr()
+    lines = cap.out.strip().split("\n")
+    assert len(lines) == 1 and len(lines[0]) <= bench.FINAL_LINE_MAX_BYTES
+    out = json.loads(lines[0])
+    assert out["roofline"]["frac"] > 0.5 and out["cpu_baseline"]["value"] > 1.0 and out["detail"] == os.path.join("gpurun_out", "bench_detail_n1.json")
+    side = json.load(open(os.path.join(str(tmp_path), out["detail"])))
+    assert "other_configs" in side and len(side["other_configs"]) == 18                   # the long record is kept -- beside stdout
+    detail = [ln for ln in cap.err.split("\n") if ln.startswith("bench.py detail: ")]
+    assert len(detail) == 19 and all(json.loads(ln[len("bench.py detail: "):]) for ln in detail)
+    assert not any(ln.lstrip().startswith("{") for ln in cap.err.split("\n"))            # nothing on stderr can be taken for the line

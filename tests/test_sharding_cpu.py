@@ -81,11 +81,11 @@ def test_gloo_world2_sharded_fir(tmp_path):
     import json
     for r in range(2):
         par = json.load(open(os.path.join(str(tmp_path), "parity%d.json" % r)))
-        hmax, imax, flags, ok = par["good"]
+        hmax, imax, flags, ok, states = par["good"]
         assert ok and hmax < 1e-12 and imax < 1e-12 and flags == [0, 0]
-        hmax, imax, flags, ok = par["bad"]
+        hmax, imax, flags, ok, states = par["bad"]
         assert not ok and hmax > 1e-3 and imax < 1e-12 and flags == [0, 1]
-        hmax, imax, flags, ok = par["good_iir"]
+        hmax, imax, flags, ok, states = par["good_iir"]
         assert ok and hmax < 1e-12 and imax < 1e-12
         # the config-5 record of an N > 1 run: whole-job rate over the slowest rank's step, per-GPU roofline fraction, speed-up
         # over the committed N = 1 line (withheld when that line is stale), the reduced parity verdict
