@@ -1,6 +1,6 @@
 """BASELINE config 5 with a real PEER: the RCCL halo of the sharded FIR (Ntaps-1 samples rank r -> r+1) between two or more
 HIP devices.  Skipped unless the box exposes more than one logical device (an 8-GPU node, or ONE MI355X in CPX partition
-mode: tools/cpx_probe.sh).  The ranks are the same `bench.py --gpus N` processes the driver launches; every rank checks the
+mode: profiles/r05/cpx_probe/).  The ranks are the same `bench.py --gpus N` processes the driver launches; every rank checks the
 outputs that consumed its neighbour's halo against the CPU oracle (bench.py: shard_parity)."""
 import json
 import os
@@ -36,7 +36,7 @@ def _bench(n_ranks, extra, env=None):
 def test_sharded_fir_halo_meets_a_peer(two_launches):
     nd = _device_count()
     if nd < 2:
-        pytest.skip("one logical HIP device on this box: the halo has no peer to meet (tools/cpx_probe.sh)")
+        pytest.skip("one logical HIP device on this box: the halo has no peer to meet (profiles/r05/cpx_probe/)")
     world = 8 if nd >= 8 else 2
     j = _bench(world, ["--scaling", "strong", "--total-log2n", "25"], {"SKDSP_SHARD_TWO_LAUNCHES": str(two_launches)})
     assert j["config"]["n_ranks_rccl"] == world
