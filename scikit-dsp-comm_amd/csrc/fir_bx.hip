@@ -277,7 +277,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int64_t ncols = (a.n_out + a.RS - 1) / a.RS;
     const int64_t nwin = (ncols + a.NS - 1) / a.NS;
-    int64_t wdx = blockIdx.x;
+    // XCD-aware walk (as ols_tile_kernel's): workgroup b runs on XCD b % 8, so every XCD takes a contiguous run of the round's windows -- neighbouring
+    // windows share their lag range (32 KB - q DS samples: 576 of 6720 for the default .dn by 12 of a 512-tap filter), which then hits that XCD's L2
+    // instead of being fetched from HBM by two XCDs (round 5 PMC: 1.09 x the algorithmic bytes for that row, 1.07 x for the 127-tap filter)
+    const int64_t w0 = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+    int64_t wdx = w0;
     if (wdx >= nwin) return;
     bool fast = interior(wdx);
     if (fast) load_window(wdx);  // first: the A operands below queue behind it
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             winv = winv_next;
             __syncthreads();  // the planes hold window w+1
-            if (__builtin_expect(wbad, 0)) careful_note(&bx_noted, (wdx - blockIdx.x) / gridDim.x);
+            if (__builtin_expect(wbad, 0)) careful_note(&bx_noted, (wdx - w0) / gridDim.x);
             wbad = wbad_next;
             const int64_t wnext2 = wnext + gridDim.x;
             fast = wnext2 < nwin && interior(wnext2);
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_s_setprio(0);
         winv = winv_next;
         __syncthreads();  // the planes hold window w+1
-        if (__builtin_expect(wbad, 0)) careful_note(&bx_noted, (wdx - blockIdx.x) / gridDim.x);
+        if (__builtin_expect(wbad, 0)) careful_note(&bx_noted, (wdx - w0) / gridDim.x);
         wbad = wbad_next;
         const int64_t wnext2 = wnext + gridDim.x;
         fast = wnext2 < nwin && interior(wnext2);
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned long long noted = careful_noted(&bx_noted);
     if (__builtin_expect(noted != 0, 0)) {
         int64_t k = 0;
-        for (int64_t w = blockIdx.x; w < nwin; w += gridDim.x, ++k)
+        for (int64_t w = w0; w < nwin; w += gridDim.x, ++k)
             if (careful_step_noted(noted, k))
                 careful_fir_range<float, CPLX>(x, y, a.n_hist, a.n_out, (int64_t)a.RS * a.NS * w, (int64_t)a.RS * a.NS, a.L, a.M, a.cf, tid);
     }

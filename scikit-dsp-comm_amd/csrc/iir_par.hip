@@ -53,6 +53,8 @@ constexpr int SK_PAR_PRIO = 3;      // wave priority in front of the recurrence 
 constexpr int SK_PAR_PRIO_ST = 1;   // ... and on a piece's way out through the image
 constexpr int SK_PAR_OCC = 2;     // waves per SIMD the register budget is set for
 constexpr int kParStageM2 = 13312;  // bytes of a wave's stage image in the DECM = 3 kernels (3072 + 3072 / 32 + 2 slots of 4 bytes, rounded up)
+// (measured and not kept, round 6: three waves per SIMD for the lean decimating kernel with float32 from-rest states -- 168 VGPRs, 148 bytes of scratch per
+// lane: 0.135 against 0.133 ms at two; the recurrence alone holds 96 sample + 32 state + 32 tap registers)
 constexpr int SK_PAR_OCC_UPL = 4;   // ... of the lean .up kernels (UPJ, up to 4 biquads: no input image, no table in LDS)
 
 template <int NSEC> struct ParCoef {
@@ -119,7 +121,11 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 // UPS (.up by 2, 3, 4 -- the factors of sigsys.interp24's stages): the stuffed zeros are compile-time facts; staged at the input rate (UP2 in the kernel).
 // The rate forms are LEAN: the bookkeeping of the general kernel (zero-stuffing unit by unit, per-lane phase tests, the pick of kept samples) was two
 // thirds of their instructions -- see UPL / DNL / UP2 at the top of the kernel and LABNOTES R5.8.
-template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0, bool UPJ = false, int UPS = 0>
+// V32 (float32 / complex64 signals, 7 - 8 biquads, where the plan's probe accepts it: par_v32_probe): V = G x on v_mfma_f32_16x16x4_f32 -- half the issue cycles
+// of the FP64 form (32 against 64; both share the vector datapath: tools/ubench_mixed_pipes.hip), G rounded to float32 once, the samples exact, a float32
+// fmaf chain over the chunk, oldest sample first.  The from-rest end states then carry ~1e-7 of error, which the output sum amplifies by the cancellation
+// between the branches -- so the form is EARNED per filter: the host runs the same chain bit for bit on probe inputs and admits the filter below 5e-7.
+template <int NSEC, typename IO, int DECM, bool CPLX, int TT = 0, bool UPJ = false, int UPS = 0, bool V32 = false>
 __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) ? SK_PAR_OCC_UPL : SK_PAR_OCC) void iir_par_kernel(ParArgs a, ParCoef<NSEC> cf, const double *__restrict__ gtab,
                                                                  const double *__restrict__ lvl, const double *__restrict__ psi,
                                                                  unsigned long long,   // (keeps upj out of the register tuple the three pointers above arrive in: that tuple was spilled as a whole, upj with it, and restored -- eight registers -- in front of every pair of row loads)
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
     constexpr bool DNL = (DECM == 1 || DECM == 3) && TT == 96;   // (3: M = 2, whose 3072 kept outputs per segment need a larger image -- see kWaveStage)
     constexpr bool UNI = DEC && TT == 96;   // (M = 2 on 96-sample chunks keeps its gathering in ranges but tests for kept samples the same way)
     constexpr bool G4 = D <= 12;   // V = G x by 4 x 4 x 4 products over the row groups in use (see phase A)
+    static_assert(!V32 || (sizeof(IO) == 4 && !G4 && !UPJ), "V32: float32 signals, more than 6 biquads, a kernel that runs V = G x on the matrix instruction");
     constexpr int T = TT ? TT : SK_PAR_T32 * 4 / (int)sizeof(IO);
     constexpr int NP = T / kPiece;
     constexpr int TI = T / UL;   // samples per chunk at the rate the signal is READ at
@@ -165,6 +172,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
     __shared__ __attribute__((aligned(16))) char lds_raw[4 * kWaveStage];
     __shared__ double gl[UPL ? 64 : (T / 4) * 64];
     __shared__ int base_sh;
+    float *glf = reinterpret_cast<float *>(gl);   // V32: the table as float32 (the first half of the same array)
     // CPLX: an interleaved complex signal.  Lane L owns component L & 1 (re / im) of complex chunk L >> 1: T complex samples
     // per chunk, 32 chunks per wave segment.  The two components are independent real signals through the same real
     // filter, so everything between the staging image and the recurrence is the real kernel with "the chunk to my left"
@@ -213,7 +221,10 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
     if (tid == 0) drawn = atomicAdd(a.ticket + blockIdx.x % kParTickets, 1ull);
     if constexpr (!UPL) {
 #pragma unroll
-        for (int i = 0; i < kTabPer; ++i) gl[tid + i * kIirThreads] = tab[i];
+        for (int i = 0; i < kTabPer; ++i) {
+            if constexpr (V32) glf[tid + i * kIirThreads] = (float)tab[i];
+            else gl[tid + i * kIirThreads] = tab[i];
+        }
     }
     if (tid == 0) base_sh = 4 * (int)((unsigned)(drawn - a.ticket_base) * kParTickets + blockIdx.x % kParTickets);
     __syncthreads();   // the only workgroup barrier
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
     // .up by 8 or more (from 4 on the unrolled column loop costs more than the zeros: rate_change(4).up 0.130 -> 0.140 ms): at most T / 8 + 1 samples of a chunk are not stuffed zeros, so V = G x is a handful of columns of G per chunk -- formed
     // per lane on the vector ALU from the INPUT samples instead of multiplying the zeros on the matrix pipe (rate_change(12).up: 11 of 128 columns;
     // the chunks of a wave start at different phases of the stuffing, so the columns differ from lane to lane and the matrix form cannot drop them)
-    const bool sparse = !DEC && a.up >= 8;                         // (.up never comes with a decimating store: none of this in those kernels)
+    const bool sparse = !DEC && !V32 && a.up >= 8;                         // (.up never comes with a decimating store: none of this in those kernels)
     const int ust = !DEC && (a.up == 2 || a.up == 4) ? a.up : 1;   // .up by 2 / 4: the column step of V = G x (see phase A)
 
     // ---- A: stream the segment in; chunk rows to registers; V = G x on the matrix pipe --------------------------------
@@ -379,8 +390,13 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
     typedef IO xv_t __attribute__((ext_vector_type(St::elems)));
     xv_t xq[T / St::elems];
     v4d_t acc[4];
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    v4f_t accf[4];   // V32
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = v4d_t{0.0, 0.0, 0.0, 0.0};
+    for (int g = 0; g < 4; ++g) {
+        acc[g] = v4d_t{0.0, 0.0, 0.0, 0.0};
+        accf[g] = v4f_t{0.f, 0.f, 0.f, 0.f};
+    }
     const int c = lane & 15, j = lane >> 4;
     IO *myrow = stage + lane * St::pitch;
     constexpr int NIN = UPL ? T / 8 : 1;   // UPL: input samples a chunk can hold
@@ -436,6 +452,10 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
 #pragma unroll
                         for (int r = 0; r < NG; ++r) acc[g][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(ga[r], b, acc[g][r], 0, 0, 0);
                     }
+                } else if constexpr (V32) {
+                    const float gaf = glf[((kcol >> 2) << 6) + ((kcol & 3) << 4) + (lane & 15)];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) accf[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(gaf, (float)xu[g * 16 * St::pitch + 4 * s], accf[g], 0, 0, 0);
                 } else {
                     const double ga = ga_p[lane & 15];
 #pragma unroll
@@ -495,6 +515,10 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
 #pragma unroll
                             for (int r = 0; r < NG; ++r) acc[g][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(ga[r], b, acc[g][r], 0, 0, 0);
                         }
+                    } else if constexpr (V32) {
+                        const float gaf = glf[((kcol >> 2) << 6) + ((kcol & 3) << 4) + (lane & 15)];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) accf[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(gaf, (float)xu[g * 16 * St::pitch + 4 * ust * s], accf[g], 0, 0, 0);
                     } else {
                         const double ga = ga_p[lane & 15];
 #pragma unroll
@@ -521,6 +545,10 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
 #pragma unroll
                     for (int r = 0; r < NG; ++r) acc[g][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(ga[r], b, acc[g][r], 0, 0, 0);
                 }
+            } else if constexpr (V32) {
+                const float gaf = glf[(p * (kPiece / 4) + s) * 64 + lane];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) accf[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(gaf, (float)xs[g * 16 * St::pitch + 4 * s], accf[g], 0, 0, 0);
             } else {
                 const double ga = gl[(p * (kPiece / 4) + s) * 64 + lane];
 #pragma unroll
@@ -587,9 +615,11 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int d = j + 4 * r;   // state row: section d >> 1, component d & 1
-            if (4 * r < D) {
-                if (d < D) E[(((d >> 1) * 64) + 16 * g + c) * 2 + (d & 1)] = UP2 ? (double)UL * acc[g][r] : acc[g][r];   // (UP2: the gain the zero-stuffed image would have carried)
+            // state row: section d >> 1, component d & 1.  The FP64 instruction leaves row (lane >> 4) + 4 reg in register reg, the float32 one row 4 (lane >> 4) + reg
+            const int d = V32 ? 4 * j + r : j + 4 * r;
+            if (V32 || 4 * r < D) {
+                const double av = V32 ? (double)accf[g][r] : acc[g][r];
+                if (d < D) E[(((d >> 1) * 64) + 16 * g + c) * 2 + (d & 1)] = UP2 ? (double)UL * av : av;   // (UP2: the gain the zero-stuffed image would have carried)
             }
         }
     wave_lds_sync();
@@ -1048,6 +1078,8 @@ struct ParTables {
     double *gt_dev = nullptr;    // G in MFMA A-operand order [T / 4][64]
     double *lvl_dev = nullptr;   // Phi^(2^l), l = 0..5: [6][nsec][4]
     double *psi_dev = nullptr;   // Psi^m, m = 1..kParMaxK-1, Psi = Phi^(chunks per segment): [kParMaxK - 1][nsec][4]
+    int v32 = 0;                 // V = G x in float32 for chunks of this length (par_v32_probe): 0 not probed, 1 admitted, -1 refused
+    double v32_err = 0.0;        // ... the worst probe error it showed
 };
 
 struct ParPlan {
@@ -1055,7 +1087,7 @@ struct ParPlan {
     int nsec = 0;
     long double a1[8], a2[8], r0[8], r1[8], c0 = 0.0L;
     double na1[8], na2[8], al[8], be[8], gamma = 0.0;
-    double kappa = 0.0, ir_err = 0.0;
+    double kappa = 0.0, ir_err = 0.0, l1h = 0.0;   // (l1h: the l1 norm of the impulse response -- the forward bound per unit input)
     ParTables tab[8];            // [0] float32 (T = 128), [1] float64 (T = 64), [2] complex64, [3] complex128 (32 chunks per segment), [4] / [5] float32 / complex64 with T = 96 (.dn, .up), [6] / [7] float64 / complex128 with T = 96 (.up)
     struct UpJump { int up; double *dev; };
     std::vector<UpJump> upj;     // per L: [L][2 nsec] rows c A^j + [nsec][4] blocks of A^L (UPJ kernels)
@@ -1183,8 +1215,116 @@ bool par_expand(const double *coef, int nsec, ParPlan &P)
     if (!(hmax > 0.0L) || !std::isfinite((double)emax) || !std::isfinite((double)l1b)) return false;
     P.ir_err = (double)(emax / hmax);
     P.kappa = (double)(l1b / l1h);
+    P.l1h = (double)l1h;
     return P.ir_err <= 1e-12 && P.kappa <= 1e3;
 }
+
+// V32 (see the kernel): may the from-rest end states of T-sample chunks of THIS filter be formed in float32?  The error such a state carries reaches the
+// outputs of the next chunks through the output taps, amplified by whatever cancels between the branches -- no norm of the expansion predicts it (an
+// elliptic band-pass with a cancellation factor of 2.8 shows 1.6e-6, one with 3.7 shows 4e-7), so it is MEASURED: the float32 chain of the matrix
+// instruction (acc = fmaf(G[t], x[t], acc), oldest sample first, G rounded to float32 -- bit for bit what v_mfma_f32_16x16x4_f32 computes) against the
+// exact from-rest state, on the inputs that are worst for it -- coherent ones: DC, the Nyquist alternation, a tone on every section's resonance -- and on
+// noise; the state errors are carried from chunk to chunk by the exact transition and through the output taps sample by sample.  Returned: the worst
+// output error over the probes, relative to the probe's output peak (or, for stop-band probes, 1 % of the forward bound -- the same floor the tests use).
+static double par_v32_probe(const ParPlan &P, int T)
+{
+    const int N = P.nsec, NCH = 24, n = NCH * T;
+    std::vector<float> g32((size_t)2 * N * T);
+    std::vector<double> gd((size_t)2 * N * T);
+    for (int k = 0; k < N; ++k) {
+        long double g0 = 1.0L, g1 = 0.0L;
+        for (int t = T - 1; t >= 0; --t) {
+            gd[((size_t)2 * k) * T + t] = (double)g0;
+            gd[((size_t)2 * k + 1) * T + t] = (double)g1;
+            g32[((size_t)2 * k) * T + t] = (float)(double)g0;
+            g32[((size_t)2 * k + 1) * T + t] = (float)(double)g1;
+            const long double g2 = -P.a1[k] * g0 - P.a2[k] * g1;
+            g1 = g0;
+            g0 = g2;
+        }
+    }
+    std::vector<std::vector<float>> probes;
+    {
+        std::vector<float> x((size_t)n);
+        unsigned long long lcg = 0x2545F4914F6CDD1Dull;
+        for (int i = 0; i < n; ++i) {
+            double a = 0.0;
+            for (int q = 0; q < 4; ++q) {
+                lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                a += (double)(lcg >> 11) / 9007199254740992.0 - 0.5;
+            }
+            x[i] = (float)(a * 1.7320508075688772);
+        }
+        probes.push_back(x);
+        for (int i = 0; i < n; ++i) x[i] = 1.0f;
+        probes.push_back(x);
+        for (int i = 0; i < n; ++i) x[i] = (i & 1) ? -1.0f : 1.0f;
+        probes.push_back(x);
+        for (int k = 0; k < N; ++k) {
+            const double a1 = (double)P.a1[k], a2 = (double)P.a2[k];
+            if (!(a2 > 0.0) || a1 * a1 >= 4.0 * a2) continue;   // (real poles: DC / Nyquist cover them)
+            const double th = std::acos(std::max(-1.0, std::min(1.0, -a1 / (2.0 * std::sqrt(a2)))));
+            for (int i = 0; i < n; ++i) x[i] = (float)std::cos(th * i);
+            probes.push_back(x);
+        }
+    }
+    double worst = 0.0;
+    for (const auto &x : probes) {
+        // the exact output (the parallel form in double, straight through) for the scale; the error by linearity: the state errors alone, carried exactly
+        double ymax = 0.0, xmax = 0.0;
+        {
+            std::vector<double> w1((size_t)N, 0.0), w2((size_t)N, 0.0);
+            for (int i = 0; i < n; ++i) {
+                double yv = P.gamma * (double)x[i];
+                for (int k = 0; k < N; ++k) {
+                    yv += P.al[k] * w1[k] + P.be[k] * w2[k];
+                    const double w0 = (double)x[i] + P.na1[k] * w1[k] + P.na2[k] * w2[k];
+                    w2[k] = w1[k];
+                    w1[k] = w0;
+                }
+                ymax = std::max(ymax, std::fabs(yv));
+                xmax = std::max(xmax, (double)std::fabs(x[i]));
+            }
+        }
+        std::vector<double> e1((size_t)N, 0.0), e2((size_t)N, 0.0);   // error of (w[n-1], w[n-2]) at the start of the current chunk
+        double emax = 0.0;
+        for (int j = 0; j < NCH; ++j) {
+            // outputs of chunk j see the start-state error through the taps; the error state runs the homogeneous recurrence
+            std::vector<double> f1 = e1, f2 = e2;
+            for (int t = 0; t < T; ++t) {
+                double ev = 0.0;
+                for (int k = 0; k < N; ++k) {
+                    ev += P.al[k] * f1[k] + P.be[k] * f2[k];
+                    const double f0 = P.na1[k] * f1[k] + P.na2[k] * f2[k];
+                    f2[k] = f1[k];
+                    f1[k] = f0;
+                }
+                emax = std::max(emax, std::fabs(ev));
+            }
+            // this chunk's from-rest end state: the float32 chain against the double sum of the same products with the unrounded G
+            for (int k = 0; k < N; ++k) {
+                for (int c = 0; c < 2; ++c) {
+                    const float *gf = g32.data() + ((size_t)2 * k + c) * T;
+                    const double *ge = gd.data() + ((size_t)2 * k + c) * T;
+                    float acc = 0.0f;
+                    long double ex = 0.0L;
+                    for (int t = 0; t < T; ++t) {
+                        acc = std::fmaf(gf[t], x[(size_t)j * T + t], acc);
+                        ex += (long double)ge[t] * (long double)x[(size_t)j * T + t];
+                    }
+                    (c == 0 ? f1[k] : f2[k]) += (double)acc - (double)ex;   // e_(j+1) = Phi e_j + delta_j (f holds Phi e_j now)
+                }
+            }
+            e1 = f1;
+            e2 = f2;
+        }
+        const double scale = std::max(ymax, 1e-2 * P.l1h * xmax);
+        if (!(scale > 0.0) || !std::isfinite(emax)) return 1.0;
+        worst = std::max(worst, emax / scale);
+    }
+    return worst;
+}
+constexpr double kParV32Limit = 5e-7;   // of the 1e-6 the float32 contract allows: the rest stays with the recurrence, the output rounding and the inputs no probe covers
 
 struct M2 { long double m[4]; };
 M2 m2mul(const M2 &x, const M2 &y)
@@ -1272,6 +1412,9 @@ int iir_par_expand_host(const double *coef, int nsec, double *out, int *accepted
         }
         out[1 + 4 * nsec] = P.kappa;
         out[2 + 4 * nsec] = P.ir_err;
+        // the float32 from-rest states of 128- and 96-sample chunks (V32): the worst probe error, admitted below kParV32Limit
+        out[3 + 4 * nsec] = ok ? par_v32_probe(P, SK_PAR_T32) : 1.0;
+        out[4 + 4 * nsec] = ok ? par_v32_probe(P, 96) : 1.0;
     }
     return SKDSP_OK;
 }
@@ -1329,11 +1472,37 @@ static int par_upj_table(ParPlan &P, int L, const double **out)
 }
 
 template <typename IO, bool CPLX, int TT = 0, bool UPJ = false, int UPS = 0>
+static int launch_par_impl(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
+                           void *y, hipStream_t s, int dec, int up);
+
+template <typename IO, bool CPLX, int TT = 0, bool UPJ = false, int UPS = 0>
 static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
                       void *y, hipStream_t s, int dec, int up = 1)
 {
+#ifdef SK_PAR_DEV_F32REAL   // (developer builds: float32 real signals only -- a third of the instantiations)
+    if constexpr (sizeof(IO) == 8 || CPLX) return 1;
+    else
+#endif
+    return launch_par_impl<IO, CPLX, TT, UPJ, UPS>(h, p, tb, x, n, nrow, x_stride, y_stride, y, s, dec, up);
+}
+
+template <typename IO, bool CPLX, int TT, bool UPJ, int UPS>
+static int launch_par_impl(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride,
+                           void *y, hipStream_t s, int dec, int up)
+{
     note_path("iir_par");   // (here, not in iir_par_launch: that function returns 1 -- nothing launched -- for every call the parallel form does not take)
     const int T = tb.T;
+    // V32 (see the kernel): float32 / complex64 signals through 7 - 8 biquads, once the probe has admitted this filter at this chunk length
+    bool v32 = false;
+    // (not for .up by 8 or more through the general kernel: its from-rest states are formed per lane on the vector ALU from the FLOAT64 table -- `sparse` in the kernel)
+    if (sizeof(IO) == 4 && !UPJ && h->nsec >= 7 && opt().iir_par_v32 > 0 && !(UPS == 0 && dec <= 1 && up >= 8)) {
+        if (tb.v32 == 0) {
+            tb.v32_err = par_v32_probe(*p, T);
+            tb.v32 = tb.v32_err <= kParV32Limit ? 1 : -1;
+        }
+        v32 = tb.v32 == 1 || opt().iir_par_v32 >= 2;
+        if (v32) note_path("iir_par_v32");
+    }
     const int64_t S = (int64_t)(CPLX ? 32 : 64) * T;   // samples per wave segment
     const int64_t nseg = (n + S - 1) / S;
     SK_CHECK(nseg * nrow < (1 << 30), SKDSP_ERR_BADARG, "iir: too many segments");
@@ -1402,23 +1571,50 @@ static int launch_par(IirHandle *h, ParPlan *p, ParTables &tb, const void *x, in
                 hipLaunchKernelGGL((iir_par_kernel<N, IO, 3, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,    \
                                    (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr);  \
         } else if (a.dec > 1) {                                                                                         \
-            if constexpr (!UPJ && UPS == 0)                                                                             \
+            if constexpr (!UPJ && UPS == 0) {                                                                           \
+                if constexpr (N >= 7 && sizeof(IO) == 4) {                                                              \
+                    if (v32) {                                                                                          \
+                        hipLaunchKernelGGL((iir_par_kernel<N, IO, 1, CPLX, TT, false, 0, true>), dim3(grid), dim3(kIirThreads), 0, s, a, cf, \
+                                           (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr); \
+                        break;                                                                                          \
+                    }                                                                                                   \
+                }                                                                                                       \
                 hipLaunchKernelGGL((iir_par_kernel<N, IO, 1, CPLX, TT>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,    \
                                    (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr);  \
+            }                                                                                                           \
         } else if constexpr (UPJ)                                                                                         \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX, TT, true>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,  \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, upj_tab); \
-        else if constexpr (UPS != 0)                                                                                    \
+        else if constexpr (UPS != 0) {                                                                                  \
+            if constexpr (N >= 7 && sizeof(IO) == 4) {                                                                  \
+                if (v32) {                                                                                              \
+                    hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX, TT, false, UPS, true>), dim3(grid), dim3(kIirThreads), 0, s, a, cf, \
+                                       (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr); \
+                    break;                                                                                              \
+                }                                                                                                       \
+            }                                                                                                           \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX, TT, false, UPS>), dim3(grid), dim3(kIirThreads), 0, s, a, cf, \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr); \
-        else if constexpr (TT == 0)                                                                                     \
+        } else if constexpr (TT == 0) {                                                                                 \
+            if constexpr (N >= 7 && sizeof(IO) == 4) {                                                                  \
+                if (v32) {                                                                                              \
+                    hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX, 0, false, 0, true>), dim3(grid), dim3(kIirThreads), 0, s, a, cf, \
+                                       (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr); \
+                    break;                                                                                              \
+                }                                                                                                       \
+            }                                                                                                           \
             hipLaunchKernelGGL((iir_par_kernel<N, IO, 0, CPLX>), dim3(grid), dim3(kIirThreads), 0, s, a, cf,            \
                                (const double *)tb.gt_dev, (const double *)tb.lvl_dev, (const double *)tb.psi_dev, 0ull, (const double *)nullptr);      \
+        }                                                                                                               \
         break;                                                                                                          \
     }
     switch (h->nsec) {
+#ifdef SK_PAR_DEV_NSEC   // (developer builds: one cascade length only -- this file is the long pole of the build)
+        SK_PAR(SK_PAR_DEV_NSEC)
+#else
         SK_PAR(1) SK_PAR(2) SK_PAR(3) SK_PAR(4) SK_PAR(5) SK_PAR(6) SK_PAR(7)
         SK_PAR(8)
+#endif
         default: SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "iir: parallel-form scan takes 1..8 biquads");
     }
 #undef SK_PAR

@@ -48,6 +48,8 @@ struct Options {
     int iir_no_mfma = 0;      // recurrence K1 instead of the matrix-pipe K1
     int iir_two_pass = 0;     // 1: K1 + carries + K3 even where the single-pass scan applies; -1: single pass wherever it applies
     int iir_par = 1;          // 0: never the parallel-form scan (iir_par.hip); the cascade kernels everywhere
+    int iir_par_v32 = 1;      // the parallel form's from-rest end states of float32 / complex64 signals, 7 - 8 biquads, on the float32 matrix instruction: 1 where the
+                              // plan's probe admits the filter (iir_par.hip: par_v32_probe), 2 always (tests, A/B), 0 never
     int iir_up_jump = 1;      // the parallel-form .up of float32 / complex64 signals by L >= 8, a divisor of 96: lean kernels whose state jumps from input sample to input sample; 0 never (A/B switch)
     int iir_seq = 1;          // cascades of more than 8 sections whose float64 spread the scans would lift past the contract run the reference's recursion (iir_seq.hip): 1 probed, 2 always, 0 never
     int iir_up_lean = 1;      // multirate_IIR.up by 2 staged at the input rate with the stuffed zeros known at compile time (A/B switch; 0: the zero-stuffed image)

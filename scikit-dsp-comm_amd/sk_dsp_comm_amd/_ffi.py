@@ -650,11 +650,13 @@ def sos_par_info(sos):
     cancellation factor, impulse-response error against the cascade, accepted)."""
     s = np.ascontiguousarray(sos, dtype=np.float64).reshape(-1, 6)
     ns = s.shape[0]
-    out = np.zeros(3 + 4 * ns)
+    out = np.zeros(5 + 4 * ns)
     ok = ctypes.c_int(0)
     check(load().skdsp_sos_par_info(_ptr(s), ns, _ptr(out), ctypes.byref(ok)))
     return {"c0": out[0], "sections": out[1:1 + 4 * ns].reshape(ns, 4).copy(), "kappa": out[1 + 4 * ns], "ir_err": out[2 + 4 * ns],
-            "accepted": bool(ok.value)}
+            "accepted": bool(ok.value),
+            # the float32 from-rest states (7 - 8 biquads, float32 / complex64 signals): worst probe error on 128- / 96-sample chunks, admitted below 5e-7
+            "v32_err": out[3 + 4 * ns], "v32_err_t96": out[4 + 4 * ns], "v32_admitted": bool(ok.value) and out[3 + 4 * ns] <= 5e-7}
 
 
 def tf2sos(b, a):

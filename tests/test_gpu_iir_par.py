@@ -172,7 +172,12 @@ def test_parallel_form_up_zero_stuffs_while_staging(dt, L):
             # jumps from input sample to input sample: the same filter in another operation order)
             jumps = L >= 8 and 96 % L == 0
             rechunked = single and L == 3   # (by 3 the fused kernel of float32 / complex64 signals runs on chunks of 96 samples, the two-step path on 128: another scan tree)
-            if np.dtype(dt).kind == "c" or jumps or rechunked:   # (the two-step path runs complex signals through other kernels: same arithmetic, other rounding)
+            # (round 6: a 7 - 8 biquad cascade admitted to the float32 from-rest states runs them in the two-step path's plain filter, while the fused kernel of
+            # L >= 8 forms its states per lane in float64 from the few non-zero columns: two arithmetics, both inside the contract)
+            v32 = single and len(sos) >= 7 and _ffi.sos_par_info(sos)["v32_admitted"]
+            if v32 and L >= 8 and not jumps:
+                assert max(rel_err(outs[1], outs[0])) <= 1e-6, (name, L, n)
+            elif np.dtype(dt).kind == "c" or jumps or rechunked:   # (the two-step path runs complex signals through other kernels: same arithmetic, other rounding)
                 # (float64 with the state jump: a one-sample input shows the head of the impulse response, where the partial-fraction branches cancel to 1e-5 of
                 # their own size -- the two operation orders then differ by 1e-12 of that small head, 1e-15 of the states)
                 assert max(rel_err(outs[1], outs[0])) <= (2e-7 if single else (5e-12 if jumps else 1e-13)), (name, L, n)
@@ -824,3 +829,83 @@ def test_well_conditioned_cascades_keep_the_scans():
     for sos in (signal.butter(24, 0.2, output="sos"), signal.butter(40, 0.4, output="sos"), signal.ellip(8, 0.5, 60, 0.3, output="sos")):
         k = _ffi.IirKernel(_ffi.F32, sos=sos)
         assert not k.sequential, (sos.shape, k.spread)
+
+
+# ---- V32: the from-rest end states on the float32 matrix instruction (7 - 8 biquads, float32 / complex64) --------------------------------
+def _resonance_probes(sos, m):
+    info = _ffi.sos_par_info(sos)
+    t = np.arange(m)
+    rng = np.random.default_rng(11)
+    probes = {"noise": rng.standard_normal(m), "dc": np.ones(m), "nyquist": (-1.0) ** t}
+    for i, (a1, a2, r0, r1) in enumerate(info["sections"]):
+        if a2 > 0 and a1 * a1 < 4 * a2:
+            probes["res%d" % i] = np.cos(np.arccos(-a1 / (2 * np.sqrt(a2))) * t)
+    return info, probes
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.complex64])
+def test_v32_config4_on_its_worst_inputs(dtype):
+    """BASELINE config 4's band-pass is admitted to the float32 from-rest states; on the coherent inputs that are worst for them (DC, Nyquist,
+    a tone on every section's resonance) and on noise .filter / .dn(x, 3) / .up(x, 2) stay inside the 1e-6 contract, the engine is the one
+    meant (skdsp_debug_path), and with the option off the same calls are the float64-state ones (<= 1e-7)."""
+    sos = np.load(os.path.join(GOLDEN, "g7_iir_sos.npz"))["sos8"]
+    m = 3 * (1 << 16)
+    info, probes = _resonance_probes(sos, m)
+    assert info["v32_admitted"]
+    k = _ffi.IirKernel(_ffi.code_of(dtype), sos=sos)
+    worst = {0: 0.0, 1: 0.0}
+    for v in (1, 0):
+        with _ffi.option("iir_par_v32", v):
+            for name, x in probes.items():
+                xs = x.astype(np.float32)
+                if dtype == np.complex64:
+                    xs = (xs + 1j * np.roll(xs, 17)).astype(np.complex64)
+                ref = orc.sos_filter(sos, xs)
+                peak = np.max(np.abs(ref))
+                xd = _ffi.DeviceArray.from_host(xs)
+                yd = _ffi.DeviceArray(m, dtype)
+                _ffi.debug_path()
+                k.filter_dev(xd, yd)
+                path = _ffi.debug_path()
+                assert ("iir_par_v32" in path) == bool(v), (path, v)
+                e = [np.max(np.abs(yd.to_host() - ref)) / peak]
+                y3 = _ffi.DeviceArray(m // 3, dtype)
+                k.dn_dev(xd, y3, 3)
+                e.append(np.max(np.abs(y3.to_host() - ref[::3])) / peak)
+                xh = _ffi.DeviceArray.from_host(xs[: m // 2])
+                k.up_dev(xh, yd, 2)
+                ref2 = orc.sos_filter(sos, 2 * orc.upsample(xs[: m // 2], 2))
+                e.append(np.max(np.abs(yd.to_host() - ref2)) / np.max(np.abs(ref2)))
+                worst[v] = max(worst[v], max(e))
+                assert max(e) < (1e-6 if v else 1e-7), (name, v, e)
+                for d in (xd, yd, y3, xh):
+                    d.free()
+    print("config 4, %s: worst error with float32 from-rest states %.2e, with float64 ones %.2e" % (np.dtype(dtype).name, worst[1], worst[0]))
+
+
+def test_v32_refuses_a_cancelling_design():
+    """An 8-biquad elliptic band-pass whose probe shows 1.2e-6 keeps the FP64 matrix form: the float32 engine is not taken (unless forced: option 2,
+    which then shows why -- above the contract on its resonances)."""
+    from scipy import signal
+    sos = signal.ellip(8, 0.5, 60, [0.1, 0.2], btype="bandpass", output="sos")[:8]
+    m = 1 << 17
+    info, probes = _resonance_probes(sos, m)
+    assert info["accepted"] and not info["v32_admitted"]
+    k = _ffi.IirKernel(_ffi.F32, sos=sos)
+    forced_worst = 0.0
+    for name, x in probes.items():
+        xs = x.astype(np.float32)
+        ref = orc.sos_filter(sos, xs)
+        xd = _ffi.DeviceArray.from_host(xs)
+        yd = _ffi.DeviceArray(m, np.float32)
+        _ffi.debug_path()
+        k.filter_dev(xd, yd)
+        path = _ffi.debug_path()
+        assert "iir_par" in path and "iir_par_v32" not in path, path
+        assert np.max(np.abs(yd.to_host() - ref)) / np.max(np.abs(ref)) < 2e-7, name
+        with _ffi.option("iir_par_v32", 2):
+            k.filter_dev(xd, yd)
+            assert "iir_par_v32" in _ffi.debug_path()
+            forced_worst = max(forced_worst, np.max(np.abs(yd.to_host() - ref)) / np.max(np.abs(ref)))
+        xd.free(); yd.free()
+    assert forced_worst > 6e-7, forced_worst      # (the probe was right to refuse it)

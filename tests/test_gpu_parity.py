@@ -1600,7 +1600,18 @@ def test_iir_dn_decimating_store(dt, M, n):
         assert np.all(got[n // M:] == 7.0)
         # (the same kernel with and without the decimating store: identical; when the two calls take different scan
         #  paths -- single-pass for the full-rate call -- they agree to float64 rounding instead)
-        assert_close(got[:n // M], y2.to_host(0, n // M), 0.0 if dt in (np.float32, np.complex64) else 1e-12, "dn vs full-rate + downsample")
+        # (round 6: this cascade is admitted to the float32 from-rest states, and the two calls then run them over chunks of different lengths -- 96 and 128
+        #  samples: two float32 sums of the same states, each within the contract; with the option off the two calls are bit-identical as before)
+        v32 = dt in (np.float32, np.complex64) and _ffi.get_option("iir_par_v32") and _ffi.sos_par_info(sos)["v32_admitted"]
+        assert_close(got[:n // M], y2.to_host(0, n // M), (1e-6 if v32 else 0.0) if dt in (np.float32, np.complex64) else 1e-12, "dn vs full-rate + downsample")
+        if v32:
+            with _ffi.option("iir_par_v32", 0):
+                _ffi.check(lib.skdsp_iir_dn_dev(ctypes.c_void_p(k.h), ctypes.c_void_p(xd.ptr), n, M, ctypes.c_void_p(yd.ptr)))
+                with _ffi.option("iir_dn_full", 1):
+                    _ffi.check(lib.skdsp_iir_dn_dev(ctypes.c_void_p(k.h), ctypes.c_void_p(xd.ptr), n, M, ctypes.c_void_p(y2.ptr)))
+            _ffi.sync()
+            got = yd.to_host(0, n // M + 8)
+            assert_close(got[:n // M], y2.to_host(0, n // M), 0.0, "dn vs full-rate + downsample, float64 from-rest states")
         tol = TOL32 if dt in (np.float32, np.complex64) else 1e-9
         m = min(n, 60000)
         ref = orc.sos_filter(sos, xd.to_host(0, m))[::M][:m // M]

@@ -358,6 +358,27 @@ def test_parallel_form_expansion_reproduces_the_cascade(name):
         assert np.max(np.abs(y - ref)) <= 2e-13 * max(np.max(np.abs(ref)), 1e-300)
 
 
+def test_float32_from_rest_states_are_earned_per_filter():
+    """V32 (csrc/iir_par.hip): float32 / complex64 signals through 7 - 8 biquads may form the chunks' from-rest end states on the float32 matrix
+    instruction -- where the plan's probe (the instruction's fmaf chain emulated bit for bit on DC, the Nyquist alternation, a tone on every
+    section's resonance, noise) shows less than 5e-7 of output error.  BASELINE config 4's band-pass is admitted; designs whose branches
+    cancel more -- among them one with a SMALLER cancellation factor, which is why the test is a measurement and not a norm -- are refused."""
+    from scipy import signal
+    sos8 = np.load(os.path.join(GOLDEN, "g7_iir_sos.npz"))["sos8"]
+    i4 = _ffi.sos_par_info(sos8)
+    assert i4["accepted"] and i4["v32_admitted"] and 1e-7 < i4["v32_err"] < 5e-7 and i4["v32_err_t96"] < 5e-7, i4
+    refused = {
+        "ellip_bpf_0.1_0.2": signal.ellip(8, 0.5, 60, [0.1, 0.2], btype="bandpass", output="sos")[:8],
+        "cheby2_highpass14": signal.cheby2(14, 50, 0.4, btype="highpass", output="sos"),
+        "butter_bpf16": signal.butter(8, [0.2, 0.3], btype="bandpass", output="sos"),
+    }
+    for name, sos in refused.items():
+        info = _ffi.sos_par_info(sos)
+        assert info["accepted"], name                       # the parallel form itself serves them (float64 states)
+        assert not info["v32_admitted"] and info["v32_err"] > 5e-7, (name, info["v32_err"], info["kappa"])
+    assert _ffi.sos_par_info(refused["ellip_bpf_0.1_0.2"])["kappa"] < i4["kappa"]      # (less cancellation by the norm, more error measured)
+
+
 def test_parallel_form_refuses_what_it_cannot_expand():
     from scipy import signal
     one = signal.butter(2, 0.3, output="sos")
