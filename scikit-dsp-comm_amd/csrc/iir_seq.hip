@@ -8,15 +8,22 @@
 // shows a float64 spread that the scans would lift above the contract (capi.hip: the probe at creation) therefore run HERE: the recursion
 // itself, in the reference's operation order, without fused multiply-adds -- bit for bit what scipy computes for float64 signals.
 //
-// One wave per row (a complex signal is two rows).  Lane s holds section s; the samples move down the lanes one per step (a systolic
-// pipeline: lane s works on sample t - s at step t), handed over by a one-lane DPP shift.  64 sections per pass; longer cascades run pass
-// after pass in place.  About 40 - 60 clocks per step: 2^26 samples take seconds -- the reference's own speed on a host core, which is
-// what such a filter costs; the Python layer logs a WARNING when it makes such a handle.
+// One wave per row (a complex signal is two rows).  Lane s holds section s; the samples move down the lanes in BLOCKS of kSeqB: at block
+// step t lane s runs block t - s through its section -- kSeqB samples one after the other, the section's state in registers -- and hands
+// the block to lane s + 1 by one-lane DPP shifts.  Round 5 handed over sample by sample: per sample a broadcast of the input to lane 0
+// (two v_readlane + two selects), of the last section's result (two more) and its placement in an output register, five range tests -- 35
+// vector instructions around the 9 of the recursion, ~150 clocks per sample on the one wave that issues them (5 - 6 MSamples/s on an
+// idle, down-clocked chip).  In blocks the hand-over is two DPP moves per sample and nothing else: lane 0's next block arrives by ITS
+// loads into the registers the shift leaves to it (`old` of the DPP move), the last section's lane stores ITS block, and the range tests
+// are one per block.  13 - 14 instructions per sample.  64 sections per pass; longer cascades run pass after pass through a float64
+// buffer of the handle (so float32 signals are rounded once, at the end, and a decimating call keeps the full rate between passes).
 #include "skdsp_internal.hpp"
 
 namespace skdsp {
 
 namespace {
+
+constexpr int kSeqB = 16;   // samples per block
 
 struct SeqArgs {
     const void *x;
@@ -29,31 +36,24 @@ struct SeqArgs {
     int dec;                      // > 1 (last pass): only y[k dec] is stored, at y[k]
 };
 
-// (v of lane - 1; lane 0 keeps its own)
-__device__ __forceinline__ double lane_shr1(double v)
+// lanes 1 .. 63: v of lane - 1; lane 0: `keep` (its own next input)
+__device__ __forceinline__ double lane_shr1_or(double keep, double v)
 {
-    const long long b = __double_as_longlong(v);
-    const int lo = (int)b, hi = (int)(b >> 32);
-    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
-    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    const long long b = __double_as_longlong(v), k = __double_as_longlong(keep);
+    const int lo2 = __builtin_amdgcn_update_dpp((int)k, (int)b, 0x138, 0xf, 0xf, false);           // wave_shr:1 (lane 0 has no source: keeps `old`)
+    const int hi2 = __builtin_amdgcn_update_dpp((int)(k >> 32), (int)(b >> 32), 0x138, 0xf, 0xf, false);
     return __longlong_as_double(((long long)hi2 << 32) | (unsigned)lo2);
 }
 
-// lane `src` (wave-uniform) of v, to every lane
-__device__ __forceinline__ double lane_bcast(double v, int src)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)b, src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-template <typename IO>
+template <typename IN, typename OUT>
 __global__ __launch_bounds__(64) void iir_seq_kernel(SeqArgs a)
 {
 #pragma clang fp contract(off)   // (the reference rounds every product and every sum: no fused multiply-adds here)
+    constexpr int B = kSeqB;
     const int lane = threadIdx.x;
     const int64_t row = blockIdx.x;
-    const IO *x = reinterpret_cast<const IO *>(a.x) + row * a.x_stride;
-    IO *y = reinterpret_cast<IO *>(a.y) + row * a.y_stride;
+    const IN *x = reinterpret_cast<const IN *>(a.x) + row * a.x_stride;
+    OUT *y = reinterpret_cast<OUT *>(a.y) + row * a.y_stride;
     const bool mine = lane < a.ns;
     double b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0, z0 = 0, z1 = 0;
     if (mine) {
@@ -64,65 +64,86 @@ __global__ __launch_bounds__(64) void iir_seq_kernel(SeqArgs a)
             z1 = a.state[row * 2 * a.ns + 2 * lane + 1];
         }
     }
-    const int64_t steps = a.n + a.ns - 1;
     const int last = a.ns - 1;
-    double out = 0.0;    // what this lane handed down at the previous step
-    double yblk = 0.0;   // lane l: output base + l of the block the last section is working on
-    // The row travels through registers: lane l holds sample t0 + l of the current block of 64 (one coalesced load per block, requested a block
-    // ahead -- which also makes in-place calls safe: a block is read before any of its samples is overwritten), lane 0 picks sample t0 + j with a
-    // v_readlane; the last section's results are dropped into lane il & 63 of yblk and leave as one coalesced store per 64.
-    auto fetch = [&](int64_t blk) -> double {
-        const int64_t i = blk * 64 + lane;
-        return i < a.n ? (double)x[i] : 0.0;
+    const int64_t nblk = (a.n + B - 1) / B;
+    const int64_t nsteps = nblk + last;
+    // lane 0's block `blk` of the row, as doubles (beyond the row: zeros; the last, partial block element by element -- nothing is read past x[n - 1])
+    auto fetch = [&](int64_t blk, double (&v)[B]) {
+        const int64_t i0 = blk * B;
+        if (i0 + B <= a.n) {
+#pragma unroll
+            for (int j = 0; j < B; ++j) v[j] = (double)x[i0 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < B; ++j) v[j] = i0 + j < a.n ? (double)x[i0 + j] : 0.0;
+        }
     };
-    double xcur = fetch(0);
+    double w[B];       // the block this lane works on: inputs, then in place its section's outputs
+    double nx[B];      // lane 0: the next block of the row (requested a block step ahead -- which also makes in-place calls safe: a block is read a step
+                       // before the first section starts on it, and written when the last section is through with it)
+#pragma unroll
+    for (int j = 0; j < B; ++j) { w[j] = 0.0; nx[j] = 0.0; }
+    if (lane == 0) fetch(0, w);
+    // (the reference's statement order: x_c = b0 x_n + z0; z0 = b1 x_n - a1 x_c + z1; z1 = b2 x_n - a2 x_c.  Plain operators under the pragma above: the
+    // __dmul_rn / __dadd_rn of the HIP headers are ordinary inline functions whose products and sums carry their own contraction licence)
+    auto section = [&](double in) -> double {
+        const double xc = b0 * in + z0;
+        z0 = b1 * in - a1 * xc + z1;
+        z1 = b2 * in - a2 * xc;
+        return xc;
+    };
 #pragma unroll 1
-    for (int64_t t0 = 0; t0 < steps; t0 += 64) {
-        const double xnext = fetch(t0 / 64 + 1);
-        // everything the 64 steps of this block test is worked out here, in 32 bits: this lane works on sample t0 - lane + j in steps
-        // j in [jlo, jhi); the last section finishes sample t0 - last + j in steps [llo, lhi) and a block of 64 outputs is complete at step jf
-        const int64_t i0 = t0 - lane, l0 = t0 - last;
-        const int jlo = i0 >= 0 ? 0 : (i0 < -64 ? 64 : (int)-i0), jhi = a.n - i0 >= 64 ? 64 : (a.n - i0 <= 0 ? 0 : (int)(a.n - i0));
-        const int llo = l0 >= 0 ? 0 : (l0 < -64 ? 64 : (int)-l0), lhi = a.n - l0 >= 64 ? 64 : (a.n - l0 <= 0 ? 0 : (int)(a.n - l0));
-        const int jf = (int)((63 - (l0 & 63)) & 63);                      // (l0 + jf) & 63 == 63
-        const int jend = a.n - 1 - l0 >= 0 && a.n - 1 - l0 < 64 ? (int)(a.n - 1 - l0) : -1;   // the row's last sample, if this block finishes it
-        const int slot0 = (int)(l0 & 63);
-        const int jmax = steps - t0 >= 64 ? 64 : (int)(steps - t0);
-#pragma unroll 2
-        for (int j = 0; j < jmax; ++j) {
-            double in = lane_shr1(out);
-            const double x0 = lane_bcast(xcur, j);
-            if (lane == 0) in = x0;
-            if (mine && j >= jlo && j < jhi) {
-                // (the reference's statement order: x_c = b0 x_n + z0; z0 = b1 x_n - a1 x_c + z1; z1 = b2 x_n - a2 x_c.  Plain operators under the pragma
-                // above: the __dmul_rn / __dadd_rn of the HIP headers are ordinary inline functions whose products and sums carry their own
-                // contraction licence and were fused all the same)
-                const double xc = b0 * in + z0;
-                z0 = b1 * in - a1 * xc + z1;
-                z1 = b2 * in - a2 * xc;
-                out = xc;
-            }
-            if (j >= llo && j < lhi) {   // the last section has just finished sample l0 + j
-                const double fin = lane_bcast(out, last);
-                yblk = lane == ((slot0 + j) & 63) ? fin : yblk;
-                if (j == jf || j == jend) {
-                    const int64_t il = l0 + j, o = (il & ~(int64_t)63) + lane;
-                    if (o <= il) {
-                        if (a.dec > 1) {
-                            if (o % a.dec == 0 && o / a.dec < a.n / a.dec) y[o / a.dec] = (IO)yblk;
-                        } else {
-                            y[o] = (IO)yblk;
-                        }
+    for (int64_t t = 0; t < nsteps; ++t) {
+        if (lane == 0 && t + 1 < nblk) fetch(t + 1, nx);
+        const int64_t blk = t - lane;                       // this lane's block
+        const int64_t left = a.n - blk * B;                 // its samples, if it is a block of the row
+        const int cnt = !mine || blk < 0 || left <= 0 ? 0 : (left >= B ? B : (int)left);
+        if (cnt == B) {                                     // (the steady state: every lane of the wave, one test per block)
+#pragma unroll
+            for (int j = 0; j < B; ++j) w[j] = section(w[j]);
+        } else if (cnt > 0) {                               // the row's last, partial block
+#pragma unroll
+            for (int j = 0; j < B; ++j)
+                if (j < cnt) w[j] = section(w[j]);
+        }
+        if (lane == last && cnt > 0) {                      // the last section's lane stores its block
+            const int64_t i0 = blk * B;
+            if (a.dec <= 1) {
+                if (cnt == B) {
+#pragma unroll
+                    for (int j = 0; j < B; ++j) y[i0 + j] = (OUT)w[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < B; ++j)
+                        if (j < cnt) y[i0 + j] = (OUT)w[j];
+                }
+            } else {
+                const int64_t n_out = a.n / a.dec;
+                int64_t o = (i0 + a.dec - 1) / a.dec;       // first kept sample of the block: o dec >= i0
+                int jn = (int)(o * a.dec - i0);
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    if (j == jn && j < cnt) {
+                        if (o < n_out) y[o] = (OUT)w[j];
+                        ++o;
+                        jn += a.dec;
                     }
                 }
             }
         }
-        xcur = xnext;
+        // hand the blocks down: lane s + 1 receives lane s's results, lane 0 its next block of the row
+#pragma unroll
+        for (int j = 0; j < B; ++j) w[j] = lane_shr1_or(nx[j], w[j]);
     }
     if (mine && a.state) {
         a.state[row * 2 * a.ns + 2 * lane] = z0;
         a.state[row * 2 * a.ns + 2 * lane + 1] = z1;
     }
+}
+
+template <typename IN, typename OUT> static void seq_launch_one(int nrow, hipStream_t s, const SeqArgs &a)
+{
+    hipLaunchKernelGGL((iir_seq_kernel<IN, OUT>), dim3((unsigned)nrow), dim3(64), 0, s, a);
 }
 
 }  // namespace
@@ -132,10 +153,10 @@ __global__ __launch_bounds__(64) void iir_seq_kernel(SeqArgs a)
 int iir_seq_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_stride, int64_t y_stride, void *y, hipStream_t s,
                    const double *zi_host, double *zf_host, int dec)
 {
-    note_path("iir_seq");
     if (n <= 0 || nrow <= 0) return SKDSP_OK;
     SK_CHECK(h->order == 2 && !h->seq_coef.empty(), SKDSP_ERR_UNSUPPORTED, "iir_seq: second-order sections only");
     SK_CHECK(dec <= 1 || nrow == 1, SKDSP_ERR_UNSUPPORTED, "iir_seq: the decimating store takes one row");
+    note_path("iir_seq");
     const int nsec = h->nsec;
     if (!h->seq_coef_dev) {
         SK_HIP(hipMalloc(&h->seq_coef_dev, h->seq_coef.size() * 8));
@@ -144,6 +165,22 @@ int iir_seq_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     const bool dbl = dtype_double(h->dtype);
     const bool with_state = zi_host || zf_host;
     const int npass = (nsec + 63) / 64;
+    // more than 64 sections: the passes meet in a float64 buffer of the handle, [rows][n] -- the signal between two passes is the reference's own float64
+    // intermediate (a float32 handle rounds once, at the last pass), and a decimating call keeps the full rate until its last pass
+    double *mid = nullptr;
+    if (npass > 1) {
+        const size_t need = (size_t)nrow * (size_t)n * 8 + 256;
+        if (need > h->group_tmp_bytes) {
+            if (h->group_tmp) {
+                SK_HIP(hipStreamSynchronize(s));
+                SK_HIP(hipFree(h->group_tmp));
+                h->group_tmp = nullptr; h->group_tmp_bytes = 0;
+            }
+            SK_HIP(hipMalloc(&h->group_tmp, need));
+            h->group_tmp_bytes = need;
+        }
+        mid = static_cast<double *>(h->group_tmp);
+    }
     std::vector<double> st;   // per pass [rows][2 ns], packed pass after pass
     double *st_dev = nullptr;
     if (with_state) {
@@ -161,24 +198,22 @@ int iir_seq_launch(IirHandle *h, const void *x, int64_t n, int nrow, int64_t x_s
     size_t at = 0;
     for (int p = 0; p < npass; ++p) {
         const int s0 = 64 * p, ns = std::min(64, nsec - s0);
-        const bool lastp = p + 1 == npass;
+        const bool first = p == 0, lastp = p + 1 == npass;
         SeqArgs a;
-        a.x = p == 0 ? x : y;   // (later passes filter the previous pass's result in place)
-        a.y = y;
+        a.x = first ? x : mid;
+        a.y = lastp ? y : mid;
         a.n = n;
-        a.x_stride = p == 0 ? x_stride : y_stride;
-        a.y_stride = y_stride;
+        a.x_stride = first ? x_stride : n;
+        a.y_stride = lastp ? y_stride : n;
         a.coef = (const double *)h->seq_coef_dev + 5 * s0;
         a.ns = ns;
         a.state = with_state ? st_dev + at : nullptr;
         a.dec = lastp && dec > 1 ? dec : 1;
-        if (npass > 1 && dec > 1 && !lastp) {
-            // (a full-rate intermediate cannot live in a y of n / dec samples)
-            if (st_dev) (void)hipFree(st_dev);
-            SK_CHECK(false, SKDSP_ERR_UNSUPPORTED, "iir_seq: a decimating call over more than 64 sections needs a full-rate buffer (not served)");
-        }
-        if (dbl) hipLaunchKernelGGL((iir_seq_kernel<double>), dim3((unsigned)nrow), dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((iir_seq_kernel<float>), dim3((unsigned)nrow), dim3(64), 0, s, a);
+        const bool in_d = dbl || !first, out_d = dbl || !lastp;   // (the buffer between passes is float64 whatever the handle)
+        if (in_d && out_d) seq_launch_one<double, double>(nrow, s, a);
+        else if (in_d) seq_launch_one<double, float>(nrow, s, a);
+        else if (out_d) seq_launch_one<float, double>(nrow, s, a);
+        else seq_launch_one<float, float>(nrow, s, a);
         at += (size_t)nrow * 2 * ns;
     }
     SK_HIP(hipGetLastError());

@@ -822,6 +822,28 @@ def test_ill_conditioned_cascade_runs_the_reference_recursion(caplog):
         k80 = _ffi.IirKernel(_ffi.F64, sos=sos80)
     assert k80.sequential
     assert np.array_equal(k80.filter(x[:5000]), signal.sosfilt(sos80, x[:5000]))
+    # ... and .dn / .up over more than 64 sections (round 5 refused the decimating call: the passes now meet in a full-rate float64 buffer of the handle),
+    # ragged lengths (the last block of 16 partial), states across two passes, float32 signals rounded ONCE (float64 between the passes),
+    # N-D rows in one launch
+    ref80 = signal.sosfilt(sos80, x[:5003])
+    assert np.array_equal(np.asarray(k80.dn(x[:5003], 3)), ref80[::3][:5003 // 3])
+    assert np.array_equal(np.asarray(k80.dn(x[:5003], 7)), ref80[::7][:5003 // 7])
+    up80 = np.zeros(4 * 1201)
+    up80[::4] = 4 * x[:1201]
+    assert np.array_equal(k80.up(x[:1201], 4), signal.sosfilt(sos80, up80))
+    zi80 = rng.standard_normal((80, 2)) * 1e-3
+    y80, zf80 = k80.filter_state(x[:3001], zi80.ravel())
+    r80, rz80 = signal.sosfilt(sos80, x[:3001], zi=zi80)
+    assert np.array_equal(y80, r80) and np.array_equal(zf80.reshape(80, 2), rz80)
+    with _ffi.option("iir_seq", 2):
+        k80f = _ffi.IirKernel(_ffi.F32, sos=sos80)
+    assert np.array_equal(k80f.filter(x32[:5003]), signal.sosfilt(sos80, x32[:5003].astype(np.float64)).astype(np.float32))
+    assert np.array_equal(np.asarray(k80f.dn(x32[:5003], 5)), signal.sosfilt(sos80, x32[:5003].astype(np.float64))[::5][:5003 // 5].astype(np.float32))
+    for n_small in (1, 15, 16, 17, 63, 64, 65):
+        assert np.array_equal(k.filter(x[:n_small]), signal.sosfilt(sos, x[:n_small])), n_small
+    rows = rng.standard_normal((5, 777))
+    mi = mrh.multirate_IIR(sos)
+    assert np.array_equal(np.asarray(mi.filter(rows)), signal.sosfilt(sos, rows))
 
 
 def test_well_conditioned_cascades_keep_the_scans():
