@@ -4,7 +4,7 @@
 #   gpurun --timeout 600 -- 'bash tools/collect_profiles.sh r03 pmc iir8 iirlp8'    (only the PMC passes of the workloads named, added to an existing collection)
 # Writes gpurun_out/profiles_<round>/ ; copy what should be judged into profiles/<round>/.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$R
 PMC_ONLY=""
@@ -18,8 +18,9 @@ cd /tmp && export TMPDIR=/tmp
 RATE="upsample4 downsample3 firup12 firdn12 firup4 firdn4 rcup12 rcdn12 iirup2 iirdn3"
 [ -n "$ONLY" ] && PMC_ONLY="$ONLY"
 [ -z "$PMC_ONLY$BENCH_ONLY" -o -n "$ONLY" ] && for w in ${ONLY:-fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE}; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python $ROOT/bench.py --workload $w --no-cpu-baseline --no-other-configs --board-seconds 0 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python $ROOT/bench.py --workload $w --no-cpu-baseline --no-other-configs --board-seconds 0 > $OUT/trace_bench_$w.json 2>/dev/null
   cp $OUT/trace_$w/*/*kernel_stats.csv $OUT/kernel_stats_$w.csv
+  cp $OUT/trace_$w/*/*kernel_trace.csv $OUT/kernel_trace_$w.csv    # per-dispatch records: tools/reduce_pmc.py takes the steady-state duration from them (scratch: not committed)
   rm -rf $OUT/trace_$w
 done
 # PMC passes, each counter group in its own run (never combined with other trace domains)
@@ -27,7 +28,8 @@ done
   sets=("FETCH_SIZE" "WRITE_SIZE")
   [ $w = fir1024 ] && sets+=("SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES")
   # the issue / wait picture of config 4, before (cascade form) and after (parallel form)
-  case $w in iir8|iir8cas|rcdn12|rcup12) sets+=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS");; esac
+  # (round 6: every row below half the roofline, not only the four of round 5)
+  case $w in iir8|iir8cas|iir8tp|iir8c64|rcdn12|rcup12|iirup2|iirdn3|firdn12|firup4|firdn4|updn43|fir1024c128) sets+=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS");; esac
   for set in "${sets[@]}"; do
     tag=$(echo $set | cut -d' ' -f1)
     rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$tag -- python $ROOT/bench.py --workload $w --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs --board-seconds 0 > /dev/null 2>&1

@@ -3,7 +3,7 @@
 # prints per-wave means (SQ_INSTS_VALU / SQ_WAVES and friends; the *_CYCLES of a wave are in quad-cycles).  What LABNOTES R5.8 is built on.
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/pmc2; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 for W in "$@"; do i=0
-for set in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SMEM"; do
+for set in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
   timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python $ROOT/bench.py --workload $W --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs --board-seconds 0 > /dev/null 2>$OUT/err_$i.txt
   cp $OUT/p$i/*/*counter_collection.csv $OUT/${W}_set$i.csv 2>/dev/null; rm -rf $OUT/p$i

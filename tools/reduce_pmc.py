@@ -56,7 +56,7 @@ for w, (pat, marker, alg) in WORK.items():
     if ONLY and w not in ONLY:
         continue
     out = {}
-    for tag in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_INSTS_MFMA"):
+    for tag in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_INSTS_MFMA"):   # (the first counter of each pass names its file)
         f = os.path.join(src, "pmc_%s_%s.csv" % (w, tag))
         if not os.path.exists(f):
             continue
@@ -79,10 +79,73 @@ for w, (pat, marker, alg) in WORK.items():
         "note": "FETCH_SIZE/WRITE_SIZE in KiB; read side doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM); "
                 "separate --pmc passes of `bench.py --workload %s`; all kernels matching %r summed per bench step" % (w, pat),
     }
+    if "SQ_WAVES" in out and out["SQ_WAVES"]["per_step"] > 0:   # the issue / wait picture per wave (the *_CYCLES counters of a wave are in quad-cycles)
+        wv = out["SQ_WAVES"]["per_step"]
+        out["per_wave"] = {k[3:].lower(): out[k]["per_step"] / wv for k in out if k.startswith("SQ_") and k != "SQ_WAVES"}
+        pw = out["per_wave"]
+        if "wave_cycles" in pw and pw["wave_cycles"] > 0:
+            out["per_wave"]["fraction_of_wave_life"] = {k: pw[k] / pw["wave_cycles"] for k in ("active_inst_any", "wait_inst_any", "wait_any", "active_inst_valu", "active_inst_lds") if k in pw}
     out["source_sha256"] = bench.source_hashes(w)     # (uncommitted edits at collection time show up as a hash no commit has)
     out["collected_at_commit"] = COMMIT
     json.dump(out, open(os.path.join(dst, "pmc_%s.json" % w), "w"), indent=1)
     print(w, "traffic/algorithmic = %.3f  (%.1f MB read + %.1f MB written per step)" % ((rd + wr) / alg, rd / 1e6, wr / 1e6))
+
+# ---- the steady-state kernel duration of every workload, from the per-dispatch records of its kernel trace ------------------------------
+# kernel_stats_<w>.csv averages over EVERY launch of the run -- the ~0.5 s of clock-settle launches included, which run on a ramping clock
+# (round 5: avg 242.3 us, min 227.3, max 348.4 over 732 calls of the headline kernel, against 233.7 un-profiled).  bench.py times its LAST
+# `steps` launches; so does this: the mean and the median of the last `steps` dispatches of the step's kernel(s), and the roofline fraction
+# that follows from them.  The traced run's own bench line (HIP events around the same launches) is kept beside it.
+def _steady(w, pat, marker, alg):
+    f = os.path.join(src, "kernel_trace_%s.csv" % w)
+    if not os.path.exists(f):
+        return None
+    rows = []
+    for r in csv.DictReader(open(f)):
+        name = r.get("Kernel_Name", "")
+        if _has(pat, name) and "fill_noise" not in name:
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
+    rows.sort()
+    if not rows:
+        return None
+    line = None
+    try:
+        line = json.loads(open(os.path.join(src, "trace_bench_%s.json" % w)).read().strip().splitlines()[-1])
+    except Exception:
+        pass
+    steps = int(line["steps"]) if line else 400
+    # a step may be several launches (the two-pass IIR): group by the marker kernel, which runs once per step
+    per_step, cur = [], 0.0
+    for st, en, name in rows:
+        cur += (en - st) * 1e-3
+        if _has(marker, name):
+            per_step.append(cur)
+            cur = 0.0
+    timed = per_step[-steps:] if len(per_step) >= steps else per_step
+    timed_sorted = sorted(timed)
+    mean = sum(timed) / len(timed)
+    med = timed_sorted[len(timed_sorted) // 2]
+    out = {"workload": w, "steps_in_trace": len(per_step), "timed_steps": len(timed),
+           "all_launches_avg_us": sum(per_step) / len(per_step), "steady_mean_us": mean, "steady_median_us": med,
+           "steady_min_us": timed_sorted[0], "steady_max_us": timed_sorted[-1],
+           "algorithmic_bytes_per_step": alg, "frac_of_8TBps_from_steady_mean": alg / (mean * 1e-6) / 8e12,
+           "what": "rocprofv3 --kernel-trace of `bench.py --workload %s`: the last %d steps (the ones bench.py times), kernel time summed per step" % (w, len(timed))}
+    if line:
+        out["same_run_bench_line"] = {"kernel_ms_hip_events": line["roofline"]["kernel_ms"], "frac": line["roofline"]["frac"], "ms_per_step": line["ms_per_step"]}
+    return out
+
+
+for w, (pat, marker, alg) in WORK.items():
+    if ONLY and w not in ONLY:
+        continue
+    st = _steady(w, pat, marker, alg)
+    if st is None:
+        continue
+    st["source_sha256"] = bench.source_hashes(w)
+    st["collected_at_commit"] = COMMIT
+    json.dump(st, open(os.path.join(dst, "kernel_steady_%s.json" % w), "w"), indent=1)
+    print(w, "steady %.1f us (median %.1f, all launches %.1f) -> %.3f of 8 TB/s%s" % (
+        st["steady_mean_us"], st["steady_median_us"], st["all_launches_avg_us"], st["frac_of_8TBps_from_steady_mean"],
+        "; same run, HIP events: %.1f us" % (1e3 * st["same_run_bench_line"]["kernel_ms_hip_events"]) if "same_run_bench_line" in st else ""))
 
 # the kernel traces of the same collection get the same stamp (which sources, which commit), next to the CSV
 for f in sorted(os.listdir(src)):
