@@ -182,6 +182,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int64_t g0 = window_g0(wdx);
         return (reinterpret_cast<uintptr_t>(x + g0 * C) & 15) == 0 && g0 >= -a.n_hist && g0 + a.win <= a.n;
     };
+    // (measured and not kept, round 6: skipping, per wave, a round of 256 units that lies wholly beyond the window -- a window of 840 units is 3.3 rounds -- made
+    // every kernel of the family 8 - 15 % SLOWER: the branches around the prefetch registers cost more than the fifth of the staging instructions they save)
     auto load_window = [&](int64_t wdx) {  // interior windows only
         const float *src = x + window_g0(wdx) * C;
 #pragma unroll
@@ -414,18 +416,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         };
         if constexpr (KSP > 1) {
-            // every wave multiplies its lags of every column tile; partial tiles [parity][wave][component, i][lane] behind the planes
+            // every wave multiplies its lags of every column tile; partial tiles [parity][wave][component, i][lane] behind the planes.
+            // Column tiles go in PAIRS (round 6): both partial tiles of a pair are written before the one barrier that lets the waves sum them -- and for the
+            // window's last pair that barrier is also the one that frees the planes, so the sums of the last pair are formed and stored while window w + 1
+            // is being split into the planes.  A window of two column tiles (the default .dn by 12 of a 512-tap filter) passes 2 barriers where it passed 4.
             float *red = reinterpret_cast<float *>(bx_smem + (size_t)(kBxPx * C) * plane_bytes);
             const int cstep = a.eo ? 2 * a.RS : a.RS;
-#pragma unroll 1
-            for (int ct = 0; ct < ntiles; ++ct) {
-                mma_tile(ct);
+            auto put_partial = [&](int ct) __attribute__((always_inline)) {
                 float *mine = red + ((size_t)((ct & 1) * 4 + wave) * (4 * C)) * 64 + lane;
 #pragma unroll
                 for (int c = 0; c < C; ++c)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) mine[(c * 4 + i) * 64] = fmaf(small[0][c][i], 1.0f / (float)(1 << kBxLift), big[0][c][i]);
-                __syncthreads();
+            };
+            auto sum_store = [&](int ct, float wi) __attribute__((always_inline)) {
                 const float *all = red + ((size_t)((ct & 1) * 4) * (4 * C)) * 64 + lane;
                 float o[C];
 #pragma unroll
@@ -436,19 +440,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 const int64_t m = (int64_t)a.RS * (S0 + col_of(ct, 4 * j)) + ncol + (int64_t)wave * cstep;
                 if (ncol < a.RS && m < a.n_out) {
-                    if (CPLX) __builtin_nontemporal_store(v2f_bx{o[0] * winv, o[C - 1] * winv}, reinterpret_cast<v2f_bx *>(y + 2 * m));
-                    else __builtin_nontemporal_store(o[0] * winv, y + m);
+                    if (CPLX) __builtin_nontemporal_store(v2f_bx{o[0] * wi, o[C - 1] * wi}, reinterpret_cast<v2f_bx *>(y + 2 * m));
+                    else __builtin_nontemporal_store(o[0] * wi, y + m);
                 }
+            };
+            int ct = 0;
+#pragma unroll 1
+            for (; ct + 2 < ntiles; ct += 2) {   // all pairs but the last
+                mma_tile(ct);
+                put_partial(ct);
+                mma_tile(ct + 1);
+                put_partial(ct + 1);
+                __syncthreads();
+                sum_store(ct, winv);
+                sum_store(ct + 1, winv);
+                __syncthreads();                 // (the partial tiles are free again)
+            }
+            const int nlast = ntiles - ct;       // 1 or 2 tiles
+            mma_tile(ct);
+            put_partial(ct);
+            if (nlast > 1) {
+                mma_tile(ct + 1);
+                put_partial(ct + 1);
             }
             if (wnext < nwin) publish_max(fast ? pre_max() : slow_max(wnext));
-            __syncthreads();  // everyone is done reading the planes
+            __syncthreads();  // everyone is done reading the planes, and the last partial tiles are complete
+            const float winv_w = winv;   // (still window w's inverse scale: fetch_scale below sets the next one's)
             if (wnext < nwin) {
                 fetch_scale();
                 if (fast) store_window();
                 else stage_window_slow(wnext);
             }
+            sum_store(ct, winv_w);
+            if (nlast > 1) sum_store(ct + 1, winv_w);
             winv = winv_next;
-            __syncthreads();  // the planes hold window w+1
+            __syncthreads();  // the planes hold window w+1 (and the partial tiles are free)
             if (__builtin_expect(wbad, 0)) careful_note(&bx_noted, (wdx - w0) / gridDim.x);
             wbad = wbad_next;
             const int64_t wnext2 = wnext + gridDim.x;
