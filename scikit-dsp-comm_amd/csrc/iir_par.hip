@@ -907,6 +907,8 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
                     ++dnl_o;
                 }
             } else if (keep) {
+                // (one chain of 2 NSEC + 1 dependent operations per output.  Measured and not kept, round 6: two chains -- even and odd sections -- and one add:
+                // config 4 0.1435 -> 0.1455 ms, .dn(x, 3) 0.136 -> 0.140; the recurrences of the same sample already fill the chain's gaps)
                 double yv = zero_in ? al[0] * z[0] : fma(al[0], z[0], gam * xd);
                 yv = fma(be[0], z[1], yv);
 #pragma unroll
