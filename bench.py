@@ -694,6 +694,8 @@ def final_line(out):
     for k in ("cpu_baseline", "cpu_baseline_scipy"):
         if k in out:
             fl[k] = _pick(out[k], ("value", "unit", "cores", "kind", "sample", "skipped", "cores_available"), clip=230) if out[k] else None
+    if "kernel_source_sha256" in out:   # (which kernel sources this line ran: what config5_n1_reference() checks a committed N = 1 line against)
+        fl["kernel_source_sha256"] = out["kernel_source_sha256"]
     if "parity_spot_check_max_err" in out:
         fl["parity_spot_check_max_err"] = _sig(out["parity_spot_check_max_err"], 3)
     if isinstance(out.get("board"), dict):
@@ -724,7 +726,7 @@ def final_line(out):
     if out.get("detail"):
         fl["detail"] = out["detail"]
     # ---- the bound, whatever was recorded: shed the least important members first
-    for drop in ("rows_what", "device_copy", "compute", "fp64_pipe", "per_rank", "detail"):
+    for drop in ("rows_what", "device_copy", "compute", "fp64_pipe", "per_rank", "detail", "kernel_source_sha256"):
         if len(json.dumps(fl)) <= FINAL_LINE_MAX_BYTES:
             break
         fl.pop(drop, None)
