@@ -42,6 +42,10 @@ struct OlsArgs {
     int64_t n, n_hist;
     const float4 *T1, *T2, *Hp;
     int ov, V, a0;  // a0 = ov / 512: first stored 512-block
+    // The first a0 and the last a0 512-sample blocks of a tile are what it shares with its neighbours (the overlap it reads from the previous tile's range, and
+    // the range the next tile will read as ITS overlap).  keep = a0: those blocks are requested with ordinary loads, so that the lines stay in the XCD's L2 for the
+    // neighbour (a nontemporal line is the first to be evicted); the blocks in between stay nontemporal.  0: every load nontemporal (round 5).
+    int keep;
     int aligned;    // x and y element-aligned (8 bytes complex64, 4 bytes float32)
     int64_t ntiles;
     int dec;        // > 1: keep every dec-th output only (multirate_FIR.dn): y[g / dec] = out[g] for g % dec == 0
@@ -112,7 +116,10 @@ __device__ __forceinline__ void load_tile(const OlsArgs &A, int64_t tile, int t,
         asm volatile("" : "+v"(tt));
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            const v4f_t nv = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(A.x + in0) + (unsigned)(a * 256 + tt));
+            const v4f_t *src = reinterpret_cast<const v4f_t *>(A.x + in0) + (unsigned)(a * 256 + tt);
+            v4f_t nv;
+            if (a < A.keep || a >= 16 - A.keep) nv = *src;   // (wave-uniform: the blocks a neighbouring tile reads too)
+            else nv = __builtin_nontemporal_load(src);
             const float4 f = make_float4(nv.x, nv.y, nv.z, nv.w);
             v[2 * a] = lo(f);
             v[2 * a + 1] = hi(f);
@@ -1069,7 +1076,7 @@ int fir_ols_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, void 
     A.n = n;
     A.n_hist = n_hist;
     A.T1 = p->T1; A.T2 = p->T2; A.Hp = p->Hp;
-    A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512;
+    A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512; A.keep = opt().ols_keep_overlap ? A.a0 : 0;
     const bool real = h->dtype == SKDSP_F32;
     // element alignment is all the vector accesses need: tile starts are odd multiples of the
     // element size anyway (V = 8192 - (Ntaps-1) is odd for even tap counts)
@@ -1168,7 +1175,7 @@ static int up_walk(FirHandle *h, int kind, const void *x, int64_t n, int64_t n_h
     A.n = n;
     A.n_hist = n_hist;
     A.T1 = p->T1; A.T2 = p->T2; A.Hp = p->Hp;
-    A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512;
+    A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512; A.keep = opt().ols_keep_overlap ? A.a0 : 0;
     const int esz = h->dtype == SKDSP_F32 ? 4 : 8;
     A.aligned = xr ? (((uintptr_t)x & 3) == 0 && ((uintptr_t)y & (L % 2 ? 3 : 7)) == 0) : ((((uintptr_t)x) | ((uintptr_t)y)) & (real ? 3 : 7)) == 0;
     int64_t ntiles = (n + p->V - 1) / p->V;
@@ -1230,7 +1237,7 @@ int fir_ols_rep_launch(FirHandle *h, const void *x, int64_t n, int64_t n_hist, i
     A.n = n * L;                  // (the rate the tiles live at)
     A.n_hist = n_hist * L;
     A.T1 = p->T1; A.T2 = p->T2; A.Hp = p->Hp;
-    A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512;
+    A.ov = p->ov; A.V = p->V; A.a0 = p->ov / 512; A.keep = opt().ols_keep_overlap ? A.a0 : 0;
     A.aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & (real ? 3 : 7)) == 0;
     int64_t ntiles = (A.n + p->V - 1) / p->V;
     if (real) ntiles = (ntiles + 1) / 2;
