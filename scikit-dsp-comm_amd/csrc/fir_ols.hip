@@ -667,7 +667,17 @@ __global__ __launch_bounds__(256, 2) void ols_tile_kernel(OlsArgs A)
         if (__builtin_expect(__any(not_finite(v[31].x) | not_finite(v[31].y)), 0)) careful_note(&ols_noted, it);
 #pragma unroll
         for (int i = 0; i < 32; ++i) v[i] = nx[i];
-        __syncthreads();  // every wave is done reading the image before the next tile overwrites it
+        // Every wave must be done reading the image before the next tile overwrites it -- unless nobody else ever touches what a thread overwrites:
+        // inv_pass1 of thread (b, q) reads lds_unit(k1, b, q), k1 = 0 .. 15, and fwd_pass1 of the same thread writes exactly those sixteen units (the
+        // inverse is the mirror image of the forward transform).  Between barrier 2 of this tile and barrier 1 of the next a thread therefore meets
+        // only its own units -- read, then overwritten, in program order -- and the third barrier of the plain complex tile is not needed (round 6).
+        // The other forms keep it: the two-real-tiles pass 1 writes another set of units, the decimating store gathers in the idle image, and the
+        // interpolating stores of complex tiles share this loop with forms that do.
+#ifdef SK_OLS_KEEP_B3   // (A/B builds)
+        __syncthreads();
+#else
+        if constexpr (REAL || DEC || UP || XR) __syncthreads();
+#endif
     }
     const unsigned long long noted = careful_noted(&ols_noted);
     if (__builtin_expect(noted != 0, 0)) {
