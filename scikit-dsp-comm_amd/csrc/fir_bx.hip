@@ -70,6 +70,7 @@ struct BxArgs {
     unsigned pad_magic;   // ceil(2^32 / s)
     float tap_inv;        // 2^-te: the taps of the table are L b 2^te (scaled into the fp16 range on the host)
     int L, M;             // of the call (the exact path of a window this kernel cannot compute: careful.hpp)
+
     CarefulFir cf;
 };
 
@@ -396,6 +397,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     v2f_bx o = {sum(big[rt][0][i], small[rt][0][i]), sum(big[rt][C - 1][i], small[rt][C - 1][i])};
                     __builtin_nontemporal_store(o, reinterpret_cast<v2f_bx *>(yb + 2 * off));
                 } else {
+                    // (float32 outputs leave as 64-byte runs, two store instructions per 128-byte line, and PMC shows 298.7 MB written for 268.4.  Ordinary stores
+                    // let the two halves meet in the L2 -- 268.4 MB, traffic 1.001 x -- and are SLOWER: 0.125 against 0.113 ms, round 6; a run-time switch between
+                    // the two forms cost another 14 %.  Nontemporal it stays.)
                     __builtin_nontemporal_store(sum(big[rt][0][i], small[rt][0][i]), yb + off);
                 }
             };
