@@ -974,12 +974,22 @@ TRAFFIC_SOURCES = {
 }
 
 
+def _code_only(text):
+    """A kernel source without its comments and white space: what the compiler sees.  The profile stamps hash THIS, so that a note added to a kernel
+    does not make the measurements of the unchanged code look stale (round 6: every comment edit cost a re-collection)."""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", "", text)
+
+
 def source_hashes(workload):
     import hashlib
     out = {}
     for f in TRAFFIC_SOURCES.get(workload, []):
         try:
-            out[f] = hashlib.sha256(open(os.path.join(ROOT, "scikit-dsp-comm_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+            txt = open(os.path.join(ROOT, "scikit-dsp-comm_amd", "csrc", f), "r", errors="replace").read()
+            out[f] = hashlib.sha256(_code_only(txt).encode()).hexdigest()[:16]
         except OSError:
             out[f] = None
     return out

@@ -232,6 +232,9 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
     // a ticket held early is a segment whose from-rest state appears a segment's time late, and its successor, drawn by another wave a moment later,
     // waits for it in the look-back.  The draw itself is 8 % of rate_change(12).up (ticket replaced by blockIdx: 0.0755 -> 0.0695 ms), which needs the
     // dispatch order the hardware happens to follow and promises nowhere.)
+    // (Round 6, measured once more for the plain filter and in the form that draws ON TIME: every wave persistent, drawing segment 16 q + class from its class's
+    // dispenser when it is free for it.  Config 4 0.143 -> 0.200 ms, .dn(x, 3) 0.135 -> 0.190: the classes drift apart, and a wave whose predecessor's class is a
+    // round behind polls for it instead of working -- the four waves of a workgroup that start four CONSECUTIVE segments together are what keeps the look-back short.)
     const int tk = __builtin_amdgcn_readfirstlane(base_sh) + wave;
     if (tk >= a.total) return;
     const int row = a.nseg == a.total ? 0 : __builtin_amdgcn_readfirstlane(tk / a.nseg), seg = tk - row * a.nseg;

@@ -474,3 +474,14 @@ def test_bench_emit_prints_exactly_one_stdout_line(tmp_path, monkeypatch, capsys
     detail = [ln for ln in cap.err.split("\n") if ln.startswith("bench.py detail: ")]
     assert len(detail) == 19 and all(json.loads(ln[len("bench.py detail: "):]) for ln in detail)
     assert not any(ln.lstrip().startswith("{") for ln in cap.err.split("\n"))            # nothing on stderr can be taken for the line
+
+
+def test_profile_stamps_hash_the_code_not_the_comments(tmp_path, monkeypatch):
+    """bench.source_hashes names the kernel sources a profile was collected with; a comment or white-space edit must not change the name, a code edit must."""
+    bench = _bench_module()
+    a = bench._code_only("int f(int x) {\n    return x + 1;   // one more\n}\n/* block\n comment */\n")
+    b = bench._code_only("int f(int x) { return x + 1; }   // reworded note\n")
+    c = bench._code_only("int f(int x) { return x + 2; }\n")
+    assert a == b and a != c
+    h = bench.source_hashes("fir1024")
+    assert set(h) == {"fir_ols.hip", "ols_core.hpp", "careful.hpp"} and all(isinstance(v, str) and len(v) == 16 for v in h.values())
