@@ -716,6 +716,9 @@ __global__ __launch_bounds__(kIirThreads, (UPJ && NSEC <= 4 && sizeof(IO) == 4) 
             }
             blocks_acc<NSEC>(psi + (size_t)(m - 1) * NSEC * 4, pm, u);
         }
+        // (Phi^j by the binary digits of j: up to six rounds of 2 x 2 products, every lane through every level some lane needs -- ~480 vector instructions per
+        // segment for the 32 multiply-adds a lane wants.  Round 6 tried the lane's own row of a [64][NSEC][4] table of Phi^j instead, requested in front of the
+        // look-back's poll: 64 more live registers next to the chunk, 180 bytes of scratch per lane in the plain 8-biquad kernel; not kept.)
 #pragma unroll 1
         for (int l = 0; l < a.n_lv; ++l) {
             if ((cj >> l) & 1) {
