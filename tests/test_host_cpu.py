@@ -485,3 +485,38 @@ def test_profile_stamps_hash_the_code_not_the_comments(tmp_path, monkeypatch):
     assert a == b and a != c
     h = bench.source_hashes("fir1024")
     assert set(h) == {"fir_ols.hip", "ols_core.hpp", "careful.hpp"} and all(isinstance(v, str) and len(v) == 16 for v in h.values())
+
+
+def test_profile_reduction_reports_the_steady_state(tmp_path):
+    """tools/reduce_pmc.py: from a per-dispatch kernel trace, the mean / median of the LAST `steps` launches (the ones bench.py times), not the average over the
+    clock-settle launches in front of them; and the HBM bytes of a step from the FETCH_SIZE / WRITE_SIZE passes (KiB; the read side doubled on gfx950)."""
+    src = tmp_path / "src"
+    dst = tmp_path / "dst"
+    src.mkdir(); dst.mkdir()
+    rows = ["Kind,Agent_Id,Queue_Id,Kernel_Id,Kernel_Name,Correlation_Id,Start_Timestamp,End_Timestamp"]
+    t = 1000
+    durs = [350000] * 50 + [300000] * 50 + [235000] * 400          # ns: a ramping clock, then 400 timed steps
+    for i, d in enumerate(durs):
+        rows.append('KERNEL_DISPATCH,1,1,7,"void skdsp::ols_tile_kernel<false, false, false, false>(skdsp::OlsArgs)",%d,%d,%d' % (i, t, t + d))
+        t += d + 2000
+    rows.append('KERNEL_DISPATCH,1,1,9,"void skdsp::fill_noise_kernel<float>(float*)",999,1,500')   # (not a step)
+    (src / "kernel_trace_fir1024.csv").write_text("\n".join(rows) + "\n")
+    (src / "trace_bench_fir1024.json").write_text(json.dumps({"steps": 400, "ms_per_step": 0.2371, "roofline": {"kernel_ms": 0.2352, "frac": 0.5706}}) + "\n")
+    (src / "kernel_stats_fir1024.csv").write_text('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n"ols_tile_kernel",500,1,1,1,1,1,1\n')
+    head = '"Correlation_Id","Dispatch_Id","Agent_Id","Kernel_Name","Counter_Name","Counter_Value"\n'
+    name = '"void skdsp::ols_tile_kernel<false, false, false, false>(skdsp::OlsArgs)"'
+    (src / "pmc_fir1024_FETCH_SIZE.csv").write_text(head + "".join('%d,%d,1,%s,"FETCH_SIZE",%f\n' % (i, i, name, 264550.0) for i in range(20)))
+    (src / "pmc_fir1024_WRITE_SIZE.csv").write_text(head + "".join('%d,%d,1,%s,"WRITE_SIZE",%f\n' % (i, i, name, 524288.0) for i in range(20)))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "reduce_pmc.py"), str(src), str(dst), "fir1024"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert out.returncode == 0, out.stdout.decode()
+    st = json.load(open(dst / "kernel_steady_fir1024.json"))
+    assert st["timed_steps"] == 400 and st["steps_in_trace"] == 500
+    assert abs(st["steady_mean_us"] - 235.0) < 1e-6 and abs(st["steady_median_us"] - 235.0) < 1e-6
+    assert abs(st["all_launches_avg_us"] - (50 * 350 + 50 * 300 + 400 * 235) / 500.0) < 1e-6          # (what `--stats` would have averaged)
+    assert abs(st["frac_of_8TBps_from_steady_mean"] - 16 * 2 ** 26 / 235e-6 / 8e12) < 1e-9
+    assert st["same_run_bench_line"]["kernel_ms_hip_events"] == 0.2352
+    pm = json.load(open(dst / "pmc_fir1024.json"))
+    d = pm["derived"]
+    assert abs(d["hbm_read_bytes_per_step"] - 264550.0 * 1024 * 2) < 1 and abs(d["hbm_write_bytes_per_step"] - 524288.0 * 1024) < 1
+    assert abs(d["traffic_over_algorithmic"] - (264550.0 * 2048 + 524288.0 * 1024) / (16 * 2 ** 26)) < 1e-9
+    assert set(pm["source_sha256"]) == {"fir_ols.hip", "ols_core.hpp", "careful.hpp"}
