@@ -114,6 +114,23 @@ __device__ __forceinline__ void bx_split2(float a, float b, unsigned (&p)[kBxPx]
     p[1] = cvt(res_lo(a, p[0]), res_hi(b, p[0]));
 }
 
+// The same pieces from the UNSCALED samples (xa, xb) and the window's scale s = 2^k (round 6): the residual (x s - piece) 2^11 = (x s) 2^11 - 2048 piece is an ldexp and ONE
+// mixed-precision multiply-add that reads the fp16 piece where it lies (v_fma_mix_f32; exact -- the difference of a float32 and its own nearest fp16 has 14 significant bits,
+// and the powers of two only move exponents), where the form above spends a conversion, a subtraction and an ldexp: 8 instructions per pair of samples for 10.
+__device__ __forceinline__ void bx_split2s(float xa, float xb, float s, float neg2048, unsigned (&p)[kBxPx])
+{
+    float sa, sb, ta, tb, ra, rb;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(sa) : "v"(xa), "v"(s));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(sb) : "v"(xb), "v"(s));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p[0]) : "v"(sa), "v"(sb));
+    asm("v_ldexp_f32 %0, %1, 11" : "=v"(ta) : "v"(sa));
+    asm("v_ldexp_f32 %0, %1, 11" : "=v"(tb) : "v"(sb));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(p[0]), "v"(neg2048), "v"(ta));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(p[0]), "v"(neg2048), "v"(tb));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p[1]) : "v"(ra), "v"(rb));
+    static_assert(kBxLift == 11 && kBxPx == 2, "the constants above carry the lift");
+}
+
 // max (MAX) / min of an unsigned value over the wave, valid in lane 63: four DPP steps inside the rows of 16 lanes (quad permutes, half-row and
 // row mirrors), then row_bcast15 into rows 1 and 3 and row_bcast31 into rows 2 and 3
 template <bool MAX> __device__ __forceinline__ unsigned bx_wave_reduce(unsigned v)
@@ -200,6 +217,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // maxima of |x| as integer bit patterns (written in front of the barrier that frees the planes, read behind it).
     unsigned *wmax_sh = reinterpret_cast<unsigned *>(bx_smem + (size_t)(kBxPx * C) * plane_bytes + (KSP > 1 ? (size_t)2 * 4 * (4 * C) * 64 * 4 : 0));
     float wscale = 1.f, winv_next = 1.f;
+    float neg2048 = -2048.f;
+    asm volatile("" : "+v"(neg2048));   // (a register operand: VOP3P takes no literal on this chip)
     bool wbad_next = false;   // the window being staged is one for the exact path (bx_careful_window)
     // Two statistics of the window: its largest magnitude (the scale) and the smallest of the lanes' largest (non-zero) magnitudes -- a window
     // whose samples span more than the fp16 pieces hold goes to the exact path.  Both reductions run on DPP row operations (no LDS round
@@ -220,16 +239,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         winv_next = __uint_as_float((unsigned)(e - 141 + 127) << 23) * a.tap_inv;
     };
     auto pre_max = [&]() -> unsigned {   // over the prefetched window
-        unsigned m = 0;
+        if constexpr (CPLX) {
+            // (complex windows keep the bit patterns -- an AND and an integer maximum per scalar: same box, alternating, the float form below made the default .dn by
+            // 12 2 % slower, 0.1265 -> 0.1291 ms, while it made the 127-tap float32 filter 1.5 % faster, 0.1124 -> 0.1107)
+            unsigned m = 0;
+#pragma unroll
+            for (int h = 0; h < UPT; ++h)
+#pragma unroll
+                for (int w = 0; w < F4; ++w) {
+                    m = max(m, __float_as_uint(pre[h][w].x) & 0x7fffffffu);
+                    m = max(m, __float_as_uint(pre[h][w].y) & 0x7fffffffu);
+                    m = max(m, __float_as_uint(pre[h][w].z) & 0x7fffffffu);
+                    m = max(m, __float_as_uint(pre[h][w].w) & 0x7fffffffu);
+                }
+            return m;
+        }
+        // float32 windows (round 6): |a|, |b| through the source modifiers of ONE v_max3_f32 per pair of samples.  A float maximum drops NaNs, and the window statistic is
+        // what notices them: one unordered compare per pair collects them in a scalar mask.
+        float mf = 0.f;
+        unsigned long long nan_any = 0;
 #pragma unroll
         for (int h = 0; h < UPT; ++h)
 #pragma unroll
             for (int w = 0; w < F4; ++w) {
-                m = max(m, __float_as_uint(pre[h][w].x) & 0x7fffffffu);
-                m = max(m, __float_as_uint(pre[h][w].y) & 0x7fffffffu);
-                m = max(m, __float_as_uint(pre[h][w].z) & 0x7fffffffu);
-                m = max(m, __float_as_uint(pre[h][w].w) & 0x7fffffffu);
+                unsigned long long u0, u1;
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(mf) : "v"(pre[h][w].x), "v"(pre[h][w].y));
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(mf) : "v"(pre[h][w].z), "v"(pre[h][w].w));
+                asm("v_cmp_u_f32_e64 %0, %1, %2" : "=s"(u0) : "v"(pre[h][w].x), "v"(pre[h][w].y));
+                asm("v_cmp_u_f32_e64 %0, %1, %2" : "=s"(u1) : "v"(pre[h][w].z), "v"(pre[h][w].w));
+                nan_any |= u0 | u1;
             }
+        unsigned m = __float_as_uint(mf);
+        if ((nan_any >> lane) & 1ull) m = 0x7fc00000u;   // (this lane met a NaN: a magnitude with the exponent the scale test looks for)
         return m;
     };
     // 8 samples v[0 .. 8 C) -> one 16-byte row per fp16 piece and component at unit u
@@ -238,7 +279,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int c = 0; c < C; ++c) {
             unsigned pc[4][kBxPx];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) bx_split2(v[(2 * w) * C + c] * wscale, v[(2 * w + 1) * C + c] * wscale, pc[w]);
+            for (int w = 0; w < 4; ++w) bx_split2s(v[(2 * w) * C + c], v[(2 * w + 1) * C + c], wscale, neg2048, pc[w]);
             char *base = bx_smem + (size_t)(kBxPx * c) * plane_bytes + (size_t)padded(u) * 16;
 #pragma unroll
             for (int i = 0; i < kBxPx; ++i) *reinterpret_cast<uint4 *>(base + (size_t)i * plane_bytes) = make_uint4(pc[0][i], pc[1][i], pc[2][i], pc[3][i]);
