@@ -523,7 +523,11 @@ __global__ __launch_bounds__(256, 2) void ols64_tile_kernel(Ols64Args A)
                 for (int b = 0; b < 16; ++b) v[b] = nx[b];
             }
         }
-        __syncthreads();  // the image is free for the next tile
+        // The image must be free for the next tile -- but in the plain complex tile the last inverse pass of thread (hi4, lo4) reads img[k1][hi4][lo4], k1 = 0 .. 15, and
+        // pass 1 of the same thread overwrites exactly those sixteen elements: between the barrier in front of that read and the one behind pass 1 a thread meets only
+        // its own elements, in program order (round 6; fir_ols.hip's tile dropped the same barrier).  The decimating store gathers in the image and keeps it, and so
+        // do the forms that share this loop with it.
+        if constexpr (REAL || DEC || UP || XR) __syncthreads();
     }
     const unsigned long long noted = careful_noted(&ols_noted);
     if (__builtin_expect(noted != 0, 0)) {
