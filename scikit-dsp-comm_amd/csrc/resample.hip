@@ -65,33 +65,70 @@ __global__ __launch_bounds__(256) void downsample_kernel(const T *__restrict__ x
 // lines per wave instruction), the kept elements are picked out of the LDS, and the outputs leave as consecutive elements -- the strided
 // gather above issues one 4 ... 16-byte request per kept element (downsample(x, 3), 2^26 complex64: 0.141 ms, 5.1 TB/s of touched bytes;
 // four of them in flight per lane changed nothing).  x 16-byte aligned; OUT outputs per block, OUT * M * sizeof(T) bytes of LDS.
-template <typename T>
+template <typename T, bool AHEAD>
 __global__ __launch_bounds__(256) void downsample_tile_kernel(const T *__restrict__ x, int64_t n_in, int64_t n_out, int M, int p, int OUT, T *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) char ds_smem[];
     typedef float v4f __attribute__((ext_vector_type(4)));
     constexpr int PER = 16 / (int)sizeof(T);                      // elements per 16-byte unit
+    constexpr int NU = 8;                                         // units per thread and block (the host keeps a block's span within 8 x 256 units)
     const int64_t nblk = (n_out + OUT - 1) / OUT;
-    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t u_lim = (n_in + PER - 1) / PER;                  // (the array's last unit may be partial: the caller's buffer ends there)
+    // the units of block `blk` this thread brings in.  AHEAD (round 6; elements of up to 8 bytes): requested a whole block ahead -- the loads of block
+    // i + 1 are in flight while block i passes through the LDS and leaves; one block at a time, a workgroup had nothing in flight between its two
+    // barriers.  Same box, 2^26 samples, old -> ahead: complex64 by 3 0.1255 -> 0.1142 ms, by 2 0.1295 -> 0.1241, by 8 0.1115 -> 0.1024, float32 by 3
+    // 0.0685 -> 0.0578; complex128 by 3 0.2395 -> 0.27 (16-byte elements keep the one-block form).  Nontemporal stores of the outputs: 5 - 9 % slower.
+    auto request = [&](int64_t blk, v4f *r) {
         const int64_t o0 = blk * OUT;
         const int cnt = (int)(n_out - o0 < OUT ? n_out - o0 : OUT);
         const int64_t e0 = o0 * M + p, e_end = (o0 + cnt - 1) * M + p + 1;   // elements [e0, e_end) hold this block's kept ones
         const int64_t u0 = e0 / PER;
         const int nu = (int)((e_end + PER - 1) / PER - u0);
-        const int64_t u_lim = (n_in + PER - 1) / PER;              // (the array's last unit may be partial: the caller's buffer ends there)
         const v4f *src = reinterpret_cast<const v4f *>(x) + u0;
-        v4f *img = reinterpret_cast<v4f *>(ds_smem);
-        for (int u = threadIdx.x; u < nu; u += 256) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const int u = (int)threadIdx.x + 256 * j;
             v4f v = {0.f, 0.f, 0.f, 0.f};
-            if ((u0 + u + 1) * PER <= n_in) v = __builtin_nontemporal_load(src + u);
-            else if (u0 + u < u_lim) {                             // the ragged last unit: element by element
-                T *e = reinterpret_cast<T *>(&v);
-                for (int i = 0; i < PER; ++i)
-                    if ((u0 + u) * PER + i < n_in) e[i] = x[(u0 + u) * PER + i];
+            if (u < nu) {
+                if ((u0 + u + 1) * PER <= n_in) v = __builtin_nontemporal_load(src + u);
+                else if (u0 + u < u_lim) {                         // the ragged last unit: element by element
+                    T *e = reinterpret_cast<T *>(&v);
+                    for (int i = 0; i < PER; ++i)
+                        if ((u0 + u) * PER + i < n_in) e[i] = x[(u0 + u) * PER + i];
+                }
             }
-            img[u] = v;
+            r[j] = v;
+        }
+    };
+    v4f r[NU];
+    int64_t blk = blockIdx.x;
+    if (AHEAD && blk < nblk) request(blk, r);
+    v4f *img = reinterpret_cast<v4f *>(ds_smem);
+    for (; blk < nblk; blk += gridDim.x) {
+        const int64_t o0 = blk * OUT;
+        const int cnt = (int)(n_out - o0 < OUT ? n_out - o0 : OUT);
+        const int64_t e0 = o0 * M + p;
+        const int64_t u0 = e0 / PER;
+        if constexpr (AHEAD) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) img[(int)threadIdx.x + 256 * j] = r[j];
+        } else {   // (16-byte elements: unit by unit, as they arrive)
+            const int64_t e_end = (o0 + cnt - 1) * M + p + 1;
+            const int nu = (int)((e_end + PER - 1) / PER - u0);
+            const v4f *src = reinterpret_cast<const v4f *>(x) + u0;
+            for (int u = threadIdx.x; u < nu; u += 256) {
+                v4f v = {0.f, 0.f, 0.f, 0.f};
+                if ((u0 + u + 1) * PER <= n_in) v = __builtin_nontemporal_load(src + u);
+                else if (u0 + u < u_lim) {
+                    T *e = reinterpret_cast<T *>(&v);
+                    for (int i = 0; i < PER; ++i)
+                        if ((u0 + u) * PER + i < n_in) e[i] = x[(u0 + u) * PER + i];
+                }
+                img[u] = v;
+            }
         }
         __syncthreads();
+        if (AHEAD && blk + gridDim.x < nblk) request(blk + gridDim.x, r);
         const T *el = reinterpret_cast<const T *>(ds_smem) + (e0 - u0 * PER);
         for (int k = threadIdx.x; k < cnt; k += 256) y[o0 + k] = el[(size_t)k * M];
         __syncthreads();
@@ -256,13 +293,19 @@ int downsample_launch(const void *x, int64_t n, int M, int p, int dtype, void *y
     // every line of x holds kept elements and x is 16-byte aligned: through the LDS (see downsample_tile_kernel)
     const size_t esz = dtype_size(dtype);
     if ((size_t)M * esz <= 64 && M > 1 && (uintptr_t)x % 16 == 0 && n_out >= 4096) {
-        int OUT = (int)(32 * 1024 / ((size_t)M * esz));
-        OUT = OUT / 256 * 256;
-        const size_t lds = (size_t)OUT * M * esz + 32;
+        // (a block's span, whatever its alignment, stays within 2048 16-byte units: 8 per thread.  Measured around this point, 2^26 complex64 by 3: 32 KiB blocks
+        // x 4 workgroups per CU 0.1205 ms; x 5 0.1215; 16 KiB x 8 0.1224, x 6 0.1250, x 10 0.1277; 8 KiB x 8 0.1293, x 16 0.1218)
+        int OUT = (int)((32 * 1024 - 32) / ((size_t)M * esz));
+        OUT = OUT / 64 * 64;   // (whole waves in the store loop)
+        size_t lds = 2048 * 16;
+        if (esz == 16) {       // (16-byte elements, the one-block form: blocks of whole workgroup sweeps and only their own bytes of LDS measured 3 - 5 % ahead)
+            OUT = (int)(32 * 1024 / ((size_t)M * esz)) / 256 * 256;
+            lds = (size_t)OUT * M * esz + 32;
+        }
         const int64_t nblk = (n_out + OUT - 1) / OUT;
         const unsigned gt = (unsigned)std::min<int64_t>(nblk, (int64_t)ctx().num_cus * 4);
         const int64_t n_in = n;
-#define SK_DST(T) hipLaunchKernelGGL((downsample_tile_kernel<T>), dim3(gt), dim3(256), lds, s, (const T *)x, n_in, n_out, M, p, OUT, (T *)y)
+#define SK_DST(T) hipLaunchKernelGGL((downsample_tile_kernel<T, (sizeof(T) < 16)>), dim3(gt), dim3(256), lds, s, (const T *)x, n_in, n_out, M, p, OUT, (T *)y)
         switch (dtype) {
         case SKDSP_F32: SK_DST(float); break;
         case SKDSP_C64: SK_DST(float2); break;
