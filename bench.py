@@ -757,7 +757,21 @@ def emit(out):
         out["detail"] = os.path.relpath(path, ROOT)
     except OSError:
         pass
-    print(json.dumps(final_line(out)), flush=True)
+    print(json.dumps(final_line(out)), file=_RESULT_STREAM or sys.stdout, flush=True)
+
+
+# The driver keeps rank 0's stdout, and what it wants there is ONE line.  Libraries write there too: librccl announces itself ("Librccl path : ...") through C
+# stdio, which on a pipe is flushed when the process EXITS -- behind the result line, from every rank of an N > 1 run (found by tests/test_gpu_bench_flow.py; a 1-GPU
+# run never loads RCCL).  So every rank hands descriptor 1 to stderr before anything is loaded, and rank 0 writes its one line to the saved descriptor.
+_RESULT_STREAM = None
+
+
+def claim_stdout():
+    global _RESULT_STREAM
+    if _RESULT_STREAM is None:
+        sys.stdout.flush()
+        _RESULT_STREAM = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
 
 
 # ------------------------------------------------------------------------------ main
@@ -783,6 +797,7 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
+    claim_stdout()
 
     from sk_dsp_comm_amd import _ffi, sharding
 
