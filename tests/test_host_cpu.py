@@ -476,6 +476,29 @@ def test_bench_emit_prints_exactly_one_stdout_line(tmp_path, monkeypatch, capsys
     assert not any(ln.lstrip().startswith("{") for ln in cap.err.split("\n"))            # nothing on stderr can be taken for the line
 
 
+def test_bench_descriptor_1_carries_the_line_and_nothing_else(tmp_path):
+    """A library that writes to descriptor 1 through C stdio (librccl announces its path there) is flushed when the process exits -- BEHIND the result line.
+    bench.claim_stdout() hands descriptor 1 to stderr before anything is loaded; emit() writes to the saved descriptor."""
+    code = (
+        "import sys, os, json, ctypes\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "bench.ROOT = %r\n"
+        "bench.claim_stdout()\n"
+        "libc = ctypes.CDLL(None)\n"
+        "libc.printf(b'a library announcing itself through C stdio\\n')\n"       # (stays in the C buffer until exit on a pipe)
+        "print('a python print behind the claim')\n"
+        "rec = json.loads(open(os.path.join(%r, 'profiles', 'r05', 'bench_fir1024.json')).read().strip().splitlines()[-1])\n"
+        "bench.emit(rec)\n"
+        "os.write(1, b'a raw write to descriptor 1 behind the line\\n')\n" % (ROOT, str(tmp_path), ROOT))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().split("\n") if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["roofline"]["frac"] > 0.5, lines
+    err = r.stderr.decode()
+    assert "announcing itself" in err and "python print behind the claim" in err and "raw write to descriptor 1" in err
+
+
 def test_profile_stamps_hash_the_code_not_the_comments(tmp_path, monkeypatch):
     """bench.source_hashes names the kernel sources a profile was collected with; a comment or white-space edit must not change the name, a code edit must."""
     bench = _bench_module()

@@ -9,22 +9,24 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$R
 PMC_ONLY=""
 BENCH_ONLY=""
+TABLES_ONLY=""
 ONLY=""
 if [ "${2:-}" = pmc ]; then shift 2; PMC_ONLY="$*"; mkdir -p $OUT;
 elif [ "${2:-}" = only ]; then shift 2; ONLY="$*"; mkdir -p $OUT;   # kernel trace + PMC passes + bench line of the workloads named (a kernel changed after the collection)
+elif [ "${2:-}" = tables ]; then TABLES_ONLY=1; mkdir -p $OUT;   # only the engine timing tables (they carry no source stamp: taken again with the final library)
 elif [ "${2:-}" = bench ]; then BENCH_ONLY=1; mkdir -p $OUT;   # only the un-profiled bench lines (taken again once the reduced counters of this collection are in the tree, so that each quotes its traffic)
 else rm -rf $OUT && mkdir -p $OUT; fi
 cd /tmp && export TMPDIR=/tmp
 RATE="upsample4 downsample3 firup12 firdn12 firup4 firdn4 rcup12 rcdn12 iirup2 iirdn3"
 [ -n "$ONLY" ] && PMC_ONLY="$ONLY"
-[ -z "$PMC_ONLY$BENCH_ONLY" -o -n "$ONLY" ] && for w in ${ONLY:-fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE}; do
+[ -z "$PMC_ONLY$BENCH_ONLY$TABLES_ONLY" -o -n "$ONLY" ] && for w in ${ONLY:-fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python $ROOT/bench.py --workload $w --no-cpu-baseline --no-other-configs --board-seconds 0 > $OUT/trace_bench_$w.json 2>/dev/null
   cp $OUT/trace_$w/*/*kernel_stats.csv $OUT/kernel_stats_$w.csv
   cp $OUT/trace_$w/*/*kernel_trace.csv $OUT/kernel_trace_$w.csv    # per-dispatch records: tools/reduce_pmc.py takes the steady-state duration from them (scratch: not committed)
   rm -rf $OUT/trace_$w
 done
 # PMC passes, each counter group in its own run (never combined with other trace domains)
-[ -z "$BENCH_ONLY" ] && for w in ${PMC_ONLY:-fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE}; do
+[ -z "$BENCH_ONLY$TABLES_ONLY" ] && for w in ${PMC_ONLY:-fir1024 updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE}; do
   sets=("FETCH_SIZE" "WRITE_SIZE")
   [ $w = fir1024 ] && sets+=("SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES")
   # the issue / wait picture of config 4, before (cascade form) and after (parallel form)
@@ -46,12 +48,14 @@ if [ -n "$ONLY" ]; then
   ls -la $OUT | tail -5; exit 0
 fi
 [ -n "$PMC_ONLY" ] && { ls -la $OUT | tail -5; exit 0; }
+if [ -z "$TABLES_ONLY" ]; then
 python bench.py > $OUT/bench_fir1024.json 2>$OUT/bench_fir1024.err
 for w in updn43 iir8 fir127 iir8tp iir8cas iirlp8 iir8c64 fir1024c128 $RATE; do
   python bench.py --workload $w --no-other-configs --no-cpu-baseline > $OUT/bench_$w.json 2>/dev/null
 done
 python bench.py --scaling strong --total-log2n 30 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_fir1024_2p30_one_gpu.json 2>/dev/null
 [ -n "$BENCH_ONLY" ] && { ls -la $OUT | tail -3; exit 0; }
+fi
 python tools/power_probe.py idle copy fir1024 fir1024f32 fir1024f64 fir1024c128 updn43 fir127 iir8 iir8cas iir8c64 iirlp8 > $OUT/power_probe.txt 2>&1
 python tools/ab_iir_par.py 26 > $OUT/ab_iir_par.txt 2>&1
 python tools/time_fir_shapes.py > $OUT/fir_shapes.txt 2>&1
