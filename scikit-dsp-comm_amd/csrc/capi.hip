@@ -365,7 +365,8 @@ static int fir_dn_any(FirHandle *h, const void *x_dev, int64_t n, int64_t n_hist
         const bool f32 = h->dtype == SKDSP_F32;
         if (kb < 0) ols = true;                                                  // (forced by the caller)
         else if (kb == 0) ols = u >= (f32 ? 64 : 24);
-        else if (fold) ols = u >= (f32 ? (M == 2 ? 192 : 128) : (M == 4 ? 0 : (M == 2 ? 96 : (M % 4 == 0 ? 64 : 128))));
+        // (end of round 6, with the matrix-pipe kernel's paired column tiles: complex64 M = 16, u = 64 0.146 against 0.162 ms; float32 M = 8, u = 128 0.093 / 0.098)
+        else if (fold) ols = u >= (f32 ? (M == 2 ? 192 : (M == 4 ? 128 : 160)) : (M == 4 ? 0 : (M == 2 ? 96 : (M % 16 == 0 ? 96 : (M % 4 == 0 ? 64 : 128)))));
         else ols = M <= 4 && kb > 12;                                            // (M = 3: complex64 512 taps 0.256 ms against 0.215, float32 0.132 / 0.100)
     }
     // M = 3: the frequency-domain decimator (fir_dn4k.hip: M forward transforms accumulated, ONE inverse per tile of kept outputs) wherever the
