@@ -109,7 +109,7 @@ const OptEntry kOptTable[] = {
     {"device", &Options::device}, {"fir_algo", &Options::fir_algo}, {"dn_no_ols", &Options::dn_no_ols},
     {"fir_mm", &Options::fir_mm}, {"fir_bx", &Options::fir_bx}, 
     
-    {"ols_reserve", &Options::ols_reserve}, {"ols_keep_overlap", &Options::ols_keep_overlap}, {"fir_dn_fold", &Options::fir_dn_fold}, {"fir_up_rep", &Options::fir_up_rep}, {"iir_seq", &Options::iir_seq}, {"iir_up_jump", &Options::iir_up_jump}, {"iir_dn_t96", &Options::iir_dn_t96}, {"iir_up_lean", &Options::iir_up_lean}, {"iir_planar", &Options::iir_planar}, 
+    {"ols_reserve", &Options::ols_reserve}, {"fir_bx_t16", &Options::fir_bx_t16}, {"ols_keep_overlap", &Options::ols_keep_overlap}, {"fir_dn_fold", &Options::fir_dn_fold}, {"fir_up_rep", &Options::fir_up_rep}, {"iir_seq", &Options::iir_seq}, {"iir_up_jump", &Options::iir_up_jump}, {"iir_dn_t96", &Options::iir_dn_t96}, {"iir_up_lean", &Options::iir_up_lean}, {"iir_planar", &Options::iir_planar}, 
     {"iir_dn_full", &Options::iir_dn_full}, {"iir_no_mfma", &Options::iir_no_mfma}, 
     {"iir_two_pass", &Options::iir_two_pass}, {"iir_par", &Options::iir_par}, {"iir_par_v32", &Options::iir_par_v32}, {"iir_up_fused", &Options::iir_up_fused}, {"fir_up_ols_min", &Options::fir_up_ols_min}, {"fir_updn_fused", &Options::fir_updn_fused}, {"fir_up4k", &Options::fir_up4k}, {"fir_up4k_group", &Options::fir_up4k_group}, {"fir_up4k_staged", &Options::fir_up4k_staged}, {"fir_up2k", &Options::fir_up2k}, {"fir_dn4k", &Options::fir_dn4k}, {"fir_up_pair", &Options::fir_up_pair}, {"fir_up_rows_min", &Options::fir_up_rows_min}, {"iir_dn_compact", &Options::iir_dn_compact}, 
     {"shard_two_launches", &Options::shard_two_launches}, {"shard_probe", &Options::shard_probe}, {"shard_halo_state", &Options::shard_halo_state},

@@ -170,7 +170,10 @@ __device__ __forceinline__ v4f_bx bx_mfma(uint4 a, uint4 b, v4f_bx c)
 // three of the four waves to do.  The waves then split the LAGS: wave w takes the blocks [KB w, KB w + KB) of every column tile (KB is
 // the per-wave count; the table holds 4 KB blocks, the last ones zero-padded), the four partial tiles meet in the LDS, and wave w
 // stores column 4 j + w of every lane's four.
-template <bool CPLX, int KB, int RT, int RSP, int KSP>
+// T16 (float32, one row tile of 16 rows with RS = 16: the plain filter): a tile IS 256 consecutive outputs, and the four columns of a lane are 16-output runs
+// 64 outputs apart -- a store instruction wrote four 64-byte runs in four different lines (PMC: 298.7 MB written for 268.4).  A 4 x 4 transpose between a lane's four
+// registers and the four 16-lane groups (two v_permlane32_swap, two v_permlane16_swap) hands every store instruction 256 consecutive bytes.
+template <bool CPLX, int KB, int RT, int RSP, int KSP, bool T16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_bx_kernel(const float *__restrict__ x, const uint4 *__restrict__ At, BxArgs a,
                                                      float *__restrict__ y)
 {
@@ -446,10 +449,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             };
             // whole tile inside the output and all 16 RT rows in use (uniform): no per-store guards
             if ((a.RS & 15) == 0 && (int64_t)a.RS * (S0 + (a.eo ? 32 * (ct >> 1) + 32 : ct * 16 + 16)) <= a.n_out) {
+                if constexpr (T16) {
+                    float o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = sum(big[0][0][i], small[0][0][i]);
+                    auto swap32 = [](float &e0, float &e1) {   // (register, lane half) transposed
+                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(e0), __float_as_uint(e1), false, false);
+                        e0 = __uint_as_float(r[0]);
+                        e1 = __uint_as_float(r[1]);
+                    };
+                    auto swap16 = [](float &e0, float &e1) {   // (register, odd / even row of 16 lanes) transposed
+                        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(e0), __float_as_uint(e1), false, false);
+                        e0 = __uint_as_float(r[0]);
+                        e1 = __uint_as_float(r[1]);
+                    };
+                    swap32(o[0], o[2]);
+                    swap32(o[1], o[3]);
+                    swap16(o[0], o[1]);
+                    swap16(o[2], o[3]);
+                    float *yt = y + 16 * (S0 + 16 * ct) + lane;   // register k of lane l: output 64 k + l of the tile
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(o[k], yt + 64 * k);
+                } else {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) put(rt, i, i * cstep + 16 * rt);
+                }
             } else {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
@@ -737,12 +763,12 @@ static int get_bx_table(FirHandle *h, int L, int M, const FirHandle::BxTab **out
     return SKDSP_OK;
 }
 
-template <bool CPLX, int KB, int RT, int RSP, int KSP = 1>
+template <bool CPLX, int KB, int RT, int RSP, int KSP = 1, bool T16 = false>
 static void bx_launch_one(unsigned grid, size_t lds, hipStream_t s, const void *x, const void *At, const BxArgs &a, void *y)
 {
     if (lds > (size_t)64 * 1024)
-        (void)hipFuncSetAttribute((const void *)fir_bx_kernel<CPLX, KB, RT, RSP, KSP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((fir_bx_kernel<CPLX, KB, RT, RSP, KSP>), dim3(grid), dim3(256), lds, s, (const float *)x, (const uint4 *)At, a, (float *)y);
+        (void)hipFuncSetAttribute((const void *)fir_bx_kernel<CPLX, KB, RT, RSP, KSP, T16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((fir_bx_kernel<CPLX, KB, RT, RSP, KSP, T16>), dim3(grid), dim3(256), lds, s, (const float *)x, (const uint4 *)At, a, (float *)y);
 }
 
 // (KB: 32-lag blocks per wave, RT: row tiles per wave)
@@ -750,6 +776,13 @@ template <bool CPLX, int KB, int RT, int RSP, int KSP>
 static bool bx_launch_if(unsigned grid, size_t lds, hipStream_t s, const void *x, const void *At, const BxArgs &a, void *y)
 {
     if constexpr (bx_fits(CPLX, KB, RT)) {
+        // (float32, one row tile, RS = 16 -- the plain filter up to ~240 taps: the tile is a run of 256 outputs, stored as such; see T16 at the kernel)
+        if constexpr (!CPLX && RT == 1 && RSP == 1 && KSP == 1 && KB <= 8) {
+            if (a.RS == 16 && !a.eo && opt().fir_bx_t16) {
+                bx_launch_one<CPLX, KB, RT, RSP, KSP, true>(grid, lds, s, x, At, a, y);
+                return true;
+            }
+        }
         bx_launch_one<CPLX, KB, RT, RSP, KSP>(grid, lds, s, x, At, a, y);
         return true;
     } else {

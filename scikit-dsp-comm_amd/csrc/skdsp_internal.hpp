@@ -42,6 +42,7 @@ struct Options {
     int dn_no_ols = 0;        // .dn never through the overlap-save decimating store
     int fir_mm = 1;           // 0: no matrix-pipe FIR kernels at all (register sliding-window kernels instead)
     int fir_bx = 1;           // 0: no bf16x3 matrix-pipe kernel (FP32 matrix pipe instead)
+    int fir_bx_t16 = 1;       // the float32 plain filter on the matrix pipe stores its 256-output tiles as runs (a 4 x 4 transpose between registers and lane groups); 0: four 64-byte runs per store (A/B switch)
     int ols_keep_overlap = 1; // overlap-save tiles: the blocks a tile shares with its neighbours are loaded with ordinary (L2-resident) loads, the rest nontemporal; 0: all nontemporal (A/B switch)
     int ols_reserve = 8;      // workgroup slots a persistent overlap-save launch leaves free
     int iir_planar = 0;       // complex IIR through two real planes (tests compare it with the interleaved kernels)
