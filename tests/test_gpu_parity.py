@@ -80,6 +80,69 @@ def test_resample_large_and_other_dtypes():
     assert np.array_equal(ss.downsample(ss.upsample(xf, 6), 6), xf.astype(np.float64))
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.complex64, np.float64, np.complex128])
+def test_downsample_device_blocks_phases_alignment(dt):
+    """sigsys.downsample on the device (sigsys.py:3078-3083: x[p::M] cut to floor(n / M) outputs), the kernel that keeps its next block in flight (resample.hip,
+    round 6): every stride whose elements share a 64-byte line and a few beyond (the strided gather), every phase, lengths that end inside a block, inside a
+    16-byte unit and on a block boundary, 16-byte aligned and element-aligned inputs (the latter take the gather), and nothing written behind the last output."""
+    import ctypes
+    L = _ffi.load()
+    rng = np.random.default_rng(11)
+    esz = np.dtype(dt).itemsize
+    nmax = 200_003
+    x = cnoise(rng, nmax + 8, dt) if np.dtype(dt).kind == "c" else rng.standard_normal(nmax + 8).astype(dt)
+    xd = _ffi.DeviceArray.from_host(x)
+    yd = _ffi.DeviceArray(nmax // 2 + 64, dt)
+    for M in (2, 3, 4, 5, 7, 8, 12, 16, 17):
+        for n in (nmax, 65536 * M, 65536 * M + 1, 4096 * M + 5, 70_001):
+            if n > nmax:
+                continue
+            for p in sorted({0, 1, M // 2, M - 1}):
+                for off in (0, 1):            # (1: the input pointer is element-aligned only)
+                    n_out = n // M
+                    _ffi.check(L.skdsp_memset(ctypes.c_void_p(yd.ptr), 0x5a, yd.n * esz))
+                    _ffi.check(L.skdsp_downsample_dev(ctypes.c_void_p(xd.ptr + off * esz), n, M, p, _ffi.code_of(dt), ctypes.c_void_p(yd.ptr)))
+                    got = yd.to_host(0, n_out)
+                    ref = x[off:off + n_out * M].reshape(-1, M)[:, p]
+                    assert np.array_equal(got, ref), (np.dtype(dt).name, M, n, p, off)
+                    guard = yd.to_host(n_out, 64).view(np.uint8)
+                    assert np.all(guard == 0x5a), ("wrote past the last output", np.dtype(dt).name, M, n, p, off)
+    xd.free(); yd.free()
+
+
+def test_fir_bx_tile_runs_are_the_same_outputs():
+    """fir_bx.hip, T16 (round 6): the float32 plain filter on the matrix pipe stores its 256-output tiles as runs -- a 4 x 4 transpose between a lane's four result
+    registers and the four 16-lane groups (v_permlane32_swap / v_permlane16_swap).  Only where results LAND changes: bit-identical to the per-column stores
+    (option fir_bx_t16 = 0) for every tap count the form serves, ragged lengths (the last, partial tile keeps the guarded per-column stores), an output offset
+    by one element, and nothing written behind the last output."""
+    import ctypes
+    L = _ffi.load()
+    rng = np.random.default_rng(5)
+    for ntaps in (17, 64, 127, 160, 192):
+        b = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+        k = _ffi.FirKernel(b, _ffi.F32)
+        k.set_algo(_ffi.FIR_DIRECT)
+        for n in (300_000, 262_144, 65_537, 4_099):
+            x = rng.standard_normal(n).astype(np.float32)
+            xd = _ffi.DeviceArray.from_host(x)
+            yd = _ffi.DeviceArray(n + 65, np.float32)
+            outs = []
+            _ffi.debug_path()   # (cleared)
+            for v in (0, 1):
+                for off in (0, 1):
+                    with _ffi.option("fir_bx_t16", v):
+                        _ffi.check(L.skdsp_memset(ctypes.c_void_p(yd.ptr), 0x5a, yd.n * 4))
+                        k.filter_dev(xd, yd.window(off, n), n)
+                        outs.append(yd.to_host(off, n))
+                        assert np.all(yd.to_host(off + n, 64 - off).view(np.uint8) == 0x5a), (ntaps, n, v, off)
+            assert "fir_bx" in _ffi.debug_path()
+            for o in outs[1:]:
+                assert np.array_equal(outs[0], o), (ntaps, n)
+            ref = orc.fir_filter(b, x[:5000])
+            assert_close(outs[0][:5000], ref, TOL32, "fir_bx float32 %d taps" % ntaps)
+            xd.free(); yd.free()
+
+
 # ------------------------------------------------------------------------ FIR
 def test_g4_fir127():
     g = load("g4_fir127.npz")
