@@ -1351,7 +1351,9 @@ int skdsp_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm
     hipDeviceProp_t prop;
     SK_HIP(hipGetDeviceProperties(&prop, ctx().device));
     if (name && name_cap > 0) {
-        snprintf(name, (size_t)name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+        // (boxes without the marketing-name table -- /opt/amdgpu/share/libdrm/amdgpu.ids -- report an empty name: the architecture string then stands alone)
+        if (prop.name[0]) snprintf(name, (size_t)name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+        else snprintf(name, (size_t)name_cap, "%s, %d CUs", prop.gcnArchName, prop.multiProcessorCount);
     }
     if (compute_units) *compute_units = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
