@@ -769,9 +769,13 @@ _RESULT_STREAM = None
 def claim_stdout():
     global _RESULT_STREAM
     if _RESULT_STREAM is None:
-        sys.stdout.flush()
-        _RESULT_STREAM = os.fdopen(os.dup(1), "w")
-        os.dup2(2, 1)
+        try:
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            _RESULT_STREAM = os.fdopen(saved, "w")
+        except OSError:   # (no descriptor 1 / 2 to work with: the line goes where print() sends it)
+            _RESULT_STREAM = None
 
 
 # ------------------------------------------------------------------------------ main
