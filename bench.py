@@ -757,6 +757,14 @@ def emit(out):
         out["detail"] = os.path.relpath(path, ROOT)
     except OSError:
         pass
+    # (what libraries left in C stdio buffers -- librccl's announcement -- leaves NOW, on stderr, so that the line is also the LAST thing a reader of both streams sees)
+    try:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(final_line(out)), file=_RESULT_STREAM or sys.stdout, flush=True)
 
 

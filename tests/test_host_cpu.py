@@ -497,6 +497,11 @@ def test_bench_descriptor_1_carries_the_line_and_nothing_else(tmp_path):
     assert len(lines) == 1 and json.loads(lines[0])["roofline"]["frac"] > 0.5, lines
     err = r.stderr.decode()
     assert "announcing itself" in err and "python print behind the claim" in err and "raw write to descriptor 1" in err
+    # a reader of BOTH streams as one (2>&1) finds the line LAST: emit() flushes what libraries left in C stdio buffers before it prints
+    merged = subprocess.run([sys.executable, "-c", code.rsplit("os.write", 1)[0]], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert merged.returncode == 0
+    mlines = [ln for ln in merged.stdout.decode().split("\n") if ln.strip()]
+    assert any("announcing itself" in ln for ln in mlines[:-1]) and json.loads(mlines[-1])["roofline"]["frac"] > 0.5, mlines[-3:]
 
 
 def test_profile_stamps_hash_the_code_not_the_comments(tmp_path, monkeypatch):
