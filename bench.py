@@ -758,13 +758,7 @@ def emit(out):
     except OSError:
         pass
     # (what libraries left in C stdio buffers -- librccl's announcement -- leaves NOW, on stderr, so that the line is also the LAST thing a reader of both streams sees)
-    try:
-        sys.stdout.flush()
-        sys.stderr.flush()
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
+    flush_library_text()
     print(json.dumps(final_line(out)), file=_RESULT_STREAM or sys.stdout, flush=True)
 
 
@@ -784,6 +778,17 @@ def claim_stdout():
             _RESULT_STREAM = os.fdopen(saved, "w")
         except OSError:   # (no descriptor 1 / 2 to work with: the line goes where print() sends it)
             _RESULT_STREAM = None
+
+
+def flush_library_text():
+    """What libraries left in C stdio buffers goes out now (to stderr, once claim_stdout() has run)."""
+    try:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 # ------------------------------------------------------------------------------ main
@@ -816,6 +821,7 @@ def main():
     rank, world, local = sharding.env_rank_world()
     args.gpus = world
     tr = sharding.RcclTransport(rank, world, local)  # binds this process to GPU LOCAL_RANK
+    flush_library_text()   # (every rank: librccl's announcement leaves now, not when the process exits -- behind rank 0's line for a reader of all streams as one)
     info = _ffi.device_info()
 
     if args.scaling == "strong":
