@@ -49,6 +49,11 @@ bench.main()
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload", ["fir1024", "iir8"])
 def test_bench_main_as_rank_0_of_2(workload):
+    if workload == "iir8":   # a reader of both streams as one (2>&1): the line is the LAST thing it sees, whatever librccl wrote through C stdio
+        m = subprocess.run([sys.executable, "-c", CODE % ROOT, "--workload", workload], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, cwd=ROOT)
+        assert m.returncode == 0, m.stdout.decode()[-3000:]
+        ml = [ln for ln in m.stdout.decode().split("\n") if ln.strip()]
+        assert any("Librccl" in ln for ln in ml[:-1]) and json.loads(ml[-1])["n_gpus"] == 2, ml[-3:]
     r = subprocess.run([sys.executable, "-c", CODE % ROOT, "--workload", workload], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().split("\n") if ln.strip()]
